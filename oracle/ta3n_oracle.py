@@ -1,0 +1,329 @@
+"""CPU oracle for the TA3N temporal-adversarial train step.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``ta3n_amd/`` may import this module;
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` do, and only as the checker / the timed CPU baseline.
+
+It is a compact functional restatement of the reference's hot path (the
+reference is a PyTorch program whose arithmetic is ATen CPU kernels, so the
+restatement uses the same ATen CPU ops through ``torch`` on CPU tensors; the
+backward pass is ``torch.autograd`` exactly as the reference's
+``loss.backward()``).  Each function cites the reference lines it follows
+(paths relative to cmhungsteve/TA3N).
+
+Parity pin: ``tests/golden/*.npz`` were produced by running the reference's own
+``models.VideoModel`` / ``main.train`` in the build container
+(``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` checks this
+module against every fixture.  The reference ships no tests or golden vectors
+of its own.
+
+Scope: frame_aggregation='trn-m', baseline_type='video', share_params='Y',
+use_bn='none', use_attn='TransAttn', add_fc=1, adv_DA='RevGrad' - the
+UCF->HMDB_full TA3N configuration of script_train_val.sh.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SUBSAMPLE_NUM = 3  # TRNmodule.py:32
+NUM_BOTTLENECK = 256  # models.py:223
+
+ARCH_FEATURE_DIM = {  # models.py:125-126 reads torchvision <arch>.fc.in_features
+    "resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnet101": 2048,
+    "resnet152": 2048,
+}
+
+
+# ----------------------------------------------------------------------------
+# integer layer (must be bit-exact)
+# ----------------------------------------------------------------------------
+def relation_scales(num_frames: int) -> List[int]:
+    """TRNmodule.py:34  scales = [T, T-1, ..., 2]."""
+    return [i for i in range(num_frames, 1, -1)]
+
+
+def selected_relations(num_frames: int) -> List[List[Tuple[int, ...]]]:
+    """Frame tuples actually used by RelationModuleMultiScale.forward.
+
+    TRNmodule.py:36-41 (all C(T,s) sorted tuples per scale, via
+    itertools.combinations, TRNmodule.py:84-86), :60 (scale 0 uses tuple 0),
+    :68-71 (later scales use idx = int(ceil(i * n_total / n_select)) for
+    i < min(3, n_total)).
+    """
+    out = []
+    for sid, scale in enumerate(relation_scales(num_frames)):
+        rel = list(itertools.combinations(range(num_frames), scale))
+        if sid == 0:
+            out.append([rel[0]])
+            continue
+        n_total = len(rel)
+        n_sel = min(SUBSAMPLE_NUM, n_total)
+        idx = [int(math.ceil(i * n_total / n_sel)) for i in range(n_sel)]
+        out.append([rel[i] for i in idx])
+    return out
+
+
+def segment_indices_test_mode(num_frames: int, num_segments: int, new_length: int = 1) -> np.ndarray:
+    """dataset.py:103-116 `_get_test_indices` (the only sampler used: every
+    TSNDataSet in main.py:171-197 is built with test_mode=True).  1-based."""
+    num_min = num_segments + new_length - 1
+    num_select = num_frames - new_length + 1
+    if num_frames >= num_min:
+        tick = float(num_select) / float(num_segments)
+        offsets = np.array([int(tick / 2.0 + tick * float(x)) for x in range(num_segments)])
+    else:
+        id_select = np.array([x for x in range(num_select)])
+        id_expand = np.ones(num_segments - num_select, dtype=int) * id_select[id_select[0] - 1]
+        offsets = np.append(id_select, id_expand)
+    return offsets + 1
+
+
+# ----------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------
+@dataclass
+class Config:
+    num_class: int = 12
+    num_segments: int = 5
+    feature_dim: int = 2048          # models.py:125-126
+    fc_dim: int = 512                # script_train_val.sh (fc_dim=512)
+    dropout_i: float = 0.5
+    dropout_v: float = 0.5
+    place_adv: Tuple[str, str, str] = ("Y", "Y", "Y")   # opts.py:67
+    add_loss_DA: str = "attentive_entropy"            # opts.py:54
+    use_attn: str = "TransAttn"
+
+    @property
+    def feat_dim(self) -> int:       # models.py:129
+        return min(self.fc_dim, self.feature_dim)
+
+
+def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys/shapes of VideoModel for the trn-m configuration
+    (models.py:141-294, TRNmodule.py:44-54).  BatchNorm buffers omitted."""
+    Fd, D, C, T, NB = cfg.feat_dim, cfg.feature_dim, cfg.num_class, cfg.num_segments, NUM_BOTTLENECK
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(name, o, i):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    lin("fc_feature_shared_source", Fd, D)          # models.py:141
+    lin("fc_feature_source", Fd, Fd)                # :156  (never used in fwd)
+    lin("fc_feature_domain", Fd, Fd)                # :161
+    lin("fc_classifier_source", C, Fd)              # :166  (dead for baseline 'video')
+    lin("fc_classifier_domain", 2, Fd)              # :170
+    for i, sc in enumerate(relation_scales(T)):     # TRNmodule.py:44-54
+        lin(f"TRN.fc_fusion_scales.{i}.1", NB, sc * Fd)
+    for bn in ("bn_trn_S", "bn_trn_T"):             # models.py:225-226 (unused)
+        s[bn + ".weight"] = (NB,)
+        s[bn + ".bias"] = (NB,)
+    lin("fc_feature_video_source", NB, NB)          # :258 (unused)
+    lin("fc_feature_video_source_2", NB, NB)        # :262 (unused)
+    lin("fc_feature_domain_video", NB, NB)          # :267
+    lin("fc_classifier_video_source", C, NB)        # :272
+    lin("fc_classifier_domain_video", 2, NB)        # :281
+    for i in range(T - 1):                          # :286-294
+        lin(f"relation_domain_classifier_all.{i}.0", NB, NB)
+        lin(f"relation_domain_classifier_all.{i}.2", 2, NB)
+    return s
+
+
+# parameters that never receive a gradient in this configuration
+DEAD_PREFIXES = ("fc_feature_source.", "fc_classifier_source.", "bn_trn_S.", "bn_trn_T.",
+                 "fc_feature_video_source.", "fc_feature_video_source_2.")
+
+
+def is_live(name: str) -> bool:
+    return not name.startswith(DEAD_PREFIXES)
+
+
+# ----------------------------------------------------------------------------
+# model forward
+# ----------------------------------------------------------------------------
+class _GradReverse(torch.autograd.Function):
+    """models.py:20-29."""
+
+    @staticmethod
+    def forward(ctx, x, beta):
+        ctx.beta = beta
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.neg() * ctx.beta, None
+
+
+def _linear(p, name, x):
+    return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+
+
+def trn_multiscale(p, x, cfg: Config):
+    """TRNmodule.py:58-82.  x [B,T,F] -> [B,T-1,256]."""
+    rel = selected_relations(cfg.num_segments)
+    B = x.size(0)
+    acts = []
+    for sid, tuples in enumerate(rel):
+        scale = len(tuples[0])
+        acc = None
+        for tup in tuples:
+            a = x[:, list(tup), :].reshape(B, scale * cfg.feat_dim)
+            a = F.relu(_linear(p, f"TRN.fc_fusion_scales.{sid}.1", F.relu(a)))
+            acc = a if acc is None else acc + a
+        acts.append(acc.unsqueeze(1))
+    return torch.cat(acts, 1)
+
+
+def trans_attn(pred_domain):
+    """models.py:351-357: w = 1 - H(softmax(pred_domain))."""
+    ent = torch.sum(-F.softmax(pred_domain, 1) * F.log_softmax(pred_domain, 1), 1)
+    return 1 - ent
+
+
+def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
+    """One domain's pass through VideoModel.forward (models.py:545-722) for the
+    trn-m / video / TransAttn configuration.  x [B,T,D].  drop_i / drop_v are
+    optional multiplicative dropout masks already scaled by 1/(1-p)
+    ([B*T,F] and [B,256]); None means dropout off (eval or p=0).
+    Returns dict with the reference's per-domain outputs."""
+    B, T = x.size(0), cfg.num_segments
+    f = F.relu(_linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1))))   # :557-572
+    if drop_i is not None:
+        f = f * drop_i                                                               # :574-575
+    feat_frame = f.view(B, T, -1)                                                    # :578
+    # frame-level adversarial branch (:456-462, :606-610)
+    h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2])))
+    pred_frame = _linear(p, "fc_classifier_domain", h).view(B, T, 2)
+    # TRN (:632-636)
+    rel = trn_multiscale(p, feat_frame, cfg)
+    # relation discriminators (:472-488)
+    preds = []
+    for i in range(T - 1):
+        r = _GradReverse.apply(rel[:, i, :], beta[0])
+        hr = F.relu(_linear(p, f"relation_domain_classifier_all.{i}.0", r))
+        preds.append(_linear(p, f"relation_domain_classifier_all.{i}.2", hr).view(-1, 1, 2))
+    pred_rel = torch.cat(preds, 1).view(-1, 2)
+    # transferable attention (:379-388, :643-645)
+    if cfg.use_attn == "TransAttn":
+        w = trans_attn(pred_rel).view(-1, T - 1, 1)
+        rel_attn = (w + 1) * rel
+        attn = w[:, :, 0]
+    else:
+        rel_attn, attn = rel, rel[:, :, 0]
+    v = torch.sum(rel_attn, 1)                                                       # :651
+    vd = v * drop_v if drop_v is not None else v                                     # :679
+    y = _linear(p, "fc_classifier_video_source", vd)                                 # :686
+    hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1])))  # :464-470
+    pred_video = _linear(p, "fc_classifier_domain_video", hv)
+    return dict(attn=attn, out=y,
+                pred_domain=[pred_rel.view(B, T - 1, 2), pred_video, pred_frame],   # :697-707, :722 reversed
+                feat=[y, v, feat_frame])                                             # :578, :675, :690, :722
+
+
+# ----------------------------------------------------------------------------
+# losses (main.py:439-562, loss.py:15-25)
+# ----------------------------------------------------------------------------
+def attentive_entropy(pred, pred_domain):
+    """loss.py:15-25."""
+    ent_d = torch.sum(-F.softmax(pred_domain, 1) * F.log_softmax(pred_domain, 1), 1)
+    w = 1 + ent_d
+    return torch.mean(w * torch.sum(-F.softmax(pred, 1) * F.log_softmax(pred, 1), 1))
+
+
+def total_loss(src, tgt, label_source, gamma, cfg: Config,
+               n_src: Optional[int] = None, n_tgt: Optional[int] = None):
+    """main.py:421-422 (removeDummy), 439-451 (classification CE), 508-538
+    (adversarial CE per enabled level), 559-562 (attentive entropy)."""
+    n_src = src["out"].size(0) if n_src is None else n_src
+    n_tgt = tgt["out"].size(0) if n_tgt is None else n_tgt
+    out_s, out_t = src["out"][:n_src], tgt["out"][:n_tgt]
+    loss_c = F.cross_entropy(out_s, label_source[:n_src])
+    loss = loss_c
+    parts = {"loss_c": loss_c}
+    pred_all = []
+    loss_a = 0
+    for l in range(3):
+        if cfg.place_adv[l] == "Y":
+            ps = src["pred_domain"][l][:n_src].reshape(-1, 2)
+            pt = tgt["pred_domain"][l][:n_tgt].reshape(-1, 2)
+            lab = torch.cat((torch.zeros(ps.size(0)), torch.ones(pt.size(0)))).long()
+            pd = torch.cat((ps, pt), 0)
+            pred_all.append(pd)
+            loss_a = loss_a + F.cross_entropy(pd, lab)
+    if pred_all:
+        loss = loss + loss_a
+        parts["loss_a"] = loss_a
+    if cfg.add_loss_DA == "attentive_entropy" and cfg.use_attn != "none":
+        loss_e = attentive_entropy(torch.cat((out_s, out_t), 0), pred_all[1])
+        loss = loss + gamma * loss_e
+        parts["loss_e"] = loss_e
+    parts["loss"] = loss
+    return loss, parts
+
+
+# ----------------------------------------------------------------------------
+# train step (main.py:348-352, 574-583, 620-621, 800-802)
+# ----------------------------------------------------------------------------
+def beta_dann(p: float) -> float:
+    """main.py:351."""
+    return float(2.0 / (1.0 + np.exp(-10 * p)) - 1)
+
+
+def lr_dann(lr0: float, p: float) -> float:
+    """main.py:800-802."""
+    return lr0 / (1.0 + 10 * p) ** 0.75
+
+
+@dataclass
+class TrainState:
+    params: Dict[str, torch.Tensor]
+    momentum: Dict[str, torch.Tensor] = field(default_factory=dict)
+    lr: float = 3e-2
+
+
+def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config,
+               momentum=0.9, weight_decay=1e-4, clip=20.0, drop_i=None, drop_v=None,
+               n_src=None, n_tgt=None, grad_hook=None):
+    """One optimisation step: forward both domains, total loss, backward,
+    clip_grad_norm_ (main.py:578-581), Nesterov SGD with weight decay
+    (main.py:83, 583; torch.optim.SGD semantics: g += wd*p; buf = mu*buf + g
+    (buf = g on first use); g = g + mu*buf; p -= lr*g).  Parameters without a
+    gradient are skipped (they are not in any BASELINE config's graph)."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in state.params.items()}
+    di_s = di_t = dv_s = dv_t = None
+    if drop_i is not None:
+        di_s, di_t = drop_i
+    if drop_v is not None:
+        dv_s, dv_t = drop_v
+    src = forward_domain(p, xs, beta, cfg, di_s, dv_s)
+    tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t)
+    loss, parts = total_loss(src, tgt, label_source, gamma, cfg, n_src, n_tgt)
+    names = [k for k in p if is_live(k)]
+    grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    g = {k: gi for k, gi in zip(names, grads) if gi is not None}
+    if grad_hook is not None:            # e.g. a data-parallel all-reduce
+        g = grad_hook(g)
+    raw = {k: v.clone() for k, v in g.items()}
+    total_norm = torch.linalg.vector_norm(
+        torch.stack([torch.linalg.vector_norm(v) for v in g.values()]))
+    if clip is not None:
+        coef = torch.clamp(clip / (total_norm + 1e-6), max=1.0)      # clip_grad_norm_
+        g = {k: v * coef for k, v in g.items()}
+    new_params = {k: v.detach().clone() for k, v in state.params.items()}
+    for k, gi in g.items():
+        d = gi + weight_decay * new_params[k]
+        buf = state.momentum.get(k)
+        buf = d.clone() if buf is None else momentum * buf + d
+        state.momentum[k] = buf
+        d = d + momentum * buf
+        new_params[k] = new_params[k] - state.lr * d
+    state.params = new_params
+    return dict(loss=loss.detach(), parts={k: v.detach() for k, v in parts.items()},
+                src=src, tgt=tgt, grads=raw, clipped=g, total_norm=total_norm)
