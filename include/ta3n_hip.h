@@ -1,0 +1,181 @@
+/*
+ * ta3n_hip.h - C ABI of libta3n_hip.so, the MI355X (gfx950) implementation of
+ * TA3N's temporal-adversarial train step.
+ *
+ * The reference (cmhungsteve/TA3N) is pure Python/PyTorch and has no FFI; the
+ * drop-in boundary is its Python surface (models.VideoModel.forward,
+ * models.py:545-722; main.train, main.py:309-667).  This header is what a
+ * Python/ctypes (or any other FFI) host binds to replace that path.  Every
+ * entry point cites the reference code it replaces.  All device pointers are
+ * plain fp32/int32 HIP device memory owned by the caller; `stream` is a
+ * hipStream_t passed as void*.  No entry point allocates per call or
+ * synchronises the device (graph-capture safe) except ta3n_plan_create /
+ * ta3n_plan_destroy / ta3n_set_hyper_sync.
+ *
+ * Layout conventions (all row-major fp32):
+ *   x       [B*T, D]   source videos first (rows [0, Bs*T)), then target
+ *   params  flat buffer, layout given by ta3n_param_info (live params first)
+ *   grads   same layout as params (only the live prefix is written)
+ *   ws      workspace of ta3n_workspace_floats() floats; named regions are
+ *           located with ta3n_ws_offset()
+ * Return value: 0 on success, negative ta3n_status otherwise;
+ * ta3n_last_error() gives a message for the calling thread.
+ */
+#ifndef TA3N_HIP_H
+#define TA3N_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TA3N_OK = 0,
+    TA3N_ERR_INVALID = -1,     /* bad argument / unsupported configuration (ValueError in the reference) */
+    TA3N_ERR_HIP = -2,         /* a HIP runtime call failed */
+    TA3N_ERR_NOMEM = -3
+} ta3n_status;
+
+/* flags for ta3n_config.flags */
+#define TA3N_FLAG_ADV_RELATION   (1u << 0)  /* place_adv[0]=='Y'  (opts.py:67, main.py:508-538) */
+#define TA3N_FLAG_ADV_VIDEO      (1u << 1)  /* place_adv[1]=='Y' */
+#define TA3N_FLAG_ADV_FRAME      (1u << 2)  /* place_adv[2]=='Y' */
+#define TA3N_FLAG_ATTN_ENTROPY   (1u << 3)  /* add_loss_DA=='attentive_entropy' (main.py:559-562) */
+#define TA3N_FLAG_TRANS_ATTN     (1u << 4)  /* use_attn=='TransAttn' (models.py:643-645) */
+
+typedef struct {
+    int32_t batch_source;    /* Bs: rows of the source half (after the reference's zero padding, main.py:359-372) */
+    int32_t batch_target;    /* Bt */
+    int32_t num_segments;    /* T  (opts.py:12; train_segments, models.py:60) */
+    int32_t feature_dim;     /* D  (models.py:125-126) */
+    int32_t fc_dim;          /* F = min(fc_dim, feature_dim) (models.py:129) */
+    int32_t num_bottleneck;  /* 256 for trn-m (models.py:223) */
+    int32_t num_class;       /* C */
+    uint32_t flags;          /* TA3N_FLAG_* */
+    int32_t tile_config;     /* 0 = auto; otherwise WM*100+WN*10+WK (e.g. 114, 212, 221) for every GEMM phase */
+    int32_t reserved[7];
+} ta3n_config;
+
+/* Per-step scalars; lives in device memory inside ws (region "hyper").  The host
+ * fills a copy and uploads it with ta3n_set_hyper (async on `stream`). */
+typedef struct {
+    float beta[3];           /* [relation, video, frame] GradReverse weights (models.py:20-29, main.py:350-352) */
+    float gamma;             /* attentive-entropy weight (main.py:562) */
+    float lr;                /* main.py:83, 620-621 */
+    float momentum;          /* opts.py:83 */
+    float weight_decay;      /* opts.py:85 */
+    float clip;              /* --clip_gradient (main.py:578-581); <= 0 disables */
+    float p_drop_i;          /* dropout_i (models.py:131); used only when train != 0 */
+    float p_drop_v;          /* dropout_v (models.py:132) */
+    uint32_t seed_i;         /* dropout stream seeds for this step */
+    uint32_t seed_v;
+    float inv_n_cls;         /* 1 / (global number of labelled source videos)      (CE mean, main.py:446) */
+    float inv_n_rel;         /* 1 / (global src+tgt videos * (T-1))                 (main.py:533) */
+    float inv_n_vid;         /* 1 / (global src+tgt videos) */
+    float inv_n_frm;         /* 1 / (global src+tgt videos * T) */
+    float inv_n_ent;         /* 1 / (global src+tgt videos)                         (loss.py:24) */
+    int32_t valid_source;    /* rows [valid_source, Bs) are the reference's dummy rows (main.py:359-372, 421-422) */
+    int32_t valid_target;
+    int32_t train;           /* nn.Module.training: dropout active */
+    int32_t reserved[4];
+} ta3n_hyper;
+
+typedef struct ta3n_plan ta3n_plan;
+
+/* ---- integer layer (host, bit-exact contract) -------------------------------- */
+
+/* Number of frame tuples RelationModuleMultiScale.forward uses for T frames:
+ * 1 + sum_{s=T-1..2} min(3, C(T,s))   (TRNmodule.py:32-41, 60, 68-71). */
+int ta3n_num_relation_tuples(int num_frames);
+
+/* The tuples themselves, scale T first, by combinatorial unranking (no C(T,s)
+ * enumeration).  tuples is [n][T] padded with -1; scale_len[r] = tuple size,
+ * scale_id[r] = index of the scale (0 = T-frame).  Replaces
+ * TRNmodule.py:30-41, 84-86 + the idx computation at :71.  Returns n or <0. */
+int ta3n_relation_table(int num_frames, int32_t *tuples, int32_t *scale_len, int32_t *scale_id);
+
+/* TSNDataSet._get_test_indices (dataset.py:103-116), 1-based frame ids.
+ * Returns TA3N_ERR_INVALID where the reference raises (no selectable frame). */
+int ta3n_segment_indices(int num_frames, int num_segments, int new_length, int64_t *out);
+
+/* ---- plan ---------------------------------------------------------------------- */
+
+/* Builds the launch plan (tile lists, workspace layout) for one configuration;
+ * replaces VideoModel.__init__/_prepare_DA's shape logic (models.py:119-325).
+ * Needs no GPU: device upload is deferred to the first launch. */
+int ta3n_plan_create(const ta3n_config *cfg, ta3n_plan **out);
+void ta3n_plan_destroy(ta3n_plan *plan);
+
+/* Parameter table.  name is the reference state_dict key (models.py:141-294,
+ * TRNmodule.py:44-54), e.g. "TRN.fc_fusion_scales.0.1.weight".  live != 0 for
+ * parameters that receive a gradient in this configuration; they occupy
+ * [0, ta3n_live_param_floats) of the flat buffer. */
+int ta3n_num_params(const ta3n_plan *plan);
+int ta3n_param_info(const ta3n_plan *plan, int index, const char **name, int64_t *offset,
+                    int32_t *rows, int32_t *cols, int32_t *live);
+int64_t ta3n_param_floats(const ta3n_plan *plan);
+int64_t ta3n_live_param_floats(const ta3n_plan *plan);
+
+/* Workspace: size and named regions ("F1","Y","Pr","Pv","Pf","attn","V","losses",
+ * "labels","hyper","gY","gPr","gPv","gPf","g_attn", ...).  Returns -1 if unknown. */
+int64_t ta3n_workspace_floats(const ta3n_plan *plan);
+int64_t ta3n_ws_offset(const ta3n_plan *plan, const char *region);
+int64_t ta3n_ws_size(const ta3n_plan *plan, const char *region);
+
+/* JSON description of buffers / phases / tasks (for tests and debugging). */
+int64_t ta3n_plan_describe(const ta3n_plan *plan, char *buf, int64_t cap);
+
+/* ---- per-step entry points (enqueue only) ------------------------------------- */
+
+/* Uploads the per-step scalars into ws["hyper"] (async copy from an internal
+ * pinned staging ring; safe to call every step before ta3n_forward). */
+int ta3n_set_hyper(ta3n_plan *plan, float *ws, const ta3n_hyper *h, void *stream);
+
+/* One-time initialisation of constant workspace regions (ones vector). */
+int ta3n_init_workspace(ta3n_plan *plan, float *ws, void *stream);
+
+/* VideoModel.forward for source+target in one pass (models.py:545-722): shared
+ * frame FC + dropout, frame/relation/video domain discriminators, multi-scale
+ * TRN, transferable attention, video classifier.  Outputs land in ws regions
+ * F1, Pf, Pr, attn, V, Y, Pv (see ta3n_ws_offset). */
+int ta3n_forward(ta3n_plan *plan, const float *x, const float *params, float *ws, void *stream);
+
+/* Loss assembly of main.train (main.py:439-451, 508-538, 559-562; loss.py:15-25):
+ * reads ws["labels"] (int32 class labels of the source rows), writes
+ * ws["losses"] = {total, cls, adv_rel, adv_vid, adv_frm, entropy} and the logit
+ * gradients gY, gPr, gPv, gPf. */
+int ta3n_loss(ta3n_plan *plan, float *ws, void *stream);
+
+/* loss.backward() (main.py:576) from the logit gradients in ws (gY, gPr, gPv,
+ * gPf and optionally g_attn) to every live parameter gradient; GradReverse
+ * (models.py:20-29) is folded in as the -beta scale of the discriminator
+ * input-gradient GEMMs.  grads is overwritten (not accumulated). */
+int ta3n_backward(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
+                  void *stream);
+
+/* clip_grad_norm_ + Nesterov SGD with weight decay (main.py:578-583) on the
+ * flat live prefix; ws["grad_norm"] receives the pre-clip global norm. */
+int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
+                  void *stream);
+
+/* Number of kernel launches the last ta3n_forward/ta3n_backward enqueued, and a
+ * name for the dominant GEMM kernel symbol (for rocprof matching). */
+int ta3n_num_phases(const ta3n_plan *plan, int which /*0 fwd,1 loss,2 bwd,3 sgd*/);
+
+/* Test/debug access to the plan's host-side descriptor arrays (Seg/Task/Phase/
+ * Geom PODs of ta3n_amd/csrc/ta3n_types.h) so the wiring can be validated on a
+ * machine without a GPU (tests/plan_interp.py). */
+int ta3n_debug_arrays(const ta3n_plan *plan, const void **segs, int64_t *n_segs, const void **tasks,
+                      int64_t *n_tasks, const void **phases, int64_t *n_phases, const void **geom,
+                      const int32_t **tuples, const int32_t **tuple_first);
+int ta3n_debug_struct_sizes(int32_t *seg, int32_t *task, int32_t *phase, int32_t *geom, int32_t *hyper);
+
+const char *ta3n_last_error(void);
+const char *ta3n_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TA3N_HIP_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of libta3n_hip.so (include/ta3n_hip.h).
+
+The library is loaded on first use.  If it has not been built the call raises -
+there is no CPU or eager-PyTorch fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+_LIB: Optional[C.CDLL] = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libta3n_hip.so")
+
+FLAG_ADV_RELATION = 1 << 0
+FLAG_ADV_VIDEO = 1 << 1
+FLAG_ADV_FRAME = 1 << 2
+FLAG_ATTN_ENTROPY = 1 << 3
+FLAG_TRANS_ATTN = 1 << 4
+
+# every symbol include/ta3n_hip.h declares (tests check the export list)
+SYMBOLS = [
+    "ta3n_num_relation_tuples", "ta3n_relation_table", "ta3n_segment_indices", "ta3n_plan_create",
+    "ta3n_plan_destroy", "ta3n_num_params", "ta3n_param_info", "ta3n_param_floats", "ta3n_live_param_floats",
+    "ta3n_workspace_floats", "ta3n_ws_offset", "ta3n_ws_size", "ta3n_plan_describe", "ta3n_set_hyper",
+    "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_sgd_step", "ta3n_num_phases",
+    "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_last_error", "ta3n_version",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("batch_source", C.c_int32), ("batch_target", C.c_int32), ("num_segments", C.c_int32),
+                ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
+                ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class Hyper(C.Structure):
+    _fields_ = [("beta", C.c_float * 3), ("gamma", C.c_float), ("lr", C.c_float), ("momentum", C.c_float),
+                ("weight_decay", C.c_float), ("clip", C.c_float), ("p_drop_i", C.c_float), ("p_drop_v", C.c_float),
+                ("seed_i", C.c_uint32), ("seed_v", C.c_uint32), ("inv_n_cls", C.c_float), ("inv_n_rel", C.c_float),
+                ("inv_n_vid", C.c_float), ("inv_n_frm", C.c_float), ("inv_n_ent", C.c_float),
+                ("valid_source", C.c_int32), ("valid_target", C.c_int32), ("train", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+class Ta3nError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it is missing: build it with
+    `python -m ta3n_amd.build` (hipcc --offload-arch=gfx950)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise Ta3nError(f"{LIB_PATH} not found: the HIP extension is required (python -m ta3n_amd.build); "
+                        "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ta3n_num_relation_tuples.argtypes = [C.c_int]
+    L.ta3n_relation_table.argtypes = [C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ta3n_segment_indices.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(i64)]
+    L.ta3n_plan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.ta3n_plan_destroy.argtypes = [vp]
+    L.ta3n_plan_destroy.restype = None
+    L.ta3n_num_params.argtypes = [vp]
+    L.ta3n_param_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
+                                  C.POINTER(i32)]
+    for fn in ("ta3n_param_floats", "ta3n_live_param_floats", "ta3n_workspace_floats"):
+        getattr(L, fn).argtypes = [vp]
+        getattr(L, fn).restype = i64
+    for fn in ("ta3n_ws_offset", "ta3n_ws_size"):
+        getattr(L, fn).argtypes = [vp, C.c_char_p]
+        getattr(L, fn).restype = i64
+    L.ta3n_plan_describe.argtypes = [vp, C.c_char_p, i64]
+    L.ta3n_plan_describe.restype = i64
+    L.ta3n_set_hyper.argtypes = [vp, vp, C.POINTER(Hyper), vp]
+    L.ta3n_init_workspace.argtypes = [vp, vp, vp]
+    L.ta3n_forward.argtypes = [vp, vp, vp, vp, vp]
+    L.ta3n_loss.argtypes = [vp, vp, vp]
+    L.ta3n_backward.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ta3n_sgd_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ta3n_num_phases.argtypes = [vp, C.c_int]
+    L.ta3n_debug_arrays.argtypes = [vp] + [C.POINTER(vp), C.POINTER(i64)] * 3 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.ta3n_debug_struct_sizes.argtypes = [C.POINTER(i32)] * 5
+    L.ta3n_last_error.restype = C.c_char_p
+    L.ta3n_version.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = lib().ta3n_last_error().decode()
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")        # the reference raises ValueError for bad configs (models.py:137, 562)
+        raise Ta3nError(f"{what}: {msg} (status {rc})")
+    return rc
+
+
+def relation_table(num_frames: int) -> List[List[Tuple[int, ...]]]:
+    """Selected frame tuples per scale, scale T first (reference TRNmodule.py:30-41, 60, 68-71)."""
+    L = lib()
+    n = check(L.ta3n_num_relation_tuples(num_frames), "ta3n_num_relation_tuples")
+    tup = (C.c_int32 * (n * num_frames))()
+    sl = (C.c_int32 * n)()
+    sid = (C.c_int32 * n)()
+    check(L.ta3n_relation_table(num_frames, tup, sl, sid), "ta3n_relation_table")
+    out: List[List[Tuple[int, ...]]] = [[] for _ in range(num_frames - 1)]
+    for r in range(n):
+        out[sid[r]].append(tuple(tup[r * num_frames + j] for j in range(sl[r])))
+    return out
+
+
+def segment_indices(num_frames: int, num_segments: int, new_length: int = 1) -> List[int]:
+    """TSNDataSet._get_test_indices (reference dataset.py:103-116); 1-based."""
+    L = lib()
+    out = (C.c_int64 * num_segments)()
+    check(L.ta3n_segment_indices(num_frames, num_segments, new_length, out), "ta3n_segment_indices")
+    return list(out)
+
+
+class Plan:
+    """Owns a ta3n_plan handle and caches its layout tables."""
+
+    def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
+                 num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0):
+        L = lib()
+        self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
+                          flags, tile_config)
+        h = C.c_void_p()
+        check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
+        self.handle = h
+        self._L = L
+        n = L.ta3n_num_params(h)
+        self.params: List[Tuple[str, int, Tuple[int, ...], bool]] = []
+        for i in range(n):
+            name = C.c_char_p(); off = C.c_int64(); r = C.c_int32(); c = C.c_int32(); live = C.c_int32()
+            check(L.ta3n_param_info(h, i, C.byref(name), C.byref(off), C.byref(r), C.byref(c), C.byref(live)))
+            shape = (r.value, c.value) if c.value else (r.value,)
+            self.params.append((name.value.decode(), off.value, shape, bool(live.value)))
+        self.param_floats = L.ta3n_param_floats(h)
+        self.live_floats = L.ta3n_live_param_floats(h)
+        self.ws_floats = L.ta3n_workspace_floats(h)
+        n = L.ta3n_plan_describe(h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        L.ta3n_plan_describe(h, buf, n + 1)
+        self.description = json.loads(buf.value.decode())
+        self.regions: Dict[str, Tuple[int, int]] = {k: tuple(v) for k, v in self.description["regions"].items()}
+
+    def region(self, name: str) -> Tuple[int, int]:
+        return self.regions[name]
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._L.ta3n_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

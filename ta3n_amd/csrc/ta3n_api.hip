@@ -1,0 +1,259 @@
+// C ABI of libta3n_hip.so (see include/ta3n_hip.h): plan lifetime, layout
+// queries and the per-step launchers.  Launchers only enqueue work on the
+// caller's stream; they never synchronise, so a whole train step can be captured
+// into a hipGraph by the host (the reference's shapes are static thanks to its
+// own pad-to-batch-size rule, main.py:359-364).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <sstream>
+#include <string>
+
+#include "../../include/ta3n_hip.h"
+#include "ta3n_kernels.h"
+#include "ta3n_plan.h"
+
+using namespace ta3n;
+
+static_assert(sizeof(ta3n_hyper) == sizeof(ta3n::Hyper), "public and device hyper structs must match");
+static_assert(sizeof(ta3n_hyper) <= 32 * sizeof(float), "hyper region is 32 floats");
+
+namespace {
+thread_local std::string g_err;
+constexpr int kHyperSlots = 64;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(TA3N_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_uploaded(ta3n_plan *p) {
+    if (p->uploaded) return TA3N_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)st;
+    HIP_TRY(hipGetDevice(&p->device));
+    HIP_TRY(hipMalloc(&p->d_segs, p->segs.size() * sizeof(Seg)));
+    HIP_TRY(hipMalloc(&p->d_tasks, p->tasks.size() * sizeof(Task)));
+    HIP_TRY(hipMemcpy(p->d_segs, p->segs.data(), p->segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_tasks, p->tasks.data(), p->tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+    HIP_TRY(hipHostMalloc(&p->h_hyper, kHyperSlots * sizeof(ta3n_hyper), hipHostMallocDefault));
+    p->uploaded = true;
+    return TA3N_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream) {
+    for (const Phase &ph : p->phases) {
+        if (ph.group != group) continue;
+        int rc = 0;
+        switch (ph.kind) {
+            case PH_GEMM:
+                rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
+                                 p->geom.o_hyper, stream);
+                break;
+            case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
+            case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
+            case PH_POOL_BWD: rc = launch_pool_bwd(p->geom, ptrs, stream); break;
+            case PH_GRAD_NORM: rc = launch_grad_norm(p->geom, ptrs.g, ptrs.ws, stream); break;
+            case PH_SGD: rc = launch_sgd(p->geom, params_rw, ptrs.g, momentum, ptrs.ws, stream); break;
+            default: rc = -1;
+        }
+        if (rc != 0) return fail(TA3N_ERR_HIP, "kernel launch failed in phase kind " + std::to_string(ph.kind) + ": " +
+                                                   hipGetErrorString(hipGetLastError()));
+    }
+    return TA3N_OK;
+}
+}  // namespace
+
+void ta3n::set_error(const std::string &msg) { g_err = msg; }
+
+extern "C" {
+
+const char *ta3n_last_error(void) { return g_err.c_str(); }
+const char *ta3n_version(void) { return "ta3n_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+
+int ta3n_plan_create(const ta3n_config *cfg, ta3n_plan **out) {
+    if (!cfg || !out) return fail(TA3N_ERR_INVALID, "null argument");
+    ta3n_plan *p = new (std::nothrow) ta3n_plan();
+    if (!p) return fail(TA3N_ERR_NOMEM, "out of memory");
+    p->cfg = *cfg;
+    std::string err;
+    const int rc = build_plan(*p, err);
+    if (rc != TA3N_OK) {
+        delete p;
+        return fail(rc, err);
+    }
+    *out = p;
+    return TA3N_OK;
+}
+
+void ta3n_plan_destroy(ta3n_plan *p) {
+    if (!p) return;
+    if (p->uploaded) {
+        (void)hipFree(p->d_segs);
+        (void)hipFree(p->d_tasks);
+        (void)hipHostFree(p->h_hyper);
+    }
+    delete p;
+}
+
+int ta3n_num_params(const ta3n_plan *p) { return p ? (int)p->params.size() : TA3N_ERR_INVALID; }
+
+int ta3n_param_info(const ta3n_plan *p, int i, const char **name, int64_t *offset, int32_t *rows, int32_t *cols,
+                    int32_t *live) {
+    if (!p || i < 0 || i >= (int)p->params.size()) return fail(TA3N_ERR_INVALID, "param index out of range");
+    const ParamInfo &pi = p->params[i];
+    if (name) *name = pi.name.c_str();
+    if (offset) *offset = pi.off;
+    if (rows) *rows = pi.rows;
+    if (cols) *cols = pi.cols;
+    if (live) *live = pi.live ? 1 : 0;
+    return TA3N_OK;
+}
+
+int64_t ta3n_param_floats(const ta3n_plan *p) { return p ? p->param_floats : -1; }
+int64_t ta3n_live_param_floats(const ta3n_plan *p) { return p ? p->live_floats : -1; }
+int64_t ta3n_workspace_floats(const ta3n_plan *p) { return p ? p->ws_floats : -1; }
+
+int64_t ta3n_ws_offset(const ta3n_plan *p, const char *region) {
+    if (!p || !region) return -1;
+    return p->woff(region);
+}
+int64_t ta3n_ws_size(const ta3n_plan *p, const char *region) {
+    if (!p || !region) return -1;
+    for (const auto &r : p->regions)
+        if (r.name == region) return r.size;
+    return -1;
+}
+
+int64_t ta3n_plan_describe(const ta3n_plan *p, char *buf, int64_t cap) {
+    if (!p) return -1;
+    std::ostringstream o;
+    o << "{\"config\":{\"Bs\":" << p->geom.Bs << ",\"Bt\":" << p->geom.Bt << ",\"T\":" << p->geom.T << ",\"D\":" << p->geom.D
+      << ",\"F\":" << p->geom.F << ",\"NB\":" << p->geom.NB << ",\"C\":" << p->geom.C << ",\"flags\":" << p->geom.flags
+      << ",\"n_tuples\":" << p->n_tuples << "},\"param_floats\":" << p->param_floats << ",\"live_floats\":" << p->live_floats
+      << ",\"ws_floats\":" << p->ws_floats << ",\"regions\":{";
+    for (size_t i = 0; i < p->regions.size(); ++i)
+        o << (i ? "," : "") << "\"" << p->regions[i].name << "\":[" << p->regions[i].off << "," << p->regions[i].size << "]";
+    o << "},\"phases\":[";
+    for (size_t i = 0; i < p->phases.size(); ++i) {
+        const Phase &ph = p->phases[i];
+        o << (i ? "," : "") << "{\"kind\":" << ph.kind << ",\"group\":" << ph.group << ",\"task_begin\":" << ph.task_begin
+          << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk) << "}";
+    }
+    o << "],\"n_tasks\":" << p->tasks.size() << ",\"n_segs\":" << p->segs.size() << "}";
+    const std::string s = o.str();
+    if (buf && cap > 0) {
+        const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size());
+        std::memcpy(buf, s.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (int64_t)s.size();
+}
+
+// Raw descriptor arrays for the CPU plan interpreter in tests/ (host memory owned by the plan).
+int ta3n_debug_arrays(const ta3n_plan *p, const void **segs, int64_t *n_segs, const void **tasks, int64_t *n_tasks,
+                      const void **phases, int64_t *n_phases, const void **geom, const int32_t **tuples,
+                      const int32_t **tuple_first) {
+    if (!p) return fail(TA3N_ERR_INVALID, "null plan");
+    if (segs) *segs = p->segs.data();
+    if (n_segs) *n_segs = (int64_t)p->segs.size();
+    if (tasks) *tasks = p->tasks.data();
+    if (n_tasks) *n_tasks = (int64_t)p->tasks.size();
+    if (phases) *phases = p->phases.data();
+    if (n_phases) *n_phases = (int64_t)p->phases.size();
+    if (geom) *geom = &p->geom;
+    if (tuples) *tuples = p->tuples.data();
+    if (tuple_first) *tuple_first = p->tuple_first.data();
+    return TA3N_OK;
+}
+
+int ta3n_debug_struct_sizes(int32_t *seg, int32_t *task, int32_t *phase, int32_t *geom, int32_t *hyper) {
+    if (seg) *seg = (int32_t)sizeof(Seg);
+    if (task) *task = (int32_t)sizeof(Task);
+    if (phase) *phase = (int32_t)sizeof(Phase);
+    if (geom) *geom = (int32_t)sizeof(Geom);
+    if (hyper) *hyper = (int32_t)sizeof(Hyper);
+    return TA3N_OK;
+}
+
+int ta3n_num_phases(const ta3n_plan *p, int which) {
+    if (!p) return TA3N_ERR_INVALID;
+    int n = 0;
+    for (const Phase &ph : p->phases)
+        if (ph.group == which) ++n;
+    return n;
+}
+
+int ta3n_init_workspace(ta3n_plan *p, float *ws, void *stream) {
+    if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(ws)) return fail(TA3N_ERR_INVALID, "workspace must be 16-byte aligned");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)p->ws_floats * sizeof(float), s));
+    if (launch_fill(ws + p->geom.o_ones, 1.0f, (int64_t)p->geom.B * p->geom.T, s) != 0)
+        return fail(TA3N_ERR_HIP, "fill launch failed");
+    HIP_TRY(hipMemcpyAsync(ws + p->geom.o_tuple_first, p->tuple_first.data(), p->tuple_first.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // tuple_first is pageable host memory owned by the plan
+    return TA3N_OK;
+}
+
+int ta3n_set_hyper(ta3n_plan *p, float *ws, const ta3n_hyper *h, void *stream) {
+    if (!p || !ws || !h) return fail(TA3N_ERR_INVALID, "null argument");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    ta3n_hyper *slot = static_cast<ta3n_hyper *>(p->h_hyper) + p->hyper_slot;
+    p->hyper_slot = (p->hyper_slot + 1) % kHyperSlots;
+    *slot = *h;
+    HIP_TRY(hipMemcpyAsync(ws + p->geom.o_hyper, slot, sizeof(ta3n_hyper), hipMemcpyHostToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return TA3N_OK;
+}
+
+int ta3n_forward(ta3n_plan *p, const float *x, const float *params, float *ws, void *stream) {
+    if (!p || !x || !params || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(ws)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{x, params, nullptr, ws};
+    return run_group(p, 0, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ta3n_loss(ta3n_plan *p, float *ws, void *stream) {
+    if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{nullptr, nullptr, nullptr, ws};
+    return run_group(p, 1, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ta3n_backward(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream) {
+    if (!p || !x || !params || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{x, params, grads, ws};
+    return run_group(p, 2, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ta3n_sgd_step(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {
+    if (!p || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{nullptr, params, grads, ws};
+    return run_group(p, 3, ptrs, params, momentum, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

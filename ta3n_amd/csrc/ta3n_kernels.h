@@ -1,0 +1,58 @@
+// Device-side helpers and launcher declarations shared by the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ta3n_types.h"
+
+namespace ta3n {
+
+struct Ptrs {
+    const float *x;   // BASE_X  input features [B*T, D]
+    const float *p;   // BASE_P  flat parameters
+    float *g;         // BASE_G  flat gradients
+    float *ws;        // BASE_WS workspace
+};
+
+__device__ __forceinline__ float hyper_scale(const Hyper *__restrict__ hy, int kind) {
+    switch (kind) {
+        case SK_NEG_BETA_REL: return -hy->beta[0];
+        case SK_NEG_BETA_VID: return -hy->beta[1];
+        case SK_NEG_BETA_FRM: return -hy->beta[2];
+        case SK_INV_KEEP_I: return (hy->train && hy->p_drop_i > 0.f) ? (hy->p_drop_i < 1.f ? 1.f / (1.f - hy->p_drop_i) : 0.f) : 1.f;
+        case SK_INV_KEEP_V: return (hy->train && hy->p_drop_v > 0.f) ? (hy->p_drop_v < 1.f ? 1.f / (1.f - hy->p_drop_v) : 0.f) : 1.f;
+        default: return 1.f;
+    }
+}
+
+// Stateless dropout stream: keep(seed, element) is recomputed in the backward
+// pass instead of storing a mask (nn.Dropout, reference models.py:131-132,
+// 574-575, 679-680; bit-matching torch's Philox/MT streams is not possible nor
+// required - SURVEY.md 7 "Dropout").
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float keep_mask(uint32_t seed, uint32_t idx, float p) {
+    const uint32_t h = mix32(mix32(idx + 0x9E3779B9U * (seed | 1u)) ^ seed);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);   // [0,1)
+    return u >= p ? 1.f : 0.f;
+}
+
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
+                hipStream_t stream);
+int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t stream);
+int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream);
+int launch_fill(float *dst, float value, int64_t n, hipStream_t stream);
+
+}  // namespace ta3n

@@ -1,0 +1,493 @@
+// Plan builder: turns a ta3n_config into parameter/workspace layouts and the
+// per-launch GEMM tile lists.  Pure host code (no HIP calls) so that the CPU
+// test-suite can validate the whole wiring against the oracle.
+//
+// Math being wired (reference file:line in SURVEY.md Appendix A):
+//   F1 = drop_i(relu(X Wsh^T + bsh))                           models.py:565-575
+//   Pf = Wcd relu(Wfd GRL(F1) + bfd) + bcd                     models.py:456-462
+//   Z_t = relu(W_j concat_{f in tau_t} F1[:,f] + b_j)          TRNmodule.py:58-82
+//   R_j = sum_{t in scale j} Z_t
+//   Pr_j = W2_j relu(W1_j GRL(R_j) + b1_j) + b2_j              models.py:472-488
+//   w = 1 - H(softmax Pr);  V = sum_j (1+w_j) R_j;  Vd = drop_v(V)   models.py:351-357, 379-388, 651, 679
+//   Y = Wcv Vd + bcv;  Pv = Wcdv relu(Wdv GRL(Vd) + bdv) + bcdv      models.py:686, 464-470
+#include "ta3n_plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+using namespace ta3n;
+
+int64_t ta3n_plan::poff(const std::string &name) const {
+    for (const auto &p : params)
+        if (p.name == name) return p.off;
+    return -1;
+}
+int64_t ta3n_plan::woff(const std::string &name) const {
+    for (const auto &r : regions)
+        if (r.name == name) return r.off;
+    return -1;
+}
+
+namespace {
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Ref {  // operand reference
+    int32_t base, off, ld, kmajor;
+};
+Ref KC(int32_t base, int64_t off, int32_t ld) { return Ref{base, (int32_t)off, ld, 0}; }  // element (r,k) at off + r*ld + k
+Ref KM(int32_t base, int64_t off, int32_t ld) { return Ref{base, (int32_t)off, ld, 1}; }  // element (r,k) at off + k*ld + r
+
+Seg mkseg(Ref a, Ref b, int klen, int scale_kind = SK_ONE) {
+    Seg s;
+    std::memset(&s, 0, sizeof(s));
+    s.a_base = a.base; s.a_off = a.off; s.a_ld = a.ld; s.a_kmajor = a.kmajor;
+    s.b_base = b.base; s.b_off = b.off; s.b_ld = b.ld; s.b_kmajor = b.kmajor;
+    s.klen = klen;
+    s.scale_kind = scale_kind;
+    return s;
+}
+
+struct GemmSpec {
+    int M, N;
+    std::vector<Seg> segs;
+    Task proto;   // epilogue fields; m0/n0/seg range filled on expansion
+};
+
+Task proto(int32_t c_base, int64_t c_off, int32_t c_ld) {
+    Task t;
+    std::memset(&t, 0, sizeof(t));
+    t.c_base = c_base; t.c_off = (int32_t)c_off; t.c_ld = c_ld;
+    t.bias_base = BASE_NONE; t.aux_base = BASE_NONE; t.add_base = BASE_NONE;
+    t.alpha_kind = SK_ONE; t.gamma_kind = SK_ONE;
+    return t;
+}
+void with_bias(Task &t, int64_t off) { t.epi |= EPI_BIAS; t.bias_base = BASE_P; t.bias_off = (int32_t)off; }
+void with_mask(Task &t, int64_t off, int32_t ld) { t.epi |= EPI_MASK; t.aux_base = BASE_WS; t.aux_off = (int32_t)off; t.aux_ld = ld; }
+void with_add(Task &t, int64_t off, int32_t ld) { t.epi |= EPI_ADD; t.add_base = BASE_WS; t.add_off = (int32_t)off; t.add_ld = ld; }
+
+struct Builder {
+    ta3n_plan &p;
+    explicit Builder(ta3n_plan &pl) : p(pl) {}
+
+    void add_param(const std::string &name, int rows, int cols, bool live) {
+        ParamInfo pi;
+        pi.name = name; pi.rows = rows; pi.cols = cols; pi.live = live;
+        pi.off = p.param_floats;
+        p.params.push_back(pi);
+        p.param_floats = align_up(p.param_floats + (int64_t)rows * (cols ? cols : 1), 4);
+    }
+    void add_linear(const std::string &name, int out, int in, bool live) {
+        add_param(name + ".weight", out, in, live);
+        add_param(name + ".bias", out, 0, live);
+    }
+    int64_t add_region(const std::string &name, int64_t size) {
+        Region r;
+        r.name = name; r.off = p.ws_floats; r.size = size;
+        p.regions.push_back(r);
+        p.ws_floats = align_up(p.ws_floats + size, 64);
+        return r.off;
+    }
+
+    // expand GEMM specs into tile tasks of one phase
+    void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
+        int wm = 1, wn = 1, wk = 4;
+        if (p.cfg.tile_config != 0) {
+            wm = p.cfg.tile_config / 100; wn = (p.cfg.tile_config / 10) % 10; wk = p.cfg.tile_config % 10;
+        } else {
+            // heuristic: largest tile that still yields >= ~1.5 waves of 256 CUs worth of blocks
+            auto count = [&](int bm, int bn) {
+                int64_t n = 0;
+                for (auto &g : specs) n += (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+                return n;
+            };
+            if (count(64, 64) >= 384) { wm = 2; wn = 2; wk = 1; }
+            else if (count(64, 32) >= 384) { wm = 2; wn = 1; wk = 2; }
+            else { wm = 1; wn = 1; wk = 4; }
+        }
+        const int BM = 32 * wm, BN = 32 * wn;
+        Phase ph;
+        std::memset(&ph, 0, sizeof(ph));
+        ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk;
+        ph.task_begin = (int32_t)p.tasks.size();
+        std::vector<Task> local;
+        for (auto &g : specs) {
+            const int seg_begin = (int)p.segs.size();
+            int cost = 0;
+            for (auto &s : g.segs) { p.segs.push_back(s); cost += (s.klen + 63) / 64 * 64; }
+            for (int m0 = 0; m0 < g.M; m0 += BM)
+                for (int n0 = 0; n0 < g.N; n0 += BN) {
+                    Task t = g.proto;
+                    t.m0 = m0; t.n0 = n0; t.m_valid = g.M; t.n_valid = g.N;
+                    t.seg_begin = seg_begin; t.seg_count = (int)g.segs.size();
+                    t.cost = cost;
+                    local.push_back(t);
+                }
+        }
+        // longest tasks first (blocks are dispatched in order); stable to keep panel locality
+        std::stable_sort(local.begin(), local.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+        for (auto &t : local) p.tasks.push_back(t);
+        ph.task_count = (int32_t)local.size();
+        p.phases.push_back(ph);
+    }
+    void add_simple_phase(int kind, int group) {
+        Phase ph;
+        std::memset(&ph, 0, sizeof(ph));
+        ph.kind = kind; ph.group = group;
+        p.phases.push_back(ph);
+    }
+};
+
+}  // namespace
+
+int ta3n::build_plan(ta3n_plan &p, std::string &err) {
+    const ta3n_config &c = p.cfg;
+    const int Bs = c.batch_source, Bt = c.batch_target, T = c.num_segments, D = c.feature_dim;
+    const int F = std::min(c.fc_dim, c.feature_dim);   // models.py:129
+    const int NB = c.num_bottleneck, C = c.num_class;
+    if (Bs < 0 || Bt < 0 || Bs + Bt <= 0) { err = "batch sizes must be non-negative and not both zero"; return TA3N_ERR_INVALID; }
+    if (T < 2 || T > 64) { err = "num_segments must be in [2,64] for trn-m"; return TA3N_ERR_INVALID; }
+    if (D <= 0 || F <= 0 || C <= 0) { err = "feature_dim, fc_dim and num_class must be positive"; return TA3N_ERR_INVALID; }
+    if (NB <= 0 || NB % 64 != 0 || NB > 1024) { err = "num_bottleneck must be a multiple of 64 (<= 1024)"; return TA3N_ERR_INVALID; }
+    if (C > 64) { err = "num_class > 64 not supported by the loss kernel"; return TA3N_ERR_INVALID; }
+    if ((c.flags & TA3N_FLAG_ATTN_ENTROPY) &&
+        !((c.flags & TA3N_FLAG_ADV_RELATION) && (c.flags & TA3N_FLAG_ADV_VIDEO))) {
+        // main.py:559-562 indexes pred_domain_all[1]; that is the video entry only when
+        // place_adv[0] and place_adv[1] are both 'Y' (otherwise the reference fails on a shape mismatch)
+        err = "attentive_entropy requires place_adv[0]=='Y' and place_adv[1]=='Y'";
+        return TA3N_ERR_INVALID;
+    }
+    if (c.tile_config != 0) {
+        int wm = c.tile_config / 100, wn = (c.tile_config / 10) % 10, wk = c.tile_config % 10;
+        if (wm * wn * wk != 4 || !(c.tile_config == 114 || c.tile_config == 212 || c.tile_config == 122 || c.tile_config == 221)) {
+            err = "tile_config must be one of 0, 114, 212, 122, 221";
+            return TA3N_ERR_INVALID;
+        }
+    }
+    const int B = Bs + Bt, BT = B * T, NR = T - 1;
+    if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+
+    // ---- relation tuples ----
+    p.n_tuples = ta3n_num_relation_tuples(T);
+    p.tuples.assign((size_t)p.n_tuples * T, -1);
+    p.scale_len.assign(p.n_tuples, 0);
+    p.scale_id.assign(p.n_tuples, 0);
+    ta3n_relation_table(T, p.tuples.data(), p.scale_len.data(), p.scale_id.data());
+    const int NT = p.n_tuples;
+    p.tuple_first.assign(NR + 1, 0);
+    for (int t = 0; t < NT; ++t) p.tuple_first[p.scale_id[t] + 1] = t + 1;
+    for (int j = 1; j <= NR; ++j) p.tuple_first[j] = std::max(p.tuple_first[j], p.tuple_first[j - 1]);
+
+    Builder b(p);
+    // ---- parameters: live first (they form the all-reduce / optimiser operand) ----
+    b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141
+    b.add_linear("fc_feature_domain", F, F, true);                     // :161
+    b.add_linear("fc_classifier_domain", 2, F, true);                  // :170
+    for (int j = 0; j < NR; ++j)                                       // TRNmodule.py:44-54
+        b.add_linear("TRN.fc_fusion_scales." + std::to_string(j) + ".1", NB, (T - j) * F, true);
+    for (int j = 0; j < NR; ++j) {                                     // models.py:286-294
+        b.add_linear("relation_domain_classifier_all." + std::to_string(j) + ".0", NB, NB, true);
+        b.add_linear("relation_domain_classifier_all." + std::to_string(j) + ".2", 2, NB, true);
+    }
+    b.add_linear("fc_feature_domain_video", NB, NB, true);             // :267
+    b.add_linear("fc_classifier_video_source", C, NB, true);           // :272
+    b.add_linear("fc_classifier_domain_video", 2, NB, true);           // :281
+    p.live_floats = p.param_floats;
+    // never receive a gradient in this configuration: kept for state_dict compatibility
+    b.add_linear("fc_feature_source", F, F, false);                    // :156
+    b.add_linear("fc_classifier_source", C, F, false);                 // :166 (dead for baseline_type 'video')
+    b.add_param("bn_trn_S.weight", NB, 0, false); b.add_param("bn_trn_S.bias", NB, 0, false);   // :225-226
+    b.add_param("bn_trn_T.weight", NB, 0, false); b.add_param("bn_trn_T.bias", NB, 0, false);
+    b.add_linear("fc_feature_video_source", NB, NB, false);            // :258
+    b.add_linear("fc_feature_video_source_2", NB, NB, false);          // :262
+
+    auto P = [&](const std::string &n) { return p.poff(n); };
+    auto trnW = [&](int j) { return P("TRN.fc_fusion_scales." + std::to_string(j) + ".1.weight"); };
+    auto trnB = [&](int j) { return P("TRN.fc_fusion_scales." + std::to_string(j) + ".1.bias"); };
+    auto W1 = [&](int j) { return P("relation_domain_classifier_all." + std::to_string(j) + ".0.weight"); };
+    auto B1 = [&](int j) { return P("relation_domain_classifier_all." + std::to_string(j) + ".0.bias"); };
+    auto W2 = [&](int j) { return P("relation_domain_classifier_all." + std::to_string(j) + ".2.weight"); };
+    auto B2 = [&](int j) { return P("relation_domain_classifier_all." + std::to_string(j) + ".2.bias"); };
+    const int64_t Wsh = P("fc_feature_shared_source.weight"), bsh = P("fc_feature_shared_source.bias");
+    const int64_t Wfd = P("fc_feature_domain.weight"), bfd = P("fc_feature_domain.bias");
+    const int64_t Wcd = P("fc_classifier_domain.weight"), bcd = P("fc_classifier_domain.bias");
+    const int64_t Wdv = P("fc_feature_domain_video.weight"), bdv = P("fc_feature_domain_video.bias");
+    const int64_t Wcv = P("fc_classifier_video_source.weight"), bcv = P("fc_classifier_video_source.bias");
+    const int64_t Wcdv = P("fc_classifier_domain_video.weight"), bcdv = P("fc_classifier_domain_video.bias");
+
+    // ---- workspace ----
+    Geom &g = p.geom;
+    std::memset(&g, 0, sizeof(g));
+    g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = NB; g.C = C;
+    g.n_tuples = NT; g.n_rel = NR; g.flags = c.flags;
+    g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
+    g.o_Hf = (int32_t)b.add_region("Hf", (int64_t)BT * F);
+    g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
+    g.o_Zr = (int32_t)b.add_region("Zr", (int64_t)B * NT * NB);
+    g.o_Hr = (int32_t)b.add_region("Hr", (int64_t)B * NR * NB);
+    g.o_Pr = (int32_t)b.add_region("Pr", (int64_t)B * NR * 2);
+    g.o_R = (int32_t)b.add_region("R", (int64_t)B * NR * NB);
+    g.o_attn = (int32_t)b.add_region("attn", (int64_t)B * NR);
+    g.o_V = (int32_t)b.add_region("V", (int64_t)B * NB);
+    g.o_Vd = (int32_t)b.add_region("Vd", (int64_t)B * NB);
+    g.o_Y = (int32_t)b.add_region("Y", (int64_t)B * C);
+    g.o_Hv = (int32_t)b.add_region("Hv", (int64_t)B * NB);
+    g.o_Pv = (int32_t)b.add_region("Pv", (int64_t)B * 2);
+    g.o_gY = (int32_t)b.add_region("gY", (int64_t)B * C);
+    g.o_gPv = (int32_t)b.add_region("gPv", (int64_t)B * 2);
+    g.o_gPr = (int32_t)b.add_region("gPr", (int64_t)B * NR * 2);
+    g.o_gPf = (int32_t)b.add_region("gPf", (int64_t)BT * 2);
+    g.o_gattn = (int32_t)b.add_region("g_attn", (int64_t)B * NR);
+    g.o_gHv = (int32_t)b.add_region("gHv", (int64_t)B * NB);
+    g.o_gHf = (int32_t)b.add_region("gHf", (int64_t)BT * F);
+    g.o_gVt = (int32_t)b.add_region("gVt", (int64_t)B * NB);
+    g.o_gPrT = (int32_t)b.add_region("gPrT", (int64_t)B * NR * 2);
+    g.o_gRa = (int32_t)b.add_region("gRa", (int64_t)B * NR * NB);
+    g.o_gHr = (int32_t)b.add_region("gHr", (int64_t)B * NR * NB);
+    g.o_gR = (int32_t)b.add_region("gR", (int64_t)B * NR * NB);
+    g.o_gZ = (int32_t)b.add_region("gZ", (int64_t)B * NT * NB);
+    g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
+    g.o_ones = (int32_t)b.add_region("ones", BT);
+    g.o_losses = (int32_t)b.add_region("losses", 8);
+    g.n_norm_blocks = 256;
+    g.o_norm_part = (int32_t)b.add_region("norm_part", g.n_norm_blocks);
+    g.o_grad_norm = (int32_t)b.add_region("grad_norm", 4);
+    g.o_hyper = (int32_t)b.add_region("hyper", 32);
+    g.o_labels = (int32_t)b.add_region("labels", B);
+    g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
+    g.live_floats = (int32_t)p.live_floats;
+    g.p_W2_0 = (int32_t)W2(0); g.p_b2_0 = (int32_t)B2(0);
+    g.p_W2_stride = NR > 1 ? (int32_t)(W2(1) - W2(0)) : 0;
+    g.p_b2_stride = NR > 1 ? (int32_t)(B2(1) - B2(0)) : 0;
+    if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+
+    const int ldZ = NT * NB, ldR = NR * NB, ldF = T * F;
+    auto tau = [&](int t, int pos) { return p.tuples[(size_t)t * T + pos]; };
+
+    // ================= forward =================
+    {   // F1: shared frame FC + ReLU + dropout_i (models.py:565-575)
+        std::vector<GemmSpec> s(1);
+        s[0].M = BT; s[0].N = F;
+        s[0].segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        s[0].proto = proto(BASE_WS, g.o_F1, F);
+        with_bias(s[0].proto, bsh);
+        s[0].proto.epi |= EPI_RELU | EPI_DROP_I;
+        s[0].proto.gamma_kind = SK_INV_KEEP_I;
+        s[0].proto.drop_ld = F;
+        b.add_gemm_phase(0, s);
+    }
+    {   // F2: frame-discriminator hidden layer (models.py:458-459) + TRN tuple GEMMs (TRNmodule.py:60-79)
+        std::vector<GemmSpec> s;
+        GemmSpec hf;
+        hf.M = BT; hf.N = F;
+        hf.segs.push_back(mkseg(KC(BASE_WS, g.o_F1, F), KC(BASE_P, Wfd, F), F));
+        hf.proto = proto(BASE_WS, g.o_Hf, F);
+        with_bias(hf.proto, bfd); hf.proto.epi |= EPI_RELU;
+        s.push_back(hf);
+        for (int t = 0; t < NT; ++t) {
+            const int j = p.scale_id[t], sl = p.scale_len[t];
+            GemmSpec z;
+            z.M = B; z.N = NB;
+            for (int pos = 0; pos < sl; ++pos)   // gather+concat folded into the A-operand addressing
+                z.segs.push_back(mkseg(KC(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF),
+                                       KC(BASE_P, trnW(j) + (int64_t)pos * F, sl * F), F));
+            z.proto = proto(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ);
+            with_bias(z.proto, trnB(j)); z.proto.epi |= EPI_RELU;
+            s.push_back(z);
+        }
+        b.add_gemm_phase(0, s);
+    }
+    {   // F3: relation-discriminator hidden layers on R_j = sum_t Z_t (models.py:475-479) + frame logits (:460)
+        std::vector<GemmSpec> s;
+        for (int j = 0; j < NR; ++j) {
+            GemmSpec h;
+            h.M = B; h.N = NB;
+            for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
+                h.segs.push_back(mkseg(KC(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ), KC(BASE_P, W1(j), NB), NB));
+            h.proto = proto(BASE_WS, g.o_Hr + (int64_t)j * NB, ldR);
+            with_bias(h.proto, B1(j)); h.proto.epi |= EPI_RELU;
+            s.push_back(h);
+        }
+        GemmSpec pf;
+        pf.M = BT; pf.N = 2;
+        pf.segs.push_back(mkseg(KC(BASE_WS, g.o_Hf, F), KC(BASE_P, Wcd, F), F));
+        pf.proto = proto(BASE_WS, g.o_Pf, 2);
+        with_bias(pf.proto, bcd);
+        s.push_back(pf);
+        b.add_gemm_phase(0, s);
+    }
+    b.add_simple_phase(PH_POOL_FWD, 0);   // Pr, attention weights, R, V, Vd
+    {   // F6: video classifier (models.py:686) + video-discriminator hidden layer (:466-467)
+        std::vector<GemmSpec> s(2);
+        s[0].M = B; s[0].N = C;
+        s[0].segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wcv, NB), NB));
+        s[0].proto = proto(BASE_WS, g.o_Y, C);
+        with_bias(s[0].proto, bcv);
+        s[1].M = B; s[1].N = NB;
+        s[1].segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wdv, NB), NB));
+        s[1].proto = proto(BASE_WS, g.o_Hv, NB);
+        with_bias(s[1].proto, bdv); s[1].proto.epi |= EPI_RELU;
+        b.add_gemm_phase(0, s);
+    }
+    {   // F7: video domain logits (models.py:468)
+        std::vector<GemmSpec> s(1);
+        s[0].M = B; s[0].N = 2;
+        s[0].segs.push_back(mkseg(KC(BASE_WS, g.o_Hv, NB), KC(BASE_P, Wcdv, NB), NB));
+        s[0].proto = proto(BASE_WS, g.o_Pv, 2);
+        with_bias(s[0].proto, bcdv);
+        b.add_gemm_phase(0, s);
+    }
+    // ================= loss =================
+    b.add_simple_phase(PH_LOSS, 1);
+    // ================= backward =================
+    auto ones_bias_grad = [&](int64_t gsrc_off, int gsrc_ld, int n, int klen, int64_t dst) {
+        GemmSpec gb;   // column sums as ones^T * G
+        gb.M = 1; gb.N = n;
+        gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 1), KM(BASE_WS, gsrc_off, gsrc_ld), klen));
+        gb.proto = proto(BASE_G, dst, n);
+        return gb;
+    };
+    {   // Q1: heads that depend only on the logit gradients
+        std::vector<GemmSpec> s;
+        GemmSpec ghv;   // gHv = (gPv Wcdv) * [Hv>0]
+        ghv.M = B; ghv.N = NB;
+        ghv.segs.push_back(mkseg(KC(BASE_WS, g.o_gPv, 2), KM(BASE_P, Wcdv, NB), 2));
+        ghv.proto = proto(BASE_WS, g.o_gHv, NB);
+        with_mask(ghv.proto, g.o_Hv, NB);
+        s.push_back(ghv);
+        GemmSpec ghf;   // gHf = (gPf Wcd) * [Hf>0]
+        ghf.M = BT; ghf.N = F;
+        ghf.segs.push_back(mkseg(KC(BASE_WS, g.o_gPf, 2), KM(BASE_P, Wcd, F), 2));
+        ghf.proto = proto(BASE_WS, g.o_gHf, F);
+        with_mask(ghf.proto, g.o_Hf, F);
+        s.push_back(ghf);
+        GemmSpec gwcdv;   // dWcdv = gPv^T Hv
+        gwcdv.M = 2; gwcdv.N = NB;
+        gwcdv.segs.push_back(mkseg(KM(BASE_WS, g.o_gPv, 2), KM(BASE_WS, g.o_Hv, NB), B));
+        gwcdv.proto = proto(BASE_G, Wcdv, NB);
+        s.push_back(gwcdv);
+        s.push_back(ones_bias_grad(g.o_gPv, 2, 2, B, bcdv));
+        GemmSpec gwcv;   // dWcv = gY^T Vd
+        gwcv.M = C; gwcv.N = NB;
+        gwcv.segs.push_back(mkseg(KM(BASE_WS, g.o_gY, C), KM(BASE_WS, g.o_Vd, NB), B));
+        gwcv.proto = proto(BASE_G, Wcv, NB);
+        s.push_back(gwcv);
+        s.push_back(ones_bias_grad(g.o_gY, C, C, B, bcv));
+        GemmSpec gwcd;   // dWcd = gPf^T Hf
+        gwcd.M = 2; gwcd.N = F;
+        gwcd.segs.push_back(mkseg(KM(BASE_WS, g.o_gPf, 2), KM(BASE_WS, g.o_Hf, F), BT));
+        gwcd.proto = proto(BASE_G, Wcd, F);
+        s.push_back(gwcd);
+        s.push_back(ones_bias_grad(g.o_gPf, 2, 2, BT, bcd));
+        b.add_gemm_phase(2, s);
+    }
+    {   // Q2: gradient at the pooled video feature + first-layer weight grads of the video/frame discriminators
+        std::vector<GemmSpec> s;
+        GemmSpec gv;   // gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv )
+        gv.M = B; gv.N = NB;
+        gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gHv, NB), KM(BASE_P, Wdv, NB), NB, SK_NEG_BETA_VID));
+        gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY, C), KM(BASE_P, Wcv, NB), C));
+        gv.proto = proto(BASE_WS, g.o_gVt, NB);
+        gv.proto.epi |= EPI_DROP_V; gv.proto.gamma_kind = SK_INV_KEEP_V; gv.proto.drop_ld = NB;
+        s.push_back(gv);
+        GemmSpec gwdv;   // dWdv = gHv^T Vd
+        gwdv.M = NB; gwdv.N = NB;
+        gwdv.segs.push_back(mkseg(KM(BASE_WS, g.o_gHv, NB), KM(BASE_WS, g.o_Vd, NB), B));
+        gwdv.proto = proto(BASE_G, Wdv, NB);
+        s.push_back(gwdv);
+        s.push_back(ones_bias_grad(g.o_gHv, NB, NB, B, bdv));
+        GemmSpec gwfd;   // dWfd = gHf^T F1
+        gwfd.M = F; gwfd.N = F;
+        gwfd.segs.push_back(mkseg(KM(BASE_WS, g.o_gHf, F), KM(BASE_WS, g.o_F1, F), BT));
+        gwfd.proto = proto(BASE_G, Wfd, F);
+        s.push_back(gwfd);
+        s.push_back(ones_bias_grad(g.o_gHf, F, F, BT, bfd));
+        b.add_gemm_phase(2, s);
+    }
+    b.add_simple_phase(PH_POOL_BWD, 2);   // gPrT (attention path), gRa = (1+w) gVt, gHr
+    {   // Q5: gR_j = gRa_j - beta0 * gHr_j W1_j, fanned out through the TRN ReLU masks; relation-disc weight grads
+        std::vector<GemmSpec> s;
+        for (int j = 0; j < NR; ++j) {
+            GemmSpec gr;
+            gr.M = B; gr.N = NB;
+            gr.segs.push_back(mkseg(KC(BASE_WS, g.o_gHr + (int64_t)j * NB, ldR), KM(BASE_P, W1(j), NB), NB));
+            gr.proto = proto(BASE_WS, g.o_gR + (int64_t)j * NB, ldR);
+            gr.proto.alpha_kind = SK_NEG_BETA_REL;
+            with_add(gr.proto, g.o_gRa + (int64_t)j * NB, ldR);
+            const int nt = p.tuple_first[j + 1] - p.tuple_first[j];
+            gr.proto.fan_count = nt; gr.proto.fan_ld = ldZ;
+            for (int k = 0; k < nt; ++k) {
+                const int t = p.tuple_first[j] + k;
+                gr.proto.fan_mask_off[k] = g.o_Zr + t * NB;
+                gr.proto.fan_out_off[k] = g.o_gZ + t * NB;
+            }
+            s.push_back(gr);
+            GemmSpec gw1;   // dW1_j = gHr_j^T R_j
+            gw1.M = NB; gw1.N = NB;
+            gw1.segs.push_back(mkseg(KM(BASE_WS, g.o_gHr + (int64_t)j * NB, ldR), KM(BASE_WS, g.o_R + (int64_t)j * NB, ldR), B));
+            gw1.proto = proto(BASE_G, W1(j), NB);
+            s.push_back(gw1);
+            s.push_back(ones_bias_grad(g.o_gHr + (int64_t)j * NB, ldR, NB, B, B1(j)));
+            GemmSpec gw2;   // dW2_j = gPrT_j^T Hr_j
+            gw2.M = 2; gw2.N = NB;
+            gw2.segs.push_back(mkseg(KM(BASE_WS, g.o_gPrT + (int64_t)j * 2, NR * 2), KM(BASE_WS, g.o_Hr + (int64_t)j * NB, ldR), B));
+            gw2.proto = proto(BASE_G, W2(j), NB);
+            s.push_back(gw2);
+            s.push_back(ones_bias_grad(g.o_gPrT + (int64_t)j * 2, NR * 2, 2, B, B2(j)));
+        }
+        b.add_gemm_phase(2, s);
+    }
+    {   // Q6: TRN weight grads + gradient at F1 (TRN dgrad per frame, frame-disc dgrad with GRL folded in)
+        std::vector<GemmSpec> s;
+        for (int j = 0; j < NR; ++j) {
+            const int sl = T - j;
+            for (int pos = 0; pos < sl; ++pos) {   // dW_j[:, pos*F:(pos+1)*F] = sum_t gZ_t^T F1[:, tau_t[pos]]
+                GemmSpec gw;
+                gw.M = NB; gw.N = F;
+                for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
+                    gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ),
+                                            KM(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF), B));
+                gw.proto = proto(BASE_G, trnW(j) + (int64_t)pos * F, sl * F);
+                s.push_back(gw);
+            }
+            GemmSpec gb;
+            gb.M = 1; gb.N = NB;
+            for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
+                gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 1), KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ), B));
+            gb.proto = proto(BASE_G, trnB(j), NB);
+            s.push_back(gb);
+        }
+        for (int f = 0; f < T; ++f) {   // gZ1[:, f] = ( -beta2 gHf[:, f] Wfd + sum_{(t,pos): tau_t[pos]==f} gZ_t W_j[:, pos] ) * [F1>0] / keep
+            GemmSpec gz;
+            gz.M = B; gz.N = F;
+            gz.segs.push_back(mkseg(KC(BASE_WS, g.o_gHf + (int64_t)f * F, ldF), KM(BASE_P, Wfd, F), F, SK_NEG_BETA_FRM));
+            for (int t = 0; t < NT; ++t) {
+                const int j = p.scale_id[t], sl = p.scale_len[t];
+                for (int pos = 0; pos < sl; ++pos)
+                    if (tau(t, pos) == f)
+                        gz.segs.push_back(mkseg(KC(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ),
+                                                KM(BASE_P, trnW(j) + (int64_t)pos * F, sl * F), NB));
+            }
+            gz.proto = proto(BASE_WS, g.o_gZ1 + (int64_t)f * F, ldF);
+            with_mask(gz.proto, g.o_F1 + (int64_t)f * F, ldF);
+            gz.proto.gamma_kind = SK_INV_KEEP_I;
+            s.push_back(gz);
+        }
+        b.add_gemm_phase(2, s);
+    }
+    {   // Q7: shared frame FC weight grad (no input gradient: the features are data)
+        std::vector<GemmSpec> s;
+        GemmSpec gw;
+        gw.M = F; gw.N = D;
+        gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ1, F), KM(BASE_X, 0, D), BT));
+        gw.proto = proto(BASE_G, Wsh, D);
+        s.push_back(gw);
+        s.push_back(ones_bias_grad(g.o_gZ1, F, F, BT, bsh));
+        b.add_gemm_phase(2, s);
+    }
+    // ================= optimiser =================
+    b.add_simple_phase(PH_GRAD_NORM, 3);
+    b.add_simple_phase(PH_SGD, 3);
+    return TA3N_OK;
+}

@@ -1,0 +1,349 @@
+// Non-GEMM kernels of the TA3N train step (gfx950, wave64).
+//
+//  pool_fwd   one wavefront per video: relation-discriminator logits (the 2-wide
+//             second layer, reference models.py:479), transferable attention
+//             w = 1 - H(softmax) (models.py:351-357), R_j = sum of the scale's
+//             tuple activations (TRNmodule.py:73-79), V = sum_j (1+w_j) R_j
+//             (models.py:379-388, 651), dropout_v (models.py:679).
+//  loss       CE + 3 adversarial CE + attentive entropy and all logit gradients
+//             (main.py:439-451, 508-538, 559-562; loss.py:15-25).
+//  pool_bwd   backward of pool_fwd including the un-detached attention path.
+//  grad_norm / sgd   clip_grad_norm_ + Nesterov SGD with weight decay over the
+//             flat live-parameter prefix (main.py:578-583).
+#include <hip/hip_runtime.h>
+
+#include "ta3n_kernels.h"
+#include "../../include/ta3n_hip.h"
+
+using namespace ta3n;
+
+namespace {
+
+struct Soft2 {
+    float p0, p1, lp0, lp1, H;
+};
+// softmax / log_softmax / entropy of a 2-vector, same formulas as torch
+// (x - max, exp, sum; log_softmax = x - max - log(sum)).
+__device__ __forceinline__ Soft2 soft2(float z0, float z1) {
+    Soft2 s;
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    const float sum = e0 + e1;
+    s.p0 = e0 / sum; s.p1 = e1 / sum;
+    const float ls = logf(sum);
+    s.lp0 = z0 - m - ls; s.lp1 = z1 - m - ls;
+    s.H = -(s.p0 * s.lp0 + s.p1 * s.lp1);
+    return s;
+}
+
+template <int Q>   // Q = NB / 64 channels per lane
+__global__ __launch_bounds__(256) void pool_fwd_kernel(Geom g, Ptrs ptrs) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= g.B) return;
+    float *__restrict__ ws = ptrs.ws;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int *__restrict__ tf = reinterpret_cast<const int *>(ws + g.o_tuple_first);
+    const int NB = g.NB, NR = g.n_rel, NT = g.n_tuples;
+    const bool attn_on = (g.flags & TA3N_FLAG_TRANS_ATTN) != 0;
+    float vacc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) vacc[q] = 0.f;
+    for (int j = 0; j < NR; ++j) {
+        const float *__restrict__ W2 = ptrs.p + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+        const float *__restrict__ b2 = ptrs.p + g.p_b2_0 + (size_t)j * g.p_b2_stride;
+        const float *__restrict__ hr = ws + g.o_Hr + ((size_t)b * NR + j) * NB;
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = q * 64 + lane;
+            const float h = hr[c];
+            d0 = fmaf(h, W2[c], d0);
+            d1 = fmaf(h, W2[NB + c], d1);
+        }
+        d0 = wave_allreduce_sum(d0) + b2[0];
+        d1 = wave_allreduce_sum(d1) + b2[1];
+        float w = 0.f;
+        if (attn_on) w = 1.f - soft2(d0, d1).H;
+        float r0 = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = q * 64 + lane;
+            float r = 0.f;
+            for (int t = tf[j]; t < tf[j + 1]; ++t) r += ws[g.o_Zr + ((size_t)b * NT + t) * NB + c];
+            ws[g.o_R + ((size_t)b * NR + j) * NB + c] = r;
+            vacc[q] += attn_on ? (w + 1.f) * r : r;
+            if (q == 0) r0 = r;
+        }
+        if (lane == 0) {
+            ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 0] = d0;
+            ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 1] = d1;
+            ws[g.o_attn + (size_t)b * NR + j] = attn_on ? w : r0;   // models.py:647-648 returns feat[:,:,0] without attention
+        }
+    }
+    const float inv_keep = hyper_scale(hy, SK_INV_KEEP_V);
+    const bool drop = hy->train != 0 && hy->p_drop_v > 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c = q * 64 + lane;
+        const float v = vacc[q];
+        ws[g.o_V + (size_t)b * NB + c] = v;
+        float vd = v;
+        if (drop) vd = v * keep_mask(hy->seed_v, (uint32_t)(b * NB + c), hy->p_drop_v) * inv_keep;
+        ws[g.o_Vd + (size_t)b * NB + c] = vd;
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(Geom g, Ptrs ptrs) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= g.B) return;
+    float *__restrict__ ws = ptrs.ws;
+    const int NB = g.NB, NR = g.n_rel;
+    const bool attn_on = (g.flags & TA3N_FLAG_TRANS_ATTN) != 0;
+    float gv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gv[q] = ws[g.o_gVt + (size_t)b * NB + q * 64 + lane];
+    for (int j = 0; j < NR; ++j) {
+        const size_t bj = (size_t)b * NR + j;
+        const float *__restrict__ W2 = ptrs.p + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+        float g0 = ws[g.o_gPr + bj * 2 + 0], g1 = ws[g.o_gPr + bj * 2 + 1];
+        float w1 = 1.f;
+        if (attn_on) {
+            // dL/dw_j = <R_j, dL/dV> (+ upstream gradient on the attention output);
+            // dw/dz_i = p_i (log p_i + H)   (the weights are not detached, models.py:351-357)
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) dot = fmaf(ws[g.o_R + bj * NB + q * 64 + lane], gv[q], dot);
+            dot = wave_allreduce_sum(dot) + ws[g.o_gattn + bj];
+            const Soft2 s = soft2(ws[g.o_Pr + bj * 2 + 0], ws[g.o_Pr + bj * 2 + 1]);
+            g0 += dot * s.p0 * (s.lp0 + s.H);
+            g1 += dot * s.p1 * (s.lp1 + s.H);
+            w1 = 1.f + (1.f - s.H);
+        }
+        if (lane == 0) {
+            ws[g.o_gPrT + bj * 2 + 0] = g0;
+            ws[g.o_gPrT + bj * 2 + 1] = g1;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = q * 64 + lane;
+            ws[g.o_gRa + bj * NB + c] = w1 * gv[q];
+            const float gh = g0 * W2[c] + g1 * W2[NB + c];
+            ws[g.o_gHr + bj * NB + c] = ws[g.o_Hr + bj * NB + c] > 0.f ? gh : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_allreduce_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// One thread per logit row: video rows [0,B), relation rows, frame rows.
+__global__ __launch_bounds__(256) void loss_kernel(Geom g, Ptrs ptrs) {
+    __shared__ float red[8];
+    float *__restrict__ ws = ptrs.ws;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int *__restrict__ labels = reinterpret_cast<const int *>(ws + g.o_labels);
+    const int B = g.B, NR = g.n_rel, T = g.T, C = g.C;
+    const int n_vid = B, n_rel = B * NR, n_frm = B * T;
+    const int rid = blockIdx.x * blockDim.x + threadIdx.x;
+    float l_cls = 0.f, l_rel = 0.f, l_vid = 0.f, l_frm = 0.f, l_ent = 0.f;
+    if (rid < n_vid) {
+        const int b = rid;
+        const bool is_src = b < g.Bs;
+        const bool valid = is_src ? (b < hy->valid_source) : (b - g.Bs < hy->valid_target);
+        const float *__restrict__ y = ws + g.o_Y + (size_t)b * C;
+        float *__restrict__ gy = ws + g.o_gY + (size_t)b * C;
+        float *__restrict__ gpv = ws + g.o_gPv + (size_t)b * 2;
+        float m = y[0];
+        for (int i = 1; i < C; ++i) m = fmaxf(m, y[i]);
+        float sum = 0.f;
+        for (int i = 0; i < C; ++i) sum += expf(y[i] - m);
+        const float ls = logf(sum);
+        float Hc = 0.f;
+        for (int i = 0; i < C; ++i) {
+            const float lp = y[i] - m - ls;
+            Hc -= expf(lp) * lp;
+        }
+        const bool cls_on = is_src && valid;
+        const int lab = cls_on ? labels[b] : -1;
+        if (cls_on) l_cls = -(y[lab] - m - ls) * hy->inv_n_cls;                      // main.py:446
+        const float z0 = ws[g.o_Pv + (size_t)b * 2], z1 = ws[g.o_Pv + (size_t)b * 2 + 1];
+        const Soft2 s = soft2(z0, z1);
+        const bool ent_on = (g.flags & TA3N_FLAG_ATTN_ENTROPY) && valid;
+        const float ce = hy->gamma * hy->inv_n_ent;
+        if (ent_on) l_ent = (1.f + s.H) * Hc * hy->inv_n_ent;                         // loss.py:20-24
+        for (int i = 0; i < C; ++i) {
+            const float lp = y[i] - m - ls;
+            const float p = expf(lp);
+            float gi = 0.f;
+            if (cls_on) gi = (p - (i == lab ? 1.f : 0.f)) * hy->inv_n_cls;
+            if (ent_on) gi += ce * (1.f + s.H) * (-p * (lp + Hc));                    // dH/dz_i = -p_i (log p_i + H)
+            gy[i] = gi;
+        }
+        float g0 = 0.f, g1 = 0.f;
+        if ((g.flags & TA3N_FLAG_ADV_VIDEO) && valid) {                              // main.py:508-538, l = 1
+            const int d = is_src ? 0 : 1;
+            l_vid = -(d ? s.lp1 : s.lp0) * hy->inv_n_vid;
+            g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_vid;
+            g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_vid;
+        }
+        if (ent_on) {
+            g0 += ce * Hc * (-s.p0 * (s.lp0 + s.H));
+            g1 += ce * Hc * (-s.p1 * (s.lp1 + s.H));
+        }
+        gpv[0] = g0; gpv[1] = g1;
+    } else if (rid < n_vid + n_rel + n_frm) {
+        const bool is_rel = rid < n_vid + n_rel;
+        const int row = is_rel ? rid - n_vid : rid - n_vid - n_rel;
+        const int b = is_rel ? row / NR : row / T;
+        const bool is_src = b < g.Bs;
+        const bool valid = is_src ? (b < hy->valid_source) : (b - g.Bs < hy->valid_target);
+        const float *__restrict__ z = ws + (is_rel ? g.o_Pr : g.o_Pf) + (size_t)row * 2;
+        float *__restrict__ gz = ws + (is_rel ? g.o_gPr : g.o_gPf) + (size_t)row * 2;
+        const bool on = valid && (g.flags & (is_rel ? TA3N_FLAG_ADV_RELATION : TA3N_FLAG_ADV_FRAME));
+        float g0 = 0.f, g1 = 0.f;
+        if (on) {
+            const float inv_n = is_rel ? hy->inv_n_rel : hy->inv_n_frm;
+            const Soft2 s = soft2(z[0], z[1]);
+            const int d = is_src ? 0 : 1;
+            const float l = -(d ? s.lp1 : s.lp0) * inv_n;
+            if (is_rel) l_rel = l; else l_frm = l;
+            g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * inv_n;
+            g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * inv_n;
+        }
+        gz[0] = g0; gz[1] = g1;
+    }
+    // loss scalars are for logging only; gradients above are exact per row
+    const float s_cls = block_sum(l_cls, red), s_rel = block_sum(l_rel, red), s_vid = block_sum(l_vid, red);
+    const float s_frm = block_sum(l_frm, red), s_ent = block_sum(l_ent, red);
+    if (threadIdx.x == 0) {
+        float *L = ws + g.o_losses;
+        const float total = s_cls + s_rel + s_vid + s_frm + hy->gamma * s_ent;
+        if (total != 0.f) atomicAdd(L + 0, total);
+        if (s_cls != 0.f) atomicAdd(L + 1, s_cls);
+        if (s_rel != 0.f) atomicAdd(L + 2, s_rel);
+        if (s_vid != 0.f) atomicAdd(L + 3, s_vid);
+        if (s_frm != 0.f) atomicAdd(L + 4, s_frm);
+        if (s_ent != 0.f) atomicAdd(L + 5, s_ent);
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_norm_kernel(const float *__restrict__ grads, float *__restrict__ part, int n4) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// clip_grad_norm_ (total_norm over all grads, coef = clip/(norm+1e-6) clamped to 1)
+// then torch.optim.SGD(nesterov=True): g += wd*p; buf = mu*buf + g; g += mu*buf; p -= lr*g.
+__global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
+                                                  float *__restrict__ mom, float *__restrict__ ws, int n4) {
+    __shared__ float red[8];
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < g.n_norm_blocks; i += blockDim.x) acc += ws[g.o_norm_part + i];
+    const float total = sqrtf(block_sum(acc, red));
+    float coef = 1.f;
+    if (hy->clip > 0.f) coef = fminf(hy->clip / (total + 1e-6f), 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ws[g.o_grad_norm] = total;
+        ws[g.o_grad_norm + 1] = coef;
+    }
+    const float lr = hy->lr, mu = hy->momentum, wd = hy->weight_decay;
+    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
+    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 p = p4[i], m = m4[i];
+        const float4 gr = g4[i];
+        float gg[4] = {gr.x, gr.y, gr.z, gr.w};
+        float pp[4] = {p.x, p.y, p.z, p.w};
+        float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = fmaf(wd, pp[e], gg[e] * coef);
+            mm[e] = fmaf(mu, mm[e], d);
+            d = fmaf(mu, mm[e], d);
+            pp[e] = fmaf(-lr, d, pp[e]);
+        }
+        p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    }
+}
+
+__global__ void fill_kernel(float *__restrict__ dst, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+}  // namespace
+
+namespace ta3n {
+
+#define TA3N_DISPATCH_Q(KERNEL, grid, stream, ...)                                                    \
+    switch (g.NB / 64) {                                                                              \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;      \
+        default: return -1;                                                                           \
+    }
+
+int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    const dim3 grid((g.B + 3) / 4);
+    TA3N_DISPATCH_Q(pool_fwd_kernel, grid, stream, g, ptrs)
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    const dim3 grid((g.B + 3) / 4);
+    TA3N_DISPATCH_Q(pool_bwd_kernel, grid, stream, g, ptrs)
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    if (hipMemsetAsync(ptrs.ws + g.o_losses, 0, 8 * sizeof(float), stream) != hipSuccess) return -2;
+    const int rows = g.B * (1 + g.n_rel + g.T);
+    hipLaunchKernelGGL(loss_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t stream) {
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(g.n_norm_blocks), dim3(256), 0, stream, grads, ws + g.o_norm_part,
+                       g.live_floats / 4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream) {
+    const int n4 = g.live_floats / 4;
+    int blocks = (n4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, n4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_fill(float *dst, float value, int64_t n, hipStream_t stream) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, dst, value, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace ta3n

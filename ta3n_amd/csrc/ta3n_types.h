@@ -1,0 +1,105 @@
+// Internal POD descriptors shared by the host-side plan builder and the device
+// kernels.  A "phase" is one kernel launch; a GEMM phase runs a list of tile
+// tasks, each task a list of K-segments.  Everything addresses memory as
+// (base id, element offset) so a plan is independent of buffer addresses.
+#pragma once
+#include <stdint.h>
+
+namespace ta3n {
+
+enum Base : int32_t { BASE_NONE = -1, BASE_X = 0, BASE_P = 1, BASE_G = 2, BASE_WS = 3, BASE_COUNT = 4 };
+
+// segment / epilogue scale kinds: value is taken from the device Hyper struct
+enum ScaleKind : int32_t {
+    SK_ONE = 0,
+    SK_NEG_BETA_REL = 1,   // -beta[0]   GradReverse on relation features  (models.py:474-476)
+    SK_NEG_BETA_VID = 2,   // -beta[1]   (models.py:465)
+    SK_NEG_BETA_FRM = 3,   // -beta[2]   (models.py:457)
+    SK_INV_KEEP_I = 4,     // 1/(1-p_drop_i) when training else 1
+    SK_INV_KEEP_V = 5,     // 1/(1-p_drop_v) when training else 1
+};
+
+enum EpiFlags : uint32_t {
+    EPI_BIAS = 1u << 0,     // v += bias[n]
+    EPI_ADD = 1u << 1,      // v = alpha*v + add[m][n]
+    EPI_RELU = 1u << 2,     // v = max(v, 0)
+    EPI_MASK = 1u << 3,     // v *= (aux[m][n] > 0)
+    EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
+    EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
+};
+
+struct Seg {
+    int32_t a_base, b_base;
+    int32_t a_off, b_off;        // element offsets of the operand origin
+    int32_t a_ld, b_ld;          // K-contiguous operand: row stride; k-major operand: stride between k rows
+    int32_t a_kmajor, b_kmajor;  // 0: element (r,k) at off + r*ld + k ; 1: at off + k*ld + r
+    int32_t klen;
+    int32_t scale_kind;          // accumulator *= scale after this segment (SK_ONE = none)
+    int32_t pad[2];
+};
+
+struct Task {
+    int32_t m0, n0;              // tile origin in the output
+    int32_t m_valid, n_valid;    // output extent (rows / cols) for guards
+    int32_t seg_begin, seg_count;
+    uint32_t epi;                // EpiFlags
+    int32_t alpha_kind;          // ScaleKind applied to the accumulator before `add`
+    int32_t gamma_kind;          // ScaleKind applied last
+    int32_t c_base, c_off, c_ld;
+    int32_t bias_base, bias_off;
+    int32_t aux_base, aux_off, aux_ld;   // mask operand
+    int32_t add_base, add_off, add_ld;   // additive operand
+    int32_t drop_ld;                     // element id for dropout = m*drop_ld + n
+    int32_t fan_count;                   // extra masked outputs (all in BASE_WS, ld = fan_ld)
+    int32_t fan_ld;
+    int32_t fan_mask_off[3];
+    int32_t fan_out_off[3];
+    int32_t cost;                        // sum of klen (for ordering / balance)
+    int32_t pad[3];
+};
+
+enum PhaseKind : int32_t {
+    PH_GEMM = 0,
+    PH_POOL_FWD = 1,
+    PH_LOSS = 2,
+    PH_POOL_BWD = 3,
+    PH_GRAD_NORM = 4,
+    PH_SGD = 5,
+};
+
+struct Phase {
+    int32_t kind;
+    int32_t group;               // 0 fwd, 1 loss, 2 bwd, 3 sgd
+    int32_t task_begin, task_count;
+    int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
+    int32_t pad;
+};
+
+// Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.
+struct Hyper {
+    float beta[3];
+    float gamma, lr, momentum, weight_decay, clip;
+    float p_drop_i, p_drop_v;
+    uint32_t seed_i, seed_v;
+    float inv_n_cls, inv_n_rel, inv_n_vid, inv_n_frm, inv_n_ent;
+    int32_t valid_source, valid_target, train;
+    int32_t reserved[4];
+};
+
+// Device-side constant geometry handed to the pointwise kernels by value.
+struct Geom {
+    int32_t Bs, Bt, B, T, D, F, NB, C;
+    int32_t n_tuples;            // total relation tuples
+    int32_t n_rel;               // T-1
+    uint32_t flags;
+    // workspace offsets (elements)
+    int32_t o_F1, o_Hf, o_Pf, o_Zr, o_Hr, o_Pr, o_R, o_attn, o_V, o_Vd, o_Y, o_Hv, o_Pv;
+    int32_t o_gY, o_gPv, o_gPr, o_gPf, o_gattn, o_gHv, o_gHf, o_gVt, o_gPrT, o_gRa, o_gHr, o_gR, o_gZ, o_gZ1;
+    int32_t o_ones, o_losses, o_norm_part, o_grad_norm, o_hyper, o_labels, o_tuple_first;
+    int32_t n_norm_blocks;
+    int32_t live_floats;
+    // relation discriminator second layers inside the flat parameter buffer
+    int32_t p_W2_0, p_b2_0, p_W2_stride, p_b2_stride;   // W2_j at p_W2_0 + j*p_W2_stride
+};
+
+}  // namespace ta3n

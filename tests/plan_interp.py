@@ -1,0 +1,292 @@
+"""CPU interpreter of a ta3n plan (test infrastructure).
+
+Executes the SAME descriptor lists the HIP kernels consume (Seg / Task / Phase
+PODs exported by ta3n_debug_arrays) with numpy, so the whole wiring of the
+train step - operand offsets, K-segments, GradReverse scales, epilogues, fan-out,
+workspace layout - is validated against the oracle on a machine without a GPU.
+The pointwise phases (pool fwd/bwd, loss, grad-norm, SGD) are executed from
+their specification in the kernel headers.  Nothing here is used by the product.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ta3n_amd import _lib
+
+BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
+EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V = 1, 2, 4, 8, 16, 32
+PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD = range(6)
+
+
+class Seg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a_base", "b_base", "a_off", "b_off", "a_ld", "b_ld", "a_kmajor", "b_kmajor",
+                                         "klen", "scale_kind")] + [("pad", C.c_int32 * 2)]
+
+
+class Task(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("m0", "n0", "m_valid", "n_valid", "seg_begin", "seg_count")] +
+                [("epi", C.c_uint32)] +
+                [(n, C.c_int32) for n in ("alpha_kind", "gamma_kind", "c_base", "c_off", "c_ld", "bias_base", "bias_off",
+                                          "aux_base", "aux_off", "aux_ld", "add_base", "add_off", "add_ld", "drop_ld",
+                                          "fan_count", "fan_ld")] +
+                [("fan_mask_off", C.c_int32 * 3), ("fan_out_off", C.c_int32 * 3), ("cost", C.c_int32),
+                 ("pad", C.c_int32 * 3)])
+
+
+class Phase(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "pad")]
+
+
+_GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", "flags",
+                "o_F1", "o_Hf", "o_Pf", "o_Zr", "o_Hr", "o_Pr", "o_R", "o_attn", "o_V", "o_Vd", "o_Y", "o_Hv", "o_Pv",
+                "o_gY", "o_gPv", "o_gPr", "o_gPf", "o_gattn", "o_gHv", "o_gHf", "o_gVt", "o_gPrT", "o_gRa", "o_gHr",
+                "o_gR", "o_gZ", "o_gZ1", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
+                "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride"]
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_uint32 if n == "flags" else C.c_int32) for n in _GEOM_FIELDS]
+
+
+def struct_sizes_ok():
+    s = [C.c_int32() for _ in range(5)]
+    _lib.lib().ta3n_debug_struct_sizes(*[C.byref(x) for x in s])
+    return (s[0].value == C.sizeof(Seg) and s[1].value == C.sizeof(Task) and s[2].value == C.sizeof(Phase)
+            and s[3].value == C.sizeof(Geom) and s[4].value == C.sizeof(_lib.Hyper))
+
+
+def plan_arrays(plan):
+    L = _lib.lib()
+    ptrs = [C.c_void_p() for _ in range(6)]
+    ns = [C.c_int64() for _ in range(3)]
+    L.ta3n_debug_arrays(plan.handle, C.byref(ptrs[0]), C.byref(ns[0]), C.byref(ptrs[1]), C.byref(ns[1]),
+                        C.byref(ptrs[2]), C.byref(ns[2]), C.byref(ptrs[3]), C.byref(ptrs[4]), C.byref(ptrs[5]))
+    segs = C.cast(ptrs[0], C.POINTER(Seg * ns[0].value)).contents
+    tasks = C.cast(ptrs[1], C.POINTER(Task * ns[1].value)).contents
+    phases = C.cast(ptrs[2], C.POINTER(Phase * ns[2].value)).contents
+    geom = C.cast(ptrs[3], C.POINTER(Geom)).contents
+    tf = np.ctypeslib.as_array(C.cast(ptrs[5], C.POINTER(C.c_int32)), shape=(geom.n_rel + 1,)).copy()
+    tup = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_int32)), shape=(geom.n_tuples, geom.T)).copy()
+    return segs, tasks, phases, geom, tup, tf
+
+
+def mix32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def keep_mask(seed, idx, p):
+    """Same stateless dropout stream as ta3n_kernels.h:keep_mask."""
+    seed = np.uint64(seed)
+    h = mix32(mix32((np.asarray(idx, np.uint64) + np.uint64(0x9E3779B9) * (seed | np.uint64(1))) & 0xFFFFFFFF) ^ seed)
+    u = (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).astype(np.float64)
+
+
+class Interp:
+    def __init__(self, plan, dtype=np.float64):
+        assert struct_sizes_ok(), "ctypes mirrors out of date with ta3n_types.h"
+        self.plan = plan
+        self.segs, self.tasks, self.phases, self.g, self.tuples, self.tf = plan_arrays(plan)
+        self.dtype = dtype
+        g = self.g
+        self.ws = np.zeros(plan.ws_floats, dtype)
+        self.ws[g.o_ones:g.o_ones + g.B * g.T] = 1.0
+        self.P = np.zeros(plan.param_floats, dtype)
+        self.G = np.zeros(plan.param_floats, dtype)
+        self.M = np.zeros(plan.param_floats, dtype)
+        self.X = None
+        self.labels = np.zeros(g.B, np.int64)
+        self.hy = None
+
+    # ---- helpers ----
+    def set_params(self, state):
+        for name, off, shape, live in self.plan.params:
+            n = int(np.prod(shape))
+            self.P[off:off + n] = state[name].detach().cpu().double().numpy().reshape(-1)
+
+    def get_params(self, src=None):
+        src = self.P if src is None else src
+        return {name: src[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape, live in self.plan.params}
+
+    def buf(self, base):
+        return {BASE_X: self.X, BASE_P: self.P, BASE_G: self.G, BASE_WS: self.ws}[base]
+
+    def scale(self, kind):
+        h = self.hy
+        if kind == 1: return -h["beta"][0]
+        if kind == 2: return -h["beta"][1]
+        if kind == 3: return -h["beta"][2]
+        if kind == 4: return 1.0 / (1.0 - h["p_drop_i"]) if (h["train"] and h["p_drop_i"] > 0) else 1.0
+        if kind == 5: return 1.0 / (1.0 - h["p_drop_v"]) if (h["train"] and h["p_drop_v"] > 0) else 1.0
+        return 1.0
+
+    def view2d(self, base, off, ld, rows, cols, r0=0, c0=0):
+        b = self.buf(base)
+        idx = off + (np.arange(r0, r0 + rows)[:, None] * ld) + np.arange(c0, c0 + cols)[None, :]
+        return idx, b
+
+    def operand(self, base, off, ld, kmajor, r0, nr, klen):
+        """[nr, klen] matrix of element (r, k)."""
+        b = self.buf(base)
+        r = np.arange(r0, r0 + nr)[:, None]
+        k = np.arange(klen)[None, :]
+        idx = off + (k * ld + r if kmajor else r * ld + k)
+        return b[idx]
+
+    # ---- phases ----
+    def run_gemm(self, ph):
+        BM, BN = 32 * ph.wm, 32 * ph.wn
+        for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
+            t = self.tasks[ti]
+            nr = min(BM, t.m_valid - t.m0); nc = min(BN, t.n_valid - t.n0)
+            assert nr > 0 and nc > 0
+            acc = np.zeros((nr, nc), self.dtype)
+            for si in range(t.seg_begin, t.seg_begin + t.seg_count):
+                s = self.segs[si]
+                A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
+                Bm = self.operand(s.b_base, s.b_off, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)
+                acc += A @ Bm.T
+                acc *= self.scale(s.scale_kind)
+            v = acc
+            m = np.arange(t.m0, t.m0 + nr)[:, None]
+            n = np.arange(t.n0, t.n0 + nc)[None, :]
+            if t.epi & EPI_BIAS:
+                v = v + self.buf(t.bias_base)[t.bias_off + n]
+            v = v * self.scale(t.alpha_kind)
+            if t.epi & EPI_ADD:
+                v = v + self.buf(t.add_base)[t.add_off + m * t.add_ld + n]
+            if t.epi & EPI_RELU:
+                v = np.maximum(v, 0)
+            if t.epi & EPI_MASK:
+                v = np.where(self.buf(t.aux_base)[t.aux_off + m * t.aux_ld + n] > 0, v, 0)
+            if (t.epi & (EPI_DROP_I | EPI_DROP_V)) and self.hy["train"]:
+                seed = self.hy["seed_i"] if t.epi & EPI_DROP_I else self.hy["seed_v"]
+                p = self.hy["p_drop_i"] if t.epi & EPI_DROP_I else self.hy["p_drop_v"]
+                v = v * keep_mask(seed, m * t.drop_ld + n, p)
+            v = v * self.scale(t.gamma_kind)
+            self.buf(t.c_base)[t.c_off + m * t.c_ld + n] = v
+            for f in range(t.fan_count):
+                mk = self.ws[t.fan_mask_off[f] + m * t.fan_ld + n]
+                self.ws[t.fan_out_off[f] + m * t.fan_ld + n] = np.where(mk > 0, v, 0)
+
+    @staticmethod
+    def soft2(z):
+        m = z.max(-1, keepdims=True)
+        e = np.exp(z - m); s = e.sum(-1, keepdims=True)
+        p = e / s; lp = z - m - np.log(s)
+        H = -(p * lp).sum(-1)
+        return p, lp, H
+
+    def r(self, off, shape):
+        n = int(np.prod(shape))
+        return self.ws[off:off + n].reshape(shape)
+
+    def run_pool_fwd(self):
+        g, h = self.g, self.hy
+        B, NR, NB, NT = g.B, g.n_rel, g.NB, g.n_tuples
+        Hr = self.r(g.o_Hr, (B, NR, NB)); Zr = self.r(g.o_Zr, (B, NT, NB))
+        R = self.r(g.o_R, (B, NR, NB)); Pr = self.r(g.o_Pr, (B, NR, 2)); attn = self.r(g.o_attn, (B, NR))
+        attn_on = bool(g.flags & _lib.FLAG_TRANS_ATTN)
+        V = np.zeros((B, NB), self.dtype)
+        for j in range(NR):
+            W2 = self.P[g.p_W2_0 + j * g.p_W2_stride:][:2 * NB].reshape(2, NB)
+            b2 = self.P[g.p_b2_0 + j * g.p_b2_stride:][:2]
+            Pr[:, j, :] = Hr[:, j, :] @ W2.T + b2
+            R[:, j, :] = Zr[:, self.tf[j]:self.tf[j + 1], :].sum(1)
+            if attn_on:
+                _, _, H = self.soft2(Pr[:, j, :])
+                w = 1 - H
+                attn[:, j] = w
+                V += (w[:, None] + 1) * R[:, j, :]
+            else:
+                attn[:, j] = R[:, j, 0]
+                V += R[:, j, :]
+        self.r(g.o_V, (B, NB))[:] = V
+        Vd = V
+        if h["train"] and h["p_drop_v"] > 0:
+            idx = np.arange(B)[:, None] * NB + np.arange(NB)[None, :]
+            Vd = V * keep_mask(h["seed_v"], idx, h["p_drop_v"]) * self.scale(5)
+        self.r(g.o_Vd, (B, NB))[:] = Vd
+
+    def run_loss(self):
+        g, h = self.g, self.hy
+        B, NR, T, Cn = g.B, g.n_rel, g.T, g.C
+        Y = self.r(g.o_Y, (B, Cn)); Pv = self.r(g.o_Pv, (B, 2)); Pr = self.r(g.o_Pr, (B * NR, 2)); Pf = self.r(g.o_Pf, (B * T, 2))
+        b = np.arange(B); is_src = b < g.Bs
+        valid = np.where(is_src, b < h["valid_source"], (b - g.Bs) < h["valid_target"])
+        d = (~is_src).astype(int)
+        m = Y.max(1, keepdims=True); lp = Y - m - np.log(np.exp(Y - m).sum(1, keepdims=True)); p = np.exp(lp)
+        Hc = -(p * lp).sum(1)
+        cls_on = is_src & valid
+        onehot = np.zeros_like(Y); onehot[b[cls_on], self.labels[cls_on]] = 1
+        gY = np.where(cls_on[:, None], (p - onehot) * h["inv_n_cls"], 0.0)
+        l_cls = float((-lp[b[cls_on], self.labels[cls_on]]).sum() * h["inv_n_cls"])
+        q, lq, Hd = self.soft2(Pv)
+        gPv = np.zeros_like(Pv); l_vid = 0.0; l_ent = 0.0
+        oh2 = np.zeros_like(Pv); oh2[b, d] = 1
+        if g.flags & _lib.FLAG_ADV_VIDEO:
+            gPv += np.where(valid[:, None], (q - oh2) * h["inv_n_vid"], 0)
+            l_vid = float((-lq[b, d] * valid).sum() * h["inv_n_vid"])
+        if g.flags & _lib.FLAG_ATTN_ENTROPY:
+            ce = h["gamma"] * h["inv_n_ent"]
+            l_ent = float(((1 + Hd) * Hc * valid).sum() * h["inv_n_ent"])
+            gY += np.where(valid[:, None], ce * (1 + Hd)[:, None] * (-p * (lp + Hc[:, None])), 0)
+            gPv += np.where(valid[:, None], ce * Hc[:, None] * (-q * (lq + Hd[:, None])), 0)
+        self.r(g.o_gY, (B, Cn))[:] = gY; self.r(g.o_gPv, (B, 2))[:] = gPv
+
+        def rows(P, per, flag, inv_n):
+            bb = np.repeat(b, per); vv = np.repeat(valid, per); dd = np.repeat(d, per)
+            qq, lqq, _ = self.soft2(P)
+            oh = np.zeros_like(P); oh[np.arange(P.shape[0]), dd] = 1
+            if not (g.flags & flag):
+                return np.zeros_like(P), 0.0
+            return np.where(vv[:, None], (qq - oh) * inv_n, 0), float((-lqq[np.arange(P.shape[0]), dd] * vv).sum() * inv_n)
+        gPr, l_rel = rows(Pr, NR, _lib.FLAG_ADV_RELATION, h["inv_n_rel"])
+        gPf, l_frm = rows(Pf, T, _lib.FLAG_ADV_FRAME, h["inv_n_frm"])
+        self.r(g.o_gPr, (B * NR, 2))[:] = gPr; self.r(g.o_gPf, (B * T, 2))[:] = gPf
+        self.ws[g.o_losses:g.o_losses + 6] = [l_cls + l_rel + l_vid + l_frm + h["gamma"] * l_ent, l_cls, l_rel, l_vid, l_frm, l_ent]
+
+    def run_pool_bwd(self):
+        g = self.g
+        B, NR, NB = g.B, g.n_rel, g.NB
+        gVt = self.r(g.o_gVt, (B, NB)); R = self.r(g.o_R, (B, NR, NB)); Pr = self.r(g.o_Pr, (B, NR, 2))
+        gPr = self.r(g.o_gPr, (B, NR, 2)); gattn = self.r(g.o_gattn, (B, NR)); Hr = self.r(g.o_Hr, (B, NR, NB))
+        gPrT = self.r(g.o_gPrT, (B, NR, 2)); gRa = self.r(g.o_gRa, (B, NR, NB)); gHr = self.r(g.o_gHr, (B, NR, NB))
+        attn_on = bool(g.flags & _lib.FLAG_TRANS_ATTN)
+        for j in range(NR):
+            W2 = self.P[g.p_W2_0 + j * g.p_W2_stride:][:2 * NB].reshape(2, NB)
+            gp = gPr[:, j, :].copy(); w1 = np.ones(B, self.dtype)
+            if attn_on:
+                dot = (R[:, j, :] * gVt).sum(1) + gattn[:, j]
+                p, lp, H = self.soft2(Pr[:, j, :])
+                gp += dot[:, None] * p * (lp + H[:, None])
+                w1 = 1 + (1 - H)
+            gPrT[:, j, :] = gp
+            gRa[:, j, :] = w1[:, None] * gVt
+            gHr[:, j, :] = np.where(Hr[:, j, :] > 0, gp @ W2, 0)
+
+    def run_sgd(self):
+        g, h = self.g, self.hy
+        n = g.live_floats
+        total = np.sqrt((self.G[:n] ** 2).sum())
+        coef = min(h["clip"] / (total + 1e-6), 1.0) if h["clip"] > 0 else 1.0
+        self.ws[g.o_grad_norm] = total; self.ws[g.o_grad_norm + 1] = coef
+        d = self.G[:n] * coef + h["weight_decay"] * self.P[:n]
+        self.M[:n] = h["momentum"] * self.M[:n] + d
+        d = d + h["momentum"] * self.M[:n]
+        self.P[:n] -= h["lr"] * d
+
+    def run_group(self, group):
+        for ph in self.phases:
+            if ph.group != group:
+                continue
+            if ph.kind == PH_GEMM: self.run_gemm(ph)
+            elif ph.kind == PH_POOL_FWD: self.run_pool_fwd()
+            elif ph.kind == PH_LOSS: self.run_loss()
+            elif ph.kind == PH_POOL_BWD: self.run_pool_bwd()
+            elif ph.kind == PH_GRAD_NORM: pass
+            elif ph.kind == PH_SGD: self.run_sgd()

@@ -1,0 +1,98 @@
+"""CPU validation of the launch plan: the descriptor lists the HIP kernels
+consume are executed with numpy (tests/plan_interp.py) and compared with the
+golden vectors produced by the reference, for every fixture.  This pins the
+wiring (offsets, K-segments, GradReverse scales, epilogues) without a GPU; the
+-m gpu tests then only have to pin the kernels themselves."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden, case_config, step_schedule
+from plan_interp import Interp
+from ta3n_amd import _lib
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+ALL_FLAGS = (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME | _lib.FLAG_ATTN_ENTROPY |
+             _lib.FLAG_TRANS_ATTN)
+SMALL = [c for c in CASES if c.startswith("tiny") or c == "mid_T12"]
+
+
+def make_hyper(c, st, T, lr):
+    n_s, n_t = st["n_src"], st["n_tgt"]
+    return dict(beta=[0.75, 0.75, 0.5], gamma=0.003, lr=lr, momentum=0.9, weight_decay=1e-4, clip=c["clip"],
+                p_drop_i=0.0, p_drop_v=0.0, seed_i=1, seed_v=2, inv_n_cls=1.0 / n_s, inv_n_rel=1.0 / ((n_s + n_t) * (T - 1)),
+                inv_n_vid=1.0 / (n_s + n_t), inv_n_frm=1.0 / ((n_s + n_t) * T), inv_n_ent=1.0 / (n_s + n_t),
+                valid_source=n_s, valid_target=n_t, train=1)
+
+
+@pytest.mark.parametrize("tile", [114, 221, 0])
+@pytest.mark.parametrize("name", SMALL)
+def test_plan_reproduces_reference(name, tile):
+    if tile != 114 and name not in ("tiny_T5", "tiny_T3"):
+        pytest.skip("tile variants checked on two cases")
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS, tile_config=tile)
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    assert live == set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.run_group(0)
+        if s == 0:   # forward outputs vs the reference's VideoModel.forward
+            B, Bs = c["Bs"] + c["Bt"], c["Bs"]
+            geo = it.g
+            outs = dict(out=it.r(geo.o_Y, (B, c["C"])), attn=it.r(geo.o_attn, (B, T - 1)),
+                        rel=it.r(geo.o_Pr, (B, T - 1, 2)), vid=it.r(geo.o_Pv, (B, 2)), frm=it.r(geo.o_Pf, (B, T, 2)),
+                        v=it.r(geo.o_V, (B, 256)), f1=it.r(geo.o_F1, (B, T, geo.F)))
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", outs["out"][sl], 5e-5, 2e-5)
+                g.check(f"fwd/attn_{dom}", outs["attn"][sl], 5e-5, 2e-5)
+                for nm in ("rel", "vid", "frm"):
+                    g.check(f"fwd/pd_{dom}_{nm}", outs[nm][sl], 5e-5, 2e-5)
+                g.check(f"fwd/feat_{dom}_v", outs["v"][sl], 5e-5, 2e-5)
+                g.check(f"fwd/feat_{dom}_f1", outs["f1"][sl], 5e-5, 2e-5)
+        it.run_group(1)
+        it.G[:] = 0
+        it.run_group(2)
+        raw = it.get_params(it.G)
+        it.run_group(3)
+        coef = it.ws[it.g.o_grad_norm + 1]
+        new = it.get_params()
+        for k in shapes:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+    if name == "tiny_clip":
+        assert it.ws[it.g.o_grad_norm + 1] < 1.0   # the clip branch was exercised
+
+
+def test_plan_rejects_bad_configs():
+    with pytest.raises(ValueError):
+        _lib.Plan(4, 4, 1, 512, 64, 12, ALL_FLAGS)                      # trn-m needs >= 2 segments
+    with pytest.raises(ValueError):
+        _lib.Plan(4, 4, 5, 512, 64, 12, _lib.FLAG_ATTN_ENTROPY | _lib.FLAG_ADV_VIDEO)   # main.py:559-562 quirk
+    with pytest.raises(ValueError):
+        _lib.Plan(0, 0, 5, 512, 64, 12, ALL_FLAGS)
+    with pytest.raises(ValueError):
+        _lib.Plan(4, 4, 5, 512, 64, 12, ALL_FLAGS, tile_config=333)
+
+
+def test_param_table_matches_reference_state_dict():
+    from oracle import ta3n_oracle as orc
+    plan = _lib.Plan(128, 74, 5, 2048, 512, 12, ALL_FLAGS)
+    want = orc.param_shapes(orc.Config())
+    got = {n: s for n, _, s, _ in plan.params}
+    assert got == want
+    assert sum(int(np.prod(s)) for n, _, s, lv in plan.params if lv) == 3483416
+    assert sum(int(np.prod(s)) for s in got.values()) == 3884836
+    offs = [o for _, o, _, _ in plan.params]
+    assert all(o % 4 == 0 for o in offs) and offs == sorted(offs)
+    assert plan.live_floats % 4 == 0
