@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Benchmark of the TA3N temporal-adversarial train step on MI355X.
+
+Metric (BASELINE.json): src+tgt videos/sec per train step, UCF->HMDB_full 5-seg
+TA3N (trn-m, RevGrad x3, TransAttn, attentive entropy; 128 source + 74 target
+videos per GPU and step, 2048-d features, 12 classes, dropout 0.5/0.5).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + loss + backward + (RCCL all-reduce of the flat gradient
+buffer when N > 1) + clip + Nesterov SGD on synthetic features already resident
+in HBM.  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
+prints ONE JSON line; `roofline` is measured live with HIP events on the launch
+stream, `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
+CPU path) on a bounded sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ta3n_amd.engine import TrainEngine, beta_dann, lr_dann  # noqa: E402
+from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
+
+# BASELINE config 2/3 (script_train_val.sh: bS=128, bS_2=128*840/1438=74, 5 segments, fc_dim 512, 12 classes)
+CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
+    """SURVEY.md 8(d) without the dead frame classifier (its output feeds nothing
+    for baseline_type='video'): fwd + dgrad + wgrad, no dgrad for the first layer."""
+    B = Bs + Bt
+    from ta3n_amd import _lib
+    gathered = sum(len(t) for scale in _lib.relation_table(T) for t in scale)   # 32 frame rows / video at T=5
+    fwd = (2 * B * T * D * F + 2 * B * T * F * (F + 2) + 2 * B * NB * F * gathered +
+           (T - 1) * 2 * B * NB * (NB + 2) + 2 * B * NB * C + 2 * B * NB * (NB + 2))
+    return 3 * fwd - 2 * B * T * D * F
+
+
+def cpu_baseline(seconds=12.0, max_steps=40):
+    """The CPU path on this host: oracle train step (same ATen CPU kernels the
+    reference dispatches), dropout on, all cores."""
+    from oracle import ta3n_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = orc.Config(num_class=CFG["C"], num_segments=CFG["T"], feature_dim=CFG["D"], fc_dim=CFG["F"])
+    params = synth_state(orc.param_shapes(cfg), seed=7, scale="init")
+    xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234)
+    state = orc.TrainState(params=params, lr=3e-2)
+
+    def one():
+        keep_i, keep_v = 1 - cfg.dropout_i, 1 - cfg.dropout_v
+        di = [torch.bernoulli(torch.full((n * CFG["T"], cfg.feat_dim), keep_i)) / keep_i for n in (CFG["Bs"], CFG["Bt"])]
+        dv = [torch.bernoulli(torch.full((n, 256), keep_v)) / keep_v for n in (CFG["Bs"], CFG["Bt"])]
+        orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, drop_i=di, drop_v=dv)
+
+    for _ in range(3):
+        one()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and (time.perf_counter() - t0) < seconds:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port",
+                sample=f"{n} full train steps (128+74 videos, fp32, dropout 0.5) of oracle/ta3n_oracle.py on {cores} "
+                       f"threads of '{model}' = {1e3 * dt / n:.1f} ms/step",
+                ms_per_step=1e3 * dt / n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--tile", type=int, default=0, help="force a GEMM tile config (114/212/122/221)")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
+                      clip=20.0, device=dev, tile_config=args.tile)
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
+    xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)
+    eng.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
+    lr0, gamma, beta = 3e-2, 0.003, [0.75, 0.75, 0.5]
+    total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
+    eng.set_hyper(beta, gamma, lr0)
+    if not args.no_graph:
+        eng.capture()
+
+    def step(i):
+        p = float(i % total_steps) / total_steps
+        eng.train_step(beta, gamma, lr0 if i == 0 else lr_dann(lr0, p))
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    videos = (CFG["Bs"] + CFG["Bt"]) * world * args.steps
+    value = videos / elapsed
+
+    if rank == 0:
+        finite = bool(torch.isfinite(eng.P).all().item())
+        # live per-launch timing of the dominant kernel (the tile-list GEMM), HIP events on the launch stream
+        phases = eng.time_phases(args.phase_reps)
+        gemm = [p for p in phases if p[0] == 0]
+        gemm_ms = sum(p[3] for p in gemm)
+        flops = algorithmic_gemm_flops(**CFG)
+        achieved = flops / (gemm_ms * 1e-3) / 1e12
+        out = {
+            "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N",
+            "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UCF->HMDB_full TA3N train step: trn-m 5 segments, RevGrad x3, TransAttn, "
+                                   "attentive entropy, 128 src + 74 tgt videos per GPU-step, 2048-d features, 12 classes, "
+                                   "dropout 0.5/0.5, clip 20, Nesterov SGD (BASELINE configs[2] arithmetic, fp32)",
+                       "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
+                       "launch": "eager" if args.no_graph else "hipGraph", "finite": finite},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "ta3n::gemm_tiles (11 launches/step)",
+                         "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
+                         "launches": len(gemm), "all_kernels_us": 1e3 * sum(p[3] for p in phases),
+                         "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]},
+        }
+        if not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

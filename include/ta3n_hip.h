@@ -160,6 +160,13 @@ int ta3n_backward(ta3n_plan *plan, const float *x, const float *params, float *g
 int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                   void *stream);
 
+/* Measurement aid: per-launch durations (ms) of every phase of one train step,
+ * taken with HIP events recorded on `stream`; GEMM/pool/loss phases are repeated
+ * `reps` times back to back.  kind_out[i]: 0 GEMM, 1 pool fwd, 2 loss, 3 pool bwd,
+ * 4 grad norm, 5 SGD.  Synchronises the stream.  Returns the number of phases. */
+int ta3n_time_phases(ta3n_plan *plan, const float *x, float *params, float *grads, float *momentum,
+                     float *ws, void *stream, int reps, float *ms_out, int32_t *kind_out, int cap);
+
 /* Number of kernel launches the last ta3n_forward/ta3n_backward enqueued, and a
  * name for the dominant GEMM kernel symbol (for rocprof matching). */
 int ta3n_num_phases(const ta3n_plan *plan, int which /*0 fwd,1 loss,2 bwd,3 sgd*/);

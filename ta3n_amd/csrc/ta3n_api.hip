@@ -10,6 +10,7 @@
 #include <new>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "../../include/ta3n_hip.h"
 #include "ta3n_kernels.h"
@@ -245,6 +246,53 @@ int ta3n_backward(ta3n_plan *p, const float *x, const float *params, float *grad
     if (rc != TA3N_OK) return rc;
     Ptrs ptrs{x, params, grads, ws};
     return run_group(p, 2, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+// Per-launch durations with HIP events recorded on `stream` (the stream the kernels
+// run on).  Each GEMM / pool / loss phase is launched `reps` times back to back
+// between two events (the phases are idempotent); optimiser phases once.
+int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws,
+                     void *stream, int reps, float *ms_out, int32_t *kind_out, int cap) {
+    if (!p || !x || !params || !grads || !momentum || !ws || !ms_out) return fail(TA3N_ERR_INVALID, "null argument");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (reps < 1) reps = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n = (int)p->phases.size();
+    if (cap < n) return fail(TA3N_ERR_INVALID, "output too small");
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    Ptrs ptrs{x, params, grads, ws};
+    for (int i = 0; i < n; ++i) {
+        const Phase &ph = p->phases[i];
+        const int r = (ph.kind == PH_SGD || ph.kind == PH_GRAD_NORM) ? 1 : reps;
+        HIP_TRY(hipEventRecord(ev[2 * i], s));
+        for (int k = 0; k < r; ++k) {
+            int lrc = 0;
+            switch (ph.kind) {
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, s); break;
+                case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
+                case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
+                case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;
+                case PH_GRAD_NORM: lrc = launch_grad_norm(p->geom, grads, ws, s); break;
+                case PH_SGD: lrc = launch_sgd(p->geom, params, grads, momentum, ws, s); break;
+                default: lrc = -1;
+            }
+            if (lrc != 0) return fail(TA3N_ERR_HIP, "launch failed while timing");
+        }
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        const Phase &ph = p->phases[i];
+        const int r = (ph.kind == PH_SGD || ph.kind == PH_GRAD_NORM) ? 1 : reps;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        ms_out[i] = ms / (float)r;
+        if (kind_out) kind_out[i] = ph.kind;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return n;
 }
 
 int ta3n_sgd_step(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {

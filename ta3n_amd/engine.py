@@ -1,0 +1,231 @@
+"""Fused TA3N train step on one MI355X: forward, loss assembly, backward, gradient
+all-reduce (RCCL, only when world_size > 1), clip + Nesterov SGD - every
+arithmetic op is a HIP kernel of libta3n_hip.so; this module only owns device
+buffers (torch tensors), the stream and the optional hipGraph capture.
+
+It is the host side of what the reference does in main.train (main.py:348-621)
+with VideoModel.forward (models.py:545-722); names follow the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ALL_FLAGS = (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME | _lib.FLAG_ATTN_ENTROPY |
+             _lib.FLAG_TRANS_ATTN)
+
+
+def flags_from_options(place_adv: Sequence[str] = ("Y", "Y", "Y"), add_loss_DA: str = "attentive_entropy",
+                       use_attn: str = "TransAttn", adv_DA: str = "RevGrad", use_target: str = "uSv") -> int:
+    """opts.py flags -> TA3N_FLAG_* (main.py:508-562 conditions)."""
+    f = 0
+    adv_on = adv_DA != "none" and use_target != "none"
+    if adv_on and place_adv[0] == "Y":
+        f |= _lib.FLAG_ADV_RELATION
+    if adv_on and place_adv[1] == "Y":
+        f |= _lib.FLAG_ADV_VIDEO
+    if adv_on and place_adv[2] == "Y":
+        f |= _lib.FLAG_ADV_FRAME
+    if add_loss_DA == "attentive_entropy" and use_attn != "none" and use_target != "none":
+        f |= _lib.FLAG_ATTN_ENTROPY
+    if use_attn == "TransAttn":
+        f |= _lib.FLAG_TRANS_ATTN
+    return f
+
+
+def beta_dann(p: float) -> float:
+    """main.py:351."""
+    return 2.0 / (1.0 + math.exp(-10 * p)) - 1
+
+
+def lr_dann(lr0: float, p: float) -> float:
+    """adjust_learning_rate_dann, main.py:800-802."""
+    return lr0 / (1.0 + 10 * p) ** 0.75
+
+
+class TrainEngine:
+    """Device-resident state of one rank: flat parameters / gradients / momentum,
+    workspace, static input buffers.  Source rows come first in every batch
+    tensor (rows [0, Bs) source, [Bs, Bs+Bt) target)."""
+
+    def __init__(self, batch_source: int, batch_target: int, num_segments: int = 5, feature_dim: int = 2048,
+                 fc_dim: int = 512, num_class: int = 12, flags: int = ALL_FLAGS, dropout_i: float = 0.5,
+                 dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
+                 device: Optional[torch.device] = None, tile_config: int = 0, process_group=None):
+        if not torch.cuda.is_available():
+            raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
+                              tile_config=tile_config)
+        self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
+        self.B = batch_source + batch_target
+        self.F = min(fc_dim, feature_dim)
+        self.dropout_i, self.dropout_v = dropout_i, dropout_v
+        self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        p = self.plan
+        with torch.cuda.device(self.device):
+            self.P = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
+            self.G = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
+            self.M = torch.zeros(p.live_floats, dtype=torch.float32, device=self.device)
+            self.ws = torch.zeros(p.ws_floats, dtype=torch.float32, device=self.device)
+            self.X = torch.zeros(self.B * self.T, self.D, dtype=torch.float32, device=self.device)
+            self._L = _lib.lib()
+            _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws.data_ptr(), self._stream()), "ta3n_init_workspace")
+        off, n = p.region("labels")
+        self._labels = self.ws[off:off + n].view(torch.int32)
+        self.step_count = 0
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._hyper = _lib.Hyper()
+
+    # ---- plumbing ----
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def region(self, name: str, shape=None) -> torch.Tensor:
+        off, n = self.plan.region(name)
+        t = self.ws[off:off + n]
+        return t.view(shape) if shape is not None else t
+
+    def param_views(self, src: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        src = self.P if src is None else src
+        out = {}
+        for name, off, shape, live in self.plan.params:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = src[off:off + n].view(shape)
+        return out
+
+    def load_state(self, state: Dict[str, torch.Tensor]) -> None:
+        """Copy reference-named tensors (state_dict keys, models.py:141-294) into the flat buffer."""
+        views = self.param_views()
+        for k, v in views.items():
+            if k in state:
+                v.copy_(state[k].to(device=self.device, dtype=torch.float32))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().clone() for k, v in self.param_views().items()}
+
+    def live_names(self):
+        return [n for n, _, _, live in self.plan.params if live]
+
+    def set_batch(self, source: torch.Tensor, target: torch.Tensor, source_label: torch.Tensor) -> None:
+        """[Bs,T,D], [Bt,T,D] float features and int labels into the static device buffers."""
+        self.X[: self.Bs * self.T].copy_(source.reshape(-1, self.D), non_blocking=True)
+        self.X[self.Bs * self.T:].copy_(target.reshape(-1, self.D), non_blocking=True)
+        self._labels[: self.Bs].copy_(source_label.to(torch.int32), non_blocking=True)
+
+    def set_hyper(self, beta: Sequence[float], gamma: float, lr: float, train: bool = True,
+                  valid_source: Optional[int] = None, valid_target: Optional[int] = None,
+                  global_source: Optional[int] = None, global_target: Optional[int] = None,
+                  seed: Optional[int] = None) -> None:
+        """Per-step scalars.  global_* are the job-wide valid video counts (all ranks):
+        losses are means over the GLOBAL batch like the reference's DataParallel gather
+        (main.py:446, 533; loss.py:24), so ranks divide by global counts and gradients are SUMMED."""
+        h = self._hyper
+        ns = self.Bs if valid_source is None else valid_source
+        nt = self.Bt if valid_target is None else valid_target
+        gs = ns * self.world if global_source is None else global_source
+        gt = nt * self.world if global_target is None else global_target
+        h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
+        h.gamma, h.lr = float(gamma), float(lr)
+        h.momentum, h.weight_decay = float(self.momentum), float(self.weight_decay)
+        h.clip = float(self.clip) if self.clip is not None else 0.0
+        h.p_drop_i, h.p_drop_v = float(self.dropout_i), float(self.dropout_v)
+        s = self.step_count if seed is None else seed
+        h.seed_i = (0x9E3779B1 * (2 * s + 1)) & 0xFFFFFFFF
+        h.seed_v = (0x85EBCA77 * (2 * s + 2)) & 0xFFFFFFFF
+        tot = max(gs + gt, 1)
+        h.inv_n_cls = 1.0 / max(gs, 1)
+        h.inv_n_rel = 1.0 / (tot * (self.T - 1))
+        h.inv_n_vid = 1.0 / tot
+        h.inv_n_frm = 1.0 / (tot * self.T)
+        h.inv_n_ent = 1.0 / tot
+        h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))
+        _lib.check(self._L.ta3n_set_hyper(self.plan.handle, self.ws.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
+
+    # ---- launches ----
+    def forward(self) -> None:
+        _lib.check(self._L.ta3n_forward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws.data_ptr(),
+                                        self._stream()), "ta3n_forward")
+
+    def loss(self) -> None:
+        _lib.check(self._L.ta3n_loss(self.plan.handle, self.ws.data_ptr(), self._stream()), "ta3n_loss")
+
+    def backward(self) -> None:
+        _lib.check(self._L.ta3n_backward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                         self.ws.data_ptr(), self._stream()), "ta3n_backward")
+
+    def all_reduce_grads(self) -> None:
+        if self.world > 1:
+            torch.distributed.all_reduce(self.G[: self.plan.live_floats], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def sgd_step(self) -> None:
+        _lib.check(self._L.ta3n_sgd_step(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                                         self.ws.data_ptr(), self._stream()), "ta3n_sgd_step")
+
+    def _enqueue_step(self) -> None:
+        self.forward()
+        self.loss()
+        self.backward()
+        self.all_reduce_grads()
+        self.sgd_step()
+
+    def capture(self) -> None:
+        """Capture forward+loss+backward(+all-reduce)+update into one hipGraph (shapes
+        are static).  set_hyper / set_batch stay outside: they only write device buffers."""
+        torch.cuda.synchronize(self.device)
+        keep_p, keep_m = self.P.clone(), self.M.clone()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._enqueue_step()      # warm-up outside capture (lazy RCCL init etc.); state restored below
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.P.copy_(keep_p)
+        self.M.copy_(keep_m)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue_step()
+        self.graph = g
+
+    def train_step(self, beta: Sequence[float], gamma: float, lr: float, **hyper_kw) -> None:
+        """One optimisation step on the batch already in the static buffers."""
+        self.set_hyper(beta, gamma, lr, train=True, **hyper_kw)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue_step()
+        self.step_count += 1
+
+    def time_phases(self, reps: int = 20):
+        """[(kind, tile, n_tasks, ms)] per launch of one train step, HIP events on the launch stream."""
+        n = len(self.plan.description["phases"])
+        ms = (C.c_float * n)()
+        kinds = (C.c_int32 * n)()
+        _lib.check(self._L.ta3n_time_phases(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                            self.M.data_ptr(), self.ws.data_ptr(), self._stream(), reps, ms, kinds, n),
+                   "ta3n_time_phases")
+        return [(int(kinds[i]), ph["tile"], ph["task_count"], float(ms[i]))
+                for i, ph in enumerate(self.plan.description["phases"])]
+
+    # ---- results ----
+    def outputs(self) -> Dict[str, torch.Tensor]:
+        B, T, NR = self.B, self.T, self.T - 1
+        return dict(out=self.region("Y", (B, self.C)), attn=self.region("attn", (B, NR)),
+                    pred_rel=self.region("Pr", (B, NR, 2)), pred_vid=self.region("Pv", (B, 2)),
+                    pred_frm=self.region("Pf", (B, T, 2)), feat_v=self.region("V", (B, -1)),
+                    feat_f1=self.region("F1", (B, T, self.F)))
+
+    def losses(self) -> Dict[str, float]:
+        v = self.region("losses")[:6].tolist()
+        return dict(loss=v[0], loss_c=v[1], loss_adv_rel=v[2], loss_adv_vid=v[3], loss_adv_frm=v[4], loss_e=v[5])

@@ -1,0 +1,220 @@
+"""GPU parity tests (run with -m gpu on a real MI355X).  Everything goes through
+the C ABI of libta3n_hip.so via ta3n_amd.engine; results are compared with
+ (a) the golden vectors produced by the reference itself, and
+ (b) the CPU oracle on the same seeded inputs.
+fp32 tolerance: class and domain logits within 1e-3 absolute of the CPU path at
+trained-scale (O(1..10)) logits - the bound BASELINE.json states - and a
+relative bound on gradients/parameters."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden, case_config, step_schedule
+from ta3n_amd import _lib
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ATOL = 1e-3          # north_star: logits within 1e-3 (fp32)
+RTOL, ATOL = 2e-4, 5e-5    # everything else (fp32 MFMA K-order differs from MKL's)
+
+
+def _engine(c, tile=0, **kw):
+    from ta3n_amd.engine import TrainEngine
+    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0,
+                       clip=c["clip"], tile_config=tile, **kw)
+
+
+def _load(eng, c):
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+
+
+def test_library_loaded_and_device_is_mi355x():
+    L = _lib.lib()
+    assert b"gfx950" in L.ta3n_version()
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("tile", [0, 114, 212, 122, 221])
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps_match_reference_golden(name, tile):
+    if tile not in (0, 114) and name not in ("tiny_T5", "tiny_T9", "headline"):
+        pytest.skip("tile variants checked on three cases")
+    g = Golden(name)
+    c = case_config(g)
+    eng = _engine(c, tile)
+    _load(eng, c)
+    live = set(eng.live_names())
+    B, Bs, T = c["Bs"] + c["Bt"], c["Bs"], c["T"]
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0            # the reference's dummy rows (main.py:359-364)
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"], train=True, valid_source=st["n_src"], valid_target=st["n_tgt"])
+        eng.forward()
+        if s == 0:
+            o = {k: v.detach().cpu() for k, v in eng.outputs().items()}
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", o["out"][sl], 0, LOGIT_ATOL, "class logits")
+                g.check(f"fwd/pd_{dom}_rel", o["pred_rel"][sl], 0, LOGIT_ATOL)
+                g.check(f"fwd/pd_{dom}_vid", o["pred_vid"][sl], 0, LOGIT_ATOL)
+                g.check(f"fwd/pd_{dom}_frm", o["pred_frm"][sl], 0, LOGIT_ATOL)
+                g.check(f"fwd/attn_{dom}", o["attn"][sl], RTOL, ATOL)
+                g.check(f"fwd/feat_{dom}_v", o["feat_v"][sl], RTOL, ATOL)
+                g.check(f"fwd/feat_{dom}_f1", o["feat_f1"][sl], RTOL, ATOL)
+        eng.loss()
+        eng.backward()
+        raw = {k: v.clone() for k, v in eng.param_views(eng.G).items()}
+        eng.sgd_step()
+        torch.cuda.synchronize()
+        coef = eng.region("grad_norm")[1].item()
+        new = eng.param_views()
+        for k in new:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 1e-4)
+            g.check(f"step{s}/param/{k}", new[k].cpu(), RTOL, ATOL)
+
+
+def test_losses_match_reference_log():
+    """Loss scalars vs the values the reference's own log line printed (main.py:590-617)."""
+    g = Golden("headline")
+    c = case_config(g)
+    eng = _engine(c)
+    _load(eng, c)
+    st = step_schedule(c)[0]
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"])
+    eng.forward(); eng.loss()
+    L = eng.losses()
+    log = str(g.meta("log")).splitlines()[0]
+    import re
+    loss = float(re.search(r"Loss ([0-9.]+)", log).group(1))
+    loss_c = float(re.search(r"loss_c ([0-9.]+)", log).group(1))
+    loss_a = float(re.search(r"loss_a ([0-9.]+)", log).group(1))
+    loss_e = float(re.search(r"loss_e ([0-9.]+)", log).group(1))
+    assert abs(L["loss"] - loss) < 2e-4 * max(1, loss)
+    assert abs(L["loss_c"] - loss_c) < 2e-4 * max(1, loss_c)
+    assert abs(L["loss_adv_rel"] + L["loss_adv_vid"] + L["loss_adv_frm"] - loss_a) < 2e-4 * max(1, loss_a)
+    assert abs(L["loss_e"] - loss_e) < 2e-4 * max(1, loss_e)
+
+
+def test_oracle_parity_with_flags_and_ragged_batches():
+    """HIP vs the CPU oracle where no golden fixture exists: some adversarial
+    levels off, very uneven source/target sizes, a batch of one."""
+    from oracle import ta3n_oracle as orc
+    for (Bs, Bt, T, place) in [(1, 1, 3, ("Y", "Y", "Y")), (33, 2, 4, ("Y", "Y", "N")), (7, 40, 5, ("Y", "Y", "Y"))]:
+        cfg = orc.Config(num_class=7, num_segments=T, feature_dim=512, fc_dim=96, dropout_i=0.0, dropout_v=0.0,
+                         place_adv=place)
+        from ta3n_amd.engine import TrainEngine, flags_from_options
+        eng = TrainEngine(Bs, Bt, T, 512, 96, 7, flags=flags_from_options(place), dropout_i=0.0, dropout_v=0.0, clip=20.0)
+        params = synth_state(orc.param_shapes(cfg), seed=3)
+        eng.load_state(params)
+        xs, xt, ys, yt = synth_batch(7, T, 512, Bs, Bt, seed=17)
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.set_hyper([0.3, 0.6, 0.9], 0.05, 1e-3)
+        eng.forward(); eng.loss(); eng.backward(); eng.sgd_step()
+        state = orc.TrainState(params=params, lr=1e-3)
+        res = orc.train_step(state, xs, xt, ys, [0.3, 0.6, 0.9], 0.05, cfg)
+        o = eng.outputs()
+        ref_out = torch.cat((res["src"]["out"], res["tgt"]["out"])).detach()
+        assert (o["out"].cpu() - ref_out).abs().max() < LOGIT_ATOL
+        newp = eng.param_views()
+        for k, v in state.params.items():
+            assert torch.allclose(newp[k].cpu(), v, rtol=RTOL, atol=ATOL), k
+        assert abs(eng.losses()["loss"] - res["loss"].item()) < 5e-4 * max(1.0, abs(res["loss"].item()))
+
+
+def test_bitwise_reproducible_and_graph_replay():
+    """Two runs give identical bits (race smoke test); a captured hipGraph replay
+    gives the same bits as eager launches."""
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    results = []
+    for mode in ("eager", "eager", "graph"):
+        eng = _engine(c)
+        _load(eng, c)
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=5)
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        if mode == "graph":
+            eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3)
+            eng.capture()
+        for _ in range(3):
+            eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3, seed=0)
+        torch.cuda.synchronize()
+        results.append(eng.P.clone())
+    assert torch.equal(results[0], results[1])
+    assert torch.equal(results[0], results[2])
+
+
+def test_dropout_statistics_and_backward_consistency():
+    """nn.Dropout semantics (models.py:574-575, 679-680): keep-rate 1-p, survivors
+    scaled by 1/(1-p), a fresh mask each step, and the backward pass uses the same
+    mask as the forward pass (gradient of dropped video features is zero)."""
+    from ta3n_amd.engine import TrainEngine
+    eng = TrainEngine(64, 64, 5, 512, 128, 12, dropout_i=0.5, dropout_v=0.5)
+    from oracle import ta3n_oracle as orc
+    cfg = orc.Config(num_class=12, num_segments=5, feature_dim=512, fc_dim=128)
+    eng.load_state(synth_state(orc.param_shapes(cfg), seed=1))
+    xs, xt, ys, yt = synth_batch(12, 5, 512, 64, 64, seed=2)
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3, train=False)
+    eng.forward(); torch.cuda.synchronize()
+    f1_eval = eng.region("F1").clone(); v_eval = eng.region("V").clone()
+    masks = []
+    for seed in (1, 2):
+        eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3, train=True, seed=seed)
+        eng.forward(); eng.loss(); eng.backward(); torch.cuda.synchronize()
+        f1 = eng.region("F1")
+        alive = f1_eval > 0
+        kept = (f1 > 0) & alive
+        rate = kept.sum().item() / alive.sum().item()
+        assert abs(rate - 0.5) < 0.01, rate
+        assert torch.allclose(f1[kept], 2 * f1_eval[kept], rtol=1e-6)
+        vd, v = eng.region("Vd"), eng.region("V")
+        keptv = vd != 0
+        assert abs(keptv.float().mean().item() - 0.5) < 0.03
+        assert torch.allclose(vd[keptv], 2 * v[keptv], rtol=1e-6)
+        gvt = eng.region("gVt")
+        assert torch.all(gvt[~keptv] == 0) and (gvt[keptv] != 0).float().mean() > 0.99
+        masks.append(kept.clone())
+    assert (masks[0] != masks[1]).float().mean() > 0.2      # different mask per step
+
+
+def test_full_size_properties():
+    """BASELINE config 2/3 size: properties that need no CPU run - gradient of the
+    frame discriminator path flips sign with beta (GradReverse), zero-padded dummy
+    rows contribute nothing, and the update is finite."""
+    from ta3n_amd.engine import TrainEngine
+    from oracle import ta3n_oracle as orc
+    cfg = orc.Config()
+    params = synth_state(orc.param_shapes(cfg), seed=7)
+    xs, xt, ys, yt = synth_batch(12, 5, 2048, 128, 74, seed=1234)
+
+    def grads(beta, n_src=128, n_tgt=74):
+        eng = TrainEngine(128, 74, 5, 2048, 512, 12, flags=_lib.FLAG_ADV_FRAME | _lib.FLAG_TRANS_ATTN,
+                          dropout_i=0.0, dropout_v=0.0)
+        eng.load_state(params)
+        a, b = xs.clone(), xt.clone()
+        a[n_src:] = 0; b[n_tgt:] = 0
+        eng.set_batch(a.cuda(), b.cuda(), ys.cuda())
+        eng.set_hyper(beta, 0.0, 1e-3, valid_source=n_src, valid_target=n_tgt)
+        eng.forward(); eng.loss(); eng.backward(); torch.cuda.synchronize()
+        return {k: v.clone() for k, v in eng.param_views(eng.G).items()}, eng
+
+    g_pos, _ = grads([0.0, 0.0, 1.0])
+    g_zero, _ = grads([0.0, 0.0, 0.0])
+    g_neg, _ = grads([0.0, 0.0, -1.0])
+    k = "fc_feature_shared_source.weight"
+    adv_pos = g_pos[k] - g_zero[k]; adv_neg = g_neg[k] - g_zero[k]
+    assert adv_pos.abs().max() > 0
+    assert torch.allclose(adv_pos, -adv_neg, rtol=1e-3, atol=1e-7)          # linear in beta, sign flips
+    # the discriminator's own weights do not see beta
+    assert torch.allclose(g_pos["fc_feature_domain.weight"], g_neg["fc_feature_domain.weight"], rtol=1e-5, atol=1e-8)
+    # dummy rows: shrinking the valid counts == dropping those rows from the loss
+    g_short, eng = grads([0.0, 0.0, 1.0], n_src=100, n_tgt=50)
+    assert all(torch.isfinite(v).all() for v in g_short.values())
+    gy = eng.region("gY", (202, 12))
+    assert torch.all(gy[100:128] == 0) and torch.all(gy[128 + 50:] == 0)
