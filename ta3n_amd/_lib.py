@@ -10,6 +10,10 @@ import json
 import os
 from typing import Dict, List, Optional, Tuple
 
+# torch bundles its own libamdhip64; it must be in the process BEFORE libta3n_hip.so is
+# dlopen'ed so both resolve to ONE HIP runtime (otherwise the second runtime sees no device).
+import torch  # noqa: F401
+
 _LIB: Optional[C.CDLL] = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libta3n_hip.so")
 
@@ -33,7 +37,7 @@ class Config(C.Structure):
     _fields_ = [("batch_source", C.c_int32), ("batch_target", C.c_int32), ("num_segments", C.c_int32),
                 ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
                 ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Hyper(C.Structure):
@@ -128,10 +132,14 @@ class Plan:
     """Owns a ta3n_plan handle and caches its layout tables."""
 
     def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
-                 num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0):
+                 num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0,
+                 phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0):
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
+        for i, t in enumerate(phase_tiles or []):
+            self.cfg.phase_tiles[i] = int(t)
+        self.cfg.xcd_aware = int(xcd_aware)
         h = C.c_void_p()
         check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
         self.handle = h

@@ -38,50 +38,78 @@ constexpr int NTHREADS = 256;
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // rows x 64 chunk of one operand -> registers.  R = rows of the tile (32 or 64).
+// Branch-free per lane: out-of-range elements are read from a clamped in-range
+// address and replaced by 0 with a select, so hipcc emits straight-line loads
+// (per-element "if (valid) load" compiles to an exec-masked branch with its own
+// s_waitcnt vmcnt(0) per element and serialises the whole stage).  The only
+// branch is wave-uniform: float4 path when the operand is 16-byte tileable.
+__device__ __forceinline__ float sel(bool c, float a) { return c ? a : 0.f; }
+
 template <int R>
 __device__ __forceinline__ void g2r(float4 (&v)[R / 16], const float *__restrict__ base, int off, int ld, int kmajor,
                                     int r0, int rvalid, int k0, int klen, int tid) {
-    const bool vec = ((off | ld) & 3) == 0;
+    const float *__restrict__ origin = base + (size_t)off;
     if (!kmajor) {
-        const int kq = (tid & 15) * 4;
-        const int k = k0 + kq;
+        // element (row, k) at row*ld + k ; this lane: 4 consecutive k of R/16 rows
+        const bool vec = ((off | ld | klen) & 3) == 0;
+        const int k = k0 + (tid & 15) * 4;
+        if (vec) {
+            const bool kin = k < klen;              // klen % 4 == 0: the float4 is all-in or all-out
+            const int kc = kin ? k : 0;
 #pragma unroll
-        for (int i = 0; i < R / 16; ++i) {
-            const int row = r0 + (tid >> 4) + 16 * i;
-            float4 x = zero4();
-            if (row < rvalid && k < klen) {
-                const float *p = base + (size_t)off + (size_t)row * ld + k;
-                if (vec && k + 3 < klen) {
-                    x = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    x.x = p[0];
-                    if (k + 1 < klen) x.y = p[1];
-                    if (k + 2 < klen) x.z = p[2];
-                    if (k + 3 < klen) x.w = p[3];
-                }
+            for (int i = 0; i < R / 16; ++i) {
+                const int row = r0 + (tid >> 4) + 16 * i;
+                const bool ok = kin && row < rvalid;
+                const int rc = row < rvalid ? row : rvalid - 1;
+                const float4 x = *reinterpret_cast<const float4 *>(origin + (size_t)rc * ld + kc);
+                v[i] = make_float4(sel(ok, x.x), sel(ok, x.y), sel(ok, x.z), sel(ok, x.w));
             }
-            v[i] = x;
+        } else {
+#pragma unroll
+            for (int i = 0; i < R / 16; ++i) {
+                const int row = r0 + (tid >> 4) + 16 * i;
+                const bool rok = row < rvalid;
+                const float *__restrict__ pr = origin + (size_t)(rok ? row : rvalid - 1) * ld;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rok && (k + j) < klen;
+                    e[j] = sel(ok, pr[ok ? k + j : 0]);
+                }
+                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
         }
     } else {
+        // element (r, k) at k*ld + r ; this lane: 4 consecutive r of R/16 k-rows
         constexpr int TPR = R / 4;          // threads per k row
         constexpr int KPP = NTHREADS / TPR;  // k rows per pass
+        const bool vec = ((off | ld | rvalid) & 3) == 0;
         const int col = r0 + (tid % TPR) * 4;
+        if (vec) {
+            const bool cin = col < rvalid;          // rvalid % 4 == 0
+            const int cc = cin ? col : 0;
 #pragma unroll
-        for (int i = 0; i < R / 16; ++i) {
-            const int k = k0 + tid / TPR + KPP * i;
-            float4 x = zero4();
-            if (k < klen && col < rvalid) {
-                const float *p = base + (size_t)off + (size_t)k * ld + col;
-                if (vec && col + 3 < rvalid) {
-                    x = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    x.x = p[0];
-                    if (col + 1 < rvalid) x.y = p[1];
-                    if (col + 2 < rvalid) x.z = p[2];
-                    if (col + 3 < rvalid) x.w = p[3];
-                }
+            for (int i = 0; i < R / 16; ++i) {
+                const int k = k0 + tid / TPR + KPP * i;
+                const bool ok = cin && k < klen;
+                const int kc = k < klen ? k : klen - 1;
+                const float4 x = *reinterpret_cast<const float4 *>(origin + (size_t)kc * ld + cc);
+                v[i] = make_float4(sel(ok, x.x), sel(ok, x.y), sel(ok, x.z), sel(ok, x.w));
             }
-            v[i] = x;
+        } else {
+#pragma unroll
+            for (int i = 0; i < R / 16; ++i) {
+                const int k = k0 + tid / TPR + KPP * i;
+                const bool kok = k < klen;
+                const float *__restrict__ pr = origin + (size_t)(kok ? k : klen - 1) * ld;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = kok && (col + j) < rvalid;
+                    e[j] = sel(ok, pr[ok ? col + j : 0]);
+                }
+                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
         }
     }
 }
@@ -143,6 +171,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     const Task &t = tasks[blockIdx.x];
+    if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
 
     float4 ra[BM / 16], rb[BN / 16];

@@ -90,11 +90,16 @@ struct Builder {
         return r.off;
     }
 
+    int gemm_phase_index = 0;
+
     // expand GEMM specs into tile tasks of one phase
     void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
         int wm = 1, wn = 1, wk = 4;
-        if (p.cfg.tile_config != 0) {
-            wm = p.cfg.tile_config / 100; wn = (p.cfg.tile_config / 10) % 10; wk = p.cfg.tile_config % 10;
+        int forced = p.cfg.tile_config;
+        if (gemm_phase_index < 16 && p.cfg.phase_tiles[gemm_phase_index] != 0) forced = p.cfg.phase_tiles[gemm_phase_index];
+        ++gemm_phase_index;
+        if (forced != 0) {
+            wm = forced / 100; wn = (forced / 10) % 10; wk = forced % 10;
         } else {
             // heuristic: largest tile that still yields >= ~1.5 waves of 256 CUs worth of blocks
             auto count = [&](int bm, int bn) {
@@ -111,22 +116,63 @@ struct Builder {
         std::memset(&ph, 0, sizeof(ph));
         ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk;
         ph.task_begin = (int32_t)p.tasks.size();
-        std::vector<Task> local;
+        // A "panel" is the set of tiles of one GEMM that share an operand slab: all
+        // column tiles of one row tile when the A side (M*K) is the larger operand,
+        // all row tiles of one column tile otherwise.  Panels are dealt to 8 queues
+        // (one per XCD: workgroup b runs on XCD b % 8 - a speed assumption only) so
+        // the larger operand is partitioned across the private L2s and only the
+        // smaller one is replicated.
+        struct Panel { std::vector<Task> tiles; int64_t cost; };
+        std::vector<Panel> panels;
         for (auto &g : specs) {
             const int seg_begin = (int)p.segs.size();
             int cost = 0;
             for (auto &s : g.segs) { p.segs.push_back(s); cost += (s.klen + 63) / 64 * 64; }
-            for (int m0 = 0; m0 < g.M; m0 += BM)
-                for (int n0 = 0; n0 < g.N; n0 += BN) {
+            const bool split_m = g.M >= g.N;
+            const int outer = split_m ? g.M : g.N, inner = split_m ? g.N : g.M;
+            const int bo = split_m ? BM : BN, bi = split_m ? BN : BM;
+            for (int o0 = 0; o0 < outer; o0 += bo) {
+                Panel pn;
+                pn.cost = 0;
+                for (int i0 = 0; i0 < inner; i0 += bi) {
                     Task t = g.proto;
-                    t.m0 = m0; t.n0 = n0; t.m_valid = g.M; t.n_valid = g.N;
+                    t.m0 = split_m ? o0 : i0; t.n0 = split_m ? i0 : o0;
+                    t.m_valid = g.M; t.n_valid = g.N;
                     t.seg_begin = seg_begin; t.seg_count = (int)g.segs.size();
                     t.cost = cost;
-                    local.push_back(t);
+                    pn.tiles.push_back(t);
+                    pn.cost += cost;
                 }
+                panels.push_back(pn);
+            }
         }
-        // longest tasks first (blocks are dispatched in order); stable to keep panel locality
-        std::stable_sort(local.begin(), local.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+        std::vector<Task> local;
+        if (p.cfg.xcd_aware == 2) {
+            for (auto &pn : panels) for (auto &t : pn.tiles) local.push_back(t);
+            std::stable_sort(local.begin(), local.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+        } else {
+            constexpr int NX = 8;
+            std::stable_sort(panels.begin(), panels.end(), [](const Panel &a, const Panel &b) { return a.cost > b.cost; });
+            std::vector<std::vector<Task>> q(NX);
+            std::vector<int64_t> load(NX, 0);
+            for (auto &pn : panels) {   // heaviest panel first onto the least loaded XCD queue
+                int best = 0;
+                for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
+                for (auto &t : pn.tiles) q[best].push_back(t);
+                load[best] += pn.cost;
+            }
+            size_t depth = 0;
+            for (auto &v : q) {
+                std::stable_sort(v.begin(), v.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+                depth = std::max(depth, v.size());
+            }
+            Task nop;
+            std::memset(&nop, 0, sizeof(nop));   // seg_count == 0: the workgroup exits immediately
+            nop.c_base = BASE_NONE; nop.bias_base = BASE_NONE; nop.aux_base = BASE_NONE; nop.add_base = BASE_NONE;
+            for (size_t d = 0; d < depth; ++d)
+                for (int x = 0; x < NX; ++x) local.push_back(d < q[x].size() ? q[x][d] : nop);
+            while (!local.empty() && local.back().seg_count == 0) local.pop_back();
+        }
         for (auto &t : local) p.tasks.push_back(t);
         ph.task_count = (int32_t)local.size();
         p.phases.push_back(ph);
@@ -158,13 +204,11 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         err = "attentive_entropy requires place_adv[0]=='Y' and place_adv[1]=='Y'";
         return TA3N_ERR_INVALID;
     }
-    if (c.tile_config != 0) {
-        int wm = c.tile_config / 100, wn = (c.tile_config / 10) % 10, wk = c.tile_config % 10;
-        if (wm * wn * wk != 4 || !(c.tile_config == 114 || c.tile_config == 212 || c.tile_config == 122 || c.tile_config == 221)) {
-            err = "tile_config must be one of 0, 114, 212, 122, 221";
-            return TA3N_ERR_INVALID;
-        }
-    }
+    auto tile_ok = [](int t) { return t == 0 || t == 114 || t == 212 || t == 122 || t == 221; };
+    if (!tile_ok(c.tile_config)) { err = "tile_config must be one of 0, 114, 212, 122, 221"; return TA3N_ERR_INVALID; }
+    for (int i = 0; i < 16; ++i)
+        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be one of 0, 114, 212, 122, 221"; return TA3N_ERR_INVALID; }
+    if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
 

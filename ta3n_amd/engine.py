@@ -56,12 +56,13 @@ class TrainEngine:
     def __init__(self, batch_source: int, batch_target: int, num_segments: int = 5, feature_dim: int = 2048,
                  fc_dim: int = 512, num_class: int = 12, flags: int = ALL_FLAGS, dropout_i: float = 0.5,
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
-                 device: Optional[torch.device] = None, tile_config: int = 0, process_group=None):
+                 device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
+                 phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
-                              tile_config=tile_config)
+                              tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware)
         self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
         self.B = batch_source + batch_target
         self.F = min(fc_dim, feature_dim)
@@ -218,6 +219,9 @@ class TrainEngine:
         return [(int(kinds[i]), ph["tile"], ph["task_count"], float(ms[i]))
                 for i, ph in enumerate(self.plan.description["phases"])]
 
+    def gemm_phase_times(self, reps: int = 20):
+        return [ms for kind, _, _, ms in self.time_phases(reps) if kind == 0]
+
     # ---- results ----
     def outputs(self) -> Dict[str, torch.Tensor]:
         B, T, NR = self.B, self.T, self.T - 1
@@ -229,3 +233,28 @@ class TrainEngine:
     def losses(self) -> Dict[str, float]:
         v = self.region("losses")[:6].tolist()
         return dict(loss=v[0], loss_c=v[1], loss_adv_rel=v[2], loss_adv_vid=v[3], loss_adv_frm=v[4], loss_e=v[5])
+
+
+def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
+                         num_class: int, flags: int = ALL_FLAGS, device=None, reps: int = 10,
+                         candidates: Sequence[int] = (114, 212, 122, 221), verbose: bool = False):
+    """Pick the fastest GEMM tile shape per launch by measuring each candidate on this
+    GPU (HIP events on the launch stream).  Returns (phase_tiles, table)."""
+    table = {}
+    for cand in candidates:
+        eng = TrainEngine(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags=flags,
+                          device=device, tile_config=cand)
+        eng.X.uniform_(0, 1)
+        for v in eng.param_views().values():
+            v.normal_(0, 0.02)
+        eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3)
+        eng.gemm_phase_times(2)
+        table[cand] = eng.gemm_phase_times(reps)
+        del eng
+    n = len(next(iter(table.values())))
+    best = [min(candidates, key=lambda c: table[c][i]) for i in range(n)]
+    if verbose:
+        for i in range(n):
+            print(f"[autotune] gemm phase {i}: " + "  ".join(f"{c}:{1e3 * table[c][i]:.1f}us" for c in candidates) +
+                  f"  -> {best[i]}", flush=True)
+    return best, table

