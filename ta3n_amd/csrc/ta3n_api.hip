@@ -58,7 +58,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
         switch (ph.kind) {
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
-                                 p->geom.o_hyper, stream);
+                                 p->geom.o_hyper, p->geom.o_zeros, stream);
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -270,7 +270,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         for (int k = 0; k < r; ++k) {
             int lrc = 0;
             switch (ph.kind) {
-                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, s); break;
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, s); break;
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;

@@ -38,16 +38,17 @@ constexpr int NTHREADS = 256;
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // rows x 64 chunk of one operand -> registers.  R = rows of the tile (32 or 64).
-// Branch-free per lane: out-of-range elements are read from a clamped in-range
-// address and replaced by 0 with a select, so hipcc emits straight-line loads
-// (per-element "if (valid) load" compiles to an exec-masked branch with its own
-// s_waitcnt vmcnt(0) per element and serialises the whole stage).  The only
-// branch is wave-uniform: float4 path when the operand is 16-byte tileable.
-__device__ __forceinline__ float sel(bool c, float a) { return c ? a : 0.f; }
-
+// Branch-free AND select-free per lane: an out-of-range element is read from a
+// 16-byte block of zeros in the workspace (the validity test selects the ADDRESS,
+// not the loaded value).  The loaded registers are therefore first touched by the
+// LDS write of the NEXT iteration, so the loads stay in flight across the MFMAs of
+// the current chunk.  (A per-element "if (valid) load" compiles to an exec-masked
+// branch with its own s_waitcnt vmcnt(0); a select on the loaded value makes hipcc
+// wait for each load right after issuing it.)  The only branch is wave-uniform:
+// float4 path when the operand is 16-byte tileable.
 template <int R>
 __device__ __forceinline__ void g2r(float4 (&v)[R / 16], const float *__restrict__ base, int off, int ld, int kmajor,
-                                    int r0, int rvalid, int k0, int klen, int tid) {
+                                    int r0, int rvalid, int k0, int klen, int tid, const float *__restrict__ zeros) {
     const float *__restrict__ origin = base + (size_t)off;
     if (!kmajor) {
         // element (row, k) at row*ld + k ; this lane: 4 consecutive k of R/16 rows
@@ -55,28 +56,22 @@ __device__ __forceinline__ void g2r(float4 (&v)[R / 16], const float *__restrict
         const int k = k0 + (tid & 15) * 4;
         if (vec) {
             const bool kin = k < klen;              // klen % 4 == 0: the float4 is all-in or all-out
-            const int kc = kin ? k : 0;
 #pragma unroll
             for (int i = 0; i < R / 16; ++i) {
                 const int row = r0 + (tid >> 4) + 16 * i;
-                const bool ok = kin && row < rvalid;
-                const int rc = row < rvalid ? row : rvalid - 1;
-                const float4 x = *reinterpret_cast<const float4 *>(origin + (size_t)rc * ld + kc);
-                v[i] = make_float4(sel(ok, x.x), sel(ok, x.y), sel(ok, x.z), sel(ok, x.w));
+                const float *p = (kin && row < rvalid) ? origin + (size_t)row * ld + k : zeros;
+                v[i] = *reinterpret_cast<const float4 *>(p);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < R / 16; ++i) {
                 const int row = r0 + (tid >> 4) + 16 * i;
+                const float *pr = origin + (size_t)row * ld + k;
                 const bool rok = row < rvalid;
-                const float *__restrict__ pr = origin + (size_t)(rok ? row : rvalid - 1) * ld;
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = rok && (k + j) < klen;
-                    e[j] = sel(ok, pr[ok ? k + j : 0]);
-                }
-                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+                v[i].x = *((rok && k + 0 < klen) ? pr + 0 : zeros);
+                v[i].y = *((rok && k + 1 < klen) ? pr + 1 : zeros);
+                v[i].z = *((rok && k + 2 < klen) ? pr + 2 : zeros);
+                v[i].w = *((rok && k + 3 < klen) ? pr + 3 : zeros);
             }
         }
     } else {
@@ -87,28 +82,22 @@ __device__ __forceinline__ void g2r(float4 (&v)[R / 16], const float *__restrict
         const int col = r0 + (tid % TPR) * 4;
         if (vec) {
             const bool cin = col < rvalid;          // rvalid % 4 == 0
-            const int cc = cin ? col : 0;
 #pragma unroll
             for (int i = 0; i < R / 16; ++i) {
                 const int k = k0 + tid / TPR + KPP * i;
-                const bool ok = cin && k < klen;
-                const int kc = k < klen ? k : klen - 1;
-                const float4 x = *reinterpret_cast<const float4 *>(origin + (size_t)kc * ld + cc);
-                v[i] = make_float4(sel(ok, x.x), sel(ok, x.y), sel(ok, x.z), sel(ok, x.w));
+                const float *p = (cin && k < klen) ? origin + (size_t)k * ld + col : zeros;
+                v[i] = *reinterpret_cast<const float4 *>(p);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < R / 16; ++i) {
                 const int k = k0 + tid / TPR + KPP * i;
+                const float *pr = origin + (size_t)k * ld + col;
                 const bool kok = k < klen;
-                const float *__restrict__ pr = origin + (size_t)(kok ? k : klen - 1) * ld;
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = kok && (col + j) < rvalid;
-                    e[j] = sel(ok, pr[ok ? col + j : 0]);
-                }
-                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+                v[i].x = *((kok && col + 0 < rvalid) ? pr + 0 : zeros);
+                v[i].y = *((kok && col + 1 < rvalid) ? pr + 1 : zeros);
+                v[i].z = *((kok && col + 2 < rvalid) ? pr + 2 : zeros);
+                v[i].w = *((kok && col + 3 < rvalid) ? pr + 3 : zeros);
             }
         }
     }
@@ -157,7 +146,7 @@ namespace ta3n {
 
 template <int WM, int WN, int WK>
 __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
-                                                        Ptrs ptrs, int hyper_off) {
+                                                        Ptrs ptrs, int hyper_off, int zeros_off) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int KW = BKC / WK;                 // k per wave per chunk
     constexpr int LA = BKC * (BM + 4), LB = BKC * (BN + 4);
@@ -173,6 +162,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     const Task &t = tasks[blockIdx.x];
     if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
+    const float *__restrict__ zeros = ptrs.ws + zeros_off;   // 64 floats that are never written
 
     float4 ra[BM / 16], rb[BN / 16];
     f32x16 acc;
@@ -181,8 +171,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
 
     int seg = 0, k0 = 0;
     Seg s = segs[t.seg_begin];
-    g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid);
-    g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid);
+    g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid, zeros);
+    g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid, zeros);
     int buf = 0;
     for (;;) {
         float *sa = lds + buf * BUF;
@@ -207,8 +197,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
             else more = false;
         }
         if (more) {
-            g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid);
-            g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid);
+            g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid, zeros);
+            g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid, zeros);
         }
         // MFMA over this wave's K slice of the chunk, 8 k (4 MFMAs) per group
         const float *pa = sa + (wk * KW + lh) * stride_a + wm * 32 + li;
@@ -251,10 +241,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && hy->train != 0;
     const uint32_t dseed = (epi & EPI_DROP_I) ? hy->seed_i : hy->seed_v;
     const float dp = (epi & EPI_DROP_I) ? hy->p_drop_i : hy->p_drop_v;
-    float *__restrict__ cbase = const_cast<float *>(base_ptr(ptrs, t.c_base));
+    float *__restrict__ cbase = const_cast<float *>(base_ptr(ptrs, t.c_base)) + (size_t)t.c_off;
+    // Operand reads are address-selected (absent / out-of-range -> a block of zeros, or of
+    // ones for the mask) so that all of a thread's epilogue loads issue together.
+    const float *__restrict__ ones = zeros + 64;   // region "ones" follows region "zeros" (plan builder)
     const float *__restrict__ bias = (epi & EPI_BIAS) ? base_ptr(ptrs, t.bias_base) + t.bias_off : nullptr;
     const float *__restrict__ aux = (epi & EPI_MASK) ? base_ptr(ptrs, t.aux_base) + t.aux_off : nullptr;
     const float *__restrict__ add = (epi & EPI_ADD) ? base_ptr(ptrs, t.add_base) + t.add_off : nullptr;
+    const bool c_vec = ((t.c_off | t.c_ld) & 3) == 0;
+    const int nfan = t.fan_count;
 
     for (int idx = tid; idx < BM * BN / 4; idx += NTHREADS) {
         const int r = idx / (BN / 4);
@@ -267,57 +262,65 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
             v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
         }
         const int m = t.m0 + r, n = t.n0 + c4;
-        if (m >= t.m_valid || n >= t.n_valid) continue;
+        const bool row_ok = m < t.m_valid;
+        const int nrem = row_ok ? t.n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const int nrem = t.n_valid - n;   // >= 1
+        float bv[4], av[4], mv[4], fm[3][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (e < nrem) {
-                float x = v[e];
-                if (bias) x += bias[n + e];
-                x *= alpha;
-                if (add) x += add[(size_t)m * t.add_ld + n + e];
-                if (epi & EPI_RELU) x = fmaxf(x, 0.f);
-                if (aux) x = aux[(size_t)m * t.aux_ld + n + e] > 0.f ? x : 0.f;
-                if (drop_on) x *= keep_mask(dseed, (uint32_t)(m * t.drop_ld + n + e), dp);
-                x *= gamma;
-                v[e] = x;
-            }
+            const bool ok = e < nrem;
+            bv[e] = *((ok && bias) ? bias + n + e : zeros);
+            av[e] = *((ok && add) ? add + (size_t)m * t.add_ld + n + e : zeros);
+            mv[e] = *((ok && aux) ? aux + (size_t)m * t.aux_ld + n + e : ones);
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                fm[f][e] = *((ok && f < nfan) ? ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n + e : zeros);
         }
-        float *cp = cbase + (size_t)t.c_off + (size_t)m * t.c_ld + n;
-        if (nrem >= 4 && ((t.c_off | t.c_ld) & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = (v[e] + bv[e]) * alpha + av[e];
+            if (epi & EPI_RELU) x = fmaxf(x, 0.f);
+            x = mv[e] > 0.f ? x : 0.f;
+            if (drop_on) x *= keep_mask(dseed, (uint32_t)(m * t.drop_ld + n + e), dp);
+            v[e] = x * gamma;
+        }
+        if (nrem <= 0) continue;
+        float *cp = cbase + (size_t)m * t.c_ld + n;
+        if (nrem >= 4 && c_vec) {
             *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (e < nrem) cp[e] = v[e];
         }
-        for (int f = 0; f < t.fan_count; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
-            const float *mk = ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n;
-            float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < nrem) op[e] = mk[e] > 0.f ? v[e] : 0.f;
+        for (int f = 0; f < 3; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
+            if (f < nfan) {
+                float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nrem) op[e] = fm[f][e] > 0.f ? v[e] : 0.f;
+            }
         }
     }
 }
 
-template __global__ void gemm_tiles<1, 1, 4>(const Task *, const Seg *, Ptrs, int);
-template __global__ void gemm_tiles<2, 1, 2>(const Task *, const Seg *, Ptrs, int);
-template __global__ void gemm_tiles<1, 2, 2>(const Task *, const Seg *, Ptrs, int);
-template __global__ void gemm_tiles<2, 2, 1>(const Task *, const Seg *, Ptrs, int);
+template __global__ void gemm_tiles<1, 1, 4>(const Task *, const Seg *, Ptrs, int, int);
+template __global__ void gemm_tiles<2, 1, 2>(const Task *, const Seg *, Ptrs, int, int);
+template __global__ void gemm_tiles<1, 2, 2>(const Task *, const Seg *, Ptrs, int, int);
+template __global__ void gemm_tiles<2, 2, 1>(const Task *, const Seg *, Ptrs, int, int);
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                hipStream_t stream) {
+                int zeros_off, hipStream_t stream) {
     if (ph.task_count == 0) return 0;
     const dim3 grid(ph.task_count), block(NTHREADS);
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     switch (cfg) {
-        case 114: hipLaunchKernelGGL((gemm_tiles<1, 1, 4>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off); break;
-        case 212: hipLaunchKernelGGL((gemm_tiles<2, 1, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off); break;
-        case 122: hipLaunchKernelGGL((gemm_tiles<1, 2, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off); break;
-        case 221: hipLaunchKernelGGL((gemm_tiles<2, 2, 1>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off); break;
+        case 114: hipLaunchKernelGGL((gemm_tiles<1, 1, 4>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
+        case 212: hipLaunchKernelGGL((gemm_tiles<2, 1, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
+        case 122: hipLaunchKernelGGL((gemm_tiles<1, 2, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
+        case 221: hipLaunchKernelGGL((gemm_tiles<2, 2, 1>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -47,7 +47,7 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                hipStream_t stream);
+                int zeros_off, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

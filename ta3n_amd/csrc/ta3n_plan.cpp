@@ -292,7 +292,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     g.o_gR = (int32_t)b.add_region("gR", (int64_t)B * NR * NB);
     g.o_gZ = (int32_t)b.add_region("gZ", (int64_t)B * NT * NB);
     g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
+    g.o_zeros = (int32_t)b.add_region("zeros", 64);   // never written: source of out-of-range operand elements
     g.o_ones = (int32_t)b.add_region("ones", BT);
+    if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
     g.o_losses = (int32_t)b.add_region("losses", 8);
     g.n_norm_blocks = 256;
     g.o_norm_part = (int32_t)b.add_region("norm_part", g.n_norm_blocks);

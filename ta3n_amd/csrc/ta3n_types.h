@@ -95,7 +95,7 @@ struct Geom {
     // workspace offsets (elements)
     int32_t o_F1, o_Hf, o_Pf, o_Zr, o_Hr, o_Pr, o_R, o_attn, o_V, o_Vd, o_Y, o_Hv, o_Pv;
     int32_t o_gY, o_gPv, o_gPr, o_gPf, o_gattn, o_gHv, o_gHf, o_gVt, o_gPrT, o_gRa, o_gHr, o_gR, o_gZ, o_gZ1;
-    int32_t o_ones, o_losses, o_norm_part, o_grad_norm, o_hyper, o_labels, o_tuple_first;
+    int32_t o_zeros, o_ones, o_losses, o_norm_part, o_grad_norm, o_hyper, o_labels, o_tuple_first;
     int32_t n_norm_blocks;
     int32_t live_floats;
     // relation discriminator second layers inside the flat parameter buffer

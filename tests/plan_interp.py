@@ -40,7 +40,7 @@ class Phase(C.Structure):
 _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", "flags",
                 "o_F1", "o_Hf", "o_Pf", "o_Zr", "o_Hr", "o_Pr", "o_R", "o_attn", "o_V", "o_Vd", "o_Y", "o_Hv", "o_Pv",
                 "o_gY", "o_gPv", "o_gPr", "o_gPf", "o_gattn", "o_gHv", "o_gHf", "o_gVt", "o_gPrT", "o_gRa", "o_gHr",
-                "o_gR", "o_gZ", "o_gZ1", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
+                "o_gR", "o_gZ", "o_gZ1", "o_zeros", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride"]
 
 
