@@ -1,0 +1,11 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ta3n_amd.engine import TrainEngine
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 114
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile)
+eng.X.uniform_(0, 1)
+for v in eng.param_views().values(): v.normal_(0, 0.02)
+eng.set_hyper([0.75,0.75,0.5], 0.003, 1e-3)
+for _ in range(3):
+    eng.forward(); eng.loss(); eng.backward(); eng.sgd_step()
+torch.cuda.synchronize()
