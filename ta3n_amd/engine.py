@@ -15,6 +15,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
+from . import parallel
 
 ALL_FLAGS = (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME | _lib.FLAG_ATTN_ENTROPY |
              _lib.FLAG_TRANS_ATTN)
@@ -145,12 +146,8 @@ class TrainEngine:
         s = self.step_count if seed is None else seed
         h.seed_i = (0x9E3779B1 * (2 * s + 1)) & 0xFFFFFFFF
         h.seed_v = (0x85EBCA77 * (2 * s + 2)) & 0xFFFFFFFF
-        tot = max(gs + gt, 1)
-        h.inv_n_cls = 1.0 / max(gs, 1)
-        h.inv_n_rel = 1.0 / (tot * (self.T - 1))
-        h.inv_n_vid = 1.0 / tot
-        h.inv_n_frm = 1.0 / (tot * self.T)
-        h.inv_n_ent = 1.0 / tot
+        for k, v in parallel.loss_normalisers(gs, gt, self.T).items():
+            setattr(h, k, v)
         h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))
         _lib.check(self._L.ta3n_set_hyper(self.plan.handle, self.ws.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
 
@@ -168,7 +165,7 @@ class TrainEngine:
 
     def all_reduce_grads(self) -> None:
         if self.world > 1:
-            torch.distributed.all_reduce(self.G[: self.plan.live_floats], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            parallel.all_reduce_sum_(self.G[: self.plan.live_floats], self.pg)
 
     def sgd_step(self) -> None:
         _lib.check(self._L.ta3n_sgd_step(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),

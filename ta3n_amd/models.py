@@ -1,0 +1,292 @@
+"""`VideoModel` - the reference's model surface (models.py:59-67 ctor, :545-722
+forward, state_dict keys of models.py:141-294 / TRNmodule.py:44-54) on top of
+libta3n_hip.so.  `main.py`/`test_models.py` of the reference construct it, call
+`forward(input_source, input_target, beta, mu, is_train, reverse)`, read the
+10-tuple, back-propagate through it with autograd and save/load its state_dict;
+all of that works here, with every arithmetic op of forward and backward executed
+by the HIP kernels (no eager-PyTorch or CPU fallback: calling forward without the
+HIP library or without a GPU raises).
+
+Supported configuration = the TA3N hot path:
+frame_aggregation='trn-m', baseline_type='video', share_params='Y', use_bn='none',
+add_fc=1, ens_DA='none', use_attn in {'TransAttn','none'}, use_attn_frame='none'.
+Anything else raises NotImplementedError at construction (several of those
+branches are broken in the reference itself).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .TRNmodule import RelationModuleMultiScale
+
+torch.manual_seed(1)          # models.py:14 seeds at import; kept so default inits are reproducible
+
+# models.py:125-126 reads torchvision.models.<arch>(True).fc.in_features; torchvision is
+# not a dependency here, the table below is that lookup.
+ARCH_FEATURE_DIM = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnet101": 2048, "resnet152": 2048,
+                    "c3d": 4096}
+
+
+class GradReverse(torch.autograd.Function):
+    """models.py:20-29.  Exported for API compatibility; inside VideoModel the
+    reversal is folded into the discriminator input-gradient GEMMs as a -beta scale."""
+
+    @staticmethod
+    def forward(ctx, x, beta):
+        ctx.beta = beta
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output.neg() * ctx.beta, None
+
+
+class _HipForward(torch.autograd.Function):
+    """One autograd node for the whole forward; backward = ta3n_backward."""
+
+    @staticmethod
+    def forward(ctx, model, xs, xt, beta, train, *params):
+        dev = model._flat.device
+        Bs, Bt = xs.shape[0], xt.shape[0]
+        plan = model._plan(Bs, Bt)
+        x = torch.cat((xs.reshape(Bs * model.train_segments, -1), xt.reshape(Bt * model.train_segments, -1)), 0)
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        ws = model._ws_template(plan).clone()
+        h = _lib.Hyper()
+        h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
+        h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,))       # consumes the global torch RNG like nn.Dropout would
+        h.seed_i, h.seed_v = int(seeds[0]), int(seeds[1])
+        h.valid_source, h.valid_target, h.train = Bs, Bt, int(bool(train))
+        h.inv_n_cls = h.inv_n_rel = h.inv_n_vid = h.inv_n_frm = h.inv_n_ent = 0.0   # the loss kernel is not used on this path
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
+        _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
+        ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
+        ctx.n_params = len(params)
+        B, T, NR, Cn = Bs + Bt, model.train_segments, model.train_segments - 1, model.num_class
+
+        def reg(name, shape):
+            off, n = plan.region(name)
+            return ws[off:off + n].view(shape).clone()
+
+        attn, y = reg("attn", (B, NR)), reg("Y", (B, Cn))
+        pr, pv, pf = reg("Pr", (B, NR, 2)), reg("Pv", (B, 2)), reg("Pf", (B, T, 2))
+        v, f1 = reg("V", (B, -1)), reg("F1", (B, T, -1))
+        ctx.mark_non_differentiable(v, f1)
+        if not model._attn_on:
+            ctx.mark_non_differentiable(attn)
+        return attn, y, pr, pv, pf, v, f1
+
+    @staticmethod
+    def backward(ctx, g_attn, g_y, g_pr, g_pv, g_pf, g_v, g_f1):
+        model, plan, ws = ctx.model, ctx.plan, ctx.ws
+        dev = ws.device
+
+        def put(name, g):
+            off, n = plan.region(name)
+            if g is None:
+                ws[off:off + n].zero_()
+            else:
+                ws[off:off + n].copy_(g.reshape(-1))
+
+        put("gY", g_y); put("gPr", g_pr); put("gPv", g_pv); put("gPf", g_pf)
+        put("g_attn", g_attn if model._attn_on else None)
+        grads = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
+                                   stream), "ta3n_backward")
+        out: List[Optional[torch.Tensor]] = []
+        for name, off, shape, live in plan.params:
+            if not live:
+                out.append(None)            # never receives a gradient in the reference either
+                continue
+            n = 1
+            for s_ in shape:
+                n *= s_
+            out.append(grads[off:off + n].view(shape))
+        return (None, None, None, None, None, *out)
+
+
+class VideoModel(nn.Module):
+    def __init__(self, num_class, baseline_type, frame_aggregation, modality,
+                 train_segments=5, val_segments=25,
+                 base_model='resnet101', path_pretrained='', new_length=None,
+                 before_softmax=True,
+                 dropout_i=0.5, dropout_v=0.5, use_bn='none', ens_DA='none',
+                 crop_num=1, partial_bn=True, verbose=True, add_fc=1, fc_dim=1024,
+                 n_rnn=1, rnn_cell='LSTM', n_directions=1, n_ts=5,
+                 use_attn='TransAttn', n_attn=1, use_attn_frame='none',
+                 share_params='Y'):
+        super().__init__()
+        unsupported = []
+        if frame_aggregation != 'trn-m': unsupported.append(f"frame_aggregation={frame_aggregation!r}")
+        if baseline_type != 'video': unsupported.append(f"baseline_type={baseline_type!r}")
+        if share_params != 'Y': unsupported.append("share_params='N'")
+        if use_bn != 'none': unsupported.append(f"use_bn={use_bn!r}")
+        if ens_DA != 'none': unsupported.append(f"ens_DA={ens_DA!r}")
+        if use_attn not in ('TransAttn', 'none'): unsupported.append(f"use_attn={use_attn!r}")
+        if use_attn_frame != 'none': unsupported.append(f"use_attn_frame={use_attn_frame!r}")
+        if not before_softmax: unsupported.append("before_softmax=False")
+        if add_fc < 1:
+            raise ValueError('add at least one fc layer')          # models.py:137-138
+        if add_fc != 1: unsupported.append(f"add_fc={add_fc}")
+        if unsupported:
+            raise NotImplementedError("ta3n_amd.VideoModel implements the TA3N hot path only; unsupported: " +
+                                      ", ".join(unsupported))
+        if base_model not in ARCH_FEATURE_DIM:
+            raise ValueError(f"unknown base_model {base_model!r}")
+        self.modality = modality
+        self.train_segments, self.val_segments = train_segments, val_segments
+        self.baseline_type, self.frame_aggregation = baseline_type, frame_aggregation
+        self.reshape, self.before_softmax = True, before_softmax
+        self.dropout_rate_i, self.dropout_rate_v = dropout_i, dropout_v
+        self.use_bn, self.ens_DA, self.crop_num = use_bn, ens_DA, crop_num
+        self.add_fc, self.fc_dim, self.share_params = add_fc, fc_dim, share_params
+        self.n_layers, self.rnn_cell, self.n_directions, self.n_ts = n_rnn, rnn_cell, n_directions, n_ts
+        self.use_attn, self.n_attn, self.use_attn_frame = use_attn, n_attn, use_attn_frame
+        self.new_length = (1 if modality == "RGB" else 5) if new_length is None else new_length
+        self.num_class = num_class
+        self._attn_on = use_attn == 'TransAttn'
+        if verbose:
+            print(f"Initializing TSN with base model: {base_model}. input_modality: {modality}, "
+                  f"num_segments: {train_segments}, new_length: {self.new_length}")
+
+        # ---- parameters, named and initialised as models.py:119-325 ----
+        self.feature_dim = ARCH_FEATURE_DIM[base_model]
+        std = 0.001
+        F_ = min(fc_dim, self.feature_dim) if fc_dim > 0 else self.feature_dim       # models.py:129
+        NB = 256                                                                     # models.py:223
+
+        def lin(i, o):
+            m = nn.Linear(i, o)
+            nn.init.normal_(m.weight, 0, std)
+            nn.init.constant_(m.bias, 0)
+            return m
+
+        self.fc_feature_shared_source = lin(self.feature_dim, F_)        # :141
+        self.fc_feature_source = lin(F_, F_)                             # :156 (unused in forward, kept for checkpoints)
+        self.fc_feature_domain = lin(F_, F_)                             # :161
+        self.fc_classifier_source = lin(F_, num_class)                   # :166 (dead for baseline_type='video')
+        self.fc_classifier_domain = lin(F_, 2)                           # :170
+        self.num_bottleneck = NB
+        self.TRN = RelationModuleMultiScale(F_, NB, train_segments, verbose=verbose)   # :224 (default nn.Linear init)
+        self.bn_trn_S = nn.BatchNorm1d(NB)                               # :225-226 (unused with use_bn='none')
+        self.bn_trn_T = nn.BatchNorm1d(NB)
+        self.fc_feature_video_source = lin(NB, NB)                       # :258 (unused)
+        self.fc_feature_video_source_2 = lin(NB, NB)                     # :262 (unused)
+        self.fc_feature_domain_video = lin(NB, NB)                       # :267
+        self.fc_classifier_video_source = lin(NB, num_class)             # :272
+        self.fc_classifier_domain_video = lin(NB, 2)                     # :281
+        self.relation_domain_classifier_all = nn.ModuleList(             # :286-294 (default init)
+            nn.Sequential(nn.Linear(NB, NB), nn.ReLU(), nn.Linear(NB, 2)) for _ in range(train_segments - 1))
+        self.alpha = torch.ones(1)                                       # :314 plain attribute
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout_i = nn.Dropout(p=dropout_i)                         # kept as attributes; the HIP kernels apply them
+        self.dropout_v = nn.Dropout(p=dropout_v)
+        self._enable_pbn = partial_bn
+        self._flat: Optional[torch.Tensor] = None
+        self._plans: Dict[Tuple[int, int], _lib.Plan] = {}
+        self._ws_init: Dict[int, torch.Tensor] = {}
+        self._feat_dim_F = F_
+
+    # ---- reference API ----
+    def partialBN(self, enable):                                          # models.py:348-349
+        self._enable_pbn = enable
+
+    def train(self, mode=True):
+        # models.py:328-346 touches a non-existent self.base_model when partial BN is on (it only
+        # works with --no_partialbn, the default, opts.py:89); there is no BatchNorm2d to freeze here.
+        return super().train(mode)
+
+    def get_trans_attn(self, pred_domain):                                # models.py:351-357 (utility, eager)
+        p = torch.softmax(pred_domain, 1)
+        return 1 - torch.sum(-p * torch.log_softmax(pred_domain, 1), 1)
+
+    # ---- plumbing ----
+    def _flags(self) -> int:
+        # the loss flags are irrelevant on this path (losses are assembled by the caller, main.py:439-562)
+        return _lib.FLAG_TRANS_ATTN if self._attn_on else 0
+
+    def _plan(self, Bs: int, Bt: int) -> _lib.Plan:
+        key = (Bs, Bt)
+        if key not in self._plans:
+            self._plans[key] = _lib.Plan(Bs, Bt, self.train_segments, self.feature_dim, self._feat_dim_F, self.num_class,
+                                         self._flags())
+        return self._plans[key]
+
+    def _ws_template(self, plan: _lib.Plan) -> torch.Tensor:
+        key = id(plan)
+        t = self._ws_init.get(key)
+        if t is None or t.device != self._flat.device:
+            t = torch.zeros(plan.ws_floats, dtype=torch.float32, device=self._flat.device)
+            stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+            _lib.check(_lib.lib().ta3n_init_workspace(plan.handle, t.data_ptr(), stream), "ta3n_init_workspace")
+            self._ws_init[key] = t
+        return t
+
+    def _named_flat_params(self, plan: _lib.Plan):
+        named = dict(self.named_parameters())
+        return [(name, off, shape, named[name]) for name, off, shape, _ in plan.params]
+
+    def _ensure_flat(self, plan: _lib.Plan, device: torch.device) -> None:
+        """Parameters are views into one flat fp32 buffer laid out as the plan wants (live
+        parameters first: that prefix is the gradient all-reduce / optimiser operand).
+        Re-established whenever .to()/.cuda()/load replaced the parameter storage."""
+        items = self._named_flat_params(plan)
+        ok = self._flat is not None and self._flat.device == device
+        if ok:
+            base = self._flat.data_ptr()
+            ok = all(p.data.data_ptr() == base + 4 * off and p.device == device for _, off, _, p in items)
+        if ok:
+            return
+        flat = torch.zeros(plan.param_floats, dtype=torch.float32, device=device)
+        for name, off, shape, p in items:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[off:off + n].view(shape)
+        for b_name, b in list(self.named_buffers()):
+            if b.device != device:
+                mod = self
+                *path, leaf = b_name.split(".")
+                for part in path:
+                    mod = getattr(mod, part)
+                mod._buffers[leaf] = b.to(device)
+        self._flat = flat
+        self._ws_init.clear()
+
+    def forward(self, input_source, input_target, beta, mu, is_train, reverse):
+        """models.py:545-722.  Returns (attn_s, out_s, out_s2, pred_domain_s, feat_s, attn_t, out_t,
+        out_t2, pred_domain_t, feat_t) with pred_domain = [relation [B,T-1,2], video [B,2],
+        frame [B,T,2]] and feat = [class logits, video feature V, frame features F1]."""
+        if not torch.cuda.is_available():
+            raise _lib.Ta3nError("ta3n_amd.VideoModel.forward needs a HIP device; there is no CPU fallback")
+        if reverse:
+            raise NotImplementedError("reverse=True is only used by ens_DA='MCD' (main.py:549)")
+        num_segments = self.train_segments if is_train else self.val_segments
+        if num_segments != self.train_segments:
+            raise ValueError("TRN needs val_segments == num_segments (models.py:222)")
+        if input_source.dim() != 3 or input_target.dim() != 3 or input_source.size(1) != num_segments or \
+                input_source.size(2) != self.feature_dim or input_target.size(2) != self.feature_dim:
+            raise ValueError("inputs must be [B, num_segments, feature_dim]")
+        device = next(self.parameters()).device
+        if device.type != "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
+        Bs, Bt = input_source.size(0), input_target.size(0)
+        plan = self._plan(Bs, Bt)
+        self._ensure_flat(plan, device)
+        params = [p for _, _, _, p in self._named_flat_params(plan)]
+        with torch.cuda.device(device):
+            attn, y, pr, pv, pf, v, f1 = _HipForward.apply(self, input_source, input_target, list(beta),
+                                                            self.training, *params)
+        s, t = slice(0, Bs), slice(Bs, Bs + Bt)
+        out_s, out_t = y[s], y[t]
+        return (attn[s], out_s, out_s, [pr[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
+                attn[t], out_t, out_t, [pr[t], pv[t], pf[t]], [y[t], v[t], f1[t]])

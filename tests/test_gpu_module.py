@@ -1,0 +1,81 @@
+"""GPU: the drop-in module path.  ta3n_amd.models.VideoModel is driven the way the
+reference's main.train drives models.VideoModel (main.py:418-583): forward, the loss
+assembled OUTSIDE the model from its outputs, autograd backward, clip_grad_norm_,
+torch.optim.SGD(nesterov) - and must land on the parameters the reference itself produced."""
+import pytest
+import torch
+
+from golden_util import Golden, case_config, step_schedule
+from oracle import ta3n_oracle as orc
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(c):
+    from ta3n_amd.models import VideoModel
+    arch = "resnet18" if c["D"] == 512 else "resnet101"
+    m = VideoModel(c["C"], "video", "trn-m", "RGB", train_segments=c["T"], val_segments=c["T"], base_model=arch,
+                   fc_dim=c["fc_dim"], dropout_i=0.0, dropout_v=0.0, partial_bn=False, verbose=False)
+    sd = m.state_dict()
+    sd.update(synth_state({k: tuple(v.shape) for k, v in sd.items()}, seed=c["wseed"], scale=c["wscale"]))
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9", "headline"])
+def test_module_autograd_path_matches_reference(name):
+    g = Golden(name)
+    c = case_config(g)
+    model = _model(c)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), c["lr"], momentum=0.9, weight_decay=1e-4, nesterov=True)
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"])
+    live = set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        for pg in opt.param_groups:
+            pg["lr"] = st["lr"]
+        out = model(xs, xt, [0.75, 0.75, 0.5], 0, True, False)          # CPU inputs, like main.py:418
+        attn_s, out_s, out_s2, pd_s, feat_s, attn_t, out_t, out_t2, pd_t, feat_t = out
+        if s == 0:
+            g.check("fwd/out_s", out_s, 0, 1e-3); g.check("fwd/out_t", out_t, 0, 1e-3)
+            g.check("fwd/attn_s", attn_s, 2e-4, 5e-5)
+            for i, nm in enumerate(("rel", "vid", "frm")):
+                g.check(f"fwd/pd_s_{nm}", pd_s[i], 0, 1e-3); g.check(f"fwd/pd_t_{nm}", pd_t[i], 0, 1e-3)
+            g.check("fwd/feat_s_v", feat_s[1], 2e-4, 5e-5); g.check("fwd/feat_t_f1", feat_t[2], 2e-4, 5e-5)
+        src = dict(out=out_s, pred_domain=pd_s)
+        tgt = dict(out=out_t, pred_domain=pd_t)
+        loss, _ = orc.total_loss(src, tgt, ys.cuda(), 0.003, cfg, st["n_src"], st["n_tgt"])   # main.py:439-562
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), c["clip"])
+        for k, p in model.named_parameters():
+            assert (p.grad is not None) == (k in live), k
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", p.grad, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 5e-2)
+        opt.step()
+        for k, p in model.named_parameters():
+            g.check(f"step{s}/param/{k}", p, 2e-4, 5e-5)
+
+
+def test_module_eval_mode_and_state_dict_roundtrip():
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    model = _model(c)
+    model.eval()
+    xs, xt, _, _ = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    with torch.no_grad():                                              # main.validate: same data in both slots, beta 0
+        o = model(xs, xs, [0, 0, 0], 0, False, False)
+    g.check("fwd/out_s", o[1], 0, 1e-3)
+    assert torch.equal(o[1], o[6])
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    from ta3n_amd.models import VideoModel
+    m2 = VideoModel(c["C"], "video", "trn-m", "RGB", train_segments=c["T"], val_segments=c["T"], base_model="resnet18",
+                    fc_dim=c["fc_dim"], dropout_i=0.0, dropout_v=0.0, verbose=False)
+    m2.load_state_dict(sd)
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        o2 = m2(xs, xs, [0, 0, 0], 0, False, False)
+    assert torch.equal(o[1], o2[1])

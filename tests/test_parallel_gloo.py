@@ -1,0 +1,119 @@
+"""N > 1 path on CPU: two gloo ranks, uneven shards.  Each rank differentiates its shard
+of the batch with losses divided by the GLOBAL row counts (ta3n_amd.parallel.
+loss_normalisers - the numbers TrainEngine.set_hyper feeds the HIP loss kernel), packs the
+gradients into the plan's flat live buffer and the product's single SUM all-reduce must
+reproduce the single-process global-batch gradient of the oracle (what the reference's
+DataParallel gather + global means compute, main.py:446, 533; loss.py:24)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ta3n_oracle as orc
+from ta3n_amd import _lib, parallel
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+CFG = dict(C=7, T=4, D=512, fc=32, Bs=5, Bt=3)
+FLAGS = (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME | _lib.FLAG_ATTN_ENTROPY | _lib.FLAG_TRANS_ATTN)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_grads(plan, grads):
+    flat = torch.zeros(plan.live_floats, dtype=torch.float64)
+    for name, off, shape, live in plan.params:
+        if live and name in grads:
+            n = int(np.prod(shape))
+            flat[off:off + n] = grads[name].reshape(-1)
+    return flat
+
+
+def _shard_grad(params, cfg, xs, xt, ys, beta, gamma, norm, T):
+    """sum over local rows / GLOBAL counts, written with the oracle's mean-reduced parts."""
+    p = {k: v.detach().clone().double().requires_grad_(True) for k, v in params.items()}
+    ns, nt = xs.size(0), xt.size(0)
+    if ns + nt == 0:
+        return {}
+    src = orc.forward_domain(p, xs.double(), beta, cfg) if ns else None
+    tgt = orc.forward_domain(p, xt.double(), beta, cfg) if nt else None
+    loss = 0
+    if ns:
+        loss = loss + torch.nn.functional.cross_entropy(src["out"], ys, reduction="sum") * norm["inv_n_cls"]
+    for l, key in enumerate(("inv_n_rel", "inv_n_vid", "inv_n_frm")):
+        for dom, lab in ((src, 0), (tgt, 1)):
+            if dom is not None:
+                z = dom["pred_domain"][l].reshape(-1, 2)
+                loss = loss + torch.nn.functional.cross_entropy(z, torch.full((z.size(0),), lab), reduction="sum") * norm[key]
+    for dom in (src, tgt):
+        if dom is not None:
+            n = dom["out"].size(0)
+            loss = loss + gamma * orc.attentive_entropy(dom["out"], dom["pred_domain"][1]) * n * norm["inv_n_ent"]
+    names = [k for k in p if orc.is_live(k)]
+    g = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    return {k: gi for k, gi in zip(names, g) if gi is not None}
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, lr_, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    c = CFG
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc"], dropout_i=0, dropout_v=0)
+    params = synth_state(orc.param_shapes(cfg), seed=5)
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    plan = _lib.Plan(parallel.padded_shard_size(c["Bs"], world), parallel.padded_shard_size(c["Bt"], world), c["T"],
+                     c["D"], c["fc"], c["C"], FLAGS)
+    lo, hi = parallel.shard_range(c["Bs"], world, rank)
+    lo_t, hi_t = parallel.shard_range(c["Bt"], world, rank)
+    gs, gt = parallel.global_counts(hi - lo, hi_t - lo_t)
+    assert (gs, gt) == (c["Bs"], c["Bt"])
+    norm = parallel.loss_normalisers(gs, gt, c["T"])
+    g = _shard_grad(params, cfg, xs[lo:hi], xt[lo_t:hi_t], ys[lo:hi], [0.75, 0.75, 0.5], 0.3, norm, c["T"])
+    flat = _flat_grads(plan, g)
+    parallel.all_reduce_sum_(flat)
+    if rank == 0:
+        torch.save(flat, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sum_allreduce_equals_global_batch_gradient(tmp_path):
+    out = str(tmp_path / "flat.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    flat = torch.load(out)
+    c = CFG
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc"], dropout_i=0, dropout_v=0)
+    params = {k: v.double() for k, v in synth_state(orc.param_shapes(cfg), seed=5).items()}
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    state = orc.TrainState(params=params, lr=0.0)
+    res = orc.train_step(state, xs.double(), xt.double(), ys, [0.75, 0.75, 0.5], 0.3, cfg, clip=None)
+    plan = _lib.Plan(3, 2, c["T"], c["D"], c["fc"], c["C"], FLAGS)
+    ref = _flat_grads(plan, res["grads"])
+    assert ref.abs().max() > 0
+    assert torch.allclose(flat, ref, rtol=1e-9, atol=1e-12), (flat - ref).abs().max()
+
+
+def test_shard_ranges_cover_batch_without_overlap():
+    for n in (0, 1, 5, 74, 128, 202):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - b for b, e in spans) <= parallel.padded_shard_size(n, world)
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+    # 74 target videos over 8 ranks: 10 per rank static, two ranks carry one dummy row less
+    assert parallel.padded_shard_size(74, 8) == 10
+    n = parallel.loss_normalisers(128, 74, 5)
+    assert n["inv_n_cls"] == 1 / 128 and n["inv_n_rel"] == 1 / (202 * 4) and n["inv_n_frm"] == 1 / (202 * 5)
