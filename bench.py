@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--tile", type=int, default=0, help="force a GEMM tile config (114/212/122/221)")
+    ap.add_argument("--tile", type=int, default=0, help="force a GEMM tile config (114/118/212/122/214/124/221/222)")
     ap.add_argument("--phase-tiles", type=str, default="", help="comma list of per-GEMM-phase tile configs")
     ap.add_argument("--autotune", action="store_true", help="measure tile configs per GEMM launch and use the best")
     ap.add_argument("--xcd", type=int, default=0, help="0/1 XCD-aware tile ordering on, 2 off")

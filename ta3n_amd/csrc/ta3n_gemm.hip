@@ -1,9 +1,9 @@
 // Tile-list fp32 GEMM for gfx950 (CDNA4) on the exact-f32 matrix cores
-// (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD, bitwise an fmaf chain, 157 TF peak).
+// (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD, an fmaf chain per element, 157 TF peak).
 //
 // One launch = one dependency level of the TA3N train step.  Each workgroup
-// (256 threads = 4 wave64) takes one Task: a (32*WM x 32*WN) output tile whose
-// K loop runs over a list of Segs.  A Seg is an affine view
+// (NW = WM*WN*WK wave64, 4 or 8) takes one Task: a (32*WM x 32*WN) output tile
+// whose K loop runs over a list of Segs.  A Seg is an affine view
 //     A(r,k) = base_a[a_off + (kmajor ? k*a_ld + r : r*a_ld + k)]
 // so the same kernel does  X W^T (forward), G W (input gradients), G^T X (weight
 // gradients), the TRN frame-tuple gather+concat (one Seg per tuple position,
@@ -11,18 +11,32 @@
 // TRN input gradient (one Seg per (tuple,position) that contains the frame) and
 // GradReverse (reference models.py:20-29) as a "scale the accumulator by -beta
 // after this Seg" flag.  WK > 1 splits every 64-deep K chunk across the
-// workgroup's waves so small outputs still occupy all 4 SIMDs of a CU.
+// workgroup's waves so small outputs still occupy all SIMDs of a CU.
 //
-// Data path per 64-deep chunk: global -> registers (float4, coalesced along the
-// operand's contiguous axis) -> LDS in k-major form [k][row] (K-contiguous
-// operands are transposed on the way in, row stride R+1 => <=2-way write
-// conflicts; k-major operands are stored as-is with ds_write_b128) -> one
-// ds_read_b32 per operand per MFMA (lanes 0-31 read 32 consecutive floats, the
-// two half-waves hit different k rows: conflict free).  LDS is double buffered:
-// one barrier per chunk, next chunk's global loads in flight during the MFMAs.
+// Data path per 64-deep chunk ("stage"):
+//   global -> LDS by LDS-DMA (global_load_lds_dwordx4: each wave instruction moves
+//   64 lanes x 16 B to 1 KiB of consecutive LDS bytes; no staging VGPRs, no
+//   ds_write pass).  Two stages are resident: the DMA of chunk c+1 is in flight
+//   while the MFMAs of chunk c run; one s_barrier per chunk.
+//   Stage image of a K-contiguous operand: [row][16 slots of 16 B], slot s of row r
+//   holds k-group s ^ (r & 15) (the swizzle is applied to the per-lane SOURCE
+//   address, the LDS side stays lane-linear) -> one conflict-free ds_read_b128 per
+//   operand feeds 4 MFMAs.
+//   Stage image of a k-major operand: [k][R] linear -> conflict-free ds_read_b32.
+//   Within an 8-deep k group MFMA j pairs k = j (lanes 0-31) with k = 4 + j (lanes
+//   32-63) for BOTH operands, so a b128 read per half-wave supplies four MFMAs.
+//   Operands that cannot be moved 16 bytes at a time (odd leading dimension, K = 2,
+//   num_class not a multiple of 4, ...) use the 4-byte LDS-DMA form with the same
+//   stage image; out-of-range elements are read from a block of zeros (the validity
+//   test selects the ADDRESS), so K tails and ragged row counts need no branches.
+//   The LDS-DMA is issued from inline asm: a compiler-visible
+//   __builtin_amdgcn_global_load_lds makes hipcc (ROCm 7.2) place s_waitcnt vmcnt(0)
+//   in front of every later ds_read, which serialises load and compute.
 // The epilogue goes through LDS once more so the K-split partials are reduced
 // and the stores / bias / mask operands are row-contiguous float4s.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "ta3n_kernels.h"
 
@@ -31,102 +45,147 @@ using namespace ta3n;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int BKC = 64;        // K chunk staged per barrier
-constexpr int NTHREADS = 256;
+constexpr int BKC = 64;        // K chunk per stage
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// rows x 64 chunk of one operand -> registers.  R = rows of the tile (32 or 64).
-// Branch-free AND select-free per lane: an out-of-range element is read from a
-// 16-byte block of zeros in the workspace (the validity test selects the ADDRESS,
-// not the loaded value).  The loaded registers are therefore first touched by the
-// LDS write of the NEXT iteration, so the loads stay in flight across the MFMAs of
-// the current chunk.  (A per-element "if (valid) load" compiles to an exec-masked
-// branch with its own s_waitcnt vmcnt(0); a select on the loaded value makes hipcc
-// wait for each load right after issuing it.)  The only branch is wave-uniform:
-// float4 path when the operand is 16-byte tileable.
-template <int R>
-__device__ __forceinline__ void g2r(float4 (&v)[R / 16], const float *__restrict__ base, int off, int ld, int kmajor,
-                                    int r0, int rvalid, int k0, int klen, int tid, const float *__restrict__ zeros) {
-    const float *__restrict__ origin = base + (size_t)off;
-    if (!kmajor) {
-        // element (row, k) at row*ld + k ; this lane: 4 consecutive k of R/16 rows
-        const bool vec = ((off | ld | klen) & 3) == 0;
-        const int k = k0 + (tid & 15) * 4;
-        if (vec) {
-            const bool kin = k < klen;              // klen % 4 == 0: the float4 is all-in or all-out
-#pragma unroll
-            for (int i = 0; i < R / 16; ++i) {
-                const int row = r0 + (tid >> 4) + 16 * i;
-                const float *p = (kin && row < rvalid) ? origin + (size_t)row * ld + k : zeros;
-                v[i] = *reinterpret_cast<const float4 *>(p);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R / 16; ++i) {
-                const int row = r0 + (tid >> 4) + 16 * i;
-                const float *pr = origin + (size_t)row * ld + k;
-                const bool rok = row < rvalid;
-                v[i].x = *((rok && k + 0 < klen) ? pr + 0 : zeros);
-                v[i].y = *((rok && k + 1 < klen) ? pr + 1 : zeros);
-                v[i].z = *((rok && k + 2 < klen) ? pr + 2 : zeros);
-                v[i].w = *((rok && k + 3 < klen) ? pr + 3 : zeros);
-            }
-        }
+// LDS-DMA, 16 or 4 bytes per lane.  lds_byte_addr must be wave-uniform (it goes to M0);
+// M0 is compiler-reserved, so it is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// NP 16-byte LDS-DMAs of one wave, destinations lds_byte_addr + i * stride: one M0 save/restore for the batch.
+template <int NP>
+__device__ __forceinline__ void glds16_batch(const float *const (&src)[NP], unsigned lds_byte_addr, unsigned stride) {
+    unsigned keep;
+    if constexpr (NP == 1) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src[0]), "s"(lds_byte_addr) : "memory");
+    } else if constexpr (NP == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "s"(lds_byte_addr), "s"(stride) : "memory", "scc");
     } else {
-        // element (r, k) at k*ld + r ; this lane: 4 consecutive r of R/16 k-rows
-        constexpr int TPR = R / 4;          // threads per k row
-        constexpr int KPP = NTHREADS / TPR;  // k rows per pass
-        const bool vec = ((off | ld | rvalid) & 3) == 0;
-        const int col = r0 + (tid % TPR) * 4;
-        if (vec) {
-            const bool cin = col < rvalid;          // rvalid % 4 == 0
+        static_assert(NP == 4, "1, 2 or 4 pieces per wave");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                     "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                     "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds_byte_addr), "s"(stride)
+                     : "memory", "scc");
+    }
+}
+__device__ __forceinline__ void glds4(const float *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// Per-lane LDS-DMA state of one operand for the Seg being streamed.  Set up once per
+// Seg (the 64-bit address arithmetic lives there); per 64-deep chunk the fast path is
+// compare + select + DMA + pointer bump per 1 KiB piece.  R rows (32 or 64), NW waves.
+// All branches are wave-uniform.
+constexpr int K_NEVER = 1 << 28;   // "k offset" of a lane whose row is out of range: never < remaining K
+
+template <int R, int NW>
+struct OperandStream {
+    static constexpr int NP = R / 4 / NW;   // 1 KiB pieces per wave per stage (16-byte path)
+    static_assert((R / 4) % NW == 0, "pieces must divide over the waves");
+    const float *p[NP];     // this lane's source address in the current chunk
+    int kofs[NP];           // this lane's k offset inside a chunk (K_NEVER: row out of range)
+    int step;               // floats between consecutive chunks
+    // slow (4-byte) path
+    const float *origin;
+    int ld, kmajor, r0, rvalid;
+    bool vec;
+
+    __device__ __forceinline__ void setup(const float *__restrict__ origin_, int ld_, int kmajor_, int klen, int r0_, int rvalid_,
+                                          int wave, int lane) {
+        origin = origin_; ld = ld_; kmajor = kmajor_; r0 = r0_; rvalid = rvalid_;
+        // 16-byte movability (base pointers and Seg offsets of 16-byte aligned regions: API contract + plan builder)
+        const int off_bits = (int)(reinterpret_cast<uintptr_t>(origin_) >> 2);
+        vec = kmajor_ ? (((off_bits | ld_ | r0_ | rvalid_) & 3) == 0) : (((off_bits | ld_ | klen) & 3) == 0);
+        if (!vec) return;
+        step = kmajor_ ? BKC * ld_ : BKC;
 #pragma unroll
-            for (int i = 0; i < R / 16; ++i) {
-                const int k = k0 + tid / TPR + KPP * i;
-                const float *p = (cin && k < klen) ? origin + (size_t)k * ld + col : zeros;
-                v[i] = *reinterpret_cast<const float4 *>(p);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R / 16; ++i) {
-                const int k = k0 + tid / TPR + KPP * i;
-                const float *pr = origin + (size_t)k * ld + col;
-                const bool kok = k < klen;
-                v[i].x = *((kok && col + 0 < rvalid) ? pr + 0 : zeros);
-                v[i].y = *((kok && col + 1 < rvalid) ? pr + 1 : zeros);
-                v[i].z = *((kok && col + 2 < rvalid) ? pr + 2 : zeros);
-                v[i].w = *((kok && col + 3 < rvalid) ? pr + 3 : zeros);
+        for (int i = 0; i < NP; ++i) {
+            const int q = wave + NW * i;
+            if (!kmajor_) {                        // piece = 4 rows x 256 B; slot s of row r holds k group s ^ (r & 15)
+                const int row = q * 4 + (lane >> 4);
+                const int k = 4 * ((lane & 15) ^ (row & 15));
+                p[i] = origin_ + (size_t)(r0_ + row) * ld_ + k;
+                kofs[i] = (r0_ + row < rvalid_) ? k : K_NEVER;
+            } else {                               // [k][R]: R/4 lanes per k row
+                constexpr int LPR = R / 4, KPP = 64 / LPR;
+                const int k = q * KPP + lane / LPR;
+                const int r = r0_ + (lane % LPR) * 4;
+                p[i] = origin_ + (size_t)k * ld_ + r;
+                kofs[i] = (r < rvalid_) ? k : K_NEVER;
             }
         }
     }
-}
 
-// registers -> LDS, k-major image [k][row] with row stride R+1 (transposing
-// path) or R+4 (straight path).
-template <int R>
-__device__ __forceinline__ void r2s(const float4 (&v)[R / 16], float *__restrict__ s, int kmajor, int tid) {
-    if (!kmajor) {
-        constexpr int S = R + 1;
-        const int kq = (tid & 15) * 4;
+    // stream the chunk starting at k0 (krem = klen - k0 valid k remain) into the stage image at lds_addr
+    __device__ __forceinline__ void issue(int k0, int krem, unsigned lds_addr, int wave, int lane, const float *__restrict__ zeros) {
+        if (vec) {
+            const float *src[NP];
 #pragma unroll
-        for (int i = 0; i < R / 16; ++i) {
-            const int row = (tid >> 4) + 16 * i;
-            s[(kq + 0) * S + row] = v[i].x;
-            s[(kq + 1) * S + row] = v[i].y;
-            s[(kq + 2) * S + row] = v[i].z;
-            s[(kq + 3) * S + row] = v[i].w;
+            for (int i = 0; i < NP; ++i) {
+                src[i] = kofs[i] < krem ? p[i] : zeros;
+                p[i] += step;
+            }
+            glds16_batch<NP>(src, lds_addr + wave * 1024, NW * 1024);
+        } else {                                   // 256 B pieces, one element per lane
+#pragma unroll 1
+            for (int q = wave; q < R; q += NW) {
+                const float *src;
+                if (!kmajor) {                     // piece = one row; lane -> (slot, element)
+                    const int k = 4 * ((lane >> 2) ^ (q & 15)) + (lane & 3);
+                    src = (r0 + q < rvalid && k < krem) ? origin + (size_t)(r0 + q) * ld + k0 + k : zeros;
+                } else {
+                    constexpr int KPP = 64 / R;    // k rows per piece (2 for R = 32, 1 for R = 64)
+                    const int k = q * KPP + lane / R;
+                    const int r = r0 + lane % R;
+                    src = (r < rvalid && k < krem) ? origin + (size_t)(k0 + k) * ld + r : zeros;
+                }
+                glds4(src, lds_addr + q * 256);
+            }
         }
-    } else {
-        constexpr int S = R + 4;
-        constexpr int TPR = R / 4;
-        constexpr int KPP = NTHREADS / TPR;
-        const int c = (tid % TPR) * 4;
+    }
+};
+
+// MFMAs of one wave over its K slice of one stage.  sa / sb: stage images.
+// FULL: all 64 k of the stage are valid (no wave-uniform skip tests).
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL>
+__device__ __forceinline__ void compute_stage(f32x16 &acc, const float *__restrict__ sa, const float *__restrict__ sb,
+                                              int ra, int rb, int wk, int lh, int krem) {
+    constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
 #pragma unroll
-        for (int i = 0; i < R / 16; ++i) {
-            const int k = tid / TPR + KPP * i;
-            *reinterpret_cast<float4 *>(&s[k * S + c]) = v[i];
+    for (int q = 0; q < GPW / 2; ++q) {
+        const int g_lo = wk * GPW + 2 * q;         // lanes 0-31: k = 4 g_lo .. +3, lanes 32-63: the next group
+        if (FULL || 4 * g_lo < krem) {
+            const int G = g_lo + lh;
+            float av[4], bv[4];
+            if (!AKM) {
+                const float4 t = *reinterpret_cast<const float4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = sa[(4 * G + j) * BM + ra];
+            }
+            if (!BKM) {
+                const float4 t = *reinterpret_cast<const float4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = sb[(4 * G + j) * BN + rb];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
         }
     }
 }
@@ -145,17 +204,18 @@ __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
 namespace ta3n {
 
 template <int WM, int WN, int WK>
-__global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
-                                                        Ptrs ptrs, int hyper_off, int zeros_off) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
+                                                                 Ptrs ptrs, int hyper_off, int zeros_off) {
+    constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM, BN = 32 * WN;
-    constexpr int KW = BKC / WK;                 // k per wave per chunk
-    constexpr int LA = BKC * (BM + 4), LB = BKC * (BN + 4);
-    constexpr int BUF = LA + LB;
-    static_assert(2 * BUF >= 4 * 32 * 36, "epilogue staging must fit");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
+    constexpr int EPI = NW * 32 * 36;                // epilogue staging (one padded 32x32 block per wave)
+    constexpr int LDS_FLOATS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
 
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t *)lds);
     const int li = lane & 31, lh = lane >> 5;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
@@ -164,62 +224,80 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
     const float *__restrict__ zeros = ptrs.ws + zeros_off;   // 64 floats that are never written
 
-    float4 ra[BM / 16], rb[BN / 16];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    int seg = 0, k0 = 0;
-    Seg s = segs[t.seg_begin];
-    g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid, zeros);
-    g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid, zeros);
+    const int m0 = t.m0, n0 = t.n0, m_valid = t.m_valid, n_valid = t.n_valid;
+    const int seg_end = t.seg_begin + t.seg_count;
+    int cseg = t.seg_begin;
+    // K loop.  Stage c+1 is streamed while stage c is computed.  Per Seg: all iterations whose
+    // two cursors both sit inside the Seg run in a tight loop specialised on the operand
+    // kinds; the iteration that computes the Seg's last chunk opens the next Seg.
+    OperandStream<BM, NW> oa;
+    OperandStream<BN, NW> ob;
+    int klen, combo, scale;
+    auto open_seg = [&](int sidx) {                // wave-uniform: Seg fields live in SGPRs
+        const Seg &sg = segs[sidx];
+        klen = sg.klen; combo = sg.a_kmajor * 2 + sg.b_kmajor; scale = sg.scale_kind;
+        oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, sg.a_kmajor, sg.klen, m0, m_valid, wave, lane);
+        ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, sg.b_kmajor, sg.klen, n0, n_valid, wave, lane);
+    };
+    auto issue = [&](int buf, int k0) {
+        const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
+        oa.issue(k0, klen - k0, st, wave, lane, zeros);
+        ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+    };
+    auto stage_ready = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
+        asm volatile("" ::: "memory");
+    };
+    const int ra = wm * 32 + li, rb = wn * 32 + li;
     int buf = 0;
+    auto inner = [&](auto akm, auto bkm, int n_inner) {      // chunks 0 .. n_inner-1 of the open Seg (all full)
+        for (int c = 0; c < n_inner; ++c) {
+            stage_ready();
+            issue(buf ^ 1, (c + 1) * BKC);
+            const float *sa = lds + buf * STAGE;
+            compute_stage<BM, BN, WK, decltype(akm)::value, decltype(bkm)::value, true>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+            buf ^= 1;
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    open_seg(cseg);
+    issue(0, 0);
     for (;;) {
-        float *sa = lds + buf * BUF;
-        float *sb = sa + LA;
-        r2s<BM>(ra, sa, s.a_kmajor, tid);
-        r2s<BN>(rb, sb, s.b_kmajor, tid);
-        __syncthreads();
-        // what the compute step of this chunk needs
-        const int stride_a = s.a_kmajor ? BM + 4 : BM + 1;
-        const int stride_b = s.b_kmajor ? BN + 4 : BN + 1;
-        const int krem = s.klen - k0;                 // valid k in this chunk (may exceed 64)
-        const bool seg_done = krem <= BKC;
-        const int scale_kind = s.scale_kind;
-        // advance and prefetch the next chunk into registers
-        bool more = true;
-        if (!seg_done) {
-            k0 += BKC;
-        } else {
-            ++seg;
-            k0 = 0;
-            if (seg < t.seg_count) s = segs[t.seg_begin + seg];
-            else more = false;
+        const int n_chunks = (klen + BKC - 1) / BKC;
+        switch (combo) {
+            case 0: inner(F_{}, F_{}, n_chunks - 1); break;
+            case 1: inner(F_{}, T_{}, n_chunks - 1); break;
+            case 2: inner(T_{}, F_{}, n_chunks - 1); break;
+            default: inner(T_{}, T_{}, n_chunks - 1); break;
         }
-        if (more) {
-            g2r<BM>(ra, base_ptr(ptrs, s.a_base), s.a_off, s.a_ld, s.a_kmajor, t.m0, t.m_valid, k0, s.klen, tid, zeros);
-            g2r<BN>(rb, base_ptr(ptrs, s.b_base), s.b_off, s.b_ld, s.b_kmajor, t.n0, t.n_valid, k0, s.klen, tid, zeros);
+        // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
+        stage_ready();
+        const int krem = klen - (n_chunks - 1) * BKC, c_combo = combo, c_scale = scale;
+        ++cseg;
+        if (cseg < seg_end) {
+            open_seg(cseg);
+            issue(buf ^ 1, 0);
         }
-        // MFMA over this wave's K slice of the chunk, 8 k (4 MFMAs) per group
-        const float *pa = sa + (wk * KW + lh) * stride_a + wm * 32 + li;
-        const float *pb = sb + (wk * KW + lh) * stride_b + wn * 32 + li;
-#pragma unroll
-        for (int g = 0; g < KW; g += 8) {
-            if (wk * KW + g < krem) {
-#pragma unroll
-                for (int kk = 0; kk < 8; kk += 2) {
-                    const float a = pa[(g + kk) * stride_a];
-                    const float b = pb[(g + kk) * stride_b];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-                }
-            }
+        const float *sa = lds + buf * STAGE;
+        const float *sb = sa + BM * BKC;
+        switch (c_combo) {
+            case 0: compute_stage<BM, BN, WK, false, false, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
+            case 1: compute_stage<BM, BN, WK, false, true, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
+            case 2: compute_stage<BM, BN, WK, true, false, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
+            default: compute_stage<BM, BN, WK, true, true, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
         }
-        if (seg_done && scale_kind != SK_ONE) {
-            const float sc = hyper_scale(hy, scale_kind);
+        if (c_scale != SK_ONE) {
+            const float sc = hyper_scale(hy, c_scale);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] *= sc;
         }
-        if (!more) break;
+        if (cseg >= seg_end) break;
         buf ^= 1;
     }
 
@@ -251,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     const bool c_vec = ((t.c_off | t.c_ld) & 3) == 0;
     const int nfan = t.fan_count;
 
-    for (int idx = tid; idx < BM * BN / 4; idx += NTHREADS) {
+    for (int idx = tid; idx < BM * BN / 4; idx += NT) {
         const int r = idx / (BN / 4);
         const int c4 = (idx % (BN / 4)) * 4;
         const int tile = (r >> 5) * WN + (c4 >> 5);
@@ -261,9 +339,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
             const float4 part = *reinterpret_cast<const float4 *>(&lds[(tile * WK + q) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
             v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
         }
-        const int m = t.m0 + r, n = t.n0 + c4;
-        const bool row_ok = m < t.m_valid;
-        const int nrem = row_ok ? t.n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
+        const int m = m0 + r, n = n0 + c4;
+        const bool row_ok = m < m_valid;
+        const int nrem = row_ok ? n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         float bv[4], av[4], mv[4], fm[3][4];
 #pragma unroll
@@ -305,24 +383,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiles(const Task *__restrict__ 
     }
 }
 
-template __global__ void gemm_tiles<1, 1, 4>(const Task *, const Seg *, Ptrs, int, int);
-template __global__ void gemm_tiles<2, 1, 2>(const Task *, const Seg *, Ptrs, int, int);
-template __global__ void gemm_tiles<1, 2, 2>(const Task *, const Seg *, Ptrs, int, int);
-template __global__ void gemm_tiles<2, 2, 1>(const Task *, const Seg *, Ptrs, int, int);
+#define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
+
+#define TA3N_INSTANTIATE(wm, wn, wk) template __global__ void gemm_tiles<wm, wn, wk>(const Task *, const Seg *, Ptrs, int, int);
+TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
+
+bool tile_config_ok(int cfg) {
+#define TA3N_CHECK(wm, wn, wk) if (cfg == wm * 100 + wn * 10 + wk) return true;
+    TA3N_TILE_CONFIGS(TA3N_CHECK)
+    return false;
+}
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
                 int zeros_off, hipStream_t stream) {
     if (ph.task_count == 0) return 0;
-    const dim3 grid(ph.task_count), block(NTHREADS);
+    const dim3 grid(ph.task_count);
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
-    switch (cfg) {
-        case 114: hipLaunchKernelGGL((gemm_tiles<1, 1, 4>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
-        case 212: hipLaunchKernelGGL((gemm_tiles<2, 1, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
-        case 122: hipLaunchKernelGGL((gemm_tiles<1, 2, 2>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
-        case 221: hipLaunchKernelGGL((gemm_tiles<2, 2, 1>), grid, block, 0, stream, tp, d_segs, ptrs, hyper_off, zeros_off); break;
-        default: return -1;
+    bool launched = false;
+#define TA3N_LAUNCH(wm, wn, wk)                                                                                     \
+    if (cfg == wm * 100 + wn * 10 + wk) {                                                                           \
+        hipLaunchKernelGGL((gemm_tiles<wm, wn, wk>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs,    \
+                           hyper_off, zeros_off);                                                                   \
+        launched = true;                                                                                            \
     }
+    TA3N_TILE_CONFIGS(TA3N_LAUNCH)
+    if (!launched) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

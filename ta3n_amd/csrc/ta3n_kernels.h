@@ -46,6 +46,7 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     return v;
 }
 
+bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
                 int zeros_off, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

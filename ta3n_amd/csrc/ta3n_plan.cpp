@@ -11,6 +11,7 @@
 //   w = 1 - H(softmax Pr);  V = sum_j (1+w_j) R_j;  Vd = drop_v(V)   models.py:351-357, 379-388, 651, 679
 //   Y = Wcv Vd + bcv;  Pv = Wcdv relu(Wdv GRL(Vd) + bdv) + bcdv      models.py:686, 464-470
 #include "ta3n_plan.h"
+#include "ta3n_kernels.h"
 
 #include <algorithm>
 #include <cstring>
@@ -101,15 +102,17 @@ struct Builder {
         if (forced != 0) {
             wm = forced / 100; wn = (forced / 10) % 10; wk = forced % 10;
         } else {
-            // heuristic: largest tile that still yields >= ~1.5 waves of 256 CUs worth of blocks
+            // heuristic from MI355X measurements (tools/proto_gemm.hip, bench.py --autotune):
+            // 64x64 tiles with an 8-wave workgroup once they still give every CU a workgroup,
+            // otherwise 32x32 tiles, K split 8 ways when there are fewer than two tiles per CU
             auto count = [&](int bm, int bn) {
                 int64_t n = 0;
                 for (auto &g : specs) n += (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
                 return n;
             };
-            if (count(64, 64) >= 384) { wm = 2; wn = 2; wk = 1; }
-            else if (count(64, 32) >= 384) { wm = 2; wn = 1; wk = 2; }
-            else { wm = 1; wn = 1; wk = 4; }
+            if (count(64, 64) >= 256) { wm = 2; wn = 2; wk = 2; }
+            else if (count(32, 32) >= 512) { wm = 1; wn = 1; wk = 4; }
+            else { wm = 1; wn = 1; wk = 8; }
         }
         const int BM = 32 * wm, BN = 32 * wn;
         Phase ph;
@@ -204,10 +207,10 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         err = "attentive_entropy requires place_adv[0]=='Y' and place_adv[1]=='Y'";
         return TA3N_ERR_INVALID;
     }
-    auto tile_ok = [](int t) { return t == 0 || t == 114 || t == 212 || t == 122 || t == 221; };
-    if (!tile_ok(c.tile_config)) { err = "tile_config must be one of 0, 114, 212, 122, 221"; return TA3N_ERR_INVALID; }
+    auto tile_ok = [](int t) { return t == 0 || tile_config_ok(t); };
+    if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222"; return TA3N_ERR_INVALID; }
     for (int i = 0; i < 16; ++i)
-        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be one of 0, 114, 212, 122, 221"; return TA3N_ERR_INVALID; }
+        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222"; return TA3N_ERR_INVALID; }
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }

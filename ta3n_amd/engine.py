@@ -234,7 +234,7 @@ class TrainEngine:
 
 def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
                          num_class: int, flags: int = ALL_FLAGS, device=None, reps: int = 10,
-                         candidates: Sequence[int] = (114, 212, 122, 221), verbose: bool = False):
+                         candidates: Sequence[int] = (114, 118, 214, 124, 221, 222), verbose: bool = False):
     """Pick the fastest GEMM tile shape per launch by measuring each candidate on this
     GPU (HIP events on the launch stream).  Returns (phase_tiles, table)."""
     table = {}

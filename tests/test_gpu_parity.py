@@ -37,7 +37,7 @@ def test_library_loaded_and_device_is_mi355x():
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
-@pytest.mark.parametrize("tile", [0, 114, 212, 122, 221])
+@pytest.mark.parametrize("tile", [0, 114, 118, 212, 122, 214, 124, 221, 222])
 @pytest.mark.parametrize("name", CASES)
 def test_train_steps_match_reference_golden(name, tile):
     if tile not in (0, 114) and name not in ("tiny_T5", "tiny_T9", "headline"):

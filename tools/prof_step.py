@@ -1,8 +1,11 @@
+"""Three eager train steps at the BASELINE shape for rocprofv3 (kernel trace / PMC passes).
+usage: python tools/prof_step.py [tile_config] [xcd_aware]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ta3n_amd.engine import TrainEngine
-tile = int(sys.argv[1]) if len(sys.argv) > 1 else 114
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile)
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+xcd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
 eng.set_hyper([0.75,0.75,0.5], 0.003, 1e-3)

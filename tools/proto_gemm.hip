@@ -1,0 +1,277 @@
+// Standalone prototype / microbenchmark of the fp32-MFMA tile kernel structure
+// (not part of the library): measures, on the GPU box,
+//   (1) the v_mfma_f32_32x32x2_f32 issue-rate ceiling with every SIMD busy,
+//   (2) LDS-DMA (global_load_lds_dwordx4) staged GEMM tiles for the three operand
+//       combinations of the TA3N step at its real shapes:
+//         NT  (A K-contiguous, B K-contiguous)  forward      X W^T
+//         NN  (A K-contiguous, B k-major)        input grad   G W
+//         TN  (A k-major,      B k-major)        weight grad  G^T X
+// build: hipcc -O3 --offload-arch=gfx950 tools/proto_gemm.hip -o gpurun_out/proto_gemm
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// ---------------------------------------------------------------- (1) MFMA ceiling
+__global__ __launch_bounds__(256) void mfma_peak(float *out, int iters) {
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    for (int i = 0; i < iters; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ---------------------------------------------------------------- (2) tile GEMM
+
+struct Gemm {
+    const float *A, *B;
+    float *C;
+    int M, N, K, lda, ldb, ldc;
+    const float *zeros;
+};
+
+// LDS-DMA issued from inline asm so that hipcc does not track it: a compiler-visible
+// __builtin_amdgcn_global_load_lds makes hipcc put s_waitcnt vmcnt(0) in front of every
+// later ds_read, which drains the prefetched stages.  Completion is counted by hand
+// (s_waitcnt vmcnt(N) + s_barrier) in the main loop.  lds_byte_addr must be wave-uniform.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// Stage image of a K-contiguous operand: [row][16 slots], slot' = slot ^ (row & 15).
+// Stage image of a k-major operand:      [k][R] linear.
+// One wave instruction moves 64 lanes x 16 B = 1 KiB to consecutive LDS bytes.
+template <int R, bool KMAJOR, int BK, int NW>
+__device__ __forceinline__ void issue_operand(const float *__restrict__ base, int ld, int r0, int rvalid, int k0, int klen,
+                                              unsigned lds_op_addr, int wave, int lane, const float *__restrict__ zeros) {
+    constexpr int NINSTR = R * BK * 4 / 1024;      // wave instructions per stage for this operand
+    constexpr int PER_WAVE = NINSTR / NW;
+    static_assert(NINSTR % NW == 0, "pieces must divide over the waves");
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int q = wave + NW * i;               // instruction id -> 1 KiB piece q
+        const float *src;
+        if (!KMAJOR) {
+            constexpr int SPR = BK / 4;            // 16-byte slots per row
+            const int row = q * (64 / SPR) + lane / SPR;
+            const int g = (lane % SPR) ^ (row & 15);
+            const int k = k0 + 4 * g;
+            src = (r0 + row < rvalid && k < klen) ? base + (size_t)(r0 + row) * ld + k : zeros;
+        } else {
+            constexpr int LPR = R / 4;             // lanes per k row
+            constexpr int KPI = 64 / LPR;          // k rows per piece
+            const int k = k0 + q * KPI + lane / LPR;
+            const int r = r0 + (lane % LPR) * 4;
+            src = (r < rvalid && k < klen) ? base + (size_t)k * ld + r : zeros;
+        }
+        glds16(src, lds_op_addr + q * 1024);
+    }
+}
+
+template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK>
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
+    constexpr int NW = WM * WN * WK;
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int STAGE = (BM + BN) * BK;          // floats
+    constexpr int LPW = (BM + BN) * BK * 4 / 1024 / NW;   // glds instructions per wave per stage
+    constexpr int GPW = BK / 4 / WK;               // 4-wide k groups per wave per stage
+    constexpr int LDS_FLOATS = NBUF * STAGE > NW * 32 * 36 ? NBUF * STAGE : NW * 32 * 36;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t *)lds);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int nchunks = (g.K + BK - 1) / BK;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    auto issue = [&](int c) {
+        const unsigned st = lds_base + (unsigned)((c % NBUF) * STAGE * 4);
+        issue_operand<BM, AKM, BK, NW>(g.A, g.lda, m0, g.M, c * BK, g.K, st, wave, lane, g.zeros);
+        issue_operand<BN, BKM, BK, NW>(g.B, g.ldb, n0, g.N, c * BK, g.K, st + BM * BK * 4, wave, lane, g.zeros);
+    };
+    // prologue: NBUF-1 stages in flight (stages past the end read zeros: keeps the vmcnt arithmetic uniform)
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c) issue(c);
+
+    for (int c = 0; c < nchunks; ++c) {
+        // this wave's pieces of stage c have landed once at most (NBUF-2) newer stages are outstanding
+        if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+        __builtin_amdgcn_s_barrier();              // everyone's pieces landed; everyone finished reading stage c-1
+        asm volatile("" ::: "memory");
+        issue(c + NBUF - 1);                       // refill the buffer stage c-1 used
+        const float *sa = lds + (c % NBUF) * STAGE;
+        const float *sb = sa + BM * BK;
+#pragma unroll
+        for (int q = 0; q < GPW / 2; ++q) {
+            const int G = wk * GPW + 2 * q + lh;   // this half-wave's k group: k = 4G .. 4G+3
+            float av[4], bv[4];
+            if (!AKM) {
+                const int r = wm * 32 + li;
+                const float4 t = *reinterpret_cast<const float4 *>(sa + r * BK + ((G ^ (r & 15)) << 2));
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = sa[(4 * G + j) * BM + wm * 32 + li];
+            }
+            if (!BKM) {
+                const int r = wn * 32 + li;
+                const float4 t = *reinterpret_cast<const float4 *>(sb + r * BK + ((G ^ (r & 15)) << 2));
+                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = sb[(4 * G + j) * BN + wn * 32 + li];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // epilogue: reduce the K split through LDS, store row-contiguous
+    float *cs = lds + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < BM * BN / 4; idx += 64 * NW) {
+        const int r = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+        const int tile = (r >> 5) * WN + (c4 >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < WK; ++q) {
+            const float4 p = *reinterpret_cast<const float4 *>(&lds[(tile * WK + q) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int m = m0 + r, n = n0 + c4;
+        if (m < g.M && n < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)m * g.ldc + n) = v;
+    }
+}
+
+static double cpu_ref(const std::vector<float> &A, const std::vector<float> &B, int lda, int ldb, bool akm, bool bkm, int K, int m, int n) {
+    double s = 0;
+    for (int k = 0; k < K; ++k) {
+        const double a = akm ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+        const double b = bkm ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
+        s += a * b;
+    }
+    return s;
+}
+
+template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK = 64>
+void run(const char *name, int M, int N, int K) {
+    const int lda = AKM ? M : K, ldb = BKM ? N : K;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto &v : hA) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto &v : hB) v = (float)rand() / RAND_MAX - 0.5f;
+    float *dA, *dB, *dC, *dz;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dz, 256));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dz, 0, 256));
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    Gemm g{dA, dB, dC, M, N, K, lda, ldb, N, dz};
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    const int reps = 50;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 400; ++t) {
+        const int m = (t * 7919) % M, n = (t * 104729) % N;
+        maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, m, n) - hC[(size_t)m * N + n]));
+    }
+    // last row / col corners
+    maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, M - 1, N - 1) - hC[(size_t)(M - 1) * N + N - 1]));
+    const double us = 1e3 * ms / reps;
+    printf("%-12s %dx%dx%d tile %dx%d wk%d nbuf%d bk%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, BM, BN, WK, NBUF, BK, grid, us,
+           2.0 * M * N * K / us * 1e-6, maxerr);
+    fflush(stdout);
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
+}
+
+int main() {
+    {   // (1) ceiling
+        float *out;
+        CK(hipMalloc(&out, 2048 * 256 * 4));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int blocks : {256, 512, 1024, 2048}) {
+            const int iters = 4096;
+            hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, out, iters);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, out, iters);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double flops = (double)blocks * 4 * iters * 2 * 4096.0;
+            printf("mfma_peak blocks %4d: %.1f us  %.1f TF\n", blocks, ms * 1e3, flops / ms * 1e-9);
+        }
+        CK(hipFree(out));
+    }
+    // (2) forward shared-FC shape
+    run<1, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
+    run<1, 1, 8, 2, false, false>("NT F1", 1010, 512, 2048);
+    run<1, 1, 8, 3, false, false>("NT F1", 1010, 512, 2048);
+    run<1, 1, 4, 2, false, false, 128>("NT F1", 1010, 512, 2048);
+    run<1, 1, 8, 2, false, false, 128>("NT F1", 1010, 512, 2048);
+    run<2, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
+    run<2, 1, 4, 3, false, false>("NT F1", 1010, 512, 2048);
+    run<1, 2, 4, 2, false, false>("NT F1", 1010, 512, 2048);
+    run<2, 1, 4, 2, false, false, 128>("NT F1", 1010, 512, 2048);
+    run<2, 2, 2, 2, false, false>("NT F1", 1010, 512, 2048);
+    run<2, 2, 2, 2, false, false, 128>("NT F1", 1010, 512, 2048);
+    // TRN tuple GEMM shape (one of ten): 202 x 256 x 2560
+    run<1, 1, 4, 2, false, false>("NT TRN s5", 202, 256, 2560);
+    run<1, 1, 8, 2, false, false>("NT TRN s5", 202, 256, 2560);
+    // input-gradient shape
+    run<1, 1, 4, 2, false, true>("NN dgrad", 202, 512, 2176);
+    run<1, 1, 8, 2, false, true>("NN dgrad", 202, 512, 2176);
+    run<1, 1, 8, 2, false, true, 128>("NN dgrad", 202, 512, 2176);
+    // weight-gradient shapes
+    run<1, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 8, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 1, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 2, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 2, 3, true, true>("TN dWsh", 512, 2048, 1010);
+    run<2, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 2, 2, true, true, 128>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 4, 2, true, true>("TN dWtrn", 256, 512, 606);
+    run<1, 1, 8, 2, true, true>("TN dWtrn", 256, 512, 606);
+    run<2, 2, 2, 2, true, true>("TN dWtrn", 256, 512, 606);
+    return 0;
+}
