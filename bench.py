@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--phase-tiles", type=str, default="", help="comma list of per-GEMM-phase tile configs")
     ap.add_argument("--autotune", action="store_true", help="measure tile configs per GEMM launch and use the best")
     ap.add_argument("--xcd", type=int, default=0, help="0/1 XCD-aware tile ordering on, 2 off")
+    ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
@@ -135,7 +136,8 @@ def main():
     if args.tile:
         phase_tiles = []
     eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
-                      clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd)
+                      clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
+                      fused=not args.unfused)
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
     xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)
@@ -191,10 +193,11 @@ def main():
                                    "dropout 0.5/0.5, clip 20, Nesterov SGD (BASELINE configs[2] arithmetic, fp32)",
                        "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else "hipGraph", "finite": finite,
-                       "phase_tiles": [p[1] for p in phases if p[0] == 0]},
+                       "step": "fused (ta3n_train_step)" if eng.fused else "forward+loss+backward",
+                       "phase_tiles": [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "ta3n::gemm_tiles (11 launches/step)",
+                         "kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step)",
                          "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
                          "launches": len(gemm), "all_kernels_us": 1e3 * sum(p[3] for p in phases),
                          "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]},

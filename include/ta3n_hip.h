@@ -158,6 +158,18 @@ int ta3n_loss(ta3n_plan *plan, float *ws, void *stream);
 int ta3n_backward(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
                   void *stream);
 
+/* ta3n_forward + ta3n_loss + ta3n_backward of one step in 7 launches instead of 15: the
+ * three GEMM levels of the forward pass, ONE kernel for everything between the hidden
+ * activations (Hr, Hf) and their gradients (both discriminator heads, attention pooling,
+ * classifier, all losses of main.py:439-562 and their backward), then three GEMM levels
+ * of the backward pass.  Same workspace regions and results (up to fp32 summation order)
+ * as the three separate calls; an upstream gradient in ws["g_attn"] is NOT consumed
+ * (main.train never produces one).  ta3n_has_fused_step() tells whether the plan has it
+ * (num_bottleneck == 256, num_class <= 64, fc_dim <= 2048); otherwise ta3n_train_step returns TA3N_ERR_INVALID. */
+int ta3n_has_fused_step(const ta3n_plan *plan);
+int ta3n_train_step(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
+                    void *stream);
+
 /* clip_grad_norm_ + Nesterov SGD with weight decay (main.py:578-583) on the
  * flat live prefix; ws["grad_norm"] receives the pre-clip global norm. */
 int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
@@ -166,13 +178,16 @@ int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum,
 /* Measurement aid: per-launch durations (ms) of every phase of one train step,
  * taken with HIP events recorded on `stream`; GEMM/pool/loss phases are repeated
  * `reps` times back to back.  kind_out[i]: 0 GEMM, 1 pool fwd, 2 loss, 3 pool bwd,
- * 4 grad norm, 5 SGD.  Synchronises the stream.  Returns the number of phases. */
+ * 4 grad norm, 5 SGD, 6 fused heads; group_out[i]: 0 forward, 1 loss, 2 backward,
+ * 3 optimiser, 4 fused step (ta3n_train_step).  Synchronises the stream.  Returns the
+ * number of phases. */
 int ta3n_time_phases(ta3n_plan *plan, const float *x, float *params, float *grads, float *momentum,
-                     float *ws, void *stream, int reps, float *ms_out, int32_t *kind_out, int cap);
+                     float *ws, void *stream, int reps, float *ms_out, int32_t *kind_out,
+                     int32_t *group_out, int cap);
 
 /* Number of kernel launches the last ta3n_forward/ta3n_backward enqueued, and a
  * name for the dominant GEMM kernel symbol (for rocprof matching). */
-int ta3n_num_phases(const ta3n_plan *plan, int which /*0 fwd,1 loss,2 bwd,3 sgd*/);
+int ta3n_num_phases(const ta3n_plan *plan, int which /*0 fwd,1 loss,2 bwd,3 sgd,4 fused step*/);
 
 /* Test/debug access to the plan's host-side descriptor arrays (Seg/Task/Phase/
  * Geom PODs of ta3n_amd/csrc/ta3n_types.h) so the wiring can be validated on a

@@ -28,7 +28,8 @@ SYMBOLS = [
     "ta3n_num_relation_tuples", "ta3n_relation_table", "ta3n_segment_indices", "ta3n_plan_create",
     "ta3n_plan_destroy", "ta3n_num_params", "ta3n_param_info", "ta3n_param_floats", "ta3n_live_param_floats",
     "ta3n_workspace_floats", "ta3n_ws_offset", "ta3n_ws_size", "ta3n_plan_describe", "ta3n_set_hyper",
-    "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_sgd_step", "ta3n_num_phases",
+    "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step",
+    "ta3n_sgd_step", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_last_error", "ta3n_version",
 ]
 
@@ -86,9 +87,12 @@ def lib() -> C.CDLL:
     L.ta3n_forward.argtypes = [vp, vp, vp, vp, vp]
     L.ta3n_loss.argtypes = [vp, vp, vp]
     L.ta3n_backward.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ta3n_has_fused_step.argtypes = [vp]
+    L.ta3n_train_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ta3n_sgd_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ta3n_num_phases.argtypes = [vp, C.c_int]
-    L.ta3n_time_phases.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i32), C.c_int]
+    L.ta3n_time_phases.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i32),
+                                   C.c_int]
     L.ta3n_debug_arrays.argtypes = [vp] + [C.POINTER(vp), C.POINTER(i64)] * 3 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ta3n_debug_struct_sizes.argtypes = [C.POINTER(i32)] * 5
     L.ta3n_last_error.restype = C.c_char_p
@@ -159,6 +163,7 @@ class Plan:
         L.ta3n_plan_describe(h, buf, n + 1)
         self.description = json.loads(buf.value.decode())
         self.regions: Dict[str, Tuple[int, int]] = {k: tuple(v) for k, v in self.description["regions"].items()}
+        self.has_fused_step = L.ta3n_has_fused_step(h) == 1
 
     def region(self, name: str) -> Tuple[int, int]:
         return self.regions[name]

@@ -63,6 +63,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
             case PH_POOL_BWD: rc = launch_pool_bwd(p->geom, ptrs, stream); break;
+            case PH_HEADS: rc = launch_heads(p->geom, ptrs, stream); break;
             case PH_GRAD_NORM: rc = launch_grad_norm(p->geom, ptrs.g, ptrs.ws, stream); break;
             case PH_SGD: rc = launch_sgd(p->geom, params_rw, ptrs.g, momentum, ptrs.ws, stream); break;
             default: rc = -1;
@@ -201,7 +202,7 @@ int ta3n_init_workspace(ta3n_plan *p, float *ws, void *stream) {
     if (rc != TA3N_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(ws, 0, (size_t)p->ws_floats * sizeof(float), s));
-    if (launch_fill(ws + p->geom.o_ones, 1.0f, (int64_t)p->geom.B * p->geom.T, s) != 0)
+    if (launch_fill(ws + p->geom.o_ones, 1.0f, (int64_t)p->geom.B * p->geom.T * 4, s) != 0)
         return fail(TA3N_ERR_HIP, "fill launch failed");
     HIP_TRY(hipMemcpyAsync(ws + p->geom.o_tuple_first, p->tuple_first.data(), p->tuple_first.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice, s));
@@ -252,7 +253,7 @@ int ta3n_backward(ta3n_plan *p, const float *x, const float *params, float *grad
 // run on).  Each GEMM / pool / loss phase is launched `reps` times back to back
 // between two events (the phases are idempotent); optimiser phases once.
 int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws,
-                     void *stream, int reps, float *ms_out, int32_t *kind_out, int cap) {
+                     void *stream, int reps, float *ms_out, int32_t *kind_out, int32_t *group_out, int cap) {
     if (!p || !x || !params || !grads || !momentum || !ws || !ms_out) return fail(TA3N_ERR_INVALID, "null argument");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
@@ -274,6 +275,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;
+                case PH_HEADS: lrc = launch_heads(p->geom, ptrs, s); break;
                 case PH_GRAD_NORM: lrc = launch_grad_norm(p->geom, grads, ws, s); break;
                 case PH_SGD: lrc = launch_sgd(p->geom, params, grads, momentum, ws, s); break;
                 default: lrc = -1;
@@ -290,9 +292,30 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
         ms_out[i] = ms / (float)r;
         if (kind_out) kind_out[i] = ph.kind;
+        if (group_out) group_out[i] = ph.group;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return n;
+}
+
+int ta3n_has_fused_step(const ta3n_plan *p) {
+    if (!p) return TA3N_ERR_INVALID;
+    for (const Phase &ph : p->phases)
+        if (ph.group == 4) return 1;
+    return 0;
+}
+
+int ta3n_train_step(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream) {
+    if (!p || !x || !params || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_fused_step(p) != 1)
+        return fail(TA3N_ERR_INVALID, "no fused step for this configuration (needs num_bottleneck == 256, num_class <= 64, fc_dim <= 2048): "
+                                      "use ta3n_forward + ta3n_loss + ta3n_backward");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{x, params, grads, ws};
+    return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int ta3n_sgd_step(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // M0 is compiler-reserved, so it is saved and restored inside the statement.
 __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
     unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
@@ -62,6 +63,7 @@ __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr
 template <int NP>
 __device__ __forceinline__ void glds16_batch(const float *const (&src)[NP], unsigned lds_byte_addr, unsigned stride) {
     unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // wave-uniform by construction; makes it provably so
     if constexpr (NP == 1) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src[0]), "s"(lds_byte_addr) : "memory");
@@ -81,6 +83,7 @@ __device__ __forceinline__ void glds16_batch(const float *const (&src)[NP], unsi
 }
 __device__ __forceinline__ void glds4(const float *gsrc, unsigned lds_byte_addr) {
     unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
@@ -221,6 +224,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
     const Task &t = tasks[blockIdx.x];
     if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
+    if (t.epi & EPI_SUMROWS8) {   // side job of one workgroup per fused step: add up the heads kernel's loss partials in a fixed order
+        const float *__restrict__ src = ptrs.ws + t.pad[1];
+        float sacc = 0.f;
+        for (int r = tid >> 3; r < t.pad[2]; r += NT / 8) sacc += src[r * 8 + (tid & 7)];
+        lds[tid] = sacc;
+        __syncthreads();
+        if (tid < 8) {
+            float v = 0.f;
+            for (int i = 0; i < NT / 8; ++i) v += lds[i * 8 + tid];
+            ptrs.ws[t.pad[0] + tid] = v;
+        }
+        __syncthreads();
+    }
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
     const float *__restrict__ zeros = ptrs.ws + zeros_off;   // 64 floats that are never written
 
@@ -240,7 +256,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     auto open_seg = [&](int sidx) {                // wave-uniform: Seg fields live in SGPRs
         const Seg &sg = segs[sidx];
         klen = sg.klen; combo = sg.a_kmajor * 2 + sg.b_kmajor; scale = sg.scale_kind;
-        oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, sg.a_kmajor, sg.klen, m0, m_valid, wave, lane);
+        oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, sg.a_kmajor, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
+                 wave, lane);
         ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, sg.b_kmajor, sg.klen, n0, n_valid, wave, lane);
     };
     auto issue = [&](int buf, int k0) {

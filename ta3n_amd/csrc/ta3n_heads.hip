@@ -1,0 +1,554 @@
+// Fused "heads" kernel of the TA3N train step (gfx950, wave64): everything between
+// the hidden activations (Hr, Hf) and their gradients (gHr, gHf) in ONE launch -
+// forward, loss assembly and backward of
+//   * the relation discriminators' 2-wide output layers, the transferable attention
+//     w = 1 - H(softmax Pr), R_j = sum of the scale's tuple activations, the pooled
+//     video feature V = sum_j (1+w_j) R_j and dropout_v
+//     (reference models.py:472-488, 351-357, 379-388, 651, 679; TRNmodule.py:73-79),
+//   * the video classifier Y and the video discriminator Hv -> Pv (models.py:686, 464-470),
+//   * the frame discriminator's output layer Pf (models.py:460),
+//   * classification CE, the three adversarial CEs and the attentive entropy with all
+//     their logit gradients (main.py:439-451, 508-538, 559-562; loss.py:15-25),
+//   * GradReverse (models.py:20-29) as the -beta factor of gVt,
+//   * the un-detached attention path (dL/dw_j = <R_j, dL/dV>) back into Pr.
+// It replaces seven launches of the unfused path (pool_fwd, two small GEMM levels, loss,
+// two small GEMM levels, pool_bwd).
+//
+// Grid: n_vid_wg video workgroups (HEADS_VPW videos each: one wave per video for the
+// per-video reductions, thread t <-> channel t for the 256-wide layers) followed by
+// n_frm_wg frame workgroups (HEADS_RPW frame rows each, 4 rows per wave).
+//
+// The kernel is a chain of short dependent stages with one wave per SIMD, so its time
+// is memory round trips, not arithmetic.  Structure follows from that:
+//   * every load whose address does not depend on a computed value is issued at the top
+//     of the kernel (classifier weights, first discriminator weight tile, output-layer
+//     rows, biases) and lands while the first stage computes;
+//   * the 256x256 video-discriminator layer is a VALU mini-GEMM over LDS-staged weight
+//     tiles (forward: 256 outputs x 64 k per tile, backward: 64 outputs x 256 k), the
+//     next tile travelling in registers while the current one is multiplied, shared by
+//     the HEADS_VPW videos of the workgroup;
+//   * a frame wave keeps its 4 rows in registers: one round trip for the forward dots,
+//     none for the backward.
+// Cross-workgroup sums made here (dWcd, dbcd, the logging scalars) are written as
+// per-workgroup partials and added in a fixed order by the next GEMM launch, so
+// results are bitwise reproducible and no atomics are used.
+#include <hip/hip_runtime.h>
+
+#include "../../include/ta3n_hip.h"
+#include "ta3n_kernels.h"
+
+using namespace ta3n;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP float4 are demoted to scratch by hipcc)
+
+constexpr int NBH = 256;           // num_bottleneck of trn-m (models.py:223); thread t <-> channel t
+constexpr int VPW = HEADS_VPW;
+constexpr int RPW = HEADS_RPW;
+constexpr int WROW = 68;           // padded row of the forward tile [256 n][64 k] (conflict-free b128 row reads)
+constexpr int TROW = 260;          // padded row of the backward tile [64 n][256 k] and of the classifier weights [C][256]
+
+// LDS carve-up (floats)
+constexpr int S_W = 0;                               // weight tile (17408 floats)
+constexpr int S_VD = S_W + NBH * WROW;               // [VPW][256] dropped-out video feature
+constexpr int S_HV = S_VD + VPW * NBH;               // [VPW][256] video-discriminator hidden
+constexpr int S_GHV = S_HV + VPW * NBH;              // [VPW][256] its gradient
+constexpr int S_GVT = S_GHV + VPW * NBH;             // [VPW][256] gradient at the pooled feature
+constexpr int S_GY = S_GVT + VPW * NBH;              // [VPW][64]  class-logit gradients
+constexpr int S_PR = S_GY + VPW * 64;                // [VPW][64][2] relation logits
+constexpr int S_GPV = S_PR + VPW * 128;              // [VPW][2]
+constexpr int S_LOSS = S_GPV + 8;                    // [4 waves][8] loss partials
+constexpr int S_TOTAL = S_LOSS + 32;
+static_assert(64 * TROW <= NBH * WROW, "backward tile / classifier staging must fit in the weight tile");
+
+__device__ __forceinline__ bool video_valid(int Bs, const Hyper *hy, int b) {
+    return b < Bs ? (b < hy->valid_source) : (b - Bs < hy->valid_target);
+}
+
+// this workgroup's loss partials -> ws["loss_part"][wg][8] = {total, cls, rel, vid, frm, ent, 0, 0}
+__device__ __forceinline__ void write_loss_part(float *smem, float *ws, int o_loss_part, int wg, float gamma) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    float v = 0.f;
+    if (tid < 8) v = (smem[S_LOSS + tid] + smem[S_LOSS + 8 + tid]) + (smem[S_LOSS + 16 + tid] + smem[S_LOSS + 24 + tid]);
+    __syncthreads();
+    if (tid < 8) smem[S_LOSS + tid] = v;
+    __syncthreads();
+    if (tid < 8) {
+        if (tid == 0) v = smem[S_LOSS + 1] + smem[S_LOSS + 2] + smem[S_LOSS + 3] + smem[S_LOSS + 4] + gamma * smem[S_LOSS + 5];
+        ws[o_loss_part + wg * 8 + tid] = v;
+    }
+}
+
+__device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *smem) {
+    float *__restrict__ ws = ptrs.ws;
+    const float *__restrict__ wsr = ptrs.ws;       // regions this kernel only reads (Hr, Zr): their loads may move over stores
+    const float *__restrict__ P = ptrs.p;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
+    const int *__restrict__ tf = reinterpret_cast<const int *>(ptrs.ws + g.o_tuple_first);
+    const int *__restrict__ labels = reinterpret_cast<const int *>(ptrs.ws + g.o_labels);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NR = g.n_rel, NT = g.n_tuples, C = g.C;
+    const int b0 = blockIdx.x * VPW;
+    const int nv = min(VPW, g.B - b0);
+    const int b = b0 + wv;                         // this wave's video (per-video stages)
+    const bool have = wv < nv;
+    const bool attn_on = (g.flags & TA3N_FLAG_TRANS_ATTN) != 0;
+    const bool train = hy->train != 0;
+    const float inv_keep_v = hyper_scale(hy, SK_INV_KEEP_V);
+    const bool drop_v = train && hy->p_drop_v > 0.f;
+    const float *__restrict__ Wdv = P + g.p_Wdv;
+    const float *__restrict__ Wcv = P + g.p_Wcv;
+    float l_cls = 0.f, l_rel = 0.f, l_vid = 0.f, l_ent = 0.f;
+
+    // ---- address-independent loads, issued first ----
+    f32x4 cw[16];                                  // classifier weights [C][256]: float4 i*256+tid of the flat array
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        cw[i] = (i * 256 + tid < C * 64) ? *reinterpret_cast<const f32x4 *>(Wcv + (size_t)(i * 256 + tid) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 stage[16];                               // forward tile 0: Wdv[all n][0..63], 16 threads per row
+    const int srow = tid >> 4, sk4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(srow + 16 * i) * NBH + sk4);
+    const float *__restrict__ Wcdv = P + g.p_Wcdv;
+    float wc0[4], wc1[4];                          // output layer of the video discriminator, this lane's channels
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { wc0[q] = Wcdv[q * 64 + lane]; wc1[q] = Wcdv[NBH + q * 64 + lane]; }
+    const float wct0 = Wcdv[tid], wct1 = Wcdv[NBH + tid];
+    const float bcdv0 = P[g.p_bcdv], bcdv1 = P[g.p_bcdv + 1];
+    const float bdv_t = P[g.p_bdv + tid];
+    const float bcv_l = lane < C ? P[g.p_bcv + lane] : 0.f;
+    const int label = (have && b < g.Bs) ? labels[b] : -1;
+
+    // ---- A: relation logits, attention, R, V, Vd (one wave per video) ----
+    if (have) {
+        float vacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NR; ++j) {
+            const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+            const float *__restrict__ b2 = P + g.p_b2_0 + (size_t)j * g.p_b2_stride;
+            const float *__restrict__ hr = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                const float h = hr[c];
+                d0 = fmaf(h, W2[c], d0);
+                d1 = fmaf(h, W2[NBH + c], d1);
+            }
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int t = tf[j]; t < tf[j + 1]; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
+            }
+            d0 = wave_allreduce_sum(d0) + b2[0];
+            d1 = wave_allreduce_sum(d1) + b2[1];
+            float w = 0.f;
+            if (attn_on) w = 1.f - soft2(d0, d1).H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ws[g.o_R + ((size_t)b * NR + j) * NBH + q * 64 + lane] = r[q];
+                vacc[q] += attn_on ? (w + 1.f) * r[q] : r[q];
+            }
+            if (lane == 0) {
+                ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 0] = d0;
+                ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 1] = d1;
+                ws[g.o_attn + (size_t)b * NR + j] = attn_on ? w : r[0];   // models.py:647-648
+                smem[S_PR + (wv * 64 + j) * 2 + 0] = d0;
+                smem[S_PR + (wv * 64 + j) * 2 + 1] = d1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 64 + lane;
+            const float v = vacc[q];
+            ws[g.o_V + (size_t)b * NBH + c] = v;
+            float vd = v;
+            if (drop_v) vd = v * keep_mask(hy->seed_v, (uint32_t)(b * NBH + c), hy->p_drop_v) * inv_keep_v;
+            ws[g.o_Vd + (size_t)b * NBH + c] = vd;
+            smem[S_VD + wv * NBH + c] = vd;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) smem[S_VD + wv * NBH + q * 64 + lane] = 0.f;
+    }
+    // classifier weights -> LDS [C][TROW]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = i * 256 + tid;               // float4 index: row c = f / 64, k4 = (f % 64) * 4
+        if (f < C * 64) *reinterpret_cast<f32x4 *>(&smem[S_W + (f >> 6) * TROW + (f & 63) * 4]) = cw[i];
+    }
+    __syncthreads();
+
+    // ---- B: class logits: wave = video, lane = class ----
+    float y = -INFINITY;
+    if (lane < C) {
+        float acc = 0.f;
+        const float *wr = &smem[S_W + lane * TROW];
+        const float *vd = &smem[S_VD + wv * NBH];
+#pragma unroll 8
+        for (int k4 = 0; k4 < NBH; k4 += 4) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
+            const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
+            acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
+        }
+        y = acc + bcv_l;
+        if (have) ws[g.o_Y + (size_t)b * C + lane] = y;
+    }
+    __syncthreads();   // done with the classifier tile
+
+    // ---- C: Hv = relu(Wdv Vd + bdv): thread t owns output channel t for all VPW videos ----
+    {
+        float acc[VPW];
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NBH; kc += 64) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i) * WROW + sk4]) = stage[i];
+            __syncthreads();
+            if (kc + 64 < NBH) {                   // next forward tile
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(srow + 16 * i) * NBH + kc + 64 + sk4);
+            } else {                               // first backward tile: Wdv[0..63][all k], 64 threads per row
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)((tid >> 6) + 4 * i) * NBH + (tid & 63) * 4);
+            }
+            const float *wr = &smem[S_W + tid * WROW];
+#pragma unroll 4
+            for (int k4 = 0; k4 < 64; k4 += 4) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
+#pragma unroll
+                for (int v = 0; v < VPW; ++v) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(&smem[S_VD + v * NBH + kc + k4]);
+                    acc[v] = fmaf(w4.x, x4.x, acc[v]); acc[v] = fmaf(w4.y, x4.y, acc[v]);
+                    acc[v] = fmaf(w4.z, x4.z, acc[v]); acc[v] = fmaf(w4.w, x4.w, acc[v]);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) {
+            const float h = fmaxf(acc[v] + bdv_t, 0.f);
+            smem[S_HV + v * NBH + tid] = h;
+            if (v < nv) ws[g.o_Hv + (size_t)(b0 + v) * NBH + tid] = h;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: video domain logits, losses, gY, gPv (one wave per video, lane = class) ----
+    {
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float h = smem[S_HV + wv * NBH + q * 64 + lane];
+            d0 = fmaf(h, wc0[q], d0);
+            d1 = fmaf(h, wc1[q], d1);
+        }
+        d0 = wave_allreduce_sum(d0) + bcdv0;
+        d1 = wave_allreduce_sum(d1) + bcdv1;
+        // class softmax over lanes (lanes >= C hold -inf)
+        const float m = wave_allreduce_max(y);
+        const float e = lane < C ? expf(y - m) : 0.f;
+        const float ls = logf(wave_allreduce_sum(e));
+        const float lp = lane < C ? y - m - ls : 0.f;
+        const float pr = lane < C ? expf(lp) : 0.f;
+        const float Hc = wave_allreduce_sum(-pr * lp);
+        float gy = 0.f, g0 = 0.f, g1 = 0.f;
+        if (have) {
+            const bool is_src = b < g.Bs;
+            const bool valid = video_valid(g.Bs, hy, b);
+            const bool cls_on = is_src && valid;
+            const Soft2 s = soft2(d0, d1);
+            const bool ent_on = (g.flags & TA3N_FLAG_ATTN_ENTROPY) && valid;
+            const float ce = hy->gamma * hy->inv_n_ent;
+            if (cls_on) {                                                              // main.py:446
+                gy = (pr - (lane == label ? 1.f : 0.f)) * hy->inv_n_cls;
+                if (lane == label) l_cls = -lp * hy->inv_n_cls;
+            }
+            if (ent_on) {                                                              // loss.py:20-24
+                gy += ce * (1.f + s.H) * (-pr * (lp + Hc));                            // dH/dz_i = -p_i (log p_i + H)
+                if (lane == 0) l_ent = (1.f + s.H) * Hc * hy->inv_n_ent;
+            }
+            if (lane >= C) gy = 0.f;
+            if ((g.flags & TA3N_FLAG_ADV_VIDEO) && valid) {                           // main.py:508-538, l = 1
+                const int d = is_src ? 0 : 1;
+                if (lane == 0) l_vid = -(d ? s.lp1 : s.lp0) * hy->inv_n_vid;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_vid;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_vid;
+            }
+            if (ent_on) {
+                g0 += ce * Hc * (-s.p0 * (s.lp0 + s.H));
+                g1 += ce * Hc * (-s.p1 * (s.lp1 + s.H));
+            }
+            if (lane < C) ws[g.o_gY + (size_t)b * C + lane] = gy;
+            if (lane == 0) {
+                ws[g.o_Pv + (size_t)b * 2] = d0; ws[g.o_Pv + (size_t)b * 2 + 1] = d1;
+                ws[g.o_gPv + (size_t)b * 2] = g0; ws[g.o_gPv + (size_t)b * 2 + 1] = g1;
+            }
+        }
+        smem[S_GY + wv * 64 + lane] = gy;
+        if (lane == 0) { smem[S_GPV + wv * 2] = g0; smem[S_GPV + wv * 2 + 1] = g1; }
+        l_cls = wave_allreduce_sum(l_cls);   // it sits in the label's lane
+    }
+    __syncthreads();
+
+    // ---- E: gHv = (gPv Wcdv) * [Hv > 0] ----
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+        const float gh = smem[S_HV + v * NBH + tid] > 0.f ? smem[S_GPV + v * 2] * wct0 + smem[S_GPV + v * 2 + 1] * wct1 : 0.f;
+        smem[S_GHV + v * NBH + tid] = gh;
+        if (v < nv) ws[g.o_gHv + (size_t)(b0 + v) * NBH + tid] = gh;
+    }
+    // no barrier needed here: the first one inside stage F orders these LDS writes before their reads
+
+    // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ): thread t owns input channel t ----
+    {
+        float acc[VPW];
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) acc[v] = 0.f;
+        const int trow = tid >> 6, tk4 = (tid & 63) * 4;   // backward tile: 64 threads per row, 4 rows per pass
+#pragma unroll
+        for (int n0 = 0; n0 < NBH; n0 += 64) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (trow + 4 * i) * TROW + tk4]) = stage[i];
+            __syncthreads();
+            if (n0 + 64 < NBH) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(n0 + 64 + trow + 4 * i) * NBH + tk4);
+            }
+#pragma unroll 4
+            for (int n = 0; n < 64; n += 4) {
+                const float w0 = smem[S_W + (n + 0) * TROW + tid], w1 = smem[S_W + (n + 1) * TROW + tid];
+                const float w2 = smem[S_W + (n + 2) * TROW + tid], w3 = smem[S_W + (n + 3) * TROW + tid];
+#pragma unroll
+                for (int v = 0; v < VPW; ++v) {
+                    const float4 g4 = *reinterpret_cast<const float4 *>(&smem[S_GHV + v * NBH + n0 + n]);
+                    acc[v] = fmaf(g4.x, w0, acc[v]); acc[v] = fmaf(g4.y, w1, acc[v]);
+                    acc[v] = fmaf(g4.z, w2, acc[v]); acc[v] = fmaf(g4.w, w3, acc[v]);
+                }
+            }
+            __syncthreads();
+        }
+        const float nb1 = -hy->beta[1];
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) acc[v] *= nb1;
+        // classifier weights are needed column-wise now: restage [C][256] (cw[] held them since the top)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = i * 256 + tid;
+            if (f < C * 64) *reinterpret_cast<f32x4 *>(&smem[S_W + (f >> 6) * TROW + (f & 63) * 4]) = cw[i];
+        }
+        __syncthreads();
+        for (int c = 0; c < C; ++c) {
+            const float w = smem[S_W + c * TROW + tid];
+#pragma unroll
+            for (int v = 0; v < VPW; ++v) acc[v] = fmaf(smem[S_GY + v * 64 + c], w, acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) {
+            float gv = acc[v];
+            if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v);
+            gv *= inv_keep_v;
+            smem[S_GVT + v * NBH + tid] = gv;
+            if (v < nv) ws[g.o_gVt + (size_t)(b0 + v) * NBH + tid] = gv;
+        }
+    }
+    __syncthreads();
+
+    // ---- G: backward of the attention pooling + relation adversarial loss (one wave per video) ----
+    if (have) {
+        const float *__restrict__ wsR = ptrs.ws;   // R: written in stage A, only read from here on
+        const bool is_src = b < g.Bs;
+        const bool valid = video_valid(g.Bs, hy, b);
+        const bool adv_rel = (g.flags & TA3N_FLAG_ADV_RELATION) && valid;
+        float gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q] = smem[S_GVT + wv * NBH + q * 64 + lane];
+        for (int j = 0; j < NR; ++j) {
+            const size_t bj = (size_t)b * NR + j;
+            const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+            float w20[4], w21[4], hrv[4], rv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                w20[q] = W2[c]; w21[q] = W2[NBH + c];
+                hrv[q] = wsr[g.o_Hr + bj * NBH + c];
+                rv[q] = wsR[g.o_R + bj * NBH + c];
+            }
+            const float z0 = smem[S_PR + (wv * 64 + j) * 2], z1 = smem[S_PR + (wv * 64 + j) * 2 + 1];
+            const Soft2 s = soft2(z0, z1);
+            float g0 = 0.f, g1 = 0.f;
+            if (adv_rel) {                                                             // main.py:508-538, l = 0
+                const int d = is_src ? 0 : 1;
+                if (lane == 0) l_rel += -(d ? s.lp1 : s.lp0) * hy->inv_n_rel;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_rel;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_rel;
+            }
+            if (lane == 0) { ws[g.o_gPr + bj * 2] = g0; ws[g.o_gPr + bj * 2 + 1] = g1; }
+            float w1 = 1.f;
+            if (attn_on) {
+                // dL/dw_j = <R_j, dL/dV>;  dw/dz_i = p_i (log p_i + H)   (the weights are not detached, models.py:351-357)
+                float dot = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dot = fmaf(rv[q], gv[q], dot);
+                dot = wave_allreduce_sum(dot);
+                g0 += dot * s.p0 * (s.lp0 + s.H);
+                g1 += dot * s.p1 * (s.lp1 + s.H);
+                w1 = 1.f + (1.f - s.H);
+            }
+            if (lane == 0) { ws[g.o_gPrT + bj * 2] = g0; ws[g.o_gPrT + bj * 2 + 1] = g1; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                ws[g.o_gRa + bj * NBH + c] = w1 * gv[q];
+                ws[g.o_gHr + bj * NBH + c] = hrv[q] > 0.f ? g0 * w20[q] + g1 * w21[q] : 0.f;
+            }
+        }
+    }
+    {
+        const float lr = __shfl(l_rel, 0, 64), lv = __shfl(l_vid, 0, 64), le = __shfl(l_ent, 0, 64);
+        if (lane < 8) {
+            float v = 0.f;
+            if (lane == 1) v = l_cls;
+            if (lane == 2) v = lr;
+            if (lane == 3) v = lv;
+            if (lane == 5) v = le;
+            smem[S_LOSS + wv * 8 + lane] = v;
+        }
+    }
+    write_loss_part(smem, ws, g.o_loss_part, blockIdx.x, hy->gamma);
+}
+
+// Frame rows: Pf, frame adversarial CE, gPf, gHf = (gPf Wcd) * [Hf > 0], and this workgroup's
+// partial sums of dWcd = gPf^T Hf and dbcd.  FQ = ceil(F / 64) channels per lane; each wave keeps
+// its 4 rows in registers.
+template <int FQ>
+__device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *smem, int wg) {
+    float *__restrict__ ws = ptrs.ws;
+    const float *__restrict__ wsr = ptrs.ws;       // Hf is only read
+    const float *__restrict__ P = ptrs.p;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int F = g.F, T = g.T, BT = g.B * g.T;
+    const float *__restrict__ W0 = P + g.p_Wcd, *__restrict__ W1 = W0 + F;
+    const float bc0 = P[g.p_bcd], bc1 = P[g.p_bcd + 1];
+    const bool adv = (g.flags & TA3N_FLAG_ADV_FRAME) != 0;
+    constexpr int NROW = RPW / 4;
+    float w0[FQ], w1[FQ], hf[NROW][FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) {
+        const int k = q * 64 + lane;
+        w0[q] = k < F ? W0[k] : 0.f;
+        w1[q] = k < F ? W1[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int r = wg * RPW + wv + 4 * i;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int k = q * 64 + lane;
+            hf[i][q] = (r < BT && k < F) ? wsr[g.o_Hf + (size_t)r * F + k] : 0.f;
+        }
+    }
+    float d0[NROW], d1[NROW];
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        d0[i] = 0.f; d1[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) { d0[i] = fmaf(hf[i][q], w0[q], d0[i]); d1[i] = fmaf(hf[i][q], w1[q], d1[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) { d0[i] = wave_allreduce_sum(d0[i]) + bc0; d1[i] = wave_allreduce_sum(d1[i]) + bc1; }
+    float a0[FQ], a1[FQ], sg0 = 0.f, sg1 = 0.f, l_frm = 0.f;
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int r = wg * RPW + wv + 4 * i;
+        if (r < BT) {   // wave-uniform
+            const int b = r / T;
+            const bool valid = video_valid(g.Bs, hy, b);
+            float g0 = 0.f, g1 = 0.f;
+            if (adv && valid) {                                                        // main.py:508-538, l = 2
+                const Soft2 s = soft2(d0[i], d1[i]);
+                const int d = b < g.Bs ? 0 : 1;
+                l_frm += -(d ? s.lp1 : s.lp0) * hy->inv_n_frm;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_frm;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_frm;
+            }
+            if (lane == 0) {
+                ws[g.o_Pf + (size_t)r * 2] = d0[i]; ws[g.o_Pf + (size_t)r * 2 + 1] = d1[i];
+                ws[g.o_gPf + (size_t)r * 2] = g0; ws[g.o_gPf + (size_t)r * 2 + 1] = g1;
+            }
+            sg0 += g0; sg1 += g1;
+#pragma unroll
+            for (int q = 0; q < FQ; ++q) {
+                const int k = q * 64 + lane;
+                const float h = hf[i][q];
+                if (k < F) ws[g.o_gHf + (size_t)r * F + k] = h > 0.f ? g0 * w0[q] + g1 * w1[q] : 0.f;
+                a0[q] = fmaf(g0, h, a0[q]);
+                a1[q] = fmaf(g1, h, a1[q]);
+            }
+        }
+    }
+    // cross-wave sums through LDS: [4 waves][2][FQ*64] then [4][2] for the bias partials
+    constexpr int FP = FQ * 64;
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) {
+        smem[(wv * 2 + 0) * FP + q * 64 + lane] = a0[q];
+        smem[(wv * 2 + 1) * FP + q * 64 + lane] = a1[q];
+    }
+    if (lane == 0) { smem[8 * FP + wv * 2] = sg0; smem[8 * FP + wv * 2 + 1] = sg1; }
+    if (lane < 8) smem[S_LOSS + wv * 8 + lane] = lane == 4 ? l_frm : 0.f;
+    __syncthreads();
+    float *__restrict__ part = ws + g.o_fh_part + (size_t)wg * 2 * F;
+    for (int i = tid; i < 2 * F; i += 256) {
+        const int c = i / F, k = i - c * F;
+        part[i] = (smem[(0 + c) * FP + k] + smem[(2 + c) * FP + k]) + (smem[(4 + c) * FP + k] + smem[(6 + c) * FP + k]);
+    }
+    if (tid < 2)
+        ws[g.o_fh_bpart + (size_t)wg * 2 + tid] = (smem[8 * FP + tid] + smem[8 * FP + 2 + tid]) + (smem[8 * FP + 4 + tid] + smem[8 * FP + 6 + tid]);
+    write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hy->gamma);
+}
+
+template <int FQ>
+__global__ __launch_bounds__(256) void heads_kernel(Geom g, Ptrs ptrs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < g.n_vid_wg) video_wg(g, ptrs, smem);
+    else frame_wg<FQ>(g, ptrs, smem, (int)blockIdx.x - g.n_vid_wg);
+}
+
+template <int FQ>
+int launch_fq(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    static_assert(8 * FQ * 64 + 16 <= S_LOSS, "the frame partials must stay below the loss slots");
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(heads_kernel<FQ>, dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)S_TOTAL * sizeof(float), stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+namespace ta3n {
+
+bool heads_supported(int NB, int C, int F) { return NB == NBH && C <= 64 && F <= 2048; }
+
+int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    if (!heads_supported(g.NB, g.C, g.F)) return -1;
+    const int fq = (g.F + 63) / 64;
+    if (fq <= 1) return launch_fq<1>(g, ptrs, stream);
+    if (fq <= 2) return launch_fq<2>(g, ptrs, stream);
+    if (fq <= 4) return launch_fq<4>(g, ptrs, stream);
+    if (fq <= 8) return launch_fq<8>(g, ptrs, stream);
+    if (fq <= 16) return launch_fq<16>(g, ptrs, stream);
+    return launch_fq<32>(g, ptrs, stream);
+}
+
+}  // namespace ta3n

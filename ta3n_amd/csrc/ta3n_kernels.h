@@ -45,10 +45,34 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+struct Soft2 {
+    float p0, p1, lp0, lp1, H;
+};
+// softmax / log_softmax / entropy of a 2-vector, same formulas as torch
+// (x - max, exp, sum; log_softmax = x - max - log(sum)).
+__device__ __forceinline__ Soft2 soft2(float z0, float z1) {
+    Soft2 s;
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    const float sum = e0 + e1;
+    s.p0 = e0 / sum; s.p1 = e1 / sum;
+    const float ls = logf(sum);
+    s.lp0 = z0 - m - ls; s.lp1 = z1 - m - ls;
+    s.H = -(s.p0 * s.lp0 + s.p1 * s.lp1);
+    return s;
+}
 
 bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
                 int zeros_off, hipStream_t stream);
+bool heads_supported(int NB, int C, int F);   // configurations the fused heads kernel (ta3n_heads.hip) covers
+int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

@@ -40,9 +40,12 @@ struct Ref {  // operand reference
 Ref KC(int32_t base, int64_t off, int32_t ld) { return Ref{base, (int32_t)off, ld, 0}; }  // element (r,k) at off + r*ld + k
 Ref KM(int32_t base, int64_t off, int32_t ld) { return Ref{base, (int32_t)off, ld, 1}; }  // element (r,k) at off + k*ld + r
 
-Seg mkseg(Ref a, Ref b, int klen, int scale_kind = SK_ONE) {
+// a_rows > 0: number of readable rows of the A operand when it exceeds the task's output rows (the [K][4] block of
+// ones behind the bias-gradient column sums: four identical rows are multiplied, one is stored)
+Seg mkseg(Ref a, Ref b, int klen, int scale_kind = SK_ONE, int a_rows = 0) {
     Seg s;
     std::memset(&s, 0, sizeof(s));
+    s.pad[0] = a_rows;
     s.a_base = a.base; s.a_off = a.off; s.a_ld = a.ld; s.a_kmajor = a.kmajor;
     s.b_base = b.base; s.b_off = b.off; s.b_ld = b.ld; s.b_kmajor = b.kmajor;
     s.klen = klen;
@@ -92,6 +95,7 @@ struct Builder {
     }
 
     int gemm_phase_index = 0;
+    int sum8[3] = {-1, 0, 0};   // {dst, src, rows}: when dst >= 0 the first workgroup of the next GEMM phase also sums an [rows][8] table
 
     // expand GEMM specs into tile tasks of one phase
     void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
@@ -130,7 +134,15 @@ struct Builder {
         for (auto &g : specs) {
             const int seg_begin = (int)p.segs.size();
             int cost = 0;
-            for (auto &s : g.segs) { p.segs.push_back(s); cost += (s.klen + 63) / 64 * 64; }
+            for (auto &s : g.segs) {
+                p.segs.push_back(s);
+                // operands the kernel cannot move 16 bytes at a time take the 4-byte LDS-DMA path: such tiles are
+                // several times slower per chunk, so they are weighted up and therefore scheduled first
+                const int a_rows = s.pad[0] > 0 ? s.pad[0] : g.M;
+                const bool a_vec = s.a_kmajor ? ((s.a_off | s.a_ld | a_rows) & 3) == 0 : ((s.a_off | s.a_ld | s.klen) & 3) == 0;
+                const bool b_vec = s.b_kmajor ? ((s.b_off | s.b_ld | g.N) & 3) == 0 : ((s.b_off | s.b_ld | s.klen) & 3) == 0;
+                cost += (s.klen + 63) / 64 * 64 * ((a_vec ? 1 : 3) + (b_vec ? 1 : 3)) / 2;
+            }
             const bool split_m = g.M >= g.N;
             const int outer = split_m ? g.M : g.N, inner = split_m ? g.N : g.M;
             const int bo = split_m ? BM : BN, bi = split_m ? BN : BM;
@@ -175,6 +187,11 @@ struct Builder {
             for (size_t d = 0; d < depth; ++d)
                 for (int x = 0; x < NX; ++x) local.push_back(d < q[x].size() ? q[x][d] : nop);
             while (!local.empty() && local.back().seg_count == 0) local.pop_back();
+        }
+        if (sum8[0] >= 0 && !local.empty()) {   // local[0] is a real task: queue 0 receives the heaviest panel
+            local[0].epi |= EPI_SUMROWS8;
+            local[0].pad[0] = sum8[0]; local[0].pad[1] = sum8[1]; local[0].pad[2] = sum8[2];
+            sum8[0] = -1;
         }
         for (auto &t : local) p.tasks.push_back(t);
         ph.task_count = (int32_t)local.size();
@@ -296,7 +313,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     g.o_gZ = (int32_t)b.add_region("gZ", (int64_t)B * NT * NB);
     g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
     g.o_zeros = (int32_t)b.add_region("zeros", 64);   // never written: source of out-of-range operand elements
-    g.o_ones = (int32_t)b.add_region("ones", BT);
+    g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);   // [BT][4] block of ones (k-major A operand of the column sums)
     if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
     g.o_losses = (int32_t)b.add_region("losses", 8);
     g.n_norm_blocks = 256;
@@ -305,7 +322,14 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     g.o_hyper = (int32_t)b.add_region("hyper", 32);
     g.o_labels = (int32_t)b.add_region("labels", B);
     g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
+    g.n_vid_wg = (B + HEADS_VPW - 1) / HEADS_VPW;
+    g.n_frm_wg = (BT + HEADS_RPW - 1) / HEADS_RPW;
+    g.o_fh_part = (int32_t)b.add_region("fh_part", (int64_t)g.n_frm_wg * 2 * F);
+    g.o_fh_bpart = (int32_t)b.add_region("fh_bpart", (int64_t)g.n_frm_wg * 2);
+    g.o_loss_part = (int32_t)b.add_region("loss_part", (int64_t)(g.n_vid_wg + g.n_frm_wg) * 8);
     g.live_floats = (int32_t)p.live_floats;
+    g.p_Wcd = (int32_t)Wcd; g.p_bcd = (int32_t)bcd; g.p_Wdv = (int32_t)Wdv; g.p_bdv = (int32_t)bdv;
+    g.p_Wcv = (int32_t)Wcv; g.p_bcv = (int32_t)bcv; g.p_Wcdv = (int32_t)Wcdv; g.p_bcdv = (int32_t)bcdv;
     g.p_W2_0 = (int32_t)W2(0); g.p_b2_0 = (int32_t)B2(0);
     g.p_W2_stride = NR > 1 ? (int32_t)(W2(1) - W2(0)) : 0;
     g.p_b2_stride = NR > 1 ? (int32_t)(B2(1) - B2(0)) : 0;
@@ -314,181 +338,157 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     const int ldZ = NT * NB, ldR = NR * NB, ldF = T * F;
     auto tau = [&](int t, int pos) { return p.tuples[(size_t)t * T + pos]; };
 
-    // ================= forward =================
-    {   // F1: shared frame FC + ReLU + dropout_i (models.py:565-575)
-        std::vector<GemmSpec> s(1);
-        s[0].M = BT; s[0].N = F;
-        s[0].segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
-        s[0].proto = proto(BASE_WS, g.o_F1, F);
-        with_bias(s[0].proto, bsh);
-        s[0].proto.epi |= EPI_RELU | EPI_DROP_I;
-        s[0].proto.gamma_kind = SK_INV_KEEP_I;
-        s[0].proto.drop_ld = F;
-        b.add_gemm_phase(0, s);
-    }
-    {   // F2: frame-discriminator hidden layer (models.py:458-459) + TRN tuple GEMMs (TRNmodule.py:60-79)
-        std::vector<GemmSpec> s;
+    // ---- GEMM specs (one per affine contraction of the step) ----
+    auto ones_bias_grad = [&](int64_t gsrc_off, int gsrc_ld, int n, int klen, int64_t dst) {
+        GemmSpec gb;   // column sums as ones^T * G
+        gb.M = 1; gb.N = n;
+        gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, gsrc_off, gsrc_ld), klen, SK_ONE, 4));
+        gb.proto = proto(BASE_G, dst, n);
+        return gb;
+    };
+    auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
+        GemmSpec s;
+        s.M = BT; s.N = F;
+        s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        s.proto = proto(BASE_WS, g.o_F1, F);
+        with_bias(s.proto, bsh);
+        s.proto.epi |= EPI_RELU | EPI_DROP_I;
+        s.proto.gamma_kind = SK_INV_KEEP_I;
+        s.proto.drop_ld = F;
+        return s;
+    };
+    auto spec_Hf = [&]() {   // frame-discriminator hidden layer (models.py:458-459)
         GemmSpec hf;
         hf.M = BT; hf.N = F;
         hf.segs.push_back(mkseg(KC(BASE_WS, g.o_F1, F), KC(BASE_P, Wfd, F), F));
         hf.proto = proto(BASE_WS, g.o_Hf, F);
         with_bias(hf.proto, bfd); hf.proto.epi |= EPI_RELU;
-        s.push_back(hf);
-        for (int t = 0; t < NT; ++t) {
-            const int j = p.scale_id[t], sl = p.scale_len[t];
-            GemmSpec z;
-            z.M = B; z.N = NB;
-            for (int pos = 0; pos < sl; ++pos)   // gather+concat folded into the A-operand addressing
-                z.segs.push_back(mkseg(KC(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF),
-                                       KC(BASE_P, trnW(j) + (int64_t)pos * F, sl * F), F));
-            z.proto = proto(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ);
-            with_bias(z.proto, trnB(j)); z.proto.epi |= EPI_RELU;
-            s.push_back(z);
-        }
-        b.add_gemm_phase(0, s);
-    }
-    {   // F3: relation-discriminator hidden layers on R_j = sum_t Z_t (models.py:475-479) + frame logits (:460)
-        std::vector<GemmSpec> s;
-        for (int j = 0; j < NR; ++j) {
-            GemmSpec h;
-            h.M = B; h.N = NB;
-            for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
-                h.segs.push_back(mkseg(KC(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ), KC(BASE_P, W1(j), NB), NB));
-            h.proto = proto(BASE_WS, g.o_Hr + (int64_t)j * NB, ldR);
-            with_bias(h.proto, B1(j)); h.proto.epi |= EPI_RELU;
-            s.push_back(h);
-        }
+        return hf;
+    };
+    auto spec_Z = [&](int t) {   // TRN tuple GEMM (TRNmodule.py:60-79): gather+concat folded into the A-operand addressing
+        const int j = p.scale_id[t], sl = p.scale_len[t];
+        GemmSpec z;
+        z.M = B; z.N = NB;
+        for (int pos = 0; pos < sl; ++pos)
+            z.segs.push_back(mkseg(KC(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF),
+                                   KC(BASE_P, trnW(j) + (int64_t)pos * F, sl * F), F));
+        z.proto = proto(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ);
+        with_bias(z.proto, trnB(j)); z.proto.epi |= EPI_RELU;
+        return z;
+    };
+    auto spec_Hr = [&](int j) {   // relation-discriminator hidden layer on R_j = sum_t Z_t (models.py:475-479)
+        GemmSpec h;
+        h.M = B; h.N = NB;
+        for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
+            h.segs.push_back(mkseg(KC(BASE_WS, g.o_Zr + (int64_t)t * NB, ldZ), KC(BASE_P, W1(j), NB), NB));
+        h.proto = proto(BASE_WS, g.o_Hr + (int64_t)j * NB, ldR);
+        with_bias(h.proto, B1(j)); h.proto.epi |= EPI_RELU;
+        return h;
+    };
+    auto spec_Pf = [&]() {   // frame domain logits (models.py:460)
         GemmSpec pf;
         pf.M = BT; pf.N = 2;
         pf.segs.push_back(mkseg(KC(BASE_WS, g.o_Hf, F), KC(BASE_P, Wcd, F), F));
         pf.proto = proto(BASE_WS, g.o_Pf, 2);
         with_bias(pf.proto, bcd);
-        s.push_back(pf);
-        b.add_gemm_phase(0, s);
-    }
-    b.add_simple_phase(PH_POOL_FWD, 0);   // Pr, attention weights, R, V, Vd
-    {   // F6: video classifier (models.py:686) + video-discriminator hidden layer (:466-467)
-        std::vector<GemmSpec> s(2);
-        s[0].M = B; s[0].N = C;
-        s[0].segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wcv, NB), NB));
-        s[0].proto = proto(BASE_WS, g.o_Y, C);
-        with_bias(s[0].proto, bcv);
-        s[1].M = B; s[1].N = NB;
-        s[1].segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wdv, NB), NB));
-        s[1].proto = proto(BASE_WS, g.o_Hv, NB);
-        with_bias(s[1].proto, bdv); s[1].proto.epi |= EPI_RELU;
-        b.add_gemm_phase(0, s);
-    }
-    {   // F7: video domain logits (models.py:468)
-        std::vector<GemmSpec> s(1);
-        s[0].M = B; s[0].N = 2;
-        s[0].segs.push_back(mkseg(KC(BASE_WS, g.o_Hv, NB), KC(BASE_P, Wcdv, NB), NB));
-        s[0].proto = proto(BASE_WS, g.o_Pv, 2);
-        with_bias(s[0].proto, bcdv);
-        b.add_gemm_phase(0, s);
-    }
-    // ================= loss =================
-    b.add_simple_phase(PH_LOSS, 1);
-    // ================= backward =================
-    auto ones_bias_grad = [&](int64_t gsrc_off, int gsrc_ld, int n, int klen, int64_t dst) {
-        GemmSpec gb;   // column sums as ones^T * G
-        gb.M = 1; gb.N = n;
-        gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 1), KM(BASE_WS, gsrc_off, gsrc_ld), klen));
-        gb.proto = proto(BASE_G, dst, n);
-        return gb;
+        return pf;
     };
-    {   // Q1: heads that depend only on the logit gradients
-        std::vector<GemmSpec> s;
-        GemmSpec ghv;   // gHv = (gPv Wcdv) * [Hv>0]
+    auto spec_Y = [&]() {   // video classifier (models.py:686)
+        GemmSpec s;
+        s.M = B; s.N = C;
+        s.segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wcv, NB), NB));
+        s.proto = proto(BASE_WS, g.o_Y, C);
+        with_bias(s.proto, bcv);
+        return s;
+    };
+    auto spec_Hv = [&]() {   // video-discriminator hidden layer (models.py:466-467)
+        GemmSpec s;
+        s.M = B; s.N = NB;
+        s.segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wdv, NB), NB));
+        s.proto = proto(BASE_WS, g.o_Hv, NB);
+        with_bias(s.proto, bdv); s.proto.epi |= EPI_RELU;
+        return s;
+    };
+    auto spec_Pv = [&]() {   // video domain logits (models.py:468)
+        GemmSpec s;
+        s.M = B; s.N = 2;
+        s.segs.push_back(mkseg(KC(BASE_WS, g.o_Hv, NB), KC(BASE_P, Wcdv, NB), NB));
+        s.proto = proto(BASE_WS, g.o_Pv, 2);
+        with_bias(s.proto, bcdv);
+        return s;
+    };
+    auto spec_gHv = [&]() {   // gHv = (gPv Wcdv) * [Hv>0]
+        GemmSpec ghv;
         ghv.M = B; ghv.N = NB;
         ghv.segs.push_back(mkseg(KC(BASE_WS, g.o_gPv, 2), KM(BASE_P, Wcdv, NB), 2));
         ghv.proto = proto(BASE_WS, g.o_gHv, NB);
         with_mask(ghv.proto, g.o_Hv, NB);
-        s.push_back(ghv);
-        GemmSpec ghf;   // gHf = (gPf Wcd) * [Hf>0]
+        return ghv;
+    };
+    auto spec_gHf = [&]() {   // gHf = (gPf Wcd) * [Hf>0]
+        GemmSpec ghf;
         ghf.M = BT; ghf.N = F;
         ghf.segs.push_back(mkseg(KC(BASE_WS, g.o_gPf, 2), KM(BASE_P, Wcd, F), 2));
         ghf.proto = proto(BASE_WS, g.o_gHf, F);
         with_mask(ghf.proto, g.o_Hf, F);
-        s.push_back(ghf);
-        GemmSpec gwcdv;   // dWcdv = gPv^T Hv
-        gwcdv.M = 2; gwcdv.N = NB;
-        gwcdv.segs.push_back(mkseg(KM(BASE_WS, g.o_gPv, 2), KM(BASE_WS, g.o_Hv, NB), B));
-        gwcdv.proto = proto(BASE_G, Wcdv, NB);
-        s.push_back(gwcdv);
-        s.push_back(ones_bias_grad(g.o_gPv, 2, 2, B, bcdv));
-        GemmSpec gwcv;   // dWcv = gY^T Vd
-        gwcv.M = C; gwcv.N = NB;
-        gwcv.segs.push_back(mkseg(KM(BASE_WS, g.o_gY, C), KM(BASE_WS, g.o_Vd, NB), B));
-        gwcv.proto = proto(BASE_G, Wcv, NB);
-        s.push_back(gwcv);
-        s.push_back(ones_bias_grad(g.o_gY, C, C, B, bcv));
-        GemmSpec gwcd;   // dWcd = gPf^T Hf
-        gwcd.M = 2; gwcd.N = F;
-        gwcd.segs.push_back(mkseg(KM(BASE_WS, g.o_gPf, 2), KM(BASE_WS, g.o_Hf, F), BT));
-        gwcd.proto = proto(BASE_G, Wcd, F);
-        s.push_back(gwcd);
-        s.push_back(ones_bias_grad(g.o_gPf, 2, 2, BT, bcd));
-        b.add_gemm_phase(2, s);
-    }
-    {   // Q2: gradient at the pooled video feature + first-layer weight grads of the video/frame discriminators
-        std::vector<GemmSpec> s;
-        GemmSpec gv;   // gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv )
+        return ghf;
+    };
+    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int64_t x_off, int x_ld, int64_t dst) {   // dW = G^T X
+        GemmSpec gw;
+        gw.M = M; gw.N = N;
+        gw.segs.push_back(mkseg(KM(BASE_WS, g_off, g_ld), KM(BASE_WS, x_off, x_ld), K));
+        gw.proto = proto(BASE_G, dst, N);
+        return gw;
+    };
+    auto spec_gVt = [&]() {   // gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv )
+        GemmSpec gv;
         gv.M = B; gv.N = NB;
         gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gHv, NB), KM(BASE_P, Wdv, NB), NB, SK_NEG_BETA_VID));
         gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY, C), KM(BASE_P, Wcv, NB), C));
         gv.proto = proto(BASE_WS, g.o_gVt, NB);
         gv.proto.epi |= EPI_DROP_V; gv.proto.gamma_kind = SK_INV_KEEP_V; gv.proto.drop_ld = NB;
-        s.push_back(gv);
-        GemmSpec gwdv;   // dWdv = gHv^T Vd
-        gwdv.M = NB; gwdv.N = NB;
-        gwdv.segs.push_back(mkseg(KM(BASE_WS, g.o_gHv, NB), KM(BASE_WS, g.o_Vd, NB), B));
-        gwdv.proto = proto(BASE_G, Wdv, NB);
-        s.push_back(gwdv);
+        return gv;
+    };
+    auto spec_gR = [&](int j) {   // gR_j = gRa_j - beta0 * gHr_j W1_j, fanned out through the TRN ReLU masks
+        GemmSpec gr;
+        gr.M = B; gr.N = NB;
+        gr.segs.push_back(mkseg(KC(BASE_WS, g.o_gHr + (int64_t)j * NB, ldR), KM(BASE_P, W1(j), NB), NB));
+        gr.proto = proto(BASE_WS, g.o_gR + (int64_t)j * NB, ldR);
+        gr.proto.alpha_kind = SK_NEG_BETA_REL;
+        with_add(gr.proto, g.o_gRa + (int64_t)j * NB, ldR);
+        const int nt = p.tuple_first[j + 1] - p.tuple_first[j];
+        gr.proto.fan_count = nt; gr.proto.fan_ld = ldZ;
+        for (int k = 0; k < nt; ++k) {
+            const int t = p.tuple_first[j] + k;
+            gr.proto.fan_mask_off[k] = g.o_Zr + t * NB;
+            gr.proto.fan_out_off[k] = g.o_gZ + t * NB;
+        }
+        return gr;
+    };
+    auto push_video_head_wgrads = [&](std::vector<GemmSpec> &s) {   // dWcdv, dbcdv, dWcv, dbcv
+        s.push_back(wgrad(2, NB, B, g.o_gPv, 2, g.o_Hv, NB, Wcdv));
+        s.push_back(ones_bias_grad(g.o_gPv, 2, 2, B, bcdv));
+        s.push_back(wgrad(C, NB, B, g.o_gY, C, g.o_Vd, NB, Wcv));
+        s.push_back(ones_bias_grad(g.o_gY, C, C, B, bcv));
+    };
+    auto push_video_disc_wgrads = [&](std::vector<GemmSpec> &s) {   // dWdv, dbdv
+        s.push_back(wgrad(NB, NB, B, g.o_gHv, NB, g.o_Vd, NB, Wdv));
         s.push_back(ones_bias_grad(g.o_gHv, NB, NB, B, bdv));
-        GemmSpec gwfd;   // dWfd = gHf^T F1
-        gwfd.M = F; gwfd.N = F;
-        gwfd.segs.push_back(mkseg(KM(BASE_WS, g.o_gHf, F), KM(BASE_WS, g.o_F1, F), BT));
-        gwfd.proto = proto(BASE_G, Wfd, F);
-        s.push_back(gwfd);
+    };
+    auto push_frame_disc_wgrads = [&](std::vector<GemmSpec> &s) {   // dWfd, dbfd
+        s.push_back(wgrad(F, F, BT, g.o_gHf, F, g.o_F1, F, Wfd));
         s.push_back(ones_bias_grad(g.o_gHf, F, F, BT, bfd));
-        b.add_gemm_phase(2, s);
-    }
-    b.add_simple_phase(PH_POOL_BWD, 2);   // gPrT (attention path), gRa = (1+w) gVt, gHr
-    {   // Q5: gR_j = gRa_j - beta0 * gHr_j W1_j, fanned out through the TRN ReLU masks; relation-disc weight grads
-        std::vector<GemmSpec> s;
+    };
+    auto push_relation_level = [&](std::vector<GemmSpec> &s) {   // gR_j (+ fan-out to gZ), dW1_j, db1_j, dW2_j, db2_j
         for (int j = 0; j < NR; ++j) {
-            GemmSpec gr;
-            gr.M = B; gr.N = NB;
-            gr.segs.push_back(mkseg(KC(BASE_WS, g.o_gHr + (int64_t)j * NB, ldR), KM(BASE_P, W1(j), NB), NB));
-            gr.proto = proto(BASE_WS, g.o_gR + (int64_t)j * NB, ldR);
-            gr.proto.alpha_kind = SK_NEG_BETA_REL;
-            with_add(gr.proto, g.o_gRa + (int64_t)j * NB, ldR);
-            const int nt = p.tuple_first[j + 1] - p.tuple_first[j];
-            gr.proto.fan_count = nt; gr.proto.fan_ld = ldZ;
-            for (int k = 0; k < nt; ++k) {
-                const int t = p.tuple_first[j] + k;
-                gr.proto.fan_mask_off[k] = g.o_Zr + t * NB;
-                gr.proto.fan_out_off[k] = g.o_gZ + t * NB;
-            }
-            s.push_back(gr);
-            GemmSpec gw1;   // dW1_j = gHr_j^T R_j
-            gw1.M = NB; gw1.N = NB;
-            gw1.segs.push_back(mkseg(KM(BASE_WS, g.o_gHr + (int64_t)j * NB, ldR), KM(BASE_WS, g.o_R + (int64_t)j * NB, ldR), B));
-            gw1.proto = proto(BASE_G, W1(j), NB);
-            s.push_back(gw1);
+            s.push_back(spec_gR(j));
+            s.push_back(wgrad(NB, NB, B, g.o_gHr + (int64_t)j * NB, ldR, g.o_R + (int64_t)j * NB, ldR, W1(j)));
             s.push_back(ones_bias_grad(g.o_gHr + (int64_t)j * NB, ldR, NB, B, B1(j)));
-            GemmSpec gw2;   // dW2_j = gPrT_j^T Hr_j
-            gw2.M = 2; gw2.N = NB;
-            gw2.segs.push_back(mkseg(KM(BASE_WS, g.o_gPrT + (int64_t)j * 2, NR * 2), KM(BASE_WS, g.o_Hr + (int64_t)j * NB, ldR), B));
-            gw2.proto = proto(BASE_G, W2(j), NB);
-            s.push_back(gw2);
+            s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j)));
             s.push_back(ones_bias_grad(g.o_gPrT + (int64_t)j * 2, NR * 2, 2, B, B2(j)));
         }
-        b.add_gemm_phase(2, s);
-    }
-    {   // Q6: TRN weight grads + gradient at F1 (TRN dgrad per frame, frame-disc dgrad with GRL folded in)
-        std::vector<GemmSpec> s;
+    };
+    auto push_trn_level = [&](std::vector<GemmSpec> &s) {   // TRN weight grads + gradient at F1
         for (int j = 0; j < NR; ++j) {
             const int sl = T - j;
             for (int pos = 0; pos < sl; ++pos) {   // dW_j[:, pos*F:(pos+1)*F] = sum_t gZ_t^T F1[:, tau_t[pos]]
@@ -503,7 +503,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             GemmSpec gb;
             gb.M = 1; gb.N = NB;
             for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
-                gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 1), KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ), B));
+                gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ), B, SK_ONE, 4));
             gb.proto = proto(BASE_G, trnB(j), NB);
             s.push_back(gb);
         }
@@ -523,20 +523,93 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             gz.proto.gamma_kind = SK_INV_KEEP_I;
             s.push_back(gz);
         }
-        b.add_gemm_phase(2, s);
-    }
-    {   // Q7: shared frame FC weight grad (no input gradient: the features are data)
-        std::vector<GemmSpec> s;
+    };
+    auto push_shared_fc_wgrad = [&](std::vector<GemmSpec> &s) {   // shared frame FC weight grad (no input gradient: the features are data)
         GemmSpec gw;
         gw.M = F; gw.N = D;
         gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ1, F), KM(BASE_X, 0, D), BT));
         gw.proto = proto(BASE_G, Wsh, D);
         s.push_back(gw);
         s.push_back(ones_bias_grad(g.o_gZ1, F, F, BT, bsh));
+    };
+
+    // ================= forward (group 0) =================
+    { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(0, s); }
+    {   // F2
+        std::vector<GemmSpec> s{spec_Hf()};
+        for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
+        b.add_gemm_phase(0, s);
+    }
+    {   // F3
+        std::vector<GemmSpec> s;
+        for (int j = 0; j < NR; ++j) s.push_back(spec_Hr(j));
+        s.push_back(spec_Pf());
+        b.add_gemm_phase(0, s);
+    }
+    b.add_simple_phase(PH_POOL_FWD, 0);   // Pr, attention weights, R, V, Vd
+    { std::vector<GemmSpec> s{spec_Y(), spec_Hv()}; b.add_gemm_phase(0, s); }   // F6
+    { std::vector<GemmSpec> s{spec_Pv()}; b.add_gemm_phase(0, s); }             // F7
+    // ================= loss (group 1) =================
+    b.add_simple_phase(PH_LOSS, 1);
+    // ================= backward (group 2) =================
+    {   // Q1: heads that depend only on the logit gradients
+        std::vector<GemmSpec> s{spec_gHv(), spec_gHf()};
+        push_video_head_wgrads(s);
+        s.push_back(wgrad(2, F, BT, g.o_gPf, 2, g.o_Hf, F, Wcd));   // dWcd = gPf^T Hf
+        s.push_back(ones_bias_grad(g.o_gPf, 2, 2, BT, bcd));
         b.add_gemm_phase(2, s);
     }
-    // ================= optimiser =================
+    {   // Q2: gradient at the pooled video feature + first-layer weight grads of the video/frame discriminators
+        std::vector<GemmSpec> s{spec_gVt()};
+        push_video_disc_wgrads(s);
+        push_frame_disc_wgrads(s);
+        b.add_gemm_phase(2, s);
+    }
+    b.add_simple_phase(PH_POOL_BWD, 2);   // gPrT (attention path), gRa = (1+w) gVt, gHr
+    { std::vector<GemmSpec> s; push_relation_level(s); b.add_gemm_phase(2, s); }    // Q5
+    { std::vector<GemmSpec> s; push_trn_level(s); b.add_gemm_phase(2, s); }         // Q6
+    { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(2, s); }   // Q7
+    // ================= optimiser (group 3) =================
     b.add_simple_phase(PH_GRAD_NORM, 3);
     b.add_simple_phase(PH_SGD, 3);
+    // ================= fused forward + loss + backward (group 4, ta3n_train_step) =================
+    // Same arithmetic in 7 launches instead of 15: everything between (Hr, Hf) and (gHr, gHf) - both
+    // discriminator heads, the attention pooling, the classifier, the losses and their backward - is one
+    // kernel (ta3n_heads.hip); its small weight gradients ride along with the relation level.
+    if (heads_supported(NB, C, F)) {
+        { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(4, s); }
+        {
+            std::vector<GemmSpec> s{spec_Hf()};
+            for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
+            b.add_gemm_phase(4, s);
+        }
+        {
+            std::vector<GemmSpec> s;
+            for (int j = 0; j < NR; ++j) s.push_back(spec_Hr(j));
+            b.add_gemm_phase(4, s);
+        }
+        b.add_simple_phase(PH_HEADS, 4);
+        b.sum8[0] = g.o_losses; b.sum8[1] = g.o_loss_part; b.sum8[2] = g.n_vid_wg + g.n_frm_wg;   // logging scalars
+        {
+            std::vector<GemmSpec> s;
+            push_relation_level(s);
+            push_video_head_wgrads(s);
+            push_video_disc_wgrads(s);
+            GemmSpec gw;   // dWcd = sum over frame workgroups of their partial sums (deterministic order)
+            gw.M = 1; gw.N = 2 * F;
+            gw.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, g.o_fh_part, 2 * F), g.n_frm_wg, SK_ONE, 4));
+            gw.proto = proto(BASE_G, Wcd, 2 * F);
+            s.push_back(gw);
+            s.push_back(ones_bias_grad(g.o_fh_bpart, 2, 2, g.n_frm_wg, bcd));
+            b.add_gemm_phase(4, s);
+        }
+        {
+            std::vector<GemmSpec> s;
+            push_trn_level(s);
+            push_frame_disc_wgrads(s);
+            b.add_gemm_phase(4, s);
+        }
+        { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }
+    }
     return TA3N_OK;
 }

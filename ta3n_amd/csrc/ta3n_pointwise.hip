@@ -19,23 +19,6 @@ using namespace ta3n;
 
 namespace {
 
-struct Soft2 {
-    float p0, p1, lp0, lp1, H;
-};
-// softmax / log_softmax / entropy of a 2-vector, same formulas as torch
-// (x - max, exp, sum; log_softmax = x - max - log(sum)).
-__device__ __forceinline__ Soft2 soft2(float z0, float z1) {
-    Soft2 s;
-    const float m = fmaxf(z0, z1);
-    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
-    const float sum = e0 + e1;
-    s.p0 = e0 / sum; s.p1 = e1 / sum;
-    const float ls = logf(sum);
-    s.lp0 = z0 - m - ls; s.lp1 = z1 - m - ls;
-    s.H = -(s.p0 * s.lp0 + s.p1 * s.lp1);
-    return s;
-}
-
 template <int Q>   // Q = NB / 64 channels per lane
 __global__ __launch_bounds__(256) void pool_fwd_kernel(Geom g, Ptrs ptrs) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -26,6 +26,8 @@ enum EpiFlags : uint32_t {
     EPI_MASK = 1u << 3,     // v *= (aux[m][n] > 0)
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
+    EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[1]] = sum of squares of the stored tile (fused grad-norm partial)
 };
 
 struct Seg {
@@ -35,7 +37,7 @@ struct Seg {
     int32_t a_kmajor, b_kmajor;  // 0: element (r,k) at off + r*ld + k ; 1: at off + k*ld + r
     int32_t klen;
     int32_t scale_kind;          // accumulator *= scale after this segment (SK_ONE = none)
-    int32_t pad[2];
+    int32_t pad[2];              // [0] > 0: readable rows of the A operand (overrides the task's m_valid for loading)
 };
 
 struct Task {
@@ -55,7 +57,7 @@ struct Task {
     int32_t fan_mask_off[3];
     int32_t fan_out_off[3];
     int32_t cost;                        // sum of klen (for ordering / balance)
-    int32_t pad[3];
+    int32_t pad[3];                      // EPI_SUMROWS8: {dst, src, rows} (ws offsets); EPI_SUMSQ: [0] = slot
 };
 
 enum PhaseKind : int32_t {
@@ -65,11 +67,16 @@ enum PhaseKind : int32_t {
     PH_POOL_BWD = 3,
     PH_GRAD_NORM = 4,
     PH_SGD = 5,
+    PH_HEADS = 6,            // fused video/frame heads: forward + loss + backward between Hr/Hf and gHr/gHf
 };
+
+// work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these
+constexpr int HEADS_VPW = 4;    // videos per video workgroup (one wave each for the per-video parts)
+constexpr int HEADS_RPW = 16;   // frame rows per frame workgroup
 
 struct Phase {
     int32_t kind;
-    int32_t group;               // 0 fwd, 1 loss, 2 bwd, 3 sgd
+    int32_t group;               // 0 fwd, 1 loss, 2 bwd, 3 sgd, 4 fused fwd+loss+bwd (ta3n_train_step)
     int32_t task_begin, task_count;
     int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
     int32_t pad;
@@ -100,6 +107,12 @@ struct Geom {
     int32_t live_floats;
     // relation discriminator second layers inside the flat parameter buffer
     int32_t p_W2_0, p_b2_0, p_W2_stride, p_b2_stride;   // W2_j at p_W2_0 + j*p_W2_stride
+    // fused heads (ta3n_heads.hip)
+    int32_t p_Wcd, p_bcd, p_Wdv, p_bdv, p_Wcv, p_bcv, p_Wcdv, p_bcdv;
+    int32_t o_fh_part, o_fh_bpart;       // per frame-workgroup partial sums of dWcd [n_frm_wg][2F] and dbcd [n_frm_wg][2]
+    int32_t o_loss_part;                 // per heads-workgroup loss partials [n_vid_wg + n_frm_wg][8]
+    int32_t n_vid_wg, n_frm_wg;
+    int32_t o_sumsq, n_sumsq;            // fused grad-norm partials (one slot per gradient tile of the fused step)
 };
 
 }  // namespace ta3n

@@ -58,7 +58,7 @@ class TrainEngine:
                  fc_dim: int = 512, num_class: int = 12, flags: int = ALL_FLAGS, dropout_i: float = 0.5,
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
-                 phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0):
+                 phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -84,6 +84,8 @@ class TrainEngine:
             _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws.data_ptr(), self._stream()), "ta3n_init_workspace")
         off, n = p.region("labels")
         self._labels = self.ws[off:off + n].view(torch.int32)
+        # fused: forward + loss + backward as ONE C-ABI call (ta3n_train_step, 7 launches) when the plan has it
+        self.fused = bool(fused) and p.has_fused_step
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._hyper = _lib.Hyper()
@@ -171,10 +173,18 @@ class TrainEngine:
         _lib.check(self._L.ta3n_sgd_step(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
                                          self.ws.data_ptr(), self._stream()), "ta3n_sgd_step")
 
+    def fused_step(self) -> None:
+        """forward + loss + backward through the fused launch sequence (include/ta3n_hip.h: ta3n_train_step)."""
+        _lib.check(self._L.ta3n_train_step(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                           self.ws.data_ptr(), self._stream()), "ta3n_train_step")
+
     def _enqueue_step(self) -> None:
-        self.forward()
-        self.loss()
-        self.backward()
+        if self.fused:
+            self.fused_step()
+        else:
+            self.forward()
+            self.loss()
+            self.backward()
         self.all_reduce_grads()
         self.sgd_step()
 
@@ -205,19 +215,23 @@ class TrainEngine:
             self._enqueue_step()
         self.step_count += 1
 
-    def time_phases(self, reps: int = 20):
-        """[(kind, tile, n_tasks, ms)] per launch of one train step, HIP events on the launch stream."""
+    def time_phases(self, reps: int = 20, all_groups: bool = False):
+        """[(kind, tile, n_tasks, ms)] per launch of one train step as this engine runs it (the fused
+        sequence + optimiser, or forward/loss/backward + optimiser), HIP events on the launch stream."""
         n = len(self.plan.description["phases"])
         ms = (C.c_float * n)()
         kinds = (C.c_int32 * n)()
+        groups = (C.c_int32 * n)()
         _lib.check(self._L.ta3n_time_phases(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
-                                            self.M.data_ptr(), self.ws.data_ptr(), self._stream(), reps, ms, kinds, n),
+                                            self.M.data_ptr(), self.ws.data_ptr(), self._stream(), reps, ms, kinds, groups, n),
                    "ta3n_time_phases")
+        want = (4, 3) if self.fused else (0, 1, 2, 3)
         return [(int(kinds[i]), ph["tile"], ph["task_count"], float(ms[i]))
-                for i, ph in enumerate(self.plan.description["phases"])]
+                for i, ph in enumerate(self.plan.description["phases"]) if all_groups or int(groups[i]) in want]
 
     def gemm_phase_times(self, reps: int = 20):
-        return [ms for kind, _, _, ms in self.time_phases(reps) if kind == 0]
+        """ms of every GEMM launch of the plan, in plan order (the index space of phase_tiles)."""
+        return [ms for kind, _, _, ms in self.time_phases(reps, all_groups=True) if kind == 0]
 
     # ---- results ----
     def outputs(self) -> Dict[str, torch.Tensor]:

@@ -14,8 +14,9 @@ import numpy as np
 from ta3n_amd import _lib
 
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
-EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V = 1, 2, 4, 8, 16, 32
-PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD = range(6)
+EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8 = 1, 2, 4, 8, 16, 32, 64
+PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS = range(7)
+HEADS_RPW = 16
 
 
 class Seg(C.Structure):
@@ -41,7 +42,9 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_F1", "o_Hf", "o_Pf", "o_Zr", "o_Hr", "o_Pr", "o_R", "o_attn", "o_V", "o_Vd", "o_Y", "o_Hv", "o_Pv",
                 "o_gY", "o_gPv", "o_gPr", "o_gPf", "o_gattn", "o_gHv", "o_gHf", "o_gVt", "o_gPrT", "o_gRa", "o_gHr",
                 "o_gR", "o_gZ", "o_gZ1", "o_zeros", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
-                "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride"]
+                "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
+                "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
+                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq"]
 
 
 class Geom(C.Structure):
@@ -94,7 +97,7 @@ class Interp:
         self.dtype = dtype
         g = self.g
         self.ws = np.zeros(plan.ws_floats, dtype)
-        self.ws[g.o_ones:g.o_ones + g.B * g.T] = 1.0
+        self.ws[g.o_ones:g.o_ones + g.B * g.T * 4] = 1.0
         self.P = np.zeros(plan.param_floats, dtype)
         self.G = np.zeros(plan.param_floats, dtype)
         self.M = np.zeros(plan.param_floats, dtype)
@@ -144,6 +147,9 @@ class Interp:
             t = self.tasks[ti]
             if t.seg_count == 0:
                 continue
+            if t.epi & EPI_SUMROWS8:
+                dst, src, rows = t.pad[0], t.pad[1], t.pad[2]
+                self.ws[dst:dst + 8] = self.ws[src:src + 8 * rows].reshape(rows, 8).sum(0)
             nr = min(BM, t.m_valid - t.m0); nc = min(BN, t.n_valid - t.n0)
             assert nr > 0 and nc > 0
             acc = np.zeros((nr, nc), self.dtype)
@@ -271,6 +277,47 @@ class Interp:
             gRa[:, j, :] = w1[:, None] * gVt
             gHr[:, j, :] = np.where(Hr[:, j, :] > 0, gp @ W2, 0)
 
+    def run_heads(self):
+        """Specification of the fused heads kernel (ta3n_heads.hip): the unfused phases it replaces,
+        in dependency order, plus the per-workgroup partial sums it hands to the next GEMM level."""
+        g, h = self.g, self.hy
+        B, T, NB, F, Cn = g.B, g.T, g.NB, g.F, g.C
+        P = self.P
+
+        def lin(xv, w_off, b_off, out, inp):
+            return xv @ P[w_off:w_off + out * inp].reshape(out, inp).T + P[b_off:b_off + out]
+        Hf = self.r(g.o_Hf, (B * T, F))
+        self.r(g.o_Pf, (B * T, 2))[:] = lin(Hf, g.p_Wcd, g.p_bcd, 2, F)
+        self.run_pool_fwd()
+        Vd = self.r(g.o_Vd, (B, NB))
+        self.r(g.o_Y, (B, Cn))[:] = lin(Vd, g.p_Wcv, g.p_bcv, Cn, NB)
+        Hv = np.maximum(lin(Vd, g.p_Wdv, g.p_bdv, NB, NB), 0)
+        self.r(g.o_Hv, (B, NB))[:] = Hv
+        self.r(g.o_Pv, (B, 2))[:] = lin(Hv, g.p_Wcdv, g.p_bcdv, 2, NB)
+        self.run_loss()
+        gPv = self.r(g.o_gPv, (B, 2)); gY = self.r(g.o_gY, (B, Cn)); gPf = self.r(g.o_gPf, (B * T, 2))
+        Wcdv = P[g.p_Wcdv:g.p_Wcdv + 2 * NB].reshape(2, NB); Wdv = P[g.p_Wdv:g.p_Wdv + NB * NB].reshape(NB, NB)
+        Wcv = P[g.p_Wcv:g.p_Wcv + Cn * NB].reshape(Cn, NB); Wcd = P[g.p_Wcd:g.p_Wcd + 2 * F].reshape(2, F)
+        gHv = np.where(Hv > 0, gPv @ Wcdv, 0)
+        self.r(g.o_gHv, (B, NB))[:] = gHv
+        gVt = -h["beta"][1] * (gHv @ Wdv) + gY @ Wcv
+        if h["train"] and h["p_drop_v"] > 0:
+            idx = np.arange(B)[:, None] * NB + np.arange(NB)[None, :]
+            gVt = gVt * keep_mask(h["seed_v"], idx, h["p_drop_v"])
+        self.r(g.o_gVt, (B, NB))[:] = gVt * self.scale(5)
+        self.r(g.o_gattn, (B, g.n_rel))[:] = 0          # the fused step does not consume an upstream attention gradient
+        self.run_pool_bwd()
+        self.r(g.o_gHf, (B * T, F))[:] = np.where(Hf > 0, gPf @ Wcd, 0)
+        lp = self.r(g.o_loss_part, (g.n_vid_wg + g.n_frm_wg, 8))
+        lp[:] = 0
+        lp[0, :6] = self.ws[g.o_losses:g.o_losses + 6]   # any split over workgroups sums to the same scalars
+        self.ws[g.o_losses:g.o_losses + 8] = 0
+        part = self.r(g.o_fh_part, (g.n_frm_wg, 2 * F)); bpart = self.r(g.o_fh_bpart, (g.n_frm_wg, 2))
+        for w in range(g.n_frm_wg):
+            rows = slice(w * HEADS_RPW, min((w + 1) * HEADS_RPW, B * T))
+            part[w] = (gPf[rows].T @ Hf[rows]).reshape(-1)
+            bpart[w] = gPf[rows].sum(0)
+
     def run_sgd(self):
         g, h = self.g, self.hy
         n = g.live_floats
@@ -290,5 +337,6 @@ class Interp:
             elif ph.kind == PH_POOL_FWD: self.run_pool_fwd()
             elif ph.kind == PH_LOSS: self.run_loss()
             elif ph.kind == PH_POOL_BWD: self.run_pool_bwd()
+            elif ph.kind == PH_HEADS: self.run_heads()
             elif ph.kind == PH_GRAD_NORM: pass
             elif ph.kind == PH_SGD: self.run_sgd()

@@ -37,11 +37,15 @@ def test_library_loaded_and_device_is_mi355x():
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tile", [0, 114, 118, 212, 122, 214, 124, 221, 222])
 @pytest.mark.parametrize("name", CASES)
-def test_train_steps_match_reference_golden(name, tile):
+def test_train_steps_match_reference_golden(name, tile, fused):
+    """fused=False: ta3n_forward + ta3n_loss + ta3n_backward (15 launches); fused=True: ta3n_train_step (7 launches)."""
     if tile not in (0, 114) and name not in ("tiny_T5", "tiny_T9", "headline"):
         pytest.skip("tile variants checked on three cases")
+    if fused and tile not in (0, 114, 222):
+        pytest.skip("fused step checked on three tile configs")
     g = Golden(name)
     c = case_config(g)
     eng = _engine(c, tile)
@@ -53,7 +57,11 @@ def test_train_steps_match_reference_golden(name, tile):
         xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0            # the reference's dummy rows (main.py:359-364)
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
         eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"], train=True, valid_source=st["n_src"], valid_target=st["n_tgt"])
-        eng.forward()
+        if fused:
+            assert eng.plan.has_fused_step
+            eng.fused_step()
+        else:
+            eng.forward()
         if s == 0:
             o = {k: v.detach().cpu() for k, v in eng.outputs().items()}
             for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
@@ -64,8 +72,9 @@ def test_train_steps_match_reference_golden(name, tile):
                 g.check(f"fwd/attn_{dom}", o["attn"][sl], RTOL, ATOL)
                 g.check(f"fwd/feat_{dom}_v", o["feat_v"][sl], RTOL, ATOL)
                 g.check(f"fwd/feat_{dom}_f1", o["feat_f1"][sl], RTOL, ATOL)
-        eng.loss()
-        eng.backward()
+        if not fused:
+            eng.loss()
+            eng.backward()
         raw = {k: v.clone() for k, v in eng.param_views(eng.G).items()}
         eng.sgd_step()
         torch.cuda.synchronize()
@@ -77,7 +86,8 @@ def test_train_steps_match_reference_golden(name, tile):
             g.check(f"step{s}/param/{k}", new[k].cpu(), RTOL, ATOL)
 
 
-def test_losses_match_reference_log():
+@pytest.mark.parametrize("fused", [False, True])
+def test_losses_match_reference_log(fused):
     """Loss scalars vs the values the reference's own log line printed (main.py:590-617)."""
     g = Golden("headline")
     c = case_config(g)
@@ -87,7 +97,10 @@ def test_losses_match_reference_log():
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
     eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
     eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"])
-    eng.forward(); eng.loss()
+    if fused:
+        eng.fused_step()
+    else:
+        eng.forward(); eng.loss()
     L = eng.losses()
     log = str(g.meta("log")).splitlines()[0]
     import re
@@ -105,17 +118,25 @@ def test_oracle_parity_with_flags_and_ragged_batches():
     """HIP vs the CPU oracle where no golden fixture exists: some adversarial
     levels off, very uneven source/target sizes, a batch of one."""
     from oracle import ta3n_oracle as orc
-    for (Bs, Bt, T, place) in [(1, 1, 3, ("Y", "Y", "Y")), (33, 2, 4, ("Y", "Y", "N")), (7, 40, 5, ("Y", "Y", "Y"))]:
+    for (Bs, Bt, T, place, fused) in [(1, 1, 3, ("Y", "Y", "Y"), False), (33, 2, 4, ("Y", "Y", "N"), False),
+                                      (7, 40, 5, ("Y", "Y", "Y"), False), (1, 1, 3, ("Y", "Y", "Y"), True),
+                                      (33, 2, 4, ("Y", "Y", "N"), True), (7, 40, 5, ("Y", "Y", "Y"), True),
+                                      (5, 6, 2, ("Y", "Y", "Y"), True)]:
         cfg = orc.Config(num_class=7, num_segments=T, feature_dim=512, fc_dim=96, dropout_i=0.0, dropout_v=0.0,
                          place_adv=place)
         from ta3n_amd.engine import TrainEngine, flags_from_options
-        eng = TrainEngine(Bs, Bt, T, 512, 96, 7, flags=flags_from_options(place), dropout_i=0.0, dropout_v=0.0, clip=20.0)
+        eng = TrainEngine(Bs, Bt, T, 512, 96, 7, flags=flags_from_options(place), dropout_i=0.0, dropout_v=0.0, clip=20.0,
+                          fused=fused)
         params = synth_state(orc.param_shapes(cfg), seed=3)
         eng.load_state(params)
         xs, xt, ys, yt = synth_batch(7, T, 512, Bs, Bt, seed=17)
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
         eng.set_hyper([0.3, 0.6, 0.9], 0.05, 1e-3)
-        eng.forward(); eng.loss(); eng.backward(); eng.sgd_step()
+        if fused:
+            eng.fused_step()
+        else:
+            eng.forward(); eng.loss(); eng.backward()
+        eng.sgd_step()
         state = orc.TrainState(params=params, lr=1e-3)
         res = orc.train_step(state, xs, xt, ys, [0.3, 0.6, 0.9], 0.05, cfg)
         o = eng.outputs()
@@ -133,8 +154,8 @@ def test_bitwise_reproducible_and_graph_replay():
     g = Golden("tiny_T5")
     c = case_config(g)
     results, losses = [], []
-    for mode in ("eager", "eager", "graph"):
-        eng = _engine(c)
+    for mode in ("eager", "eager", "graph", "unfused"):
+        eng = _engine(c, fused=(mode != "unfused"))
         _load(eng, c)
         xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=5)
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
@@ -148,17 +169,20 @@ def test_bitwise_reproducible_and_graph_replay():
         losses.append(eng.losses())
     assert torch.equal(results[0], results[1])
     assert torch.equal(results[0], results[2])
+    # fused and unfused steps differ only in fp32 summation order
+    assert torch.allclose(results[0], results[3], rtol=1e-4, atol=1e-6)
     for k in losses[0]:                                   # logging scalars are atomics: equal up to summation order
         assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k])), (k, losses)
     assert 0 < losses[2]["loss"] < 100
 
 
-def test_dropout_statistics_and_backward_consistency():
+@pytest.mark.parametrize("fused", [False, True])
+def test_dropout_statistics_and_backward_consistency(fused):
     """nn.Dropout semantics (models.py:574-575, 679-680): keep-rate 1-p, survivors
     scaled by 1/(1-p), a fresh mask each step, and the backward pass uses the same
     mask as the forward pass (gradient of dropped video features is zero)."""
     from ta3n_amd.engine import TrainEngine
-    eng = TrainEngine(64, 64, 5, 512, 128, 12, dropout_i=0.5, dropout_v=0.5)
+    eng = TrainEngine(64, 64, 5, 512, 128, 12, dropout_i=0.5, dropout_v=0.5, fused=fused)
     from oracle import ta3n_oracle as orc
     cfg = orc.Config(num_class=12, num_segments=5, feature_dim=512, fc_dim=128)
     eng.load_state(synth_state(orc.param_shapes(cfg), seed=1))
@@ -170,7 +194,11 @@ def test_dropout_statistics_and_backward_consistency():
     masks = []
     for seed in (1, 2):
         eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3, train=True, seed=seed)
-        eng.forward(); eng.loss(); eng.backward(); torch.cuda.synchronize()
+        if fused:
+            eng.fused_step()
+        else:
+            eng.forward(); eng.loss(); eng.backward()
+        torch.cuda.synchronize()
         f1 = eng.region("F1")
         alive = f1_eval > 0
         kept = (f1 > 0) & alive

@@ -25,9 +25,11 @@ def make_hyper(c, st, T, lr):
                 valid_source=n_s, valid_target=n_t, train=1)
 
 
-@pytest.mark.parametrize("tile", [114, 221, 0])
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("tile", [114, 222, 0])
 @pytest.mark.parametrize("name", SMALL)
-def test_plan_reproduces_reference(name, tile):
+def test_plan_reproduces_reference(name, tile, fused):
+    """fused=False: ta3n_forward / ta3n_loss / ta3n_backward launch lists; fused=True: the ta3n_train_step list."""
     if tile != 114 and name not in ("tiny_T5", "tiny_T3"):
         pytest.skip("tile variants checked on two cases")
     g = Golden(name)
@@ -45,7 +47,12 @@ def test_plan_reproduces_reference(name, tile):
         it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
         it.labels[:c["Bs"]] = ys.numpy()
         it.hy = make_hyper(c, st, T, st["lr"])
-        it.run_group(0)
+        it.G[:] = 0
+        if fused:
+            assert plan.has_fused_step
+            it.run_group(4)
+        else:
+            it.run_group(0)
         if s == 0:   # forward outputs vs the reference's VideoModel.forward
             B, Bs = c["Bs"] + c["Bt"], c["Bs"]
             geo = it.g
@@ -59,9 +66,9 @@ def test_plan_reproduces_reference(name, tile):
                     g.check(f"fwd/pd_{dom}_{nm}", outs[nm][sl], 5e-5, 2e-5)
                 g.check(f"fwd/feat_{dom}_v", outs["v"][sl], 5e-5, 2e-5)
                 g.check(f"fwd/feat_{dom}_f1", outs["f1"][sl], 5e-5, 2e-5)
-        it.run_group(1)
-        it.G[:] = 0
-        it.run_group(2)
+        if not fused:
+            it.run_group(1)
+            it.run_group(2)
         raw = it.get_params(it.G)
         it.run_group(3)
         coef = it.ws[it.g.o_grad_norm + 1]

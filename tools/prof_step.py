@@ -1,5 +1,5 @@
 """Three eager train steps at the BASELINE shape for rocprofv3 (kernel trace / PMC passes).
-usage: python tools/prof_step.py [tile_config] [xcd_aware]"""
+usage: python tools/prof_step.py [tile_config] [xcd_aware] [fused|unfused]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ta3n_amd.engine import TrainEngine
@@ -9,6 +9,11 @@ eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
 eng.set_hyper([0.75,0.75,0.5], 0.003, 1e-3)
+fused = (sys.argv[3] != "unfused") if len(sys.argv) > 3 else True
 for _ in range(3):
-    eng.forward(); eng.loss(); eng.backward(); eng.sgd_step()
+    if fused and eng.plan.has_fused_step:
+        eng.fused_step()
+    else:
+        eng.forward(); eng.loss(); eng.backward()
+    eng.sgd_step()
 torch.cuda.synchronize()
