@@ -88,6 +88,28 @@ __device__ __forceinline__ void glds4(const float *gsrc, unsigned lds_byte_addr)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
+// 4-byte LDS-DMA path for operands that cannot be moved 16 bytes at a time (256 B pieces, one element per
+// lane).  Out of line on purpose: inlined, its address arithmetic costs every tile ~22 VGPRs, i.e. one
+// resident workgroup per CU; only a handful of tiny tasks take this path.
+template <int R, int NW>
+__device__ __attribute__((noinline)) void issue_slow(const float *__restrict__ origin, int ld, int kmajor, int r0, int rvalid, int k0,
+                                                     int krem, unsigned lds_addr, int wave, int lane, const float *__restrict__ zeros) {
+#pragma unroll 1
+    for (int q = wave; q < R; q += NW) {
+        const float *src;
+        if (!kmajor) {                             // piece = one row; lane -> (slot, element)
+            const int k = 4 * ((lane >> 2) ^ (q & 15)) + (lane & 3);
+            src = (r0 + q < rvalid && k < krem) ? origin + (size_t)(r0 + q) * ld + k0 + k : zeros;
+        } else {
+            constexpr int KPP = 64 / R;            // k rows per piece (2 for R = 32, 1 for R = 64)
+            const int k = q * KPP + lane / R;
+            const int r = r0 + lane % R;
+            src = (r < rvalid && k < krem) ? origin + (size_t)(k0 + k) * ld + r : zeros;
+        }
+        glds4(src, lds_addr + q * 256);
+    }
+}
+
 // Per-lane LDS-DMA state of one operand for the Seg being streamed.  Set up once per
 // Seg (the 64-bit address arithmetic lives there); per 64-deep chunk the fast path is
 // compare + select + DMA + pointer bump per 1 KiB piece.  R rows (32 or 64), NW waves.
@@ -142,53 +164,46 @@ struct OperandStream {
                 p[i] += step;
             }
             glds16_batch<NP>(src, lds_addr + wave * 1024, NW * 1024);
-        } else {                                   // 256 B pieces, one element per lane
-#pragma unroll 1
-            for (int q = wave; q < R; q += NW) {
-                const float *src;
-                if (!kmajor) {                     // piece = one row; lane -> (slot, element)
-                    const int k = 4 * ((lane >> 2) ^ (q & 15)) + (lane & 3);
-                    src = (r0 + q < rvalid && k < krem) ? origin + (size_t)(r0 + q) * ld + k0 + k : zeros;
-                } else {
-                    constexpr int KPP = 64 / R;    // k rows per piece (2 for R = 32, 1 for R = 64)
-                    const int k = q * KPP + lane / R;
-                    const int r = r0 + lane % R;
-                    src = (r < rvalid && k < krem) ? origin + (size_t)(k0 + k) * ld + r : zeros;
-                }
-                glds4(src, lds_addr + q * 256);
-            }
+        } else {
+            issue_slow<R, NW>(origin, ld, kmajor, r0, rvalid, k0, krem, lds_addr, wave, lane, zeros);
         }
     }
 };
 
 // MFMAs of one wave over its K slice of one stage.  sa / sb: stage images.
 // FULL: all 64 k of the stage are valid (no wave-uniform skip tests).
+// All fragment reads of the stage are issued before the first MFMA (the compiler then waits with
+// counted lgkmcnt): one exposed LDS latency per stage instead of one per group of four MFMAs.
 template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL>
 __device__ __forceinline__ void compute_stage(f32x16 &acc, const float *__restrict__ sa, const float *__restrict__ sb,
                                               int ra, int rb, int wk, int lh, int krem) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
+    constexpr int NQ = GPW / 2;
+    float av[NQ][4], bv[NQ][4];
 #pragma unroll
-    for (int q = 0; q < GPW / 2; ++q) {
-        const int g_lo = wk * GPW + 2 * q;         // lanes 0-31: k = 4 g_lo .. +3, lanes 32-63: the next group
-        if (FULL || 4 * g_lo < krem) {
-            const int G = g_lo + lh;
-            float av[4], bv[4];
-            if (!AKM) {
-                const float4 t = *reinterpret_cast<const float4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
-                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-            } else {
+    for (int q = 0; q < NQ; ++q) {
+        const int G = wk * GPW + 2 * q + lh;       // lanes 0-31: k = 4 G .. 4 G + 3 of the lower group, lanes 32-63: the next group
+        if (!AKM) {
+            const float4 t = *reinterpret_cast<const float4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
+            av[q][0] = t.x; av[q][1] = t.y; av[q][2] = t.z; av[q][3] = t.w;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) av[j] = sa[(4 * G + j) * BM + ra];
-            }
-            if (!BKM) {
-                const float4 t = *reinterpret_cast<const float4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
-                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-            } else {
+            for (int j = 0; j < 4; ++j) av[q][j] = sa[(4 * G + j) * BM + ra];
+        }
+        if (!BKM) {
+            const float4 t = *reinterpret_cast<const float4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+            bv[q][0] = t.x; bv[q][1] = t.y; bv[q][2] = t.z; bv[q][3] = t.w;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = sb[(4 * G + j) * BN + rb];
-            }
+            for (int j = 0; j < 4; ++j) bv[q][j] = sb[(4 * G + j) * BN + rb];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) {
+        if (FULL || 4 * (wk * GPW + 2 * q) < krem) {   // groups past the K tail hold zeros: skip them (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[q][j], acc, 0, 0, 0);
         }
     }
 }
@@ -248,74 +263,75 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const int seg_end = t.seg_begin + t.seg_count;
     int cseg = t.seg_begin;
     // K loop.  Stage c+1 is streamed while stage c is computed.  Per Seg: all iterations whose
-    // two cursors both sit inside the Seg run in a tight loop specialised on the operand
-    // kinds; the iteration that computes the Seg's last chunk opens the next Seg.
-    OperandStream<BM, NW> oa;
-    OperandStream<BN, NW> ob;
-    int klen, combo, scale;
-    auto open_seg = [&](int sidx) {                // wave-uniform: Seg fields live in SGPRs
-        const Seg &sg = segs[sidx];
-        klen = sg.klen; combo = sg.a_kmajor * 2 + sg.b_kmajor; scale = sg.scale_kind;
-        oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, sg.a_kmajor, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
-                 wave, lane);
-        ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, sg.b_kmajor, sg.klen, n0, n_valid, wave, lane);
-    };
-    auto issue = [&](int buf, int k0) {
-        const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
-        oa.issue(k0, klen - k0, st, wave, lane, zeros);
-        ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
-    };
-    auto stage_ready = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
-        __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
-        asm volatile("" ::: "memory");
-    };
+    // two cursors both sit inside the Seg run in a tight loop; the iteration that computes the
+    // Seg's last chunk opens the next Seg.  All Segs of a task have the same operand kinds (the
+    // plan builder guarantees it), so the whole loop nest is instantiated per kind combination and
+    // selected once per task: the register allocation is the maximum over the combinations, not
+    // their union (loop-invariant LDS addresses of every combination used to be live together).
     const int ra = wm * 32 + li, rb = wn * 32 + li;
-    int buf = 0;
-    auto inner = [&](auto akm, auto bkm, int n_inner) {      // chunks 0 .. n_inner-1 of the open Seg (all full)
-        for (int c = 0; c < n_inner; ++c) {
+    auto k_loop = [&](auto akm, auto bkm) {
+        constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value;
+        OperandStream<BM, NW> oa;
+        OperandStream<BN, NW> ob;
+        int klen = 0, scale = SK_ONE;
+        auto open_seg = [&](int sidx) {            // wave-uniform: Seg fields live in SGPRs
+            const Seg &sg = segs[sidx];
+            klen = sg.klen; scale = sg.scale_kind;
+            oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
+                     wave, lane);
+            ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
+        };
+        auto issue = [&](int buf, int k0) {
+            const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
+            oa.issue(k0, klen - k0, st, wave, lane, zeros);
+            ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+        };
+        auto stage_ready = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
+            __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
+            asm volatile("" ::: "memory");
+        };
+        int buf = 0;
+        open_seg(cseg);
+        issue(0, 0);
+        for (;;) {
+            const int n_chunks = (klen + BKC - 1) / BKC;
+            for (int c = 0; c < n_chunks - 1; ++c) {             // chunks whose successor is in the same Seg (all full)
+                stage_ready();
+                issue(buf ^ 1, (c + 1) * BKC);
+                const float *sa = lds + buf * STAGE;
+                compute_stage<BM, BN, WK, AKM, BKM, true>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                buf ^= 1;
+            }
+            // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
             stage_ready();
-            issue(buf ^ 1, (c + 1) * BKC);
+            const int krem = klen - (n_chunks - 1) * BKC, c_scale = scale;
+            ++cseg;
+            if (cseg < seg_end) {
+                open_seg(cseg);
+                issue(buf ^ 1, 0);
+            }
             const float *sa = lds + buf * STAGE;
-            compute_stage<BM, BN, WK, decltype(akm)::value, decltype(bkm)::value, true>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+            compute_stage<BM, BN, WK, AKM, BKM, false>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
+            if (c_scale != SK_ONE) {
+                const float sc = hyper_scale(hy, c_scale);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= sc;
+            }
+            if (cseg >= seg_end) break;
             buf ^= 1;
         }
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    open_seg(cseg);
-    issue(0, 0);
-    for (;;) {
-        const int n_chunks = (klen + BKC - 1) / BKC;
-        switch (combo) {
-            case 0: inner(F_{}, F_{}, n_chunks - 1); break;
-            case 1: inner(F_{}, T_{}, n_chunks - 1); break;
-            case 2: inner(T_{}, F_{}, n_chunks - 1); break;
-            default: inner(T_{}, T_{}, n_chunks - 1); break;
+    {
+        const Seg &s0 = segs[cseg];
+        switch (s0.a_kmajor * 2 + s0.b_kmajor) {
+            case 0: k_loop(F_{}, F_{}); break;
+            case 1: k_loop(F_{}, T_{}); break;
+            case 2: k_loop(T_{}, F_{}); break;
+            default: k_loop(T_{}, T_{}); break;
         }
-        // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
-        stage_ready();
-        const int krem = klen - (n_chunks - 1) * BKC, c_combo = combo, c_scale = scale;
-        ++cseg;
-        if (cseg < seg_end) {
-            open_seg(cseg);
-            issue(buf ^ 1, 0);
-        }
-        const float *sa = lds + buf * STAGE;
-        const float *sb = sa + BM * BKC;
-        switch (c_combo) {
-            case 0: compute_stage<BM, BN, WK, false, false, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
-            case 1: compute_stage<BM, BN, WK, false, true, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
-            case 2: compute_stage<BM, BN, WK, true, false, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
-            default: compute_stage<BM, BN, WK, true, true, false>(acc, sa, sb, ra, rb, wk, lh, krem); break;
-        }
-        if (c_scale != SK_ONE) {
-            const float sc = hyper_scale(hy, c_scale);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= sc;
-        }
-        if (cseg >= seg_end) break;
-        buf ^= 1;
     }
 
     // ---- epilogue: accumulators -> LDS (reduces the K split, makes rows contiguous) ----
@@ -360,16 +376,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         const bool row_ok = m < m_valid;
         const int nrem = row_ok ? n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        float bv[4], av[4], mv[4], fm[3][4];
+        float bv[4], av[4], mv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool ok = e < nrem;
             bv[e] = *((ok && bias) ? bias + n + e : zeros);
             av[e] = *((ok && add) ? add + (size_t)m * t.add_ld + n + e : zeros);
             mv[e] = *((ok && aux) ? aux + (size_t)m * t.aux_ld + n + e : ones);
-#pragma unroll
-            for (int f = 0; f < 3; ++f)
-                fm[f][e] = *((ok && f < nfan) ? ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n + e : zeros);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -391,10 +404,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 #pragma unroll
         for (int f = 0; f < 3; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
             if (f < nfan) {
+                const float *mp = ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n;
                 float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < nrem) op[e] = fm[f][e] > 0.f ? v[e] : 0.f;
+                    if (e < nrem) op[e] = mp[e] > 0.f ? v[e] : 0.f;
             }
         }
     }

@@ -95,6 +95,7 @@ struct Builder {
     }
 
     int gemm_phase_index = 0;
+    bool mixed_kinds = false;   // a GEMM spec whose Segs differ in operand kinds (not supported by the kernel)
     int sum8[3] = {-1, 0, 0};   // {dst, src, rows}: when dst >= 0 the first workgroup of the next GEMM phase also sums an [rows][8] table
 
     // expand GEMM specs into tile tasks of one phase
@@ -134,6 +135,8 @@ struct Builder {
         for (auto &g : specs) {
             const int seg_begin = (int)p.segs.size();
             int cost = 0;
+            for (auto &s : g.segs)   // the kernel selects its K loop by the operand kinds of the task's first Seg
+                if (s.a_kmajor != g.segs[0].a_kmajor || s.b_kmajor != g.segs[0].b_kmajor) mixed_kinds = true;
             for (auto &s : g.segs) {
                 p.segs.push_back(s);
                 // operands the kernel cannot move 16 bytes at a time take the 4-byte LDS-DMA path: such tiles are
@@ -611,5 +614,6 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         }
         { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }
     }
+    if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
     return TA3N_OK;
 }
