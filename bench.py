@@ -33,9 +33,14 @@ from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
 
 # BASELINE config 2/3 (script_train_val.sh: bS=128, bS_2=128*840/1438=74, 5 segments, fc_dim 512, 12 classes)
 CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
-DEFAULT_PHASE_TILES = []          # per-GEMM-launch tile shapes measured best on MI355X (bench.py --autotune)
+# per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
+# forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
+DEFAULT_PHASE_TILES = [214, 114, 118, 118, 118, 118, 124, 114, 222, 114, 124, 118, 118, 114, 124, 114]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
+# HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
+# profiles/r01_pmc_fused_step.txt: (sum FETCH_SIZE x 2 [gfx950 half-count correction] + sum WRITE_SIZE) KiB / 6
+GEMM_TRAFFIC_BYTES_PER_LAUNCH = (2 * 105815 + 26265) * 1024 / 6
 
 
 def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
@@ -196,7 +201,9 @@ def main():
                        "step": "fused (ta3n_train_step)" if eng.fused else "forward+loss+backward",
                        "phase_tiles": [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if eng.fused else None,
+                         "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step.txt)",
                          "kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step)",
                          "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
                          "launches": len(gemm), "all_kernels_us": 1e3 * sum(p[3] for p in phases),

@@ -175,6 +175,12 @@ int ta3n_train_step(ta3n_plan *plan, const float *x, const float *params, float 
 int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                   void *stream);
 
+/* The same update directly after ta3n_train_step on the same ws, with the gradient buffer untouched in
+ * between (single rank: no all-reduce): the global norm is taken from the per-tile sums of squares the
+ * fused step's gradient tiles left in ws["sumsq"], which saves the pass over the gradient buffer. */
+int ta3n_sgd_step_fused(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
+                        void *stream);
+
 /* Measurement aid: per-launch durations (ms) of every phase of one train step,
  * taken with HIP events recorded on `stream`; GEMM/pool/loss phases are repeated
  * `reps` times back to back.  kind_out[i]: 0 GEMM, 1 pool fwd, 2 loss, 3 pool bwd,

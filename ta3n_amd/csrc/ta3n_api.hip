@@ -318,6 +318,17 @@ int ta3n_train_step(ta3n_plan *p, const float *x, const float *params, float *gr
     return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
+int ta3n_sgd_step_fused(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {
+    if (!p || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_fused_step(p) != 1) return fail(TA3N_ERR_INVALID, "no fused step for this configuration: use ta3n_sgd_step");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (launch_sgd(p->geom, params, grads, momentum, ws, static_cast<hipStream_t>(stream), true) != 0)
+        return fail(TA3N_ERR_HIP, std::string("sgd launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
 int ta3n_sgd_step(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {
     if (!p || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");

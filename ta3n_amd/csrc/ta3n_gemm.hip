@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const float *__restrict__ add = (epi & EPI_ADD) ? base_ptr(ptrs, t.add_base) + t.add_off : nullptr;
     const bool c_vec = ((t.c_off | t.c_ld) & 3) == 0;
     const int nfan = t.fan_count;
+    float sumsq = 0.f;   // EPI_SUMSQ: this thread's share of the tile's sum of squares
 
     for (int idx = tid; idx < BM * BN / 4; idx += NT) {
         const int r = idx / (BN / 4);
@@ -393,6 +394,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             v[e] = x * gamma;
         }
         if (nrem <= 0) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nrem) sumsq = fmaf(v[e], v[e], sumsq);
         float *cp = cbase + (size_t)m * t.c_ld + n;
         if (nrem >= 4 && c_vec) {
             *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -410,6 +414,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 for (int e = 0; e < 4; ++e)
                     if (e < nrem) op[e] = mp[e] > 0.f ? v[e] : 0.f;
             }
+        }
+    }
+    if (epi & EPI_SUMSQ) {   // wave-uniform: fixed-order block sum -> this tile's slot (fused grad-norm partial)
+        __syncthreads();
+        sumsq = wave_allreduce_sum(sumsq);
+        if (lane == 0) lds[wave] = sumsq;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int i = 0; i < NW; ++i) tot += lds[i];
+            ptrs.ws[t.pad[3]] = tot;
         }
     }
 }

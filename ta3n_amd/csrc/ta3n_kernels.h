@@ -77,7 +77,8 @@ int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t stream);
-int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream);
+int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream,
+               bool fused_norm = false);
 int launch_fill(float *dst, float value, int64_t n, hipStream_t stream);
 
 }  // namespace ta3n

@@ -613,6 +613,20 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             b.add_gemm_phase(4, s);
         }
         { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }
+        // every gradient tile of the fused step leaves the sum of its squares in its own slot: the optimiser
+        // (ta3n_sgd_step_fused) adds the slots in a fixed order instead of re-reading the gradient buffer
+        std::vector<size_t> grad_tasks;
+        for (const Phase &ph : p.phases)
+            if (ph.group == 4 && ph.kind == PH_GEMM)
+                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
+                    if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
+        g.n_sumsq = (int32_t)grad_tasks.size();
+        g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
+        for (size_t k = 0; k < grad_tasks.size(); ++k) {
+            p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
+            p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
+        }
+        if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
     return TA3N_OK;

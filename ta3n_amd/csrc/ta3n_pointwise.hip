@@ -239,12 +239,14 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float *__restrict_
 
 // clip_grad_norm_ (total_norm over all grads, coef = clip/(norm+1e-6) clamped to 1)
 // then torch.optim.SGD(nesterov=True): g += wd*p; buf = mu*buf + g; g += mu*buf; p -= lr*g.
+// norm_off / norm_n: the partial sums of squares to add up (grad_norm_kernel's per-block partials, or the
+// per-tile partials the fused step's gradient tiles left behind).
 __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
-                                                  float *__restrict__ mom, float *__restrict__ ws, int n4) {
+                                                  float *__restrict__ mom, float *__restrict__ ws, int n4, int norm_off, int norm_n) {
     __shared__ float red[8];
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
     float acc = 0.f;
-    for (int i = threadIdx.x; i < g.n_norm_blocks; i += blockDim.x) acc += ws[g.o_norm_part + i];
+    for (int i = threadIdx.x; i < norm_n; i += blockDim.x) acc += ws[norm_off + i];
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (hy->clip > 0.f) coef = fminf(hy->clip / (total + 1e-6f), 1.f);
@@ -315,12 +317,13 @@ int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t s
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream) {
+int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream, bool fused_norm) {
     const int n4 = g.live_floats / 4;
     int blocks = (n4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, n4);
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, n4,
+                       fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

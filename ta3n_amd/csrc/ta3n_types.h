@@ -27,7 +27,7 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
-    EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[1]] = sum of squares of the stored tile (fused grad-norm partial)
+    EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[3]] = sum of squares of the stored tile (fused grad-norm partial)
 };
 
 struct Seg {
@@ -57,7 +57,7 @@ struct Task {
     int32_t fan_mask_off[3];
     int32_t fan_out_off[3];
     int32_t cost;                        // sum of klen (for ordering / balance)
-    int32_t pad[3];                      // EPI_SUMROWS8: {dst, src, rows} (ws offsets); EPI_SUMSQ: [0] = slot
+    int32_t pad[4];                      // EPI_SUMROWS8: [0..2] = {dst, src, rows} (ws offsets); EPI_SUMSQ: [3] = ws offset of the slot
 };
 
 enum PhaseKind : int32_t {

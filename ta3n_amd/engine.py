@@ -169,6 +169,11 @@ class TrainEngine:
         if self.world > 1:
             parallel.all_reduce_sum_(self.G[: self.plan.live_floats], self.pg)
 
+    def sgd_step_fused(self) -> None:
+        """Update with the global norm taken from the fused step's per-tile partials (single rank only)."""
+        _lib.check(self._L.ta3n_sgd_step_fused(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                                               self.ws.data_ptr(), self._stream()), "ta3n_sgd_step_fused")
+
     def sgd_step(self) -> None:
         _lib.check(self._L.ta3n_sgd_step(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
                                          self.ws.data_ptr(), self._stream()), "ta3n_sgd_step")
@@ -186,7 +191,10 @@ class TrainEngine:
             self.loss()
             self.backward()
         self.all_reduce_grads()
-        self.sgd_step()
+        if self.fused and self.world == 1:
+            self.sgd_step_fused()       # local gradients are final: their norm partials are already in ws
+        else:
+            self.sgd_step()
 
     def capture(self) -> None:
         """Capture forward+loss+backward(+all-reduce)+update into one hipGraph (shapes
@@ -226,8 +234,10 @@ class TrainEngine:
                                             self.M.data_ptr(), self.ws.data_ptr(), self._stream(), reps, ms, kinds, groups, n),
                    "ta3n_time_phases")
         want = (4, 3) if self.fused else (0, 1, 2, 3)
+        skip_norm = self.fused and self.world == 1      # ta3n_sgd_step_fused has no grad-norm launch
         return [(int(kinds[i]), ph["tile"], ph["task_count"], float(ms[i]))
-                for i, ph in enumerate(self.plan.description["phases"]) if all_groups or int(groups[i]) in want]
+                for i, ph in enumerate(self.plan.description["phases"])
+                if all_groups or (int(groups[i]) in want and not (skip_norm and int(kinds[i]) == 4))]
 
     def gemm_phase_times(self, reps: int = 20):
         """ms of every GEMM launch of the plan, in plan order (the index space of phase_tiles)."""

@@ -14,7 +14,7 @@ import numpy as np
 from ta3n_amd import _lib
 
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
-EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8 = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ = 1, 2, 4, 8, 16, 32, 64, 128
 PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS = range(7)
 HEADS_RPW = 16
 
@@ -31,7 +31,7 @@ class Task(C.Structure):
                                           "aux_base", "aux_off", "aux_ld", "add_base", "add_off", "add_ld", "drop_ld",
                                           "fan_count", "fan_ld")] +
                 [("fan_mask_off", C.c_int32 * 3), ("fan_out_off", C.c_int32 * 3), ("cost", C.c_int32),
-                 ("pad", C.c_int32 * 3)])
+                 ("pad", C.c_int32 * 4)])
 
 
 class Phase(C.Structure):
@@ -177,6 +177,8 @@ class Interp:
                 v = v * keep_mask(seed, m * t.drop_ld + n, p)
             v = v * self.scale(t.gamma_kind)
             self.buf(t.c_base)[t.c_off + m * t.c_ld + n] = v
+            if t.epi & EPI_SUMSQ:
+                self.ws[t.pad[3]] = float((v * v).sum())
             for f in range(t.fan_count):
                 mk = self.ws[t.fan_mask_off[f] + m * t.fan_ld + n]
                 self.ws[t.fan_out_off[f] + m * t.fan_ld + n] = np.where(mk > 0, v, 0)
@@ -318,10 +320,14 @@ class Interp:
             part[w] = (gPf[rows].T @ Hf[rows]).reshape(-1)
             bpart[w] = gPf[rows].sum(0)
 
-    def run_sgd(self):
+    def run_sgd(self, fused_norm=False):
+        """fused_norm: global norm from the per-tile partials the fused step's gradient tiles left in ws["sumsq"]
+        (ta3n_sgd_step_fused) instead of a pass over the gradient buffer."""
         g, h = self.g, self.hy
         n = g.live_floats
         total = np.sqrt((self.G[:n] ** 2).sum())
+        if fused_norm:
+            total = np.sqrt(self.ws[g.o_sumsq:g.o_sumsq + g.n_sumsq].sum())
         coef = min(h["clip"] / (total + 1e-6), 1.0) if h["clip"] > 0 else 1.0
         self.ws[g.o_grad_norm] = total; self.ws[g.o_grad_norm + 1] = coef
         d = self.G[:n] * coef + h["weight_decay"] * self.P[:n]
@@ -329,7 +335,7 @@ class Interp:
         d = d + h["momentum"] * self.M[:n]
         self.P[:n] -= h["lr"] * d
 
-    def run_group(self, group):
+    def run_group(self, group, fused_norm=False):
         for ph in self.phases:
             if ph.group != group:
                 continue
@@ -339,4 +345,4 @@ class Interp:
             elif ph.kind == PH_POOL_BWD: self.run_pool_bwd()
             elif ph.kind == PH_HEADS: self.run_heads()
             elif ph.kind == PH_GRAD_NORM: pass
-            elif ph.kind == PH_SGD: self.run_sgd()
+            elif ph.kind == PH_SGD: self.run_sgd(fused_norm)

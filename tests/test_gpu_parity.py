@@ -76,7 +76,10 @@ def test_train_steps_match_reference_golden(name, tile, fused):
             eng.loss()
             eng.backward()
         raw = {k: v.clone() for k, v in eng.param_views(eng.G).items()}
-        eng.sgd_step()
+        if fused:
+            eng.sgd_step_fused()       # global norm from the gradient tiles' own partial sums
+        else:
+            eng.sgd_step()
         torch.cuda.synchronize()
         coef = eng.region("grad_norm")[1].item()
         new = eng.param_views()

@@ -70,7 +70,7 @@ def test_plan_reproduces_reference(name, tile, fused):
             it.run_group(1)
             it.run_group(2)
         raw = it.get_params(it.G)
-        it.run_group(3)
+        it.run_group(3, fused_norm=fused)
         coef = it.ws[it.g.o_grad_norm + 1]
         new = it.get_params()
         for k in shapes:
