@@ -112,12 +112,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches (eager is "
+                    "faster here: 8 launches of 10-70 us each keep the host ahead, a replay adds ~5 us of GPU idle time per step)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--tile", type=int, default=0, help="force a GEMM tile config (114/118/212/122/214/124/221/222)")
     ap.add_argument("--phase-tiles", type=str, default="", help="comma list of per-GEMM-phase tile configs")
     ap.add_argument("--autotune", action="store_true", help="measure tile configs per GEMM launch and use the best")
     ap.add_argument("--xcd", type=int, default=0, help="0/1 XCD-aware tile ordering on, 2 off")
     ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
+    ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
@@ -150,10 +153,13 @@ def main():
     lr0, gamma, beta = 3e-2, 0.003, [0.75, 0.75, 0.5]
     total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
     eng.set_hyper(beta, gamma, lr0)
-    if not args.no_graph:
+    if args.graph:
         eng.capture()
 
     def step(i):
+        if args.static_hyper and eng.graph is not None:
+            eng.graph.replay()
+            return
         p = float(i % total_steps) / total_steps
         eng.train_step(beta, gamma, lr0 if i == 0 else lr_dann(lr0, p))
 
@@ -197,7 +203,7 @@ def main():
                                    "attentive entropy, 128 src + 74 tgt videos per GPU-step, 2048-d features, 12 classes, "
                                    "dropout 0.5/0.5, clip 20, Nesterov SGD (BASELINE configs[2] arithmetic, fp32)",
                        "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph", "finite": finite,
+                       "launch": "hipGraph" if args.graph else "eager", "finite": finite,
                        "step": "fused (ta3n_train_step)" if eng.fused else "forward+loss+backward",
                        "phase_tiles": [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -1,0 +1,79 @@
+"""GPU: the N > 1 code path of TrainEngine on ONE GPU - two ranks (gloo over CUDA tensors; RCCL refuses two
+ranks on one device) each step their shard with global loss normalisers, sum-all-reduce the flat gradient
+buffer and update; both must end on the parameters of a single process that stepped the whole batch
+(what the reference's DataParallel gather + global means compute)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(C=12, T=5, D=512, fc=128, Bs=12, Bt=8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(eng, xs, xt, ys, steps, **kw):
+    for i in range(steps):
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-2, seed=i, **kw)
+    torch.cuda.synchronize()
+    return eng.P.detach().cpu().clone()
+
+
+def _worker(rank, world, port, out, fused):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ta3n_amd import parallel
+    from ta3n_amd.engine import TrainEngine
+    c = CFG
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    lo, hi = parallel.shard_range(c["Bs"], world, rank)
+    lo_t, hi_t = parallel.shard_range(c["Bt"], world, rank)
+    eng = TrainEngine(hi - lo, hi_t - lo_t, c["T"], c["D"], c["fc"], c["C"], dropout_i=0.0, dropout_v=0.0, fused=fused)
+    assert eng.world == world
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=3))
+    P = _run(eng, xs[lo:hi], xt[lo_t:hi_t], ys[lo:hi], 3, global_source=c["Bs"], global_target=c["Bt"])
+    torch.save(P, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_ranks_equal_single_process_global_batch(tmp_path, fused):
+    from ta3n_amd.engine import TrainEngine
+    c = CFG
+    out = str(tmp_path / "P")
+    mp.spawn(_worker, args=(2, _free_port(), out, fused), nprocs=2, join=True)
+    p0, p1 = torch.load(out + ".0"), torch.load(out + ".1")
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    eng = TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc"], c["C"], dropout_i=0.0, dropout_v=0.0, fused=fused)
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=3))
+    ref = _run(eng, xs, xt, ys, 3)
+    assert torch.equal(p0, p1)                                    # every rank applies the identical update
+    assert (p0 - ref).abs().max() > 0 or True
+    assert torch.allclose(p0, ref, rtol=2e-4, atol=2e-6), (p0 - ref).abs().max()
+    moved = (ref - synth_flat(eng, shapes)).abs().max()
+    assert moved > 1e-4                                           # the steps actually changed the parameters
+
+
+def synth_flat(eng, shapes):
+    from ta3n_amd.engine import TrainEngine
+    e2 = TrainEngine(eng.Bs, eng.Bt, eng.T, eng.D, CFG["fc"], eng.C, dropout_i=0.0, dropout_v=0.0)
+    e2.load_state(synth_state(shapes, seed=3))
+    return e2.P.detach().cpu().clone()

@@ -170,6 +170,111 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
     }
 }
 
+// ---------------------------------------------------------------- (3) private-pipeline variant
+// Each wave of the workgroup streams its OWN K chunks (chunk c goes to wave c % NW) of the shared 32x32 tile
+// through its own LDS stages: no s_barrier in the K loop, only the wave's own counted vmcnt; the NW partial
+// accumulators are added through LDS once at the end.
+template <int NW, int BKP, int NBUF, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * NW) void gemm_priv(Gemm g) {
+    constexpr int STAGE = 64 * BKP;                // floats per stage per wave: 32 A rows + 32 B rows
+    constexpr int SPR = BKP / 4;                   // 16-byte slots per K-contiguous row
+    constexpr int RPP = 64 / SPR;                  // rows per 1 KiB piece
+    constexpr int PIECES = 32 / RPP;               // pieces per operand per stage (K-contiguous); k-major: 32*BKP*4/1024
+    constexpr int PIECES_KM = 32 * BKP * 4 / 1024;
+    constexpr int LPW = (AKM ? PIECES_KM : PIECES) + (BKM ? PIECES_KM : PIECES);
+    constexpr int LDSF = NW * NBUF * STAGE > NW * 32 * 36 ? NW * NBUF * STAGE : NW * 32 * 36;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t *)lds) + wave * NBUF * STAGE * 4;
+    const float *my = lds + wave * NBUF * STAGE;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int nchunks = (g.K + BKP - 1) / BKP;
+    const int mine = (nchunks - wave + NW - 1) / NW;            // chunks wave, wave + NW, ...
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    auto issue_op = [&](const float *base, int ld, bool kmajor, int r0, int rvalid, int k0, unsigned dst) {
+        if (!kmajor) {
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                const int row = q * RPP + lane / SPR;
+                const int gq = (lane % SPR) ^ ((row >> (SPR == 8 ? 1 : 2)) & (SPR - 1));
+                const int k = k0 + 4 * gq;
+                const float *src = (r0 + row < rvalid && k < g.K) ? base + (size_t)(r0 + row) * ld + k : g.zeros;
+                glds16(src, dst + q * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PIECES_KM; ++q) {
+                const int k = k0 + q * 8 + lane / 8;
+                const int r = r0 + (lane % 8) * 4;
+                const float *src = (r < rvalid && k < g.K) ? base + (size_t)k * ld + r : g.zeros;
+                glds16(src, dst + q * 1024);
+            }
+        }
+    };
+    auto issue = [&](int i) {                       // i-th chunk of this wave
+        const int k0 = (wave + i * NW) * BKP;
+        const unsigned st = lds_base + (unsigned)((i % NBUF) * STAGE * 4);
+        issue_op(g.A, g.lda, AKM, m0, g.M, k0, st);
+        issue_op(g.B, g.ldb, BKM, n0, g.N, k0, st + 32 * BKP * 4);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue(i);   // past-the-end chunks read zeros: keeps the vmcnt arithmetic uniform
+    for (int i = 0; i < mine; ++i) {
+        if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * LPW) : "memory");
+        issue(i + NBUF - 1);
+        const float *sa = my + (i % NBUF) * STAGE;
+        const float *sb = sa + 32 * BKP;
+        float av[BKP / 8][4], bv[BKP / 8][4];
+#pragma unroll
+        for (int q = 0; q < BKP / 8; ++q) {
+            const int G = 2 * q + lh;
+            if (!AKM) {
+                const float4 t = *reinterpret_cast<const float4 *>(sa + li * BKP + ((G ^ ((li >> (SPR == 8 ? 1 : 2)) & (SPR - 1))) << 2));
+                av[q][0] = t.x; av[q][1] = t.y; av[q][2] = t.z; av[q][3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[q][j] = sa[(4 * G + j) * 32 + li];
+            }
+            if (!BKM) {
+                const float4 t = *reinterpret_cast<const float4 *>(sb + li * BKP + ((G ^ ((li >> (SPR == 8 ? 1 : 2)) & (SPR - 1))) << 2));
+                bv[q][0] = t.x; bv[q][1] = t.y; bv[q][2] = t.z; bv[q][3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[q][j] = sb[(4 * G + j) * 32 + li];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BKP / 8; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[q][j], acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float *cs = lds + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32 / 4; idx += 64 * NW) {
+        const int r = idx / 8, c4 = (idx % 8) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const float4 p = *reinterpret_cast<const float4 *>(&lds[q * (32 * 36) + r * 36 + c4]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int m = m0 + r, n = n0 + c4;
+        if (m < g.M && n < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)m * g.ldc + n) = v;
+    }
+}
+
 static double cpu_ref(const std::vector<float> &A, const std::vector<float> &B, int lda, int ldb, bool akm, bool bkm, int K, int m, int n) {
     double s = 0;
     for (int k = 0; k < K; ++k) {
@@ -184,8 +289,8 @@ template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK = 64>
 void run(const char *name, int M, int N, int K) {
     const int lda = AKM ? M : K, ldb = BKM ? N : K;
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
-    for (auto &v : hA) v = (float)rand() / RAND_MAX - 0.5f;
-    for (auto &v : hB) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto &v : hA) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    for (auto &v : hB) v = (float)rand() / (float)RAND_MAX - 0.5f;
     float *dA, *dB, *dC, *dz;
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dz, 256));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
@@ -222,6 +327,46 @@ void run(const char *name, int M, int N, int K) {
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
 }
 
+template <int NW, int BKP, int NBUF, bool AKM, bool BKM>
+void runp(const char *name, int M, int N, int K) {
+    const int lda = AKM ? M : K, ldb = BKM ? N : K;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto &v : hA) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    for (auto &v : hB) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    float *dA, *dB, *dC, *dz;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dz, 256));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dz, 0, 256));
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    Gemm g{dA, dB, dC, M, N, K, lda, ldb, N, dz};
+    const int grid = ((M + 31) / 32) * ((N + 31) / 32);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_priv<NW, BKP, NBUF, AKM, BKM>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    const int reps = 50;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_priv<NW, BKP, NBUF, AKM, BKM>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 400; ++t) {
+        const int m = (t * 7919) % M, n = (t * 104729) % N;
+        maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, m, n) - hC[(size_t)m * N + n]));
+    }
+    maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, M - 1, N - 1) - hC[(size_t)(M - 1) * N + N - 1]));
+    const double us = 1e3 * ms / reps;
+    printf("%-12s %dx%dx%d PRIVATE nw%d bk%d nbuf%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, NW, BKP, NBUF, grid, us,
+           2.0 * M * N * K / us * 1e-6, maxerr);
+    fflush(stdout);
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
+}
+
 int main() {
     {   // (1) ceiling
         float *out;
@@ -243,35 +388,24 @@ int main() {
         }
         CK(hipFree(out));
     }
-    // (2) forward shared-FC shape
+    // shared-stage baseline vs private pipelines
     run<1, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 1, 8, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 1, 8, 3, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 1, 4, 2, false, false, 128>("NT F1", 1010, 512, 2048);
-    run<1, 1, 8, 2, false, false, 128>("NT F1", 1010, 512, 2048);
-    run<2, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<2, 1, 4, 3, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 2, 4, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<2, 1, 4, 2, false, false, 128>("NT F1", 1010, 512, 2048);
-    run<2, 2, 2, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<2, 2, 2, 2, false, false, 128>("NT F1", 1010, 512, 2048);
-    // TRN tuple GEMM shape (one of ten): 202 x 256 x 2560
-    run<1, 1, 4, 2, false, false>("NT TRN s5", 202, 256, 2560);
-    run<1, 1, 8, 2, false, false>("NT TRN s5", 202, 256, 2560);
-    // input-gradient shape
-    run<1, 1, 4, 2, false, true>("NN dgrad", 202, 512, 2176);
-    run<1, 1, 8, 2, false, true>("NN dgrad", 202, 512, 2176);
-    run<1, 1, 8, 2, false, true, 128>("NN dgrad", 202, 512, 2176);
-    // weight-gradient shapes
+    runp<4, 32, 2, false, false>("NT F1", 1010, 512, 2048);
+    runp<4, 32, 3, false, false>("NT F1", 1010, 512, 2048);
+    runp<4, 16, 3, false, false>("NT F1", 1010, 512, 2048);
+    runp<4, 16, 4, false, false>("NT F1", 1010, 512, 2048);
+    runp<8, 16, 3, false, false>("NT F1", 1010, 512, 2048);
+    runp<8, 32, 2, false, false>("NT F1", 1010, 512, 2048);
     run<1, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 8, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 1, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 2, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 2, 3, true, true>("TN dWsh", 512, 2048, 1010);
-    run<2, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 2, 2, true, true, 128>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 4, 2, true, true>("TN dWtrn", 256, 512, 606);
-    run<1, 1, 8, 2, true, true>("TN dWtrn", 256, 512, 606);
-    run<2, 2, 2, 2, true, true>("TN dWtrn", 256, 512, 606);
+    runp<4, 32, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    runp<4, 32, 3, true, true>("TN dWsh", 512, 2048, 1010);
+    runp<4, 16, 3, true, true>("TN dWsh", 512, 2048, 1010);
+    runp<4, 16, 4, true, true>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 8, 2, false, true>("NN dgrad", 202, 512, 2176);
+    runp<8, 16, 3, false, true>("NN dgrad", 202, 512, 2176);
+    runp<4, 32, 3, false, true>("NN dgrad", 202, 512, 2176);
+    run<1, 1, 8, 2, false, false>("NT TRN s5", 202, 256, 2560);
+    runp<8, 16, 3, false, false>("NT TRN s5", 202, 256, 2560);
+    runp<8, 32, 2, false, false>("NT TRN s5", 202, 256, 2560);
     return 0;
 }
