@@ -62,6 +62,13 @@ constexpr int S_LOSS = S_GPV + 8;                    // [4 waves][8] loss partia
 constexpr int S_TOTAL = S_LOSS + 32;
 static_assert(64 * TROW <= NBH * WROW, "backward tile / classifier staging must fit in the weight tile");
 
+// -DTA3N_HEADS_TIMING: workgroup 0 stamps s_memtime at every stage boundary into ws["g_attn"] (debug builds only)
+#ifdef TA3N_HEADS_TIMING
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned long long *>(ptrs.ws + g.o_gattn)[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ bool video_valid(int Bs, const Hyper *hy, int b) {
     return b < Bs ? (b < hy->valid_source) : (b - Bs < hy->valid_target);
 }
@@ -121,6 +128,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const float bcv_l = lane < C ? P[g.p_bcv + lane] : 0.f;
     const int label = (have && b < g.Bs) ? labels[b] : -1;
 
+    STAMP(0);
     // ---- A: relation logits, attention, R, V, Vd (one wave per video) ----
     if (have) {
         float vacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -172,6 +180,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll
         for (int q = 0; q < 4; ++q) smem[S_VD + wv * NBH + q * 64 + lane] = 0.f;
     }
+    STAMP(1);
     // classifier weights -> LDS [C][TROW]
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -180,6 +189,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
+    STAMP(2);
     // ---- B: class logits: wave = video, lane = class ----
     float y = -INFINITY;
     if (lane < C) {
@@ -197,6 +207,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();   // done with the classifier tile
 
+    STAMP(3);
     // ---- C: Hv = relu(Wdv Vd + bdv): thread t owns output channel t for all VPW videos ----
     {
         float acc[VPW];
@@ -238,6 +249,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
+    STAMP(4);
     // ---- D: video domain logits, losses, gY, gPv (one wave per video, lane = class) ----
     {
         float d0 = 0.f, d1 = 0.f;
@@ -295,6 +307,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
+    STAMP(5);
     // ---- E: gHv = (gPv Wcdv) * [Hv > 0] ----
 #pragma unroll
     for (int v = 0; v < VPW; ++v) {
@@ -359,6 +372,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
+    STAMP(6);
     // ---- G: backward of the attention pooling + relation adversarial loss (one wave per video) ----
     if (have) {
         const float *__restrict__ wsR = ptrs.ws;   // R: written in stage A, only read from here on
@@ -410,7 +424,8 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         }
     }
     {
-        const float lr = __shfl(l_rel, 0, 64), lv = __shfl(l_vid, 0, 64), le = __shfl(l_ent, 0, 64);
+        auto lane0 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0)); };
+        const float lr = lane0(l_rel), lv = lane0(l_vid), le = lane0(l_ent);
         if (lane < 8) {
             float v = 0.f;
             if (lane == 1) v = l_cls;
@@ -420,7 +435,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
             smem[S_LOSS + wv * 8 + lane] = v;
         }
     }
+    STAMP(7);
     write_loss_part(smem, ws, g.o_loss_part, blockIdx.x, hy->gamma);
+    STAMP(8);
 }
 
 // Frame rows: Pf, frame adversarial CE, gPf, gHf = (gPf Wcd) * [Hf > 0], and this workgroup's

@@ -40,15 +40,32 @@ __device__ __forceinline__ float keep_mask(uint32_t seed, uint32_t idx, float p)
     return u >= p ? 1.f : 0.f;
 }
 
+// Wave64 all-reduce on the DPP network (row-local butterflies, then row_bcast 15 / 31, then a readlane of lane 63):
+// ~13 VALU instructions.  The __shfl_xor form compiles to six dependent ds_bpermute_b32 round trips through
+// the LDS crossbar, which dominated the latency of the per-video stages of the heads kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1, 0xF>(0.f, v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(0.f, v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xF>(0.f, v);   // row_half_mirror
+    v += dpp_move<0x140, 0xF>(0.f, v);   // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_move<0x142, 0xA>(0.f, v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xC>(0.f, v);   // row_bcast:31 into rows 2 and 3: lanes 48-63 hold the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_allreduce_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    const float ninf = -INFINITY;
+    v = fmaxf(v, dpp_move<0xB1, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_move<0x4E, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_move<0x141, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_move<0x140, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(ninf, v));
+    v = fmaxf(v, dpp_move<0x143, 0xC>(ninf, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 struct Soft2 {

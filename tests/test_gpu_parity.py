@@ -255,3 +255,38 @@ def test_full_size_properties():
     assert all(torch.isfinite(v).all() for v in g_short.values())
     gy = eng.region("gY", (202, 12))
     assert torch.all(gy[100:128] == 0) and torch.all(gy[128 + 50:] == 0)
+
+
+@pytest.mark.parametrize("shape", ["config4_T9_C30_b512", "config5_T12_D1024"])
+def test_other_baseline_config_shapes_match_oracle(shape):
+    """BASELINE.json configs[3] (30 classes, 9 segments, 512+512 videos per GPU) and configs[4] (one 1024-d
+    stream, 12 segments, 128+128): one fused train step at the full shape vs the CPU oracle on the same
+    seeded inputs, trained-scale weights so the 1e-3 logit bound means something."""
+    from oracle import ta3n_oracle as orc
+    from ta3n_amd.engine import TrainEngine
+    if shape.startswith("config4"):
+        Bs, Bt, T, D, Fc, Cn, arch = 512, 512, 9, 2048, 512, 30, "resnet101"
+    else:
+        Bs, Bt, T, D, Fc, Cn, arch = 128, 128, 12, 1024, 512, 12, None
+    cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0)
+    params = synth_state(orc.param_shapes(cfg), seed=11)
+    xs, xt, ys, yt = synth_batch(Cn, T, D, Bs, Bt, seed=21)
+    eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=20.0)
+    assert eng.fused
+    eng.load_state(params)
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3)
+    torch.cuda.synchronize()
+    state = orc.TrainState(params=params, lr=1e-3)
+    res = orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg)
+    o = eng.outputs()
+    ref_out = torch.cat((res["src"]["out"], res["tgt"]["out"])).detach()
+    assert ref_out.abs().max() > 1.0
+    assert (o["out"].cpu() - ref_out).abs().max() < LOGIT_ATOL
+    for i, key in enumerate(("pred_rel", "pred_vid", "pred_frm")):
+        ref = torch.cat((res["src"]["pred_domain"][i], res["tgt"]["pred_domain"][i])).detach().reshape(o[key].shape)
+        assert (o[key].cpu() - ref).abs().max() < LOGIT_ATOL, key
+    assert abs(eng.losses()["loss"] - res["loss"].item()) < 5e-4 * max(1.0, abs(res["loss"].item()))
+    newp = eng.param_views()
+    for k, v in state.params.items():
+        assert torch.allclose(newp[k].cpu(), v, rtol=RTOL, atol=ATOL), k
