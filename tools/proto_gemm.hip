@@ -83,7 +83,7 @@ __device__ __forceinline__ void issue_operand(const float *__restrict__ base, in
     }
 }
 
-template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK>
+template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
     constexpr int NW = WM * WN * WK;
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
         __builtin_amdgcn_s_barrier();              // everyone's pieces landed; everyone finished reading stage c-1
         asm volatile("" ::: "memory");
-        issue(c + NBUF - 1);                       // refill the buffer stage c-1 used
+        if (MODE != 1) issue(c + NBUF - 1);        // refill the buffer stage c-1 used (MODE 1: compute-only ceiling)
         const float *sa = lds + (c % NBUF) * STAGE;
         const float *sb = sa + BM * BK;
 #pragma unroll
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
                 for (int j = 0; j < 4; ++j) bv[j] = sb[(4 * G + j) * BN + wn * 32 + li];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+                else acc[j] += av[j] * bv[j];      // MODE 2: DMA + LDS reads without the matrix pipe
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -275,6 +278,77 @@ __global__ __launch_bounds__(64 * NW) void gemm_priv(Gemm g) {
     }
 }
 
+// ---------------------------------------------------------------- (4) direct-to-register variant
+// With the K split across the waves of a workgroup no two waves share operand data, so LDS staging buys
+// nothing: each wave loads its own MFMA fragments straight from global memory (whole 128-byte lines per
+// row and stage), double-buffered in registers; no LDS, no barrier and no DMA in the K loop.
+// Stage = 32 k: lanes 0-31 hold k0..k0+15 of their row, lanes 32-63 hold k0+16..k0+31; MFMA j pairs k0+j with k0+16+j.
+template <int NW, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * NW) void gemm_direct(Gemm g) {
+    __shared__ __attribute__((aligned(16))) float lds[NW * 32 * 36];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int nstages = (g.K + 31) / 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_ok = m0 + li < g.M, b_ok = n0 + li < g.N;
+    auto load = [&](float (&a)[16], float (&b)[16], int s) {
+        const int k0 = s * 32 + 16 * lh;
+        if (!AKM) {
+            const float *p = g.A + (size_t)(m0 + li) * g.lda + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>((a_ok && k0 + 4 * q < g.K) ? p + 4 * q : g.zeros);
+                a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = *((a_ok && k0 + j < g.K) ? g.A + (size_t)(k0 + j) * g.lda + m0 + li : g.zeros);
+        }
+        if (!BKM) {
+            const float *p = g.B + (size_t)(n0 + li) * g.ldb + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4 *>((b_ok && k0 + 4 * q < g.K) ? p + 4 * q : g.zeros);
+                b[4 * q] = t.x; b[4 * q + 1] = t.y; b[4 * q + 2] = t.z; b[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = *((b_ok && k0 + j < g.K) ? g.B + (size_t)(k0 + j) * g.ldb + n0 + li : g.zeros);
+        }
+    };
+    float a0[16], b0[16], a1[16], b1[16];
+    int s = wave;
+    load(a0, b0, s);
+    for (; s < nstages; s += 2 * NW) {
+        load(a1, b1, s + NW);                       // past-the-end stages read zeros
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc, 0, 0, 0);
+        load(a0, b0, s + 2 * NW);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc, 0, 0, 0);
+    }
+    float *cs = lds + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32 / 4; idx += 64 * NW) {
+        const int r = idx / 8, c4 = (idx % 8) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const float4 p = *reinterpret_cast<const float4 *>(&lds[q * (32 * 36) + r * 36 + c4]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int m = m0 + r, n = n0 + c4;
+        if (m < g.M && n < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)m * g.ldc + n) = v;
+    }
+}
+
 static double cpu_ref(const std::vector<float> &A, const std::vector<float> &B, int lda, int ldb, bool akm, bool bkm, int K, int m, int n) {
     double s = 0;
     for (int k = 0; k < K; ++k) {
@@ -285,7 +359,7 @@ static double cpu_ref(const std::vector<float> &A, const std::vector<float> &B, 
     return s;
 }
 
-template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK = 64>
+template <int WM, int WN, int WK, int NBUF, bool AKM, bool BKM, int BK = 64, int MODE = 0>
 void run(const char *name, int M, int N, int K) {
     const int lda = AKM ? M : K, ldb = BKM ? N : K;
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
@@ -302,11 +376,11 @@ void run(const char *name, int M, int N, int K) {
     const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK, MODE>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
     CK(hipDeviceSynchronize());
     const int reps = 50;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_proto<WM, WN, WK, NBUF, AKM, BKM, BK, MODE>), dim3(grid), dim3(64 * WM * WN * WK), 0, 0, g);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms;
@@ -321,7 +395,7 @@ void run(const char *name, int M, int N, int K) {
     // last row / col corners
     maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, M - 1, N - 1) - hC[(size_t)(M - 1) * N + N - 1]));
     const double us = 1e3 * ms / reps;
-    printf("%-12s %dx%dx%d tile %dx%d wk%d nbuf%d bk%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, BM, BN, WK, NBUF, BK, grid, us,
+    printf("%-12s %dx%dx%d mode%d tile %dx%d wk%d nbuf%d bk%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, MODE, BM, BN, WK, NBUF, BK, grid, us,
            2.0 * M * N * K / us * 1e-6, maxerr);
     fflush(stdout);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
@@ -367,6 +441,46 @@ void runp(const char *name, int M, int N, int K) {
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
 }
 
+template <int NW, bool AKM, bool BKM>
+void rund(const char *name, int M, int N, int K) {
+    const int lda = AKM ? M : K, ldb = BKM ? N : K;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto &v : hA) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    for (auto &v : hB) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    float *dA, *dB, *dC, *dz;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dz, 256));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dz, 0, 256));
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    Gemm g{dA, dB, dC, M, N, K, lda, ldb, N, dz};
+    const int grid = ((M + 31) / 32) * ((N + 31) / 32);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_direct<NW, AKM, BKM>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    const int reps = 50;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_direct<NW, AKM, BKM>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 400; ++t) {
+        const int m = (t * 7919) % M, n = (t * 104729) % N;
+        maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, m, n) - hC[(size_t)m * N + n]));
+    }
+    maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, M - 1, N - 1) - hC[(size_t)(M - 1) * N + N - 1]));
+    const double us = 1e3 * ms / reps;
+    printf("%-12s %dx%dx%d DIRECT nw%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, NW, grid, us,
+           2.0 * M * N * K / us * 1e-6, maxerr);
+    fflush(stdout);
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
+}
+
 int main() {
     {   // (1) ceiling
         float *out;
@@ -388,24 +502,15 @@ int main() {
         }
         CK(hipFree(out));
     }
-    // shared-stage baseline vs private pipelines
-    run<1, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
-    runp<4, 32, 2, false, false>("NT F1", 1010, 512, 2048);
-    runp<4, 32, 3, false, false>("NT F1", 1010, 512, 2048);
-    runp<4, 16, 3, false, false>("NT F1", 1010, 512, 2048);
-    runp<4, 16, 4, false, false>("NT F1", 1010, 512, 2048);
-    runp<8, 16, 3, false, false>("NT F1", 1010, 512, 2048);
-    runp<8, 32, 2, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    runp<4, 32, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    runp<4, 32, 3, true, true>("TN dWsh", 512, 2048, 1010);
-    runp<4, 16, 3, true, true>("TN dWsh", 512, 2048, 1010);
-    runp<4, 16, 4, true, true>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 8, 2, false, true>("NN dgrad", 202, 512, 2176);
-    runp<8, 16, 3, false, true>("NN dgrad", 202, 512, 2176);
-    runp<4, 32, 3, false, true>("NN dgrad", 202, 512, 2176);
-    run<1, 1, 8, 2, false, false>("NT TRN s5", 202, 256, 2560);
-    runp<8, 16, 3, false, false>("NT TRN s5", 202, 256, 2560);
-    runp<8, 32, 2, false, false>("NT TRN s5", 202, 256, 2560);
+    // where does the time go: normal / compute-only (no DMA in the loop) / DMA-only (no MFMA)
+    run<1, 1, 4, 2, false, false, 64, 0>("NT F1", 1010, 512, 2048);
+    run<1, 1, 4, 2, false, false, 64, 1>("NT F1", 1010, 512, 2048);
+    run<1, 1, 4, 2, false, false, 64, 2>("NT F1", 1010, 512, 2048);
+    run<2, 2, 2, 2, true, true, 64, 0>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 2, 2, true, true, 64, 1>("TN dWsh", 512, 2048, 1010);
+    run<2, 2, 2, 2, true, true, 64, 2>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 4, 2, true, true, 64, 0>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 4, 2, true, true, 64, 1>("TN dWsh", 512, 2048, 1010);
+    run<1, 1, 4, 2, true, true, 64, 2>("TN dWsh", 512, 2048, 1010);
     return 0;
 }
