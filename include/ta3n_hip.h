@@ -102,6 +102,19 @@ int ta3n_relation_table(int num_frames, int32_t *tuples, int32_t *scale_len, int
  * Returns TA3N_ERR_INVALID where the reference raises (no selectable frame). */
 int ta3n_segment_indices(int num_frames, int num_segments, int new_length, int64_t *out);
 
+/* TSNDataSet.__getitem__ for a whole batch on the device (dataset.py:118-144 with the test-mode sampler
+ * dataset.py:103-116 - the only one main.py uses, main.py:171-197 - and new_length 1): the dataset lives in HBM
+ * as one packed fp32 store [total_frames, feature_dim] (ta3n_amd/feature_store.py writes it from the reference's
+ * one-.t7-file-per-frame layout); video i owns rows [first_row[i], first_row[i] + num_frames[i]).  For each of the
+ * n_videos ids the segment indices are computed in float64 exactly like the reference's Python and the selected
+ * rows are copied to out [n_videos * num_segments, feature_dim] - the `x` operand of ta3n_forward.  labels_out
+ * [n_videos] and segment_ids_out [n_videos * num_segments] (1-based frame ids) are optional.  num_frames must be
+ * >= 1 for every id (the reference fails on empty clips).  Enqueue only. */
+int ta3n_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames,
+                         const int32_t *labels, const int32_t *video_ids, int n_videos, int num_segments,
+                         int feature_dim, float *out, int32_t *labels_out, int32_t *segment_ids_out,
+                         void *stream);
+
 /* ---- plan ---------------------------------------------------------------------- */
 
 /* Builds the launch plan (tile lists, workspace layout) for one configuration;
@@ -169,6 +182,13 @@ int ta3n_backward(ta3n_plan *plan, const float *x, const float *params, float *g
 int ta3n_has_fused_step(const ta3n_plan *plan);
 int ta3n_train_step(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
                     void *stream);
+
+/* Validation bookkeeping of main.validate / test_models.py (main.py:707-735, accuracy() main.py:809-822,
+ * confusion matrix test_models.py:198) on the device: after a ta3n_forward with hyper.train = 0 and beta = 0,
+ * adds the cross-entropy sum, the top-1 and top-5 hit counts and the video count of the first n_videos source
+ * rows (labels in ws["labels"]) to ws["metrics"][0..3] and their (label, argmax) pairs to the int32 [C][C]
+ * matrix ws["confusion"]; reset != 0 clears both first.  No host synchronisation per batch. */
+int ta3n_eval_metrics(ta3n_plan *plan, float *ws, int n_videos, int reset, void *stream);
 
 /* clip_grad_norm_ + Nesterov SGD with weight decay (main.py:578-583) on the
  * flat live prefix; ws["grad_norm"] receives the pre-clip global norm. */

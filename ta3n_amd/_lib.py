@@ -25,10 +25,10 @@ FLAG_TRANS_ATTN = 1 << 4
 
 # every symbol include/ta3n_hip.h declares (tests check the export list)
 SYMBOLS = [
-    "ta3n_num_relation_tuples", "ta3n_relation_table", "ta3n_segment_indices", "ta3n_plan_create",
+    "ta3n_num_relation_tuples", "ta3n_relation_table", "ta3n_segment_indices", "ta3n_gather_segments", "ta3n_plan_create",
     "ta3n_plan_destroy", "ta3n_num_params", "ta3n_param_info", "ta3n_param_floats", "ta3n_live_param_floats",
     "ta3n_workspace_floats", "ta3n_ws_offset", "ta3n_ws_size", "ta3n_plan_describe", "ta3n_set_hyper",
-    "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step",
+    "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step", "ta3n_eval_metrics",
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_last_error", "ta3n_version",
 ]
@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
     L.ta3n_num_relation_tuples.argtypes = [C.c_int]
     L.ta3n_relation_table.argtypes = [C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ta3n_segment_indices.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(i64)]
+    L.ta3n_gather_segments.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_plan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.ta3n_plan_destroy.argtypes = [vp]
     L.ta3n_plan_destroy.restype = None
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
     L.ta3n_forward.argtypes = [vp, vp, vp, vp, vp]
     L.ta3n_loss.argtypes = [vp, vp, vp]
     L.ta3n_backward.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ta3n_eval_metrics.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.ta3n_has_fused_step.argtypes = [vp]
     L.ta3n_train_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ta3n_sgd_step.argtypes = [vp, vp, vp, vp, vp, vp]

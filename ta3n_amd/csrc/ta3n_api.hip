@@ -298,6 +298,28 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
     return n;
 }
 
+int ta3n_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
+                         const int32_t *video_ids, int n_videos, int num_segments, int feature_dim, float *out,
+                         int32_t *labels_out, int32_t *segment_ids_out, void *stream) {
+    if (!store || !first_row || !num_frames || !video_ids || !out) return fail(TA3N_ERR_INVALID, "null argument");
+    if (labels_out && !labels) return fail(TA3N_ERR_INVALID, "labels_out needs labels");
+    if (n_videos < 0 || num_segments <= 0 || feature_dim <= 0) return fail(TA3N_ERR_INVALID, "bad sizes");
+    if ((feature_dim & 3) == 0 && (!aligned16(store) || !aligned16(out))) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (launch_gather_segments(store, first_row, num_frames, labels, video_ids, n_videos, num_segments, feature_dim, out, labels_out,
+                               segment_ids_out, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
+int ta3n_eval_metrics(ta3n_plan *p, float *ws, int n_videos, int reset, void *stream) {
+    if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (n_videos < 0 || n_videos > p->geom.Bs) return fail(TA3N_ERR_INVALID, "n_videos must be in [0, batch_source]");
+    if (p->geom.C > 64) return fail(TA3N_ERR_INVALID, "num_class > 64 not supported");
+    if (launch_eval_metrics(p->geom, ws, n_videos, reset, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("metrics launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
 int ta3n_has_fused_step(const ta3n_plan *p) {
     if (!p) return TA3N_ERR_INVALID;
     for (const Phase &ph : p->phases)

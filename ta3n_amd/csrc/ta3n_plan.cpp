@@ -330,6 +330,8 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     g.o_fh_part = (int32_t)b.add_region("fh_part", (int64_t)g.n_frm_wg * 2 * F);
     g.o_fh_bpart = (int32_t)b.add_region("fh_bpart", (int64_t)g.n_frm_wg * 2);
     g.o_loss_part = (int32_t)b.add_region("loss_part", (int64_t)(g.n_vid_wg + g.n_frm_wg) * 8);
+    g.o_metrics = (int32_t)b.add_region("metrics", 8);
+    g.o_confusion = (int32_t)b.add_region("confusion", (int64_t)C * C);
     g.live_floats = (int32_t)p.live_floats;
     g.p_Wcd = (int32_t)Wcd; g.p_bcd = (int32_t)bcd; g.p_Wdv = (int32_t)Wdv; g.p_bdv = (int32_t)bdv;
     g.p_Wcv = (int32_t)Wcv; g.p_bcv = (int32_t)bcv; g.p_Wcdv = (int32_t)Wcdv; g.p_bcdv = (int32_t)bcdv;

@@ -276,6 +276,80 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
     }
 }
 
+// TSNDataSet.__getitem__ for a whole batch on the device (reference dataset.py:103-116, 128-144, new_length 1):
+// one workgroup per output row (video v, segment x).  The segment index is computed in float64 exactly as the
+// reference's Python does (tick = n / T; int(tick / 2.0 + tick * x)); clips shorter than T repeat their last frame.
+__global__ __launch_bounds__(256) void gather_segments_kernel(const float *__restrict__ store, const int64_t *__restrict__ first_row,
+                                                              const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                                              const int32_t *__restrict__ video_ids, int T, int D,
+                                                              float *__restrict__ out, int32_t *__restrict__ labels_out,
+                                                              int32_t *__restrict__ seg_out) {
+    const int row = blockIdx.x, v = row / T, x = row - v * T;
+    const int vid = video_ids[v];
+    const int nf = num_frames[vid];
+    int off;
+    if (nf >= T) {
+        const double tick = (double)nf / (double)T;
+        off = (int)(tick / 2.0 + tick * (double)x);
+    } else {
+        off = x < nf ? x : nf - 1;
+    }
+    if (threadIdx.x == 0) {
+        if (seg_out) seg_out[row] = off + 1;                    // the reference's ids are 1-based (img_00001.t7)
+        if (labels_out && x == 0) labels_out[v] = labels[vid];
+    }
+    const float *__restrict__ src = store + (size_t)(first_row[vid] + off) * D;
+    float *__restrict__ dst = out + (size_t)row * D;
+    if ((D & 3) == 0) {
+        const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
+        float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
+        for (int i = threadIdx.x; i < D / 4; i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
+    }
+}
+
+// Validation metrics of main.validate / test_models.py (reference main.py:707-735, 809-822; test_models.py:155-198)
+// over the first n source rows of Y: cross-entropy sum, top-1 / top-5 hits (torch.topk order: ties go to the lower
+// class index) and the confusion matrix (rows = label, cols = argmax), ACCUMULATED into ws["metrics"] / ws["confusion"]
+// so a validation epoch needs no host synchronisation.  One workgroup, one wave per video, fixed summation order.
+__global__ __launch_bounds__(1024) void eval_metrics_kernel(Geom g, float *__restrict__ ws, int n, int reset) {
+    __shared__ float part[16][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, C = g.C;
+    const int *__restrict__ labels = reinterpret_cast<const int *>(ws + g.o_labels);
+    int *__restrict__ conf = reinterpret_cast<int *>(ws + g.o_confusion);
+    if (reset)
+        for (int i = threadIdx.x; i < C * C; i += 1024) conf[i] = 0;
+    __syncthreads();
+    float ce = 0.f, t1 = 0.f, t5 = 0.f;
+    for (int b = wv; b < n; b += 16) {
+        const float y = lane < C ? ws[g.o_Y + (size_t)b * C + lane] : -INFINITY;
+        const int lab = labels[b];
+        const float m = wave_allreduce_max(y);
+        const float ls = logf(wave_allreduce_sum(lane < C ? expf(y - m) : 0.f));
+        const float ylab = wave_allreduce_sum(lane == lab ? y : 0.f);
+        // rank of the label among the logits, torch.topk order
+        const float ahead = wave_allreduce_sum((lane < C && (y > ylab || (y == ylab && lane < lab))) ? 1.f : 0.f);
+        // argmax with the same tie rule: the class that has nobody ahead of it
+        const float myahead_key = (lane < C && y == m) ? (float)lane : 1e9f;
+        float amin = myahead_key;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amin = fminf(amin, __shfl_xor(amin, off, 64));
+        ce += -(ylab - m - ls);
+        t1 += ahead < 1.f ? 1.f : 0.f;
+        t5 += ahead < 5.f ? 1.f : 0.f;
+        if (lane == 0 && lab >= 0 && lab < C) atomicAdd(&conf[lab * C + (int)amin], 1);
+    }
+    if (lane == 0) { part[wv][0] = ce; part[wv][1] = t1; part[wv][2] = t5; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float v = reset ? 0.f : ws[g.o_metrics + threadIdx.x];
+        for (int w = 0; w < 16; ++w) v += part[w][threadIdx.x];
+        ws[g.o_metrics + threadIdx.x] = v;
+    }
+    if (threadIdx.x == 3) ws[g.o_metrics + 3] = (reset ? 0.f : ws[g.o_metrics + 3]) + (float)n;
+}
+
 __global__ void fill_kernel(float *__restrict__ dst, float v, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
 }
@@ -324,6 +398,20 @@ int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, n4,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
+                           const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
+                           hipStream_t stream) {
+    if (n_videos <= 0) return 0;
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(n_videos * T), dim3(256), 0, stream, store, first_row, num_frames, labels, video_ids,
+                       T, D, out, labels_out, seg_out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream) {
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3(1), dim3(1024), 0, stream, g, ws, n, reset);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -113,6 +113,7 @@ struct Geom {
     int32_t o_loss_part;                 // per heads-workgroup loss partials [n_vid_wg + n_frm_wg][8]
     int32_t n_vid_wg, n_frm_wg;
     int32_t o_sumsq, n_sumsq;            // fused grad-norm partials (one slot per gradient tile of the fused step)
+    int32_t o_metrics, o_confusion;      // validation: {sum CE, top-1 hits, top-5 hits, videos} and the int32 [C][C] confusion matrix
 };
 
 }  // namespace ta3n

@@ -243,6 +243,26 @@ class TrainEngine:
         """ms of every GEMM launch of the plan, in plan order (the index space of phase_tiles)."""
         return [ms for kind, _, _, ms in self.time_phases(reps, all_groups=True) if kind == 0]
 
+    # ---- validation (main.validate, main.py:669-761) ----
+    def evaluate_batch(self, val_data: torch.Tensor, val_label: torch.Tensor, reset: bool = False) -> None:
+        """Forward in eval mode (no dropout, beta = 0: main.py:707) on up to batch_source videos and accumulate
+        loss / top-1 / top-5 / confusion matrix on the device; read them with eval_results()."""
+        n = val_data.shape[0]
+        if n > self.Bs:
+            raise ValueError(f"at most batch_source = {self.Bs} validation videos per call")
+        self.X[: n * self.T].copy_(val_data.reshape(-1, self.D), non_blocking=True)
+        self._labels[:n].copy_(val_label.to(torch.int32), non_blocking=True)
+        self.set_hyper([0.0, 0.0, 0.0], 0.0, 0.0, train=False, valid_source=n, valid_target=0)
+        self.forward()
+        _lib.check(self._L.ta3n_eval_metrics(self.plan.handle, self.ws.data_ptr(), n, int(reset), self._stream()), "ta3n_eval_metrics")
+
+    def eval_results(self) -> Dict[str, object]:
+        m = self.region("metrics")[:4].tolist()
+        n = max(m[3], 1.0)
+        off, cnt = self.plan.region("confusion")
+        conf = self.ws[off:off + cnt].view(torch.int32).view(self.C, self.C).cpu()
+        return dict(loss=m[0] / n, prec1=100.0 * m[1] / n, prec5=100.0 * m[2] / n, n=int(m[3]), confusion=conf)
+
     # ---- results ----
     def outputs(self) -> Dict[str, torch.Tensor]:
         B, T, NR = self.B, self.T, self.T - 1

@@ -44,7 +44,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_gR", "o_gZ", "o_gZ1", "o_zeros", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
-                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq"]
+                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion"]
 
 
 class Geom(C.Structure):

@@ -1,0 +1,82 @@
+"""Packed feature store: packing on the CPU, batch assembly on the GPU; both against the
+host mirror of the reference's TSNDataSet (whose segment indices are pinned bit-exact against the reference in
+tests/test_index.py)."""
+import numpy as np
+import pytest
+import torch
+
+from ta3n_amd import feature_store
+from ta3n_amd.dataset import TSNDataSet
+
+
+def _make_dataset(tmp_path, D=64, lengths=(1, 2, 3, 4, 5, 6, 9, 17, 40, 101, 250)):
+    g = torch.Generator().manual_seed(3)
+    lines = []
+    for v, n in enumerate(lengths):
+        d = tmp_path / f"vid{v}"
+        d.mkdir()
+        for f in range(1, n + 1):
+            torch.save(torch.randn(D, generator=g).abs(), str(d / f"img_{f:05d}.t7"))
+        lines.append(f"{d}/ {n} {v % 7}")
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    return str(lst), D, list(lengths)
+
+
+def test_pack_layout(tmp_path):
+    lst, D, lengths = _make_dataset(tmp_path)
+    prefix = str(tmp_path / "packed")
+    n, dim = feature_store.pack(lst, prefix)
+    assert (n, dim) == (len(lengths), D)
+    idx = np.load(prefix + ".idx.npy")
+    assert idx[:, 1].tolist() == lengths and idx[:, 2].tolist() == [v % 7 for v in range(len(lengths))]
+    assert idx[:, 0].tolist() == np.concatenate(([0], np.cumsum(lengths)[:-1])).tolist()
+    blob = np.fromfile(prefix + ".f32", dtype=np.float32).reshape(-1, D)
+    assert blob.shape[0] == sum(lengths)
+    ds = TSNDataSet("", lst, num_dataload=n, num_segments=5, new_length=1, modality="RGB", test_mode=True)
+    x, y = ds[9]                                       # 101 frames: segment ids 11, 31, 51, 71, 91 (dataset.py:103-116)
+    rows = idx[9, 0] + np.array([10, 30, 50, 70, 90])
+    assert np.array_equal(x.numpy(), blob[rows]) and y == idx[9, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [2, 5, 9])
+def test_device_gather_is_bit_exact_with_the_dataset(tmp_path, T):
+    lst, D, lengths = _make_dataset(tmp_path)
+    prefix = str(tmp_path / "packed")
+    n, dim = feature_store.pack(lst, prefix)
+    fs = feature_store.FeatureStore(prefix, dim)
+    ds = TSNDataSet("", lst, num_dataload=n, num_segments=T, new_length=1, modality="RGB", test_mode=True)
+    ids = torch.tensor([10, 0, 3, 3, 9, 1, 2, 4, 5, 6, 7, 8], dtype=torch.int32, device="cuda")
+    seg = torch.empty(ids.numel() * T, dtype=torch.int32, device="cuda")
+    x, y = fs.gather(ids, T, segment_ids_out=seg)
+    torch.cuda.synchronize()
+    for k, vid in enumerate(ids.tolist()):
+        ref_x, ref_y = ds[vid]
+        assert torch.equal(x[k].cpu(), ref_x), (vid, T)
+        assert int(y[k]) == ref_y
+        assert seg[k * T:(k + 1) * T].tolist() == ds._get_test_indices(ds.video_list[vid])
+
+
+@pytest.mark.gpu
+def test_gather_feeds_the_train_step_input_buffer(tmp_path):
+    from ta3n_amd.engine import TrainEngine
+    lst, D, lengths = _make_dataset(tmp_path, D=512)
+    prefix = str(tmp_path / "packed")
+    n, dim = feature_store.pack(lst, prefix)
+    fs = feature_store.FeatureStore(prefix, dim)
+    eng = TrainEngine(6, 4, 5, 512, 64, 7, dropout_i=0.0, dropout_v=0.0)
+    src = torch.tensor([0, 1, 2, 3, 4, 5], dtype=torch.int32, device="cuda")
+    tgt = torch.tensor([6, 7, 8, 9], dtype=torch.int32, device="cuda")
+    fs.gather(src, 5, out=eng.X[: 6 * 5], labels_out=eng._labels[:6])          # straight into the static buffers
+    fs.gather(tgt, 5, out=eng.X[6 * 5:])
+    ds = TSNDataSet("", lst, num_dataload=n, num_segments=5, new_length=1, modality="RGB", test_mode=True)
+    ref = torch.cat([ds[i][0] for i in range(10)])
+    torch.cuda.synchronize()
+    assert torch.equal(eng.X.cpu(), ref)
+    assert eng._labels[:6].tolist() == [ds[i][1] for i in range(6)]
+    for v in eng.param_views().values():
+        v.normal_(0, 0.05)
+    eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.P).all() and eng.losses()["loss"] > 0

@@ -79,3 +79,34 @@ def test_module_eval_mode_and_state_dict_roundtrip():
     with torch.no_grad():
         o2 = m2(xs, xs, [0, 0, 0], 0, False, False)
     assert torch.equal(o[1], o2[1])
+
+
+def test_validation_metrics_match_reference_accuracy():
+    """main.validate's bookkeeping (CE, accuracy() top-1/top-5 of main.py:809-822, confusion matrix of
+    test_models.py:198) accumulated on the device over several ragged batches vs torch on the CPU."""
+    from ta3n_amd.engine import TrainEngine
+    C_, T, D, Fc = 12, 5, 512, 64
+    eng = TrainEngine(16, 4, T, D, Fc, C_, dropout_i=0.5, dropout_v=0.5)
+    cfg = orc.Config(num_class=C_, num_segments=T, feature_dim=D, fc_dim=Fc)
+    params = synth_state(orc.param_shapes(cfg), seed=4)
+    eng.load_state(params)
+    g = torch.Generator().manual_seed(8)
+    logits, labels = [], []
+    for i, n in enumerate((16, 7, 1, 12)):
+        x = torch.randn(n, T, D, generator=g).abs()
+        y = torch.randint(0, C_, (n,), generator=g)
+        eng.evaluate_batch(x.cuda(), y.cuda(), reset=(i == 0))
+        with torch.no_grad():
+            ref = orc.forward_domain({k: v for k, v in params.items()}, x, [0.0, 0.0, 0.0], cfg)
+        logits.append(ref["out"]); labels.append(y)
+    res = eng.eval_results()
+    out, lab = torch.cat(logits), torch.cat(labels)
+    assert res["n"] == 36
+    assert abs(res["loss"] - torch.nn.functional.cross_entropy(out, lab).item()) < 1e-4
+    top5 = out.topk(5, 1).indices
+    assert abs(res["prec1"] - 100.0 * (top5[:, 0] == lab).float().mean().item()) < 1e-4
+    assert abs(res["prec5"] - 100.0 * (top5 == lab[:, None]).any(1).float().mean().item()) < 1e-4
+    conf = torch.zeros(C_, C_, dtype=torch.int32)
+    for p_, l_ in zip(out.argmax(1).tolist(), lab.tolist()):
+        conf[l_, p_] += 1
+    assert torch.equal(res["confusion"], conf)
