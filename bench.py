@@ -215,7 +215,7 @@ def main():
                          "launches": len(gemm), "all_kernels_us": 1e3 * sum(p[3] for p in phases),
                          "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]},
         }
-        if not args.skip_cpu_baseline:
+        if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

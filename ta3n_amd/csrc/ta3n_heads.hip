@@ -114,10 +114,17 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         cw[i] = (i * 256 + tid < C * 64) ? *reinterpret_cast<const f32x4 *>(Wcv + (size_t)(i * 256 + tid) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 stage[16];                               // forward tile 0: Wdv[all n][0..63], 16 threads per row
+    // The whole 256 x 256 video-discriminator weight matrix lives in this workgroup's registers (64 float4 per
+    // thread; one wave per SIMD leaves 512 registers per lane): thread (srow, sk4) holds W[srow + 16 i][64 kc + sk4 ..]
+    // as wreg[16 kc + i].  Both the forward tiles (all n x 64 k) and the backward tiles (64 n x all k) are staged to
+    // LDS from it, so the matrix crosses the memory system once per workgroup and no stage waits on a load.
+    f32x4 wreg[64];
     const int srow = tid >> 4, sk4 = (tid & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(srow + 16 * i) * NBH + sk4);
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            wreg[kc * 16 + i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(srow + 16 * i) * NBH + kc * 64 + sk4);
     const float *__restrict__ Wcdv = P + g.p_Wcdv;
     float wc0[4], wc1[4];                          // output layer of the video discriminator, this lane's channels
 #pragma unroll
@@ -216,17 +223,8 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll
         for (int kc = 0; kc < NBH; kc += 64) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i) * WROW + sk4]) = stage[i];
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i) * WROW + sk4]) = wreg[(kc / 64) * 16 + i];
             __syncthreads();
-            if (kc + 64 < NBH) {                   // next forward tile
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(srow + 16 * i) * NBH + kc + 64 + sk4);
-            } else {                               // first backward tile: Wdv[0..63][all k], 64 threads per row
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)((tid >> 6) + 4 * i) * NBH + (tid & 63) * 4);
-            }
             const float *wr = &smem[S_W + tid * WROW];
 #pragma unroll 4
             for (int k4 = 0; k4 < 64; k4 += 4) {
@@ -322,17 +320,15 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         float acc[VPW];
 #pragma unroll
         for (int v = 0; v < VPW; ++v) acc[v] = 0.f;
-        const int trow = tid >> 6, tk4 = (tid & 63) * 4;   // backward tile: 64 threads per row, 4 rows per pass
 #pragma unroll
         for (int n0 = 0; n0 < NBH; n0 += 64) {
+            // backward tile [64 n][256 k] from the register copy: this thread holds rows srow + 16 i, i = n0/16 .. n0/16 + 3
 #pragma unroll
-            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (trow + 4 * i) * TROW + tk4]) = stage[i];
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i4) * TROW + kc * 64 + sk4]) = wreg[kc * 16 + n0 / 16 + i4];
             __syncthreads();
-            if (n0 + 64 < NBH) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    stage[i] = *reinterpret_cast<const f32x4 *>(Wdv + (size_t)(n0 + 64 + trow + 4 * i) * NBH + tk4);
-            }
 #pragma unroll 4
             for (int n = 0; n < 64; n += 4) {
                 const float w0 = smem[S_W + (n + 0) * TROW + tid], w1 = smem[S_W + (n + 1) * TROW + tid];

@@ -80,3 +80,26 @@ def test_gather_feeds_the_train_step_input_buffer(tmp_path):
     eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3)
     torch.cuda.synchronize()
     assert torch.isfinite(eng.P).all() and eng.losses()["loss"] > 0
+
+
+@pytest.mark.gpu
+def test_train_script_end_to_end_from_packed_stores(tmp_path):
+    """train_ddp.py on one GPU: batches gathered on the device from packed stores, DANN schedules, device-side
+    validation - the reference's train/validate loop (main.py:228-274) without its per-frame file reads."""
+    import os
+    import subprocess
+    import sys
+    lst, D, lengths = _make_dataset(tmp_path, D=512, lengths=(3, 5, 8, 13, 21, 34, 55, 9, 6, 40, 17, 25))
+    prefix = str(tmp_path / "packed")
+    feature_store.pack(lst, prefix)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_ddp.py"), "no_class_file", "RGB", "a", "b", "c",
+           "--frame_aggregation", "trn-m", "--baseline_type", "video", "--arch", "resnet18", "--num_segments", "5",
+           "--add_fc", "1", "--fc_dim", "64", "-b", "6", "4", "6", "--epochs", "3", "--lr", "0.01", "--lr_adaptive", "dann",
+           "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "TransAttn", "--add_loss_DA", "attentive_entropy",
+           "--place_adv", "Y", "Y", "Y", "--beta", "0.75", "0.75", "0.5", "--gamma", "0.003", "--print_freq", "1",
+           "--feature_store", prefix, prefix, prefix]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("Train: [") >= 3 and r.stdout.count("Test: [") == 3, r.stdout[-2000:]
+    assert "nan" not in r.stdout.lower()

@@ -48,7 +48,9 @@ def list_loader(list_file, batch, T, seed):
 def main():
     parser.add_argument("--synthetic", type=int, nargs=2, default=None, metavar=("N_SRC", "N_TGT"),
                         help="train on synthetic features instead of the list files")
-    parser.add_argument("--no_graph", action="store_true")
+    parser.add_argument("--graph", action="store_true", help="replay a captured hipGraph (default: eager launches, faster here)")
+    parser.add_argument("--feature_store", type=str, nargs="+", default=None, metavar="PREFIX",
+                        help="packed feature stores (ta3n_amd.feature_store.pack): SRC TGT [VAL]; batches are assembled on the GPU")
     args = parser.parse_args()
     rank, local_rank, world = parallel.init_distributed()
     torch.cuda.set_device(local_rank)
@@ -71,14 +73,45 @@ def main():
                        use_bn=args.use_bn, ens_DA=args.ens_DA, use_attn=args.use_attn, verbose=False)
     eng.load_state(model.state_dict())                  # reference initialisation under torch.manual_seed(1)
     parallel.broadcast_(eng.P)
-    n_src, n_tgt = args.synthetic if args.synthetic else (sum(1 for _ in open(args.train_source_list)),
-                                                           sum(1 for _ in open(args.train_target_list)))
+    if args.synthetic:
+        n_src, n_tgt = args.synthetic
+    elif args.feature_store:
+        n_src, n_tgt = 1, 1                              # set from the stores below
+    else:
+        n_src, n_tgt = sum(1 for _ in open(args.train_source_list)), sum(1 for _ in open(args.train_target_list))
     steps_per_epoch = max(n_src // Bs_g, 1)
     total_steps = args.epochs * steps_per_epoch
     captured = False
+    stores = None
+    if args.feature_store:
+        from ta3n_amd.feature_store import FeatureStore
+        stores = [FeatureStore(pfx, D, dev) for pfx in args.feature_store]
+        n_src, n_tgt = len(stores[0]), len(stores[1])
+        steps_per_epoch = max(n_src // Bs_g, 1)
+        total_steps = args.epochs * steps_per_epoch
+
+    def store_loader(n_videos, batch, seed):
+        """Video ids of one epoch: a seeded permutation (RandomSampler, main.py:176-190), identical on every rank."""
+        perm = torch.randperm(n_videos, generator=torch.Generator().manual_seed(seed))
+        for b in range(max(n_videos // batch, 1)):
+            yield perm[b * batch:(b + 1) * batch].to(torch.int32)
+
+    def validate(epoch):
+        """main.validate (main.py:669-761) on rank 0: eval-mode forward + device-side CE / top-k / confusion matrix."""
+        val = stores[2]
+        for b0 in range(0, len(val), Bs):
+            ids = torch.arange(b0, min(b0 + Bs, len(val)), dtype=torch.int32, device=dev)
+            x, y = val.gather(ids, T)
+            eng.evaluate_batch(x, y, reset=(b0 == 0))
+        r = eng.eval_results()
+        print(f"Test: [{epoch}] Prec@1 {r['prec1']:.3f} Prec@5 {r['prec5']:.3f} Loss {r['loss']:.5f} ({r['n']} videos)", flush=True)
+
     t_start = time.time()
     for epoch in range(1, args.epochs + 1):
-        if args.synthetic:
+        if stores:
+            src = ((ids, None) for ids in store_loader(n_src, Bs_g, 1000 + epoch))
+            tgt = ((ids, None) for ids in store_loader(max(n_tgt, 1), Bt_g, 2000 + epoch))
+        elif args.synthetic:
             src = synthetic_loader(n_src, Bs_g, T, D, num_class, 1000 + epoch)
             tgt = synthetic_loader(max(n_tgt, Bt_g * steps_per_epoch), Bt_g, T, D, num_class, 2000 + epoch)
         else:
@@ -90,12 +123,17 @@ def main():
             beta = [bd if b < 0 else b for b in args.beta]                            # main.py:352
             lo, hi = parallel.shard_range(xs.size(0), world, rank)                    # this rank's videos
             lo_t, hi_t = parallel.shard_range(xt.size(0), world, rank)
-            xs_r = torch.zeros(Bs, T, D); xs_r[: hi - lo] = xs[lo:hi]
-            xt_r = torch.zeros(Bt, T, D); xt_r[: hi_t - lo_t] = xt[lo_t:hi_t]
-            ys_r = torch.zeros(Bs, dtype=torch.long); ys_r[: hi - lo] = ys[lo:hi]
-            eng.set_batch(xs_r.to(dev, non_blocking=True), xt_r.to(dev, non_blocking=True), ys_r.to(dev))
+            if stores:                                                                # batch assembled on the device
+                eng.X.zero_()
+                stores[0].gather(xs[lo:hi].to(dev), T, out=eng.X[: Bs * T], labels_out=eng._labels[:Bs])
+                stores[1].gather(xt[lo_t:hi_t].to(dev), T, out=eng.X[Bs * T:])
+            else:
+                xs_r = torch.zeros(Bs, T, D); xs_r[: hi - lo] = xs[lo:hi]
+                xt_r = torch.zeros(Bt, T, D); xt_r[: hi_t - lo_t] = xt[lo_t:hi_t]
+                ys_r = torch.zeros(Bs, dtype=torch.long); ys_r[: hi - lo] = ys[lo:hi]
+                eng.set_batch(xs_r.to(dev, non_blocking=True), xt_r.to(dev, non_blocking=True), ys_r.to(dev))
             lr = args.lr if (epoch == 1 and i == 0) or args.lr_adaptive != "dann" else eng._lr_next
-            if not captured and not args.no_graph:
+            if not captured and args.graph:
                 eng.set_hyper(beta, args.gamma, lr)
                 eng.capture()
                 captured = True
@@ -107,6 +145,8 @@ def main():
                 print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr:.5f} loss {L['loss']:.4f} loss_c {L['loss_c']:.4f} "
                       f"loss_a {L['loss_adv_rel'] + L['loss_adv_vid'] + L['loss_adv_frm']:.4f} loss_e {L['loss_e']:.4f} "
                       f"beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
+        if stores and len(stores) > 2 and rank == 0:
+            validate(epoch)
     torch.cuda.synchronize(dev)
     if rank == 0:
         print(f"total training time: {time.time() - t_start:.1f}s")
