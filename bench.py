@@ -35,7 +35,7 @@ from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
 CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
 # per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
 # forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
-DEFAULT_PHASE_TILES = [214, 114, 118, 118, 118, 118, 124, 114, 222, 114, 124, 118, 118, 114, 124, 114]
+DEFAULT_PHASE_TILES = [214, 114, 118, 118, 118, 118, 124, 114, 124, 222, 124, 118, 118, 124, 124, 222]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes

@@ -174,8 +174,10 @@ struct OperandStream {
 // FULL: all 64 k of the stage are valid (no wave-uniform skip tests).
 // All fragment reads of the stage are issued before the first MFMA (the compiler then waits with
 // counted lgkmcnt): one exposed LDS latency per stage instead of one per group of four MFMAs.
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL>
-__device__ __forceinline__ void compute_stage(f32x16 &acc, const float *__restrict__ sa, const float *__restrict__ sb,
+// RS: also accumulate the K-sum of this lane's A values (bias gradient of a weight-gradient tile; elements past the
+// K tail and rows past m_valid were staged as zeros, so no masking is needed).
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS>
+__device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const float *__restrict__ sa, const float *__restrict__ sb,
                                               int ra, int rb, int wk, int lh, int krem) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
@@ -197,6 +199,10 @@ __device__ __forceinline__ void compute_stage(f32x16 &acc, const float *__restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[q][j] = sb[(4 * G + j) * BN + rb];
         }
+    }
+    if (RS) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rs += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
 #pragma unroll
@@ -269,8 +275,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     // selected once per task: the register allocation is the maximum over the combinations, not
     // their union (loop-invariant LDS addresses of every combination used to be live together).
     const int ra = wm * 32 + li, rb = wn * 32 + li;
-    auto k_loop = [&](auto akm, auto bkm) {
-        constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value;
+    float rs = 0.f;   // EPI_ROWSUM_A: K-sum of A(row ra, this half-wave's k) over this wave's K slices
+    auto k_loop = [&](auto akm, auto bkm, auto rsum) {
+        constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
         OperandStream<BM, NW> oa;
         OperandStream<BN, NW> ob;
         int klen = 0, scale = SK_ONE;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 stage_ready();
                 issue(buf ^ 1, (c + 1) * BKC);
                 const float *sa = lds + buf * STAGE;
-                compute_stage<BM, BN, WK, AKM, BKM, true>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                compute_stage<BM, BN, WK, AKM, BKM, true, RS>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
                 buf ^= 1;
             }
             // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 issue(buf ^ 1, 0);
             }
             const float *sa = lds + buf * STAGE;
-            compute_stage<BM, BN, WK, AKM, BKM, false>(acc, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
+            compute_stage<BM, BN, WK, AKM, BKM, false, RS>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
             if (c_scale != SK_ONE) {
                 const float sc = hyper_scale(hy, c_scale);
 #pragma unroll
@@ -327,10 +334,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     {
         const Seg &s0 = segs[cseg];
         switch (s0.a_kmajor * 2 + s0.b_kmajor) {
-            case 0: k_loop(F_{}, F_{}); break;
-            case 1: k_loop(F_{}, T_{}); break;
-            case 2: k_loop(T_{}, F_{}); break;
-            default: k_loop(T_{}, T_{}); break;
+            case 0: k_loop(F_{}, F_{}, F_{}); break;
+            case 1: k_loop(F_{}, T_{}, F_{}); break;
+            case 2: k_loop(T_{}, F_{}, F_{}); break;
+            default:   // weight gradients (both operands k-major) are the only tiles that also produce a bias gradient
+                if (t.epi & EPI_ROWSUM_A) k_loop(T_{}, T_{}, T_{});
+                else k_loop(T_{}, T_{}, F_{});
+                break;
         }
     }
 
@@ -413,6 +423,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (e < nrem) op[e] = mp[e] > 0.f ? v[e] : 0.f;
+            }
+        }
+    }
+    if (epi & EPI_ROWSUM_A) {   // wave-uniform: bias gradient = K-sums of the A rows, added over the two k halves and the K-split waves
+        __syncthreads();
+        if (wn == 0) lds[(wk * 2 + lh) * BM + ra] = rs;
+        __syncthreads();
+        if (tid < BM) {
+            float b = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * WK; ++i) b += lds[i * BM + tid];
+            if (m0 + tid < m_valid) {
+                const_cast<float *>(base_ptr(ptrs, t.bias_base))[(size_t)t.bias_off + m0 + tid] = b;
+                sumsq = fmaf(b, b, sumsq);
             }
         }
     }

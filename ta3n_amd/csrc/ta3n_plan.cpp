@@ -136,7 +136,9 @@ struct Builder {
             const int seg_begin = (int)p.segs.size();
             int cost = 0;
             for (auto &s : g.segs)   // the kernel selects its K loop by the operand kinds of the task's first Seg
-                if (s.a_kmajor != g.segs[0].a_kmajor || s.b_kmajor != g.segs[0].b_kmajor) mixed_kinds = true;
+                if (s.a_kmajor != g.segs[0].a_kmajor || s.b_kmajor != g.segs[0].b_kmajor ||
+                    ((g.proto.epi & EPI_ROWSUM_A) && !(s.a_kmajor && s.b_kmajor)))   // row sums exist in the k-major/k-major loop only
+                    mixed_kinds = true;
             for (auto &s : g.segs) {
                 p.segs.push_back(s);
                 // operands the kernel cannot move 16 bytes at a time take the 4-byte LDS-DMA path: such tiles are
@@ -157,6 +159,7 @@ struct Builder {
                     t.m0 = split_m ? o0 : i0; t.n0 = split_m ? i0 : o0;
                     t.m_valid = g.M; t.n_valid = g.N;
                     t.seg_begin = seg_begin; t.seg_count = (int)g.segs.size();
+                    if (t.n0 != 0) t.epi &= ~(uint32_t)EPI_ROWSUM_A;   // the bias gradient is written once per row block
                     t.cost = cost;
                     pn.tiles.push_back(t);
                     pn.cost += cost;
@@ -438,11 +441,14 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         with_mask(ghf.proto, g.o_Hf, F);
         return ghf;
     };
-    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int64_t x_off, int x_ld, int64_t dst) {   // dW = G^T X
+    // dW = G^T X; bias_dst >= 0: the tiles of the first column block also write db = column sums of G, i.e. the row sums of
+    // their own A operand (EPI_ROWSUM_A) - no separate ones^T G tasks, which were as long as a weight-gradient tile each
+    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int64_t x_off, int x_ld, int64_t dst, int64_t bias_dst = -1) {
         GemmSpec gw;
         gw.M = M; gw.N = N;
         gw.segs.push_back(mkseg(KM(BASE_WS, g_off, g_ld), KM(BASE_WS, x_off, x_ld), K));
         gw.proto = proto(BASE_G, dst, N);
+        if (bias_dst >= 0) { gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bias_dst; }
         return gw;
     };
     auto spec_gVt = [&]() {   // gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv )
@@ -471,26 +477,20 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         return gr;
     };
     auto push_video_head_wgrads = [&](std::vector<GemmSpec> &s) {   // dWcdv, dbcdv, dWcv, dbcv
-        s.push_back(wgrad(2, NB, B, g.o_gPv, 2, g.o_Hv, NB, Wcdv));
-        s.push_back(ones_bias_grad(g.o_gPv, 2, 2, B, bcdv));
-        s.push_back(wgrad(C, NB, B, g.o_gY, C, g.o_Vd, NB, Wcv));
-        s.push_back(ones_bias_grad(g.o_gY, C, C, B, bcv));
+        s.push_back(wgrad(2, NB, B, g.o_gPv, 2, g.o_Hv, NB, Wcdv, bcdv));
+        s.push_back(wgrad(C, NB, B, g.o_gY, C, g.o_Vd, NB, Wcv, bcv));
     };
     auto push_video_disc_wgrads = [&](std::vector<GemmSpec> &s) {   // dWdv, dbdv
-        s.push_back(wgrad(NB, NB, B, g.o_gHv, NB, g.o_Vd, NB, Wdv));
-        s.push_back(ones_bias_grad(g.o_gHv, NB, NB, B, bdv));
+        s.push_back(wgrad(NB, NB, B, g.o_gHv, NB, g.o_Vd, NB, Wdv, bdv));
     };
     auto push_frame_disc_wgrads = [&](std::vector<GemmSpec> &s) {   // dWfd, dbfd
-        s.push_back(wgrad(F, F, BT, g.o_gHf, F, g.o_F1, F, Wfd));
-        s.push_back(ones_bias_grad(g.o_gHf, F, F, BT, bfd));
+        s.push_back(wgrad(F, F, BT, g.o_gHf, F, g.o_F1, F, Wfd, bfd));
     };
     auto push_relation_level = [&](std::vector<GemmSpec> &s) {   // gR_j (+ fan-out to gZ), dW1_j, db1_j, dW2_j, db2_j
         for (int j = 0; j < NR; ++j) {
             s.push_back(spec_gR(j));
-            s.push_back(wgrad(NB, NB, B, g.o_gHr + (int64_t)j * NB, ldR, g.o_R + (int64_t)j * NB, ldR, W1(j)));
-            s.push_back(ones_bias_grad(g.o_gHr + (int64_t)j * NB, ldR, NB, B, B1(j)));
-            s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j)));
-            s.push_back(ones_bias_grad(g.o_gPrT + (int64_t)j * 2, NR * 2, 2, B, B2(j)));
+            s.push_back(wgrad(NB, NB, B, g.o_gHr + (int64_t)j * NB, ldR, g.o_R + (int64_t)j * NB, ldR, W1(j), B1(j)));
+            s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j)));
         }
     };
     auto push_trn_level = [&](std::vector<GemmSpec> &s) {   // TRN weight grads + gradient at F1
@@ -503,14 +503,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
                     gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ),
                                             KM(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF), B));
                 gw.proto = proto(BASE_G, trnW(j) + (int64_t)pos * F, sl * F);
+                if (pos == 0) { gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)trnB(j); }   // db_j = sum_t column sums of gZ_t
                 s.push_back(gw);
             }
-            GemmSpec gb;
-            gb.M = 1; gb.N = NB;
-            for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
-                gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ), B, SK_ONE, 4));
-            gb.proto = proto(BASE_G, trnB(j), NB);
-            s.push_back(gb);
         }
         for (int f = 0; f < T; ++f) {   // gZ1[:, f] = ( -beta2 gHf[:, f] Wfd + sum_{(t,pos): tau_t[pos]==f} gZ_t W_j[:, pos] ) * [F1>0] / keep
             GemmSpec gz;
@@ -534,8 +529,8 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         gw.M = F; gw.N = D;
         gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ1, F), KM(BASE_X, 0, D), BT));
         gw.proto = proto(BASE_G, Wsh, D);
+        gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bsh;   // dbsh
         s.push_back(gw);
-        s.push_back(ones_bias_grad(g.o_gZ1, F, F, BT, bsh));
     };
 
     // ================= forward (group 0) =================
@@ -560,8 +555,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     {   // Q1: heads that depend only on the logit gradients
         std::vector<GemmSpec> s{spec_gHv(), spec_gHf()};
         push_video_head_wgrads(s);
-        s.push_back(wgrad(2, F, BT, g.o_gPf, 2, g.o_Hf, F, Wcd));   // dWcd = gPf^T Hf
-        s.push_back(ones_bias_grad(g.o_gPf, 2, 2, BT, bcd));
+        s.push_back(wgrad(2, F, BT, g.o_gPf, 2, g.o_Hf, F, Wcd, bcd));   // dWcd = gPf^T Hf, dbcd
         b.add_gemm_phase(2, s);
     }
     {   // Q2: gradient at the pooled video feature + first-layer weight grads of the video/frame discriminators

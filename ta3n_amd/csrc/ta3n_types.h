@@ -27,6 +27,7 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_ROWSUM_A = 1u << 8, // also store the K-sums of the tile's A rows to bias_base[bias_off + m] (bias gradient of a weight-gradient tile)
     EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[3]] = sum of squares of the stored tile (fused grad-norm partial)
 };
 

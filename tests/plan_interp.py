@@ -14,7 +14,7 @@ import numpy as np
 from ta3n_amd import _lib
 
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
-EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS = range(7)
 HEADS_RPW = 16
 
@@ -153,9 +153,11 @@ class Interp:
             nr = min(BM, t.m_valid - t.m0); nc = min(BN, t.n_valid - t.n0)
             assert nr > 0 and nc > 0
             acc = np.zeros((nr, nc), self.dtype)
+            rowsum = np.zeros(nr, self.dtype)
             for si in range(t.seg_begin, t.seg_begin + t.seg_count):
                 s = self.segs[si]
                 A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
+                rowsum += A.sum(1)
                 Bm = self.operand(s.b_base, s.b_off, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)
                 acc += A @ Bm.T
                 acc *= self.scale(s.scale_kind)
@@ -177,8 +179,10 @@ class Interp:
                 v = v * keep_mask(seed, m * t.drop_ld + n, p)
             v = v * self.scale(t.gamma_kind)
             self.buf(t.c_base)[t.c_off + m * t.c_ld + n] = v
+            if t.epi & EPI_ROWSUM_A:
+                self.buf(t.bias_base)[t.bias_off + np.arange(t.m0, t.m0 + nr)] = rowsum
             if t.epi & EPI_SUMSQ:
-                self.ws[t.pad[3]] = float((v * v).sum())
+                self.ws[t.pad[3]] = float((v * v).sum()) + (float((rowsum * rowsum).sum()) if t.epi & EPI_ROWSUM_A else 0.0)
             for f in range(t.fan_count):
                 mk = self.ws[t.fan_mask_off[f] + m * t.fan_ld + n]
                 self.ws[t.fan_out_off[f] + m * t.fan_ld + n] = np.where(mk > 0, v, 0)

@@ -502,15 +502,14 @@ int main() {
         }
         CK(hipFree(out));
     }
-    // where does the time go: normal / compute-only (no DMA in the loop) / DMA-only (no MFMA)
-    run<1, 1, 4, 2, false, false, 64, 0>("NT F1", 1010, 512, 2048);
-    run<1, 1, 4, 2, false, false, 64, 1>("NT F1", 1010, 512, 2048);
-    run<1, 1, 4, 2, false, false, 64, 2>("NT F1", 1010, 512, 2048);
-    run<2, 2, 2, 2, true, true, 64, 0>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 2, 2, true, true, 64, 1>("TN dWsh", 512, 2048, 1010);
-    run<2, 2, 2, 2, true, true, 64, 2>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 4, 2, true, true, 64, 0>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 4, 2, true, true, 64, 1>("TN dWsh", 512, 2048, 1010);
-    run<1, 1, 4, 2, true, true, 64, 2>("TN dWsh", 512, 2048, 1010);
+    // residency probe: 64x64 tiles, 8 waves, 64 KiB of LDS per workgroup - 256 vs 264 vs 512 workgroups
+    run<2, 2, 2, 2, true, true>("TN resid", 512, 2048, 1010);
+    run<2, 2, 2, 2, true, true>("TN resid", 528, 2048, 1010);
+    run<2, 2, 2, 2, true, true>("TN resid", 1024, 2048, 1010);
+    run<2, 2, 1, 2, true, true>("TN resid", 512, 2048, 1010);
+    run<2, 2, 1, 2, true, true>("TN resid", 1024, 2048, 1010);
+    run<1, 1, 4, 2, true, true>("TN resid", 512, 2048, 1010);
+    run<1, 1, 4, 2, true, true>("TN resid", 640, 2048, 1010);
+    run<1, 1, 4, 2, true, true>("TN resid", 1024, 2048, 1010);
     return 0;
 }
