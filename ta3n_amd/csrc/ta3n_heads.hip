@@ -58,8 +58,11 @@ constexpr int S_GVT = S_GHV + VPW * NBH;             // [VPW][256] gradient at t
 constexpr int S_GY = S_GVT + VPW * NBH;              // [VPW][64]  class-logit gradients
 constexpr int S_PR = S_GY + VPW * 64;                // [VPW][64][2] relation logits
 constexpr int S_GPV = S_PR + VPW * 128;              // [VPW][2]
-constexpr int S_LOSS = S_GPV + 8;                    // [4 waves][8] loss partials
+constexpr int S_VPART = S_GPV + 8;                   // [4 waves][256] per-wave partial sums of V
+constexpr int S_LOSS = S_VPART + 4 * NBH;            // [4 waves][8] loss partials
 constexpr int S_TOTAL = S_LOSS + 32;
+constexpr int WPV = 4 / VPW;                         // waves per video: they split the relations of the per-video stages
+static_assert(VPW == 1 || VPW == 2 || VPW == 4, "1, 2 or 4 videos per workgroup");
 static_assert(64 * TROW <= NBH * WROW, "backward tile / classifier staging must fit in the weight tile");
 
 // -DTA3N_HEADS_TIMING: workgroup 0 stamps s_memtime at every stage boundary into ws["g_attn"] (debug builds only)
@@ -99,8 +102,10 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const int NR = g.n_rel, NT = g.n_tuples, C = g.C;
     const int b0 = blockIdx.x * VPW;
     const int nv = min(VPW, g.B - b0);
-    const int b = b0 + wv;                         // this wave's video (per-video stages)
-    const bool have = wv < nv;
+    const int vloc = wv / WPV, sub = wv % WPV;     // per-video stages: this wave's video slot and its share of the relations
+    const int b = b0 + vloc;
+    const bool have = vloc < nv;
+    const bool lead = sub == 0;                    // the wave that does the video's un-splittable parts (logits, losses)
     const bool attn_on = (g.flags & TA3N_FLAG_TRANS_ATTN) != 0;
     const bool train = hy->train != 0;
     const float inv_keep_v = hyper_scale(hy, SK_INV_KEEP_V);
@@ -136,56 +141,61 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const int label = (have && b < g.Bs) ? labels[b] : -1;
 
     STAMP(0);
-    // ---- A: relation logits, attention, R, V, Vd (one wave per video) ----
-    if (have) {
+    // ---- A: relation logits, attention, R, V, Vd (WPV waves per video, relations dealt round-robin) ----
+    {
         float vacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < NR; ++j) {
-            const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
-            const float *__restrict__ b2 = P + g.p_b2_0 + (size_t)j * g.p_b2_stride;
-            const float *__restrict__ hr = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
-            float d0 = 0.f, d1 = 0.f;
+        if (have) {
+            for (int j = sub; j < NR; j += WPV) {
+                const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+                const float *__restrict__ b2 = P + g.p_b2_0 + (size_t)j * g.p_b2_stride;
+                const float *__restrict__ hr = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
+                float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = q * 64 + lane;
-                const float h = hr[c];
-                d0 = fmaf(h, W2[c], d0);
-                d1 = fmaf(h, W2[NBH + c], d1);
-            }
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int t = tf[j]; t < tf[j + 1]; ++t) {
+                for (int q = 0; q < 4; ++q) {
+                    const int c = q * 64 + lane;
+                    const float h = hr[c];
+                    d0 = fmaf(h, W2[c], d0);
+                    d1 = fmaf(h, W2[NBH + c], d1);
+                }
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int t = tf[j]; t < tf[j + 1]; ++t) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
-            }
-            d0 = wave_allreduce_sum(d0) + b2[0];
-            d1 = wave_allreduce_sum(d1) + b2[1];
-            float w = 0.f;
-            if (attn_on) w = 1.f - soft2(d0, d1).H;
+                    for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
+                }
+                d0 = wave_allreduce_sum(d0) + b2[0];
+                d1 = wave_allreduce_sum(d1) + b2[1];
+                float w = 0.f;
+                if (attn_on) w = 1.f - soft2(d0, d1).H;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ws[g.o_R + ((size_t)b * NR + j) * NBH + q * 64 + lane] = r[q];
-                vacc[q] += attn_on ? (w + 1.f) * r[q] : r[q];
-            }
-            if (lane == 0) {
-                ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 0] = d0;
-                ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 1] = d1;
-                ws[g.o_attn + (size_t)b * NR + j] = attn_on ? w : r[0];   // models.py:647-648
-                smem[S_PR + (wv * 64 + j) * 2 + 0] = d0;
-                smem[S_PR + (wv * 64 + j) * 2 + 1] = d1;
+                for (int q = 0; q < 4; ++q) {
+                    ws[g.o_R + ((size_t)b * NR + j) * NBH + q * 64 + lane] = r[q];
+                    vacc[q] += attn_on ? (w + 1.f) * r[q] : r[q];
+                }
+                if (lane == 0) {
+                    ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 0] = d0;
+                    ws[g.o_Pr + ((size_t)b * NR + j) * 2 + 1] = d1;
+                    ws[g.o_attn + (size_t)b * NR + j] = attn_on ? w : r[0];   // models.py:647-648
+                    smem[S_PR + (vloc * 64 + j) * 2 + 0] = d0;
+                    smem[S_PR + (vloc * 64 + j) * 2 + 1] = d1;
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * 64 + lane;
-            const float v = vacc[q];
-            ws[g.o_V + (size_t)b * NBH + c] = v;
-            float vd = v;
-            if (drop_v) vd = v * keep_mask(hy->seed_v, (uint32_t)(b * NBH + c), hy->p_drop_v) * inv_keep_v;
-            ws[g.o_Vd + (size_t)b * NBH + c] = vd;
-            smem[S_VD + wv * NBH + c] = vd;
-        }
-    } else {
+        for (int q = 0; q < 4; ++q) smem[S_VPART + wv * NBH + q * 64 + lane] = vacc[q];
+    }
+    __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) smem[S_VD + wv * NBH + q * 64 + lane] = 0.f;
+    for (int v = 0; v < VPW; ++v) {                // thread t <-> channel t: add the waves' partial sums in a fixed order
+        float val = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < WPV; ++s_) val += smem[S_VPART + (v * WPV + s_) * NBH + tid];
+        float vd = val;
+        if (drop_v) vd = val * keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v) * inv_keep_v;
+        if (v < nv) {
+            ws[g.o_V + (size_t)(b0 + v) * NBH + tid] = val;
+            ws[g.o_Vd + (size_t)(b0 + v) * NBH + tid] = vd;
+        }
+        smem[S_VD + v * NBH + tid] = v < nv ? vd : 0.f;
     }
     STAMP(1);
     // classifier weights -> LDS [C][TROW]
@@ -197,12 +207,12 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     __syncthreads();
 
     STAMP(2);
-    // ---- B: class logits: wave = video, lane = class ----
+    // ---- B: class logits: the video's lead wave, lane = class ----
     float y = -INFINITY;
-    if (lane < C) {
+    if (lane < C && lead) {
         float acc = 0.f;
         const float *wr = &smem[S_W + lane * TROW];
-        const float *vd = &smem[S_VD + wv * NBH];
+        const float *vd = &smem[S_VD + vloc * NBH];
 #pragma unroll 8
         for (int k4 = 0; k4 < NBH; k4 += 4) {
             const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
@@ -248,12 +258,12 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     __syncthreads();
 
     STAMP(4);
-    // ---- D: video domain logits, losses, gY, gPv (one wave per video, lane = class) ----
+    // ---- D: video domain logits, losses, gY, gPv (the video's lead wave, lane = class) ----
     {
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float h = smem[S_HV + wv * NBH + q * 64 + lane];
+            const float h = smem[S_HV + vloc * NBH + q * 64 + lane];
             d0 = fmaf(h, wc0[q], d0);
             d1 = fmaf(h, wc1[q], d1);
         }
@@ -267,7 +277,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         const float pr = lane < C ? expf(lp) : 0.f;
         const float Hc = wave_allreduce_sum(-pr * lp);
         float gy = 0.f, g0 = 0.f, g1 = 0.f;
-        if (have) {
+        if (have && lead) {
             const bool is_src = b < g.Bs;
             const bool valid = video_valid(g.Bs, hy, b);
             const bool cls_on = is_src && valid;
@@ -299,8 +309,10 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                 ws[g.o_gPv + (size_t)b * 2] = g0; ws[g.o_gPv + (size_t)b * 2 + 1] = g1;
             }
         }
-        smem[S_GY + wv * 64 + lane] = gy;
-        if (lane == 0) { smem[S_GPV + wv * 2] = g0; smem[S_GPV + wv * 2 + 1] = g1; }
+        if (lead) {
+            smem[S_GY + vloc * 64 + lane] = gy;
+            if (lane == 0) { smem[S_GPV + vloc * 2] = g0; smem[S_GPV + vloc * 2 + 1] = g1; }
+        }
         l_cls = wave_allreduce_sum(l_cls);   // it sits in the label's lane
     }
     __syncthreads();
@@ -369,7 +381,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     __syncthreads();
 
     STAMP(6);
-    // ---- G: backward of the attention pooling + relation adversarial loss (one wave per video) ----
+    // ---- G: backward of the attention pooling + relation adversarial loss (WPV waves per video) ----
     if (have) {
         const float *__restrict__ wsR = ptrs.ws;   // R: written in stage A, only read from here on
         const bool is_src = b < g.Bs;
@@ -377,8 +389,8 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         const bool adv_rel = (g.flags & TA3N_FLAG_ADV_RELATION) && valid;
         float gv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gv[q] = smem[S_GVT + wv * NBH + q * 64 + lane];
-        for (int j = 0; j < NR; ++j) {
+        for (int q = 0; q < 4; ++q) gv[q] = smem[S_GVT + vloc * NBH + q * 64 + lane];
+        for (int j = sub; j < NR; j += WPV) {
             const size_t bj = (size_t)b * NR + j;
             const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
             float w20[4], w21[4], hrv[4], rv[4];
@@ -389,7 +401,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                 hrv[q] = wsr[g.o_Hr + bj * NBH + c];
                 rv[q] = wsR[g.o_R + bj * NBH + c];
             }
-            const float z0 = smem[S_PR + (wv * 64 + j) * 2], z1 = smem[S_PR + (wv * 64 + j) * 2 + 1];
+            const float z0 = smem[S_PR + (vloc * 64 + j) * 2], z1 = smem[S_PR + (vloc * 64 + j) * 2 + 1];
             const Soft2 s = soft2(z0, z1);
             float g0 = 0.f, g1 = 0.f;
             if (adv_rel) {                                                             // main.py:508-538, l = 0

@@ -72,7 +72,7 @@ enum PhaseKind : int32_t {
 };
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these
-constexpr int HEADS_VPW = 4;    // videos per video workgroup (one wave each for the per-video parts)
+constexpr int HEADS_VPW = 1;    // videos per video workgroup (one wave each for the per-video parts; 1, 2 or 4)
 constexpr int HEADS_RPW = 16;   // frame rows per frame workgroup
 
 struct Phase {
