@@ -58,7 +58,9 @@ constexpr int S_GVT = S_GHV + VPW * NBH;             // [VPW][256] gradient at t
 constexpr int S_GY = S_GVT + VPW * NBH;              // [VPW][64]  class-logit gradients
 constexpr int S_PR = S_GY + VPW * 64;                // [VPW][64][2] relation logits
 constexpr int S_GPV = S_PR + VPW * 128;              // [VPW][2]
-constexpr int S_VPART = S_GPV + 8;                   // [4 waves][256] per-wave partial sums of V
+constexpr int S_Y = S_GPV + 8;                       // [64] class logits
+constexpr int S_FPART = S_Y + 64;                    // [16][256] partial sums of the backward mini-GEMM
+constexpr int S_VPART = S_FPART + 16 * NBH;                   // [4 waves][256] per-wave partial sums of V
 constexpr int S_LOSS = S_VPART + 4 * NBH;            // [4 waves][8] loss partials
 constexpr int S_TOTAL = S_LOSS + 32;
 constexpr int WPV = 4 / VPW;                         // waves per video: they split the relations of the per-video stages
@@ -136,8 +138,6 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     for (int q = 0; q < 4; ++q) { wc0[q] = Wcdv[q * 64 + lane]; wc1[q] = Wcdv[NBH + q * 64 + lane]; }
     const float wct0 = Wcdv[tid], wct1 = Wcdv[NBH + tid];
     const float bcdv0 = P[g.p_bcdv], bcdv1 = P[g.p_bcdv + 1];
-    const float bdv_t = P[g.p_bdv + tid];
-    const float bcv_l = lane < C ? P[g.p_bcv + lane] : 0.f;
     const int label = (have && b < g.Bs) ? labels[b] : -1;
 
     STAMP(0);
@@ -207,53 +207,60 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     __syncthreads();
 
     STAMP(2);
-    // ---- B: class logits: the video's lead wave, lane = class ----
-    float y = -INFINITY;
-    if (lane < C && lead) {
-        float acc = 0.f;
-        const float *wr = &smem[S_W + lane * TROW];
-        const float *vd = &smem[S_VD + vloc * NBH];
-#pragma unroll 8
-        for (int k4 = 0; k4 < NBH; k4 += 4) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
-            const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
-            acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
-        }
-        y = acc + bcv_l;
-        if (have) ws[g.o_Y + (size_t)b * C + lane] = y;
-    }
-    __syncthreads();   // done with the classifier tile
-
-    STAMP(3);
-    // ---- C: Hv = relu(Wdv Vd + bdv): thread t owns output channel t for all VPW videos ----
+    // ---- B: class logits: 4 threads per class, each a quarter of K; combined on the DPP quad network ----
     {
-        float acc[VPW];
+        const int c = tid >> 2, part = tid & 3;
+        float acc = 0.f;
+        if (c < C) {
+            const float *wr = &smem[S_W + c * TROW + part * 64];
+            const float *vd = &smem[S_VD + part * 64];
 #pragma unroll
-        for (int v = 0; v < VPW; ++v) acc[v] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < NBH; kc += 64) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i) * WROW + sk4]) = wreg[(kc / 64) * 16 + i];
-            __syncthreads();
-            const float *wr = &smem[S_W + tid * WROW];
-#pragma unroll 4
             for (int k4 = 0; k4 < 64; k4 += 4) {
                 const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
-#pragma unroll
-                for (int v = 0; v < VPW; ++v) {
-                    const float4 x4 = *reinterpret_cast<const float4 *>(&smem[S_VD + v * NBH + kc + k4]);
-                    acc[v] = fmaf(w4.x, x4.x, acc[v]); acc[v] = fmaf(w4.y, x4.y, acc[v]);
-                    acc[v] = fmaf(w4.z, x4.z, acc[v]); acc[v] = fmaf(w4.w, x4.w, acc[v]);
-                }
+                const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
+                acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
             }
-            __syncthreads();
         }
+        acc += dpp_move<0xB1, 0xF>(0.f, acc);      // quad_perm [1,0,3,2]
+        acc += dpp_move<0x4E, 0xF>(0.f, acc);      // quad_perm [2,3,0,1]: every lane of the quad holds the class logit
+        if (c < C && part == 0) {
+            const float yc = acc + P[g.p_bcv + c];
+            smem[S_Y + c] = yc;
+            if (have) ws[g.o_Y + (size_t)b * C + c] = yc;
+        }
+    }
+    __syncthreads();   // logits visible; done with the classifier tile
+    const float y = (lane < C) ? smem[S_Y + lane] : -INFINITY;
+
+    STAMP(3);
+    // ---- C: Hv = relu(Wdv Vd + bdv) straight from the register copy of Wdv ----
+    // Thread (srow, c16) holds W[srow + 16 i][64 kc + 4 c16 .. +3]: 16 partial dot products over its 16 k, then a sum over the
+    // 16 lanes of its DPP row (they share srow and cover all 256 k).  Lane c16 keeps output channel srow + 16 c16.
+    {
+        static_assert(VPW == 1, "stages C and F are written for one video per workgroup");
+        const int c16 = tid & 15;
+        f32x4 xk[4];
 #pragma unroll
-        for (int v = 0; v < VPW; ++v) {
-            const float h = fmaxf(acc[v] + bdv_t, 0.f);
-            smem[S_HV + v * NBH + tid] = h;
-            if (v < nv) ws[g.o_Hv + (size_t)(b0 + v) * NBH + tid] = h;
+        for (int kc = 0; kc < 4; ++kc) xk[kc] = *reinterpret_cast<const f32x4 *>(&smem[S_VD + kc * 64 + sk4]);
+        float hv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float p = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const f32x4 w4 = wreg[kc * 16 + i];
+                p = fmaf(w4.x, xk[kc].x, p); p = fmaf(w4.y, xk[kc].y, p); p = fmaf(w4.z, xk[kc].z, p); p = fmaf(w4.w, xk[kc].w, p);
+            }
+            p += dpp_move<0xB1, 0xF>(0.f, p);      // quad_perm [1,0,3,2]
+            p += dpp_move<0x4E, 0xF>(0.f, p);      // quad_perm [2,3,0,1]
+            p += dpp_move<0x141, 0xF>(0.f, p);     // row_half_mirror
+            p += dpp_move<0x140, 0xF>(0.f, p);     // row_mirror: all 16 lanes of the row hold the sum
+            if (c16 == i) hv = p;
         }
+        const int n = srow + 16 * c16;
+        const float h = fmaxf(hv + P[g.p_bdv + n], 0.f);
+        smem[S_HV + n] = h;
+        if (have) ws[g.o_Hv + (size_t)b * NBH + n] = h;
     }
     __syncthreads();
 
@@ -325,58 +332,37 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         smem[S_GHV + v * NBH + tid] = gh;
         if (v < nv) ws[g.o_gHv + (size_t)(b0 + v) * NBH + tid] = gh;
     }
-    // no barrier needed here: the first one inside stage F orders these LDS writes before their reads
+    __syncthreads();
 
-    // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ): thread t owns input channel t ----
+    // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ) from the register copy of Wdv ----
+    // Thread (srow, c16) multiplies its 16 rows n = srow + 16 i into partial sums for its 16 input channels
+    // k = 64 kc + 4 c16 + e; the 16 threads that share c16 (one per srow) are added through LDS, thread t <-> channel t.
     {
-        float acc[VPW];
+        float gh[16];
 #pragma unroll
-        for (int v = 0; v < VPW; ++v) acc[v] = 0.f;
+        for (int i = 0; i < 16; ++i) gh[i] = smem[S_GHV + srow + 16 * i];
 #pragma unroll
-        for (int n0 = 0; n0 < NBH; n0 += 64) {
-            // backward tile [64 n][256 k] from the register copy: this thread holds rows srow + 16 i, i = n0/16 .. n0/16 + 3
+        for (int kc = 0; kc < 4; ++kc) {
+            f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc)
-                    *reinterpret_cast<f32x4 *>(&smem[S_W + (srow + 16 * i4) * TROW + kc * 64 + sk4]) = wreg[kc * 16 + n0 / 16 + i4];
-            __syncthreads();
-#pragma unroll 4
-            for (int n = 0; n < 64; n += 4) {
-                const float w0 = smem[S_W + (n + 0) * TROW + tid], w1 = smem[S_W + (n + 1) * TROW + tid];
-                const float w2 = smem[S_W + (n + 2) * TROW + tid], w3 = smem[S_W + (n + 3) * TROW + tid];
-#pragma unroll
-                for (int v = 0; v < VPW; ++v) {
-                    const float4 g4 = *reinterpret_cast<const float4 *>(&smem[S_GHV + v * NBH + n0 + n]);
-                    acc[v] = fmaf(g4.x, w0, acc[v]); acc[v] = fmaf(g4.y, w1, acc[v]);
-                    acc[v] = fmaf(g4.z, w2, acc[v]); acc[v] = fmaf(g4.w, w3, acc[v]);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 w4 = wreg[kc * 16 + i];
+                p.x = fmaf(gh[i], w4.x, p.x); p.y = fmaf(gh[i], w4.y, p.y); p.z = fmaf(gh[i], w4.z, p.z); p.w = fmaf(gh[i], w4.w, p.w);
             }
-            __syncthreads();
-        }
-        const float nb1 = -hy->beta[1];
-#pragma unroll
-        for (int v = 0; v < VPW; ++v) acc[v] *= nb1;
-        // classifier weights are needed column-wise now: restage [C][256] (cw[] held them since the top)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int f = i * 256 + tid;
-            if (f < C * 64) *reinterpret_cast<f32x4 *>(&smem[S_W + (f >> 6) * TROW + (f & 63) * 4]) = cw[i];
+            *reinterpret_cast<f32x4 *>(&smem[S_FPART + srow * NBH + kc * 64 + sk4]) = p;
         }
         __syncthreads();
-        for (int c = 0; c < C; ++c) {
-            const float w = smem[S_W + c * TROW + tid];
+        float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < VPW; ++v) acc[v] = fmaf(smem[S_GY + v * 64 + c], w, acc[v]);
-        }
-#pragma unroll
-        for (int v = 0; v < VPW; ++v) {
-            float gv = acc[v];
-            if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v);
-            gv *= inv_keep_v;
-            smem[S_GVT + v * NBH + tid] = gv;
-            if (v < nv) ws[g.o_gVt + (size_t)(b0 + v) * NBH + tid] = gv;
-        }
+        for (int r = 0; r < 16; ++r) acc += smem[S_FPART + r * NBH + tid];
+        acc *= -hy->beta[1];
+        // classifier weights column-wise: the [C][TROW] tile staged for stage B is still in place
+        for (int c = 0; c < C; ++c) acc = fmaf(smem[S_GY + c], smem[S_W + c * TROW + tid], acc);
+        float gv = acc;
+        if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)(b * NBH + tid), hy->p_drop_v);
+        gv *= inv_keep_v;
+        smem[S_GVT + tid] = gv;
+        if (have) ws[g.o_gVt + (size_t)b * NBH + tid] = gv;
     }
     __syncthreads();
 
