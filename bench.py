@@ -35,7 +35,7 @@ from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
 CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
 # per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
 # forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
-DEFAULT_PHASE_TILES = [214, 114, 118, 118, 118, 118, 124, 114, 124, 222, 124, 118, 118, 124, 124, 222]
+DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--phase-tiles", type=str, default="", help="comma list of per-GEMM-phase tile configs")
     ap.add_argument("--autotune", action="store_true", help="measure tile configs per GEMM launch and use the best")
     ap.add_argument("--xcd", type=int, default=0, help="0/1 XCD-aware tile ordering on, 2 off")
+    ap.add_argument("--overlap", action="store_true", help="deferred optimiser update overlapped with the next step's first launch on a "
+                    "second stream (measured slower on MI355X: 226 vs 213 us/step - the two cross-stream events cost more than "
+                    "the ~9 us of HBM streaming they hide)")
     ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
     ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -161,10 +164,16 @@ def main():
             eng.graph.replay()
             return
         p = float(i % total_steps) / total_steps
-        eng.train_step(beta, gamma, lr0 if i == 0 else lr_dann(lr0, p))
+        lr = lr0 if i == 0 else lr_dann(lr0, p)
+        if deferred:
+            eng.train_step_deferred(beta, gamma, lr)
+        else:
+            eng.train_step(beta, gamma, lr)
 
+    deferred = eng.fused and not args.graph and args.overlap
     for i in range(args.warmup):
         step(i)
+    eng.flush()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -176,6 +185,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    eng.flush()                                  # the K-th update is inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -205,6 +215,7 @@ def main():
                        "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
                        "launch": "hipGraph" if args.graph else "eager", "finite": finite,
                        "step": "fused (ta3n_train_step)" if eng.fused else "forward+loss+backward",
+                       "update": "deferred: overlaps the next step's first launch" if deferred else "end of step",
                        "phase_tiles": [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,

@@ -195,6 +195,20 @@ int ta3n_eval_metrics(ta3n_plan *plan, float *ws, int n_videos, int reset, void 
 int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                   void *stream);
 
+/* Overlapping the optimiser with the next step.  The first launch of ta3n_train_step reads only x and the shared frame
+ * FC (the first parameter of the flat layout), while the update is a pure HBM stream; so a host may update
+ * [0, n1) (n1 = offset of the second parameter) on `stream`, put the rest of the update on a second stream, and start the
+ * next step at once: ta3n_train_step_join enqueues its first launch, then makes `stream` wait for `join_event`
+ * (a hipEvent_t recorded on the second stream after the rest of the update; NULL = ta3n_train_step) before the other six.
+ * ta3n_sgd_range is the update over floats [begin, end) of the live prefix with the scalars passed by value (so a newer
+ * ta3n_set_hyper cannot change them under it); fused_norm as in ta3n_sgd_step_fused, otherwise the range starting at 0
+ * first runs the gradient-norm pass.  ws["grad_norm"] is written by the range that starts at 0. */
+int ta3n_sgd_range(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws, int64_t begin,
+                   int64_t end, int fused_norm, float lr, float momentum_coef, float weight_decay, float clip,
+                   void *stream);
+int ta3n_train_step_join(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
+                         void *stream, void *join_event);
+
 /* The same update directly after ta3n_train_step on the same ws, with the gradient buffer untouched in
  * between (single rank: no all-reduce): the global norm is taken from the per-tile sums of squares the
  * fused step's gradient tiles left in ws["sumsq"], which saves the pass over the gradient buffer. */

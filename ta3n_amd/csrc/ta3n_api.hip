@@ -51,9 +51,16 @@ int ensure_uploaded(ta3n_plan *p) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream) {
+int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream,
+              hipEvent_t join_after_first = nullptr) {
+    bool first = true;
     for (const Phase &ph : p->phases) {
         if (ph.group != group) continue;
+        if (!first && join_after_first) {   // everything after the first launch also depends on work the caller put on another stream
+            if (hipStreamWaitEvent(stream, join_after_first, 0) != hipSuccess) return fail(TA3N_ERR_HIP, "hipStreamWaitEvent failed");
+            join_after_first = nullptr;
+        }
+        first = false;
         int rc = 0;
         switch (ph.kind) {
             case PH_GEMM:
@@ -328,6 +335,28 @@ int ta3n_has_fused_step(const ta3n_plan *p) {
 }
 
 int ta3n_train_step(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream) {
+    return ta3n_train_step_join(p, x, params, grads, ws, stream, nullptr);
+}
+
+int ta3n_sgd_range(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, int64_t begin, int64_t end, int fused_norm,
+                   float lr, float momentum_coef, float weight_decay, float clip, void *stream) {
+    if (!p || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (begin < 0 || end > p->live_floats || begin > end || (begin & 3) || (end & 3))
+        return fail(TA3N_ERR_INVALID, "range must be 4-float aligned and inside the live parameter prefix");
+    if (fused_norm && ta3n_has_fused_step(p) != 1) return fail(TA3N_ERR_INVALID, "no fused step for this configuration");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (!fused_norm && begin == 0) {
+        if (launch_grad_norm(p->geom, grads, ws, static_cast<hipStream_t>(stream)) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+    }
+    if (launch_sgd_range(p->geom, params, grads, momentum, ws, begin, end, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                         static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("sgd launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
+int ta3n_train_step_join(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream, void *join_event) {
     if (!p || !x || !params || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(ws))
         return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
@@ -337,7 +366,7 @@ int ta3n_train_step(ta3n_plan *p, const float *x, const float *params, float *gr
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
     Ptrs ptrs{x, params, grads, ws};
-    return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(join_event));
 }
 
 int ta3n_sgd_step_fused(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, void *stream) {

@@ -600,12 +600,12 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             gw.proto = proto(BASE_G, Wcd, 2 * F);
             s.push_back(gw);
             s.push_back(ones_bias_grad(g.o_fh_bpart, 2, 2, g.n_frm_wg, bcd));
+            push_frame_disc_wgrads(s);   // gHf is ready after the heads kernel: fills the CUs this short level leaves idle
             b.add_gemm_phase(4, s);
         }
         {
             std::vector<GemmSpec> s;
             push_trn_level(s);
-            push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
         { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }

@@ -350,6 +350,43 @@ __global__ __launch_bounds__(1024) void eval_metrics_kernel(Geom g, float *__res
     if (threadIdx.x == 3) ws[g.o_metrics + 3] = (reset ? 0.f : ws[g.o_metrics + 3]) + (float)n;
 }
 
+// The same update over floats [4 i0, 4 i1) of the flat prefix with the step's scalars passed by value: lets the host
+// split the update so that the first launch of the NEXT step (which only reads the shared frame FC) runs beside the rest
+// of this one on a second stream, and keeps it independent of a newer ta3n_set_hyper upload.
+__global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
+                                                        float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
+                                                        int norm_n, float lr, float mu, float wd, float clip) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < norm_n; i += blockDim.x) acc += ws[norm_off + i];
+    const float total = sqrtf(block_sum(acc, red));
+    float coef = 1.f;
+    if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && i0 == 0) {
+        ws[g.o_grad_norm] = total;
+        ws[g.o_grad_norm + 1] = coef;
+    }
+    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
+    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += gridDim.x * blockDim.x) {
+        float4 p = p4[i], m = m4[i];
+        const float4 gr = g4[i];
+        float gg[4] = {gr.x, gr.y, gr.z, gr.w};
+        float pp[4] = {p.x, p.y, p.z, p.w};
+        float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = fmaf(wd, pp[e], gg[e] * coef);
+            mm[e] = fmaf(mu, mm[e], d);
+            d = fmaf(mu, mm[e], d);
+            pp[e] = fmaf(-lr, d, pp[e]);
+        }
+        p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    }
+}
+
 __global__ void fill_kernel(float *__restrict__ dst, float v, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
 }
@@ -412,6 +449,17 @@ int launch_gather_segments(const float *store, const int64_t *first_row, const i
 
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream) {
     hipLaunchKernelGGL(eval_metrics_kernel, dim3(1), dim3(1024), 0, stream, g, ws, n, reset);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
+                     bool fused_norm, float lr, float mu, float wd, float clip, hipStream_t stream) {
+    const int i0 = (int)(begin / 4), i1 = (int)(end / 4);
+    if (i1 <= i0) return 0;
+    int blocks = (i1 - i0 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
+                       fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -86,6 +86,11 @@ class TrainEngine:
         self._labels = self.ws[off:off + n].view(torch.int32)
         # fused: forward + loss + backward as ONE C-ABI call (ta3n_train_step, 7 launches) when the plan has it
         self.fused = bool(fused) and p.has_fused_step
+        # deferred update: the optimiser step of call s is enqueued at the start of call s + 1, split so that everything but
+        # the shared frame FC updates on a side stream beside the next step's first launch (include/ta3n_hip.h: ta3n_sgd_range)
+        self._pending = None
+        self._side: Optional[torch.cuda.Stream] = None
+        self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._hyper = _lib.Hyper()
@@ -195,6 +200,52 @@ class TrainEngine:
             self.sgd_step_fused()       # local gradients are final: their norm partials are already in ws
         else:
             self.sgd_step()
+
+    # ---- deferred, overlapped update ----
+    def _apply_pending(self, overlap: bool):
+        """Enqueue the pending update.  overlap: returns the event the next step must join after its first launch."""
+        if self._pending is None:
+            return None
+        lr, mu, wd, clip = self._pending
+        self._pending = None
+        fused_norm = int(self.fused and self.world == 1)
+        main = torch.cuda.current_stream(self.device)
+        L, h = self._L, self.plan.handle
+
+        def rng(lo, hi, stream):
+            _lib.check(L.ta3n_sgd_range(h, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.ws.data_ptr(), lo, hi,
+                                        fused_norm, lr, mu, wd, clip, C.c_void_p(stream.cuda_stream)), "ta3n_sgd_range")
+        if not overlap:
+            rng(0, self.plan.live_floats, main)
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        rng(0, self._n_first, main)                 # (+ the gradient-norm pass when the norm is not fused)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self._side.wait_event(fork)
+        rng(self._n_first, self.plan.live_floats, self._side)
+        join = torch.cuda.Event()
+        join.record(self._side)
+        return join
+
+    def flush(self) -> None:
+        """Apply a deferred update (train_step(defer_update=True)) so that the parameters are current."""
+        self._apply_pending(overlap=False)
+
+    def train_step_deferred(self, beta: Sequence[float], gamma: float, lr: float, **hyper_kw) -> None:
+        """train_step whose optimiser update is postponed to the start of the next call, where all of it except the shared
+        frame FC overlaps the next step's first launch.  Same arithmetic; call flush() before reading parameters."""
+        if not self.fused:
+            raise _lib.Ta3nError("deferred updates need the fused step")
+        join = self._apply_pending(overlap=True)
+        self.set_hyper(beta, gamma, lr, train=True, **hyper_kw)
+        ev = C.c_void_p(join.cuda_event) if join is not None else None
+        _lib.check(self._L.ta3n_train_step_join(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                                self.ws.data_ptr(), self._stream(), ev), "ta3n_train_step_join")
+        self.all_reduce_grads()
+        self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
+        self.step_count += 1
 
     def capture(self) -> None:
         """Capture forward+loss+backward(+all-reduce)+update into one hipGraph (shapes

@@ -290,3 +290,25 @@ def test_other_baseline_config_shapes_match_oracle(shape):
     newp = eng.param_views()
     for k, v in state.params.items():
         assert torch.allclose(newp[k].cpu(), v, rtol=RTOL, atol=ATOL), k
+
+
+def test_deferred_overlapped_update_is_the_same_arithmetic():
+    """train_step_deferred (update of step s enqueued at the start of step s+1, all but the shared frame FC on a side
+    stream beside the next step's first launch) must give bit-identical parameters to the plain sequence."""
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    results = []
+    for mode in ("plain", "deferred"):
+        eng = _engine(c)
+        _load(eng, c)
+        for i in range(4):
+            xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=5 + i)
+            eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+            if mode == "plain":
+                eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3 * (i + 1), seed=i)
+            else:
+                eng.train_step_deferred([0.75, 0.75, 0.5], 0.003, 1e-3 * (i + 1), seed=i)
+        eng.flush()
+        torch.cuda.synchronize()
+        results.append((eng.P.clone(), eng.M.clone()))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
