@@ -40,7 +40,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
 # profiles/r01_pmc_fused_step.txt: (sum FETCH_SIZE x 2 [gfx950 half-count correction] + sum WRITE_SIZE) KiB / 6
-GEMM_TRAFFIC_BYTES_PER_LAUNCH = (2 * 105815 + 26265) * 1024 / 6
+GEMM_TRAFFIC_BYTES_PER_LAUNCH = (2 * 99698 + 26270) * 1024 / 6
 
 
 def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):

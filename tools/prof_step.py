@@ -5,7 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ta3n_amd.engine import TrainEngine
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 xcd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd)
+phase_tiles = []
+if tile == 0:                     # the bench's measured per-launch tile shapes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    phase_tiles = bench.DEFAULT_PHASE_TILES
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
 eng.set_hyper([0.75,0.75,0.5], 0.003, 1e-3)
