@@ -349,6 +349,124 @@ __global__ __launch_bounds__(64 * NW) void gemm_direct(Gemm g) {
     }
 }
 
+// ---------------------------------------------------------------- (5) loader-wave variant
+// Wave specialisation: WK consumer waves (K split of one 32x32 tile) only read LDS and issue MFMAs; one extra wave
+// issues every LDS-DMA of the workgroup, NBUF stages deep.  One s_barrier per chunk joins them.
+template <int WK, int NBUF, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * (WK + 1)) void gemm_loader(Gemm g) {
+    constexpr int BK = 64;
+    constexpr int STAGE = 64 * BK;                 // floats: 32 A rows + 32 B rows
+    constexpr int LDSF = NBUF * STAGE > WK * 32 * 36 ? NBUF * STAGE : WK * 32 * 36;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t *)lds);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_n = (g.N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int nchunks = (g.K + BK - 1) / BK;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (wave == WK) {
+        // ---- loader: 8 pieces per operand per stage ----
+        auto issue = [&](int c) {
+            const unsigned st = lds_base + (unsigned)((c % NBUF) * STAGE * 4);
+            const int k0 = c * BK;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float *src;
+                if (!AKM) {
+                    const int row = q * 4 + (lane >> 4);
+                    const int k = k0 + 4 * ((lane & 15) ^ (row & 15));
+                    src = (m0 + row < g.M && k < g.K) ? g.A + (size_t)(m0 + row) * g.lda + k : g.zeros;
+                } else {
+                    const int k = k0 + q * 8 + lane / 8;
+                    const int r = m0 + (lane % 8) * 4;
+                    src = (r < g.M && k < g.K) ? g.A + (size_t)k * g.lda + r : g.zeros;
+                }
+                glds16(src, st + q * 1024);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float *src;
+                if (!BKM) {
+                    const int row = q * 4 + (lane >> 4);
+                    const int k = k0 + 4 * ((lane & 15) ^ (row & 15));
+                    src = (n0 + row < g.N && k < g.K) ? g.B + (size_t)(n0 + row) * g.ldb + k : g.zeros;
+                } else {
+                    const int k = k0 + q * 8 + lane / 8;
+                    const int r = n0 + (lane % 8) * 4;
+                    src = (r < g.N && k < g.K) ? g.B + (size_t)k * g.ldb + r : g.zeros;
+                }
+                glds16(src, st + 32 * BK * 4 + q * 1024);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c) issue(c);
+        for (int c = 0; c < nchunks; ++c) {
+            if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(c + NBUF - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        const int wk = wave;
+        constexpr int GPW = 16 / WK;
+        for (int c = 0; c < nchunks; ++c) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const float *sa = lds + (c % NBUF) * STAGE;
+            const float *sb = sa + 32 * BK;
+            float av[GPW / 2][4], bv[GPW / 2][4];
+#pragma unroll
+            for (int q = 0; q < GPW / 2; ++q) {
+                const int G = wk * GPW + 2 * q + lh;
+                if (!AKM) {
+                    const float4 t = *reinterpret_cast<const float4 *>(sa + li * BK + ((G ^ (li & 15)) << 2));
+                    av[q][0] = t.x; av[q][1] = t.y; av[q][2] = t.z; av[q][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[q][j] = sa[(4 * G + j) * 32 + li];
+                }
+                if (!BKM) {
+                    const float4 t = *reinterpret_cast<const float4 *>(sb + li * BK + ((G ^ (li & 15)) << 2));
+                    bv[q][0] = t.x; bv[q][1] = t.y; bv[q][2] = t.z; bv[q][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[q][j] = sb[(4 * G + j) * 32 + li];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < GPW / 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[q][j], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (wave < WK) {
+        float *cs = lds + wave * (32 * 36);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32 / 4; idx += 64 * (WK + 1)) {
+        const int r = idx / 8, c4 = (idx % 8) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < WK; ++q) {
+            const float4 p = *reinterpret_cast<const float4 *>(&lds[q * (32 * 36) + r * 36 + c4]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int m = m0 + r, n = n0 + c4;
+        if (m < g.M && n < g.N) *reinterpret_cast<float4 *>(g.C + (size_t)m * g.ldc + n) = v;
+    }
+}
+
 static double cpu_ref(const std::vector<float> &A, const std::vector<float> &B, int lda, int ldb, bool akm, bool bkm, int K, int m, int n) {
     double s = 0;
     for (int k = 0; k < K; ++k) {
@@ -481,6 +599,46 @@ void rund(const char *name, int M, int N, int K) {
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
 }
 
+template <int WK, int NBUF, bool AKM, bool BKM>
+void runl(const char *name, int M, int N, int K) {
+    const int lda = AKM ? M : K, ldb = BKM ? N : K;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto &v : hA) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    for (auto &v : hB) v = (float)rand() / (float)RAND_MAX - 0.5f;
+    float *dA, *dB, *dC, *dz;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dz, 256));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dz, 0, 256));
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    Gemm g{dA, dB, dC, M, N, K, lda, ldb, N, dz};
+    const int grid = ((M + 31) / 32) * ((N + 31) / 32);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((gemm_loader<WK, NBUF, AKM, BKM>), dim3(grid), dim3(64 * (WK + 1)), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    const int reps = 50;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_loader<WK, NBUF, AKM, BKM>), dim3(grid), dim3(64 * (WK + 1)), 0, 0, g);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 400; ++t) {
+        const int m = (t * 7919) % M, n = (t * 104729) % N;
+        maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, m, n) - hC[(size_t)m * N + n]));
+    }
+    maxerr = fmax(maxerr, fabs(cpu_ref(hA, hB, lda, ldb, AKM, BKM, K, M - 1, N - 1) - hC[(size_t)(M - 1) * N + N - 1]));
+    const double us = 1e3 * ms / reps;
+    printf("%-12s %dx%dx%d LOADER wk%d nbuf%d grid %5d : %8.2f us  %6.1f TF  maxerr %.2e\n", name, M, N, K, WK, NBUF, grid, us,
+           2.0 * M * N * K / us * 1e-6, maxerr);
+    fflush(stdout);
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dz));
+}
+
 int main() {
     {   // (1) ceiling
         float *out;
@@ -502,14 +660,15 @@ int main() {
         }
         CK(hipFree(out));
     }
-    // residency probe: 64x64 tiles, 8 waves, 64 KiB of LDS per workgroup - 256 vs 264 vs 512 workgroups
-    run<2, 2, 2, 2, true, true>("TN resid", 512, 2048, 1010);
-    run<2, 2, 2, 2, true, true>("TN resid", 528, 2048, 1010);
-    run<2, 2, 2, 2, true, true>("TN resid", 1024, 2048, 1010);
-    run<2, 2, 1, 2, true, true>("TN resid", 512, 2048, 1010);
-    run<2, 2, 1, 2, true, true>("TN resid", 1024, 2048, 1010);
-    run<1, 1, 4, 2, true, true>("TN resid", 512, 2048, 1010);
-    run<1, 1, 4, 2, true, true>("TN resid", 640, 2048, 1010);
-    run<1, 1, 4, 2, true, true>("TN resid", 1024, 2048, 1010);
+    // shared-stage baseline vs a dedicated loader wave
+    run<1, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
+    runl<4, 2, false, false>("NT F1", 1010, 512, 2048);
+    runl<4, 3, false, false>("NT F1", 1010, 512, 2048);
+    runl<4, 4, false, false>("NT F1", 1010, 512, 2048);
+    runl<8, 3, false, false>("NT F1", 1010, 512, 2048);
+    run<1, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
+    runl<4, 3, true, true>("TN dWsh", 512, 2048, 1010);
+    runl<4, 4, true, true>("TN dWsh", 512, 2048, 1010);
+    runl<8, 3, true, true>("TN dWsh", 512, 2048, 1010);
     return 0;
 }
