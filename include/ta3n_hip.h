@@ -195,6 +195,14 @@ int ta3n_eval_metrics(ta3n_plan *plan, float *ws, int n_videos, int reset, void 
 int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                   void *stream);
 
+/* Launches [first_launch, first_launch + n_launches) of the ta3n_train_step sequence (ta3n_num_phases(plan, 4)
+ * launches in all).  The last launch produces only the gradient of the shared frame FC - the first parameter
+ * of the flat layout - so a data-parallel host can start the all-reduce of everything else while it runs:
+ *   ta3n_train_step_range(.., 0, n - 1, ..); all-reduce grads[n1 .. live) asynchronously;
+ *   ta3n_train_step_range(.., n - 1, 1, ..); all-reduce grads[0 .. n1); wait for both; ta3n_sgd_step. */
+int ta3n_train_step_range(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
+                          int first_launch, int n_launches, void *stream);
+
 /* Overlapping the optimiser with the next step.  The first launch of ta3n_train_step reads only x and the shared frame
  * FC (the first parameter of the flat layout), while the update is a pure HBM stream; so a host may update
  * [0, n1) (n1 = offset of the second parameter) on `stream`, put the rest of the update on a second stream, and start the

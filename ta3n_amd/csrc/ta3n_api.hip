@@ -52,10 +52,13 @@ int ensure_uploaded(ta3n_plan *p) {
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream,
-              hipEvent_t join_after_first = nullptr) {
+              hipEvent_t join_after_first = nullptr, int first_launch = 0, int n_launches = 1 << 30) {
     bool first = true;
+    int index = -1;
     for (const Phase &ph : p->phases) {
         if (ph.group != group) continue;
+        ++index;
+        if (index < first_launch || index >= first_launch + n_launches) continue;
         if (!first && join_after_first) {   // everything after the first launch also depends on work the caller put on another stream
             if (hipStreamWaitEvent(stream, join_after_first, 0) != hipSuccess) return fail(TA3N_ERR_HIP, "hipStreamWaitEvent failed");
             join_after_first = nullptr;
@@ -336,6 +339,21 @@ int ta3n_has_fused_step(const ta3n_plan *p) {
 
 int ta3n_train_step(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream) {
     return ta3n_train_step_join(p, x, params, grads, ws, stream, nullptr);
+}
+
+int ta3n_train_step_range(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, int first_launch,
+                          int n_launches, void *stream) {
+    if (!p || !x || !params || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_fused_step(p) != 1) return fail(TA3N_ERR_INVALID, "no fused step for this configuration");
+    const int total = ta3n_num_phases(p, 4);
+    if (first_launch < 0 || n_launches < 0 || first_launch + n_launches > total)
+        return fail(TA3N_ERR_INVALID, "launch range outside the fused sequence");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    Ptrs ptrs{x, params, grads, ws};
+    return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, first_launch, n_launches);
 }
 
 int ta3n_sgd_range(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, int64_t begin, int64_t end, int fused_norm,

@@ -188,7 +188,25 @@ class TrainEngine:
         _lib.check(self._L.ta3n_train_step(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                            self.ws.data_ptr(), self._stream()), "ta3n_train_step")
 
+    def _fused_step_overlapped_allreduce(self) -> None:
+        """N > 1: the all-reduce of every gradient but the shared frame FC's (the last launch's output, 4.2 of the
+        13.9 MB) starts before that launch and runs beside it over xGMI; the rest follows; both are joined before
+        the update.  Same collectives in the same order on every rank."""
+        n = self._L.ta3n_num_phases(self.plan.handle, 4)
+        args = (self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(), self.ws.data_ptr())
+        _lib.check(self._L.ta3n_train_step_range(*args, 0, n - 1, self._stream()), "ta3n_train_step_range")
+        w1 = parallel.all_reduce_sum_async(self.G[self._n_first: self.plan.live_floats], self.pg)
+        _lib.check(self._L.ta3n_train_step_range(*args, n - 1, 1, self._stream()), "ta3n_train_step_range")
+        w2 = parallel.all_reduce_sum_async(self.G[: self._n_first], self.pg)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+
     def _enqueue_step(self) -> None:
+        if self.fused and self.world > 1 and self.graph is None and not torch.cuda.is_current_stream_capturing():
+            self._fused_step_overlapped_allreduce()
+            self.sgd_step()
+            return
         if self.fused:
             self.fused_step()
         else:

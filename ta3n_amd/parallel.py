@@ -76,6 +76,15 @@ def all_reduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def all_reduce_sum_async(flat: torch.Tensor, group=None):
+    """Asynchronous SUM all-reduce of one gradient bucket; returns the work handle (None when not distributed).
+    RCCL runs it on its own stream, ordered after everything already enqueued on the current stream, so kernels
+    enqueued afterwards overlap with it; handle.wait() orders the current stream after the collective."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     """Initial parameter synchronisation (once, not per step)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
