@@ -135,7 +135,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1" and "RANK" in os.environ   # N > 1 code path on 1 rank
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
@@ -177,7 +178,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or selftest:
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
@@ -229,7 +230,7 @@ def main():
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or selftest:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

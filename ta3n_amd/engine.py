@@ -12,6 +12,7 @@ import ctypes as C
 import math
 from typing import Dict, Optional, Sequence
 
+import os
 import torch
 
 from . import _lib
@@ -90,6 +91,9 @@ class TrainEngine:
         # the shared frame FC updates on a side stream beside the next step's first launch (include/ta3n_hip.h: ta3n_sgd_range)
         self._pending = None
         self._side: Optional[torch.cuda.Stream] = None
+        # TA3N_DDP_SELFTEST=1: take the N > 1 code path (split launches + RCCL buckets) in a 1-rank process group
+        self._ddp_selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1"
+        self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "2"))      # 1: one all-reduce after the last launch
         self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -173,6 +177,10 @@ class TrainEngine:
     def all_reduce_grads(self) -> None:
         if self.world > 1:
             parallel.all_reduce_sum_(self.G[: self.plan.live_floats], self.pg)
+        elif self._ddp_selftest:
+            w = parallel.all_reduce_sum_async(self.G[: self.plan.live_floats], self.pg, True)
+            if w is not None:
+                w.wait()
 
     def sgd_step_fused(self) -> None:
         """Update with the global norm taken from the fused step's per-tile partials (single rank only)."""
@@ -195,15 +203,16 @@ class TrainEngine:
         n = self._L.ta3n_num_phases(self.plan.handle, 4)
         args = (self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(), self.ws.data_ptr())
         _lib.check(self._L.ta3n_train_step_range(*args, 0, n - 1, self._stream()), "ta3n_train_step_range")
-        w1 = parallel.all_reduce_sum_async(self.G[self._n_first: self.plan.live_floats], self.pg)
+        w1 = parallel.all_reduce_sum_async(self.G[self._n_first: self.plan.live_floats], self.pg, self._ddp_selftest)
         _lib.check(self._L.ta3n_train_step_range(*args, n - 1, 1, self._stream()), "ta3n_train_step_range")
-        w2 = parallel.all_reduce_sum_async(self.G[: self._n_first], self.pg)
+        w2 = parallel.all_reduce_sum_async(self.G[: self._n_first], self.pg, self._ddp_selftest)
         for w in (w1, w2):
             if w is not None:
                 w.wait()
 
     def _enqueue_step(self) -> None:
-        if self.fused and self.world > 1 and self.graph is None and not torch.cuda.is_current_stream_capturing():
+        if (self.fused and (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2 and self.graph is None
+                and not torch.cuda.is_current_stream_capturing()):
             self._fused_step_overlapped_allreduce()
             self.sgd_step()
             return
@@ -214,7 +223,7 @@ class TrainEngine:
             self.loss()
             self.backward()
         self.all_reduce_grads()
-        if self.fused and self.world == 1:
+        if self.fused and self.world == 1 and not self._ddp_selftest:
             self.sgd_step_fused()       # local gradients are final: their norm partials are already in ws
         else:
             self.sgd_step()

@@ -76,11 +76,11 @@ def all_reduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
-def all_reduce_sum_async(flat: torch.Tensor, group=None):
+def all_reduce_sum_async(flat: torch.Tensor, group=None, even_if_single: bool = False):
     """Asynchronous SUM all-reduce of one gradient bucket; returns the work handle (None when not distributed).
     RCCL runs it on its own stream, ordered after everything already enqueued on the current stream, so kernels
     enqueued afterwards overlap with it; handle.wait() orders the current stream after the collective."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or even_if_single):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
