@@ -211,8 +211,7 @@ class TrainEngine:
                 w.wait()
 
     def _enqueue_step(self) -> None:
-        if (self.fused and (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2 and self.graph is None
-                and not torch.cuda.is_current_stream_capturing()):
+        if self.fused and (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2:
             self._fused_step_overlapped_allreduce()
             self.sgd_step()
             return
