@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
     ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
+                         "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1])")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -143,13 +146,16 @@ def main():
     phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or DEFAULT_PHASE_TILES
     if args.autotune:
         from ta3n_amd.engine import autotune_phase_tiles
+        from ta3n_amd.engine import ALL_FLAGS
+        from ta3n_amd import _lib
         phase_tiles, _ = autotune_phase_tiles(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], device=dev,
-                                              verbose=(rank == 0))
+                                              flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if args.dtype == "bf16" else 0),
+                                              candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
     if args.tile:
         phase_tiles = []
     eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
                       clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                      fused=not args.unfused)
+                      fused=not args.unfused, bf16=(args.dtype == "bf16"))
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
     xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)

@@ -44,6 +44,10 @@ typedef enum {
 #define TA3N_FLAG_ADV_FRAME      (1u << 2)  /* place_adv[2]=='Y' */
 #define TA3N_FLAG_ATTN_ENTROPY   (1u << 3)  /* add_loss_DA=='attentive_entropy' (main.py:559-562) */
 #define TA3N_FLAG_TRANS_ATTN     (1u << 4)  /* use_attn=='TransAttn' (models.py:643-645) */
+/* Arithmetic of BASELINE.json configs[1]: every contraction rounds its two operands to bf16 (round to nearest
+ * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and
+ * everything outside the contractions (biases, softmax, losses, update) stay fp32.  Off = fp32 MFMA (configs[2]). */
+#define TA3N_FLAG_BF16_MFMA      (1u << 8)
 
 typedef struct {
     int32_t batch_source;    /* Bs: rows of the source half (after the reference's zero padding, main.py:359-372) */

@@ -22,6 +22,7 @@ FLAG_ADV_VIDEO = 1 << 1
 FLAG_ADV_FRAME = 1 << 2
 FLAG_ATTN_ENTROPY = 1 << 3
 FLAG_TRANS_ATTN = 1 << 4
+FLAG_BF16_MFMA = 1 << 8
 
 # every symbol include/ta3n_hip.h declares (tests check the export list)
 SYMBOLS = [

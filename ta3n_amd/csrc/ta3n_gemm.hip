@@ -176,7 +176,21 @@ struct OperandStream {
 // counted lgkmcnt): one exposed LDS latency per stage instead of one per group of four MFMAs.
 // RS: also accumulate the K-sum of this lane's A values (bias gradient of a weight-gradient tile; elements past the
 // K tail and rows past m_valid were staged as zeros, so no masking is needed).
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS>
+// BF: the operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and multiplied by the bf16 MFMA with
+// fp32 accumulation; the LDS images and their reads are the fp32 ones (BASELINE configs[1] arithmetic).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, bool BF>
 __device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const float *__restrict__ sa, const float *__restrict__ sb,
                                               int ra, int rb, int wk, int lh, int krem) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
@@ -205,6 +219,32 @@ __device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const floa
         for (int q = 0; q < NQ; ++q) rs += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
+    if (BF) {
+        if (NQ % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; q += 2) {      // 16 k per MFMA: two of this lane's 4-deep groups
+                if (FULL || 4 * (wk * GPW + 2 * q) < krem) {
+                    const u32x4 a = {pack_bf16(av[q][0], av[q][1]), pack_bf16(av[q][2], av[q][3]),
+                                     pack_bf16(av[q + 1][0], av[q + 1][1]), pack_bf16(av[q + 1][2], av[q + 1][3])};
+                    const u32x4 b = {pack_bf16(bv[q][0], bv[q][1]), pack_bf16(bv[q][2], bv[q][3]),
+                                     pack_bf16(bv[q + 1][0], bv[q + 1][1]), pack_bf16(bv[q + 1][2], bv[q + 1][3])};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                  acc, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (FULL || 4 * (wk * GPW + 2 * q) < krem) {
+                    const u32x2 a = {pack_bf16(av[q][0], av[q][1]), pack_bf16(av[q][2], av[q][3])};
+                    const u32x2 b = {pack_bf16(bv[q][0], bv[q][1]), pack_bf16(bv[q][2], bv[q][3])};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc,
+                                                                   0, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (FULL || 4 * (wk * GPW + 2 * q) < krem) {   // groups past the K tail hold zeros: skip them (wave-uniform)
@@ -227,14 +267,16 @@ __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
 
 namespace ta3n {
 
-template <int WM, int WN, int WK>
+// BF: bf16 MFMA on operands rounded in registers; NS: LDS stages in flight (2, or 3 with BF: once the MFMA is cheap the
+// loop is latency-bound and a third stage pays for long K; short-K tasks prefer the extra resident workgroup of NS = 2).
+template <int WM, int WN, int WK, bool BF, int NS>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
                                                                  Ptrs ptrs, int hyper_off, int zeros_off) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
     constexpr int EPI = NW * 32 * 36;                // epilogue staging (one padded 32x32 block per wave)
-    constexpr int LDS_FLOATS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr int LDS_FLOATS = NS * STAGE > EPI ? NS * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -268,66 +310,147 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const int m0 = t.m0, n0 = t.n0, m_valid = t.m_valid, n_valid = t.n_valid;
     const int seg_end = t.seg_begin + t.seg_count;
     int cseg = t.seg_begin;
-    // K loop.  Stage c+1 is streamed while stage c is computed.  Per Seg: all iterations whose
-    // two cursors both sit inside the Seg run in a tight loop; the iteration that computes the
-    // Seg's last chunk opens the next Seg.  All Segs of a task have the same operand kinds (the
-    // plan builder guarantees it), so the whole loop nest is instantiated per kind combination and
-    // selected once per task: the register allocation is the maximum over the combinations, not
-    // their union (loop-invariant LDS addresses of every combination used to be live together).
+    // K loop: NS stages, chunk c + NS - 1 is streamed while chunk c is computed, across Seg boundaries.  All Segs of a
+    // task have the same operand kinds (the plan builder guarantees it), so the whole loop nest is instantiated per
+    // kind combination and selected once per task: the register allocation is the maximum over the combinations,
+    // not their union (loop-invariant LDS addresses of every combination used to be live together).
     const int ra = wm * 32 + li, rb = wn * 32 + li;
     float rs = 0.f;   // EPI_ROWSUM_A: K-sum of A(row ra, this half-wave's k) over this wave's K slices
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
-        OperandStream<BM, NW> oa;
-        OperandStream<BN, NW> ob;
-        int klen = 0, scale = SK_ONE;
-        auto open_seg = [&](int sidx) {            // wave-uniform: Seg fields live in SGPRs
-            const Seg &sg = segs[sidx];
-            klen = sg.klen; scale = sg.scale_kind;
-            oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
-                     wave, lane);
-            ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
-        };
-        auto issue = [&](int buf, int k0) {
-            const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
-            oa.issue(k0, klen - k0, st, wave, lane, zeros);
-            ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
-        };
-        auto stage_ready = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
-            __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
-            asm volatile("" ::: "memory");
-        };
-        int buf = 0;
-        open_seg(cseg);
-        issue(0, 0);
-        for (;;) {
-            const int n_chunks = (klen + BKC - 1) / BKC;
-            for (int c = 0; c < n_chunks - 1; ++c) {             // chunks whose successor is in the same Seg (all full)
+        if constexpr (NS == 2) {
+            // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
+            // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
+            OperandStream<BM, NW> oa;
+            OperandStream<BN, NW> ob;
+            int klen = 0, scale = SK_ONE;
+            auto open_seg = [&](int sidx) {            // wave-uniform: Seg fields live in SGPRs
+                const Seg &sg = segs[sidx];
+                klen = sg.klen; scale = sg.scale_kind;
+                oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
+                         wave, lane);
+                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
+            };
+            auto issue = [&](int buf, int k0) {
+                const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
+                oa.issue(k0, klen - k0, st, wave, lane, zeros);
+                ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+            };
+            auto stage_ready = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
+                __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
+                asm volatile("" ::: "memory");
+            };
+            int buf = 0;
+            open_seg(cseg);
+            issue(0, 0);
+            for (;;) {
+                const int n_chunks = (klen + BKC - 1) / BKC;
+                for (int c = 0; c < n_chunks - 1; ++c) {             // chunks whose successor is in the same Seg (all full)
+                    stage_ready();
+                    issue(buf ^ 1, (c + 1) * BKC);
+                    const float *sa = lds + buf * STAGE;
+                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                    buf ^= 1;
+                }
+                // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
                 stage_ready();
-                issue(buf ^ 1, (c + 1) * BKC);
+                const int krem = klen - (n_chunks - 1) * BKC, c_scale = scale;
+                ++cseg;
+                if (cseg < seg_end) {
+                    open_seg(cseg);
+                    issue(buf ^ 1, 0);
+                }
                 const float *sa = lds + buf * STAGE;
-                compute_stage<BM, BN, WK, AKM, BKM, true, RS>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
+                if (c_scale != SK_ONE) {
+                    const float sc = hyper_scale(hy, c_scale);
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] *= sc;
+                }
+                if (cseg >= seg_end) break;
                 buf ^= 1;
             }
-            // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
-            stage_ready();
-            const int krem = klen - (n_chunks - 1) * BKC, c_scale = scale;
-            ++cseg;
-            if (cseg < seg_end) {
-                open_seg(cseg);
-                issue(buf ^ 1, 0);
+            } else {
+            // Two cursors walk the task's Segs chunk by chunk: the issue cursor (per-lane DMA state) runs up to NS - 1
+            // chunks ahead of the compute cursor (scalar state only).
+            OperandStream<BM, NW> oa;
+            OperandStream<BN, NW> ob;
+            constexpr int LPW = OperandStream<BM, NW>::NP + OperandStream<BN, NW>::NP;   // DMAs per lane and chunk (16-byte path;
+                                                                                         // the 4-byte path issues more, never fewer)
+            int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
+            auto open_issue_seg = [&]() {            // wave-uniform: Seg fields live in SGPRs
+                const Seg &sg = segs[i_seg];
+                i_klen = sg.klen; i_nchunks = (sg.klen + BKC - 1) / BKC; i_chunk = 0;
+                oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
+                         wave, lane);
+                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
+            };
+            auto issue_one = [&]() {                 // stream the chunk under the issue cursor, advance the cursor
+                const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
+                const int k0 = i_chunk * BKC;
+                oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
+                ob.issue(k0, i_klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
+                ++ahead;
+                if (++i_chunk == i_nchunks) {
+                    if (++i_seg < seg_end) open_issue_seg();
+                }
+            };
+            auto wait_landed = [&](int younger) {     // the oldest chunk in flight has landed once only the younger ones' DMAs are out
+                if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (NS == 3 || younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+                __builtin_amdgcn_s_barrier();          // ... everyone's pieces have; and everyone is done reading the stage refilled next
+                asm volatile("" ::: "memory");
+            };
+            open_issue_seg();
+    #pragma unroll 1
+            for (int sidx = 0; sidx < NS - 1 && i_seg < seg_end; ++sidx) issue_one();
+
+            int c_buf = 0;
+            for (;;) {
+                const Seg &cs = segs[cseg];
+                const int klen = cs.klen, c_scale = cs.scale_kind;
+                const int n_chunks = (klen + BKC - 1) / BKC;
+                int c = 0;
+                // interior of the Seg: both cursors inside it, NS - 1 chunks in flight, nothing to decide per chunk
+                if (i_seg == cseg) {
+                    for (; c + (NS - 1) < n_chunks; ++c) {
+                        wait_landed(NS - 2);
+                        const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
+                        const int k0 = (c + NS - 1) * BKC;
+                        oa.issue(k0, klen - k0, st, wave, lane, zeros);
+                        ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                        i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
+                        const float *sa = lds + c_buf * STAGE;
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                        c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
+                    }
+                    // (issue cursor inside this Seg => NS - 1 of its chunks were in flight => the loop ran and sent its last chunk)
+                    if (++i_seg < seg_end) open_issue_seg();
+                }
+                // last NS - 1 chunks of the Seg: the issue cursor is in a later Seg (or done)
+    #pragma unroll 1
+                for (; c < n_chunks; ++c) {
+                    wait_landed(ahead - 1);
+                    if (i_seg < seg_end) issue_one();
+                    const float *sa = lds + c_buf * STAGE;
+                    if (c < n_chunks - 1)
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                    else
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * BKC);
+                    c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
+                    --ahead;
+                }
+                if (c_scale != SK_ONE) {
+                    const float sc = hyper_scale(hy, c_scale);
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] *= sc;
+                }
+                if (++cseg >= seg_end) break;
             }
-            const float *sa = lds + buf * STAGE;
-            compute_stage<BM, BN, WK, AKM, BKM, false, RS>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
-            if (c_scale != SK_ONE) {
-                const float sc = hyper_scale(hy, c_scale);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= sc;
             }
-            if (cseg >= seg_end) break;
-            buf ^= 1;
-        }
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -455,10 +578,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
 
-#define TA3N_INSTANTIATE(wm, wn, wk) template __global__ void gemm_tiles<wm, wn, wk>(const Task *, const Seg *, Ptrs, int, int);
+#define TA3N_INSTANTIATE(wm, wn, wk)                                                                       \
+    template __global__ void gemm_tiles<wm, wn, wk, false, 2>(const Task *, const Seg *, Ptrs, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, true, 2>(const Task *, const Seg *, Ptrs, int, int);  \
+    template __global__ void gemm_tiles<wm, wn, wk, true, 3>(const Task *, const Seg *, Ptrs, int, int);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 
 bool tile_config_ok(int cfg) {
+    const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice)
+    if (stages != 0 && stages != 2 && stages != 3) return false;
+    cfg %= 1000;
 #define TA3N_CHECK(wm, wn, wk) if (cfg == wm * 100 + wn * 10 + wk) return true;
     TA3N_TILE_CONFIGS(TA3N_CHECK)
     return false;
@@ -471,11 +600,15 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
-#define TA3N_LAUNCH(wm, wn, wk)                                                                                     \
-    if (cfg == wm * 100 + wn * 10 + wk) {                                                                           \
-        hipLaunchKernelGGL((gemm_tiles<wm, wn, wk>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs,    \
-                           hyper_off, zeros_off);                                                                   \
-        launched = true;                                                                                            \
+#define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
+    hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
+                       hyper_off, zeros_off)
+#define TA3N_LAUNCH(wm, wn, wk)                            \
+    if (cfg == wm * 100 + wn * 10 + wk) {                  \
+        if (ph.bf16 == 3) TA3N_LAUNCH_ONE(wm, wn, wk, true, 3);      \
+        else if (ph.bf16 != 0) TA3N_LAUNCH_ONE(wm, wn, wk, true, 2); \
+        else TA3N_LAUNCH_ONE(wm, wn, wk, false, 2);        \
+        launched = true;                                   \
     }
     TA3N_TILE_CONFIGS(TA3N_LAUNCH)
     if (!launched) return -1;

@@ -104,6 +104,8 @@ struct Builder {
         int forced = p.cfg.tile_config;
         if (gemm_phase_index < 16 && p.cfg.phase_tiles[gemm_phase_index] != 0) forced = p.cfg.phase_tiles[gemm_phase_index];
         ++gemm_phase_index;
+        const int forced_stages = forced / 1000;
+        forced %= 1000;
         if (forced != 0) {
             wm = forced / 100; wn = (forced / 10) % 10; wk = forced % 10;
         } else {
@@ -123,6 +125,16 @@ struct Builder {
         Phase ph;
         std::memset(&ph, 0, sizeof(ph));
         ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk;
+        if (p.cfg.flags & TA3N_FLAG_BF16_MFMA) {
+            // a third stage pays once every tile streams a long K; short-K launches keep the extra resident workgroup
+            int min_k = 1 << 30;
+            for (auto &g : specs) {
+                int k = 0;
+                for (auto &sg : g.segs) k += sg.klen;
+                min_k = std::min(min_k, k);
+            }
+            ph.bf16 = forced_stages ? forced_stages : (min_k >= 1024 ? 3 : 2);
+        }
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all
         // column tiles of one row tile when the A side (M*K) is the larger operand,
@@ -231,9 +243,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         return TA3N_ERR_INVALID;
     }
     auto tile_ok = [](int t) { return t == 0 || tile_config_ok(t); };
-    if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222"; return TA3N_ERR_INVALID; }
+    if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages)"; return TA3N_ERR_INVALID; }
     for (int i = 0; i < 16; ++i)
-        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222"; return TA3N_ERR_INVALID; }
+        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages)"; return TA3N_ERR_INVALID; }
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }

@@ -80,7 +80,7 @@ struct Phase {
     int32_t group;               // 0 fwd, 1 loss, 2 bwd, 3 sgd, 4 fused fwd+loss+bwd (ta3n_train_step)
     int32_t task_begin, task_count;
     int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
-    int32_t pad;
+    int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages
 };
 
 // Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.

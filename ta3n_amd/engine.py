@@ -59,9 +59,13 @@ class TrainEngine:
                  fc_dim: int = 512, num_class: int = 12, flags: int = ALL_FLAGS, dropout_i: float = 0.5,
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
-                 phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True):
+                 phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
+                 bf16: bool = False):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
+        if bf16:      # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
+            flags |= _lib.FLAG_BF16_MFMA
+        self.bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware)
@@ -358,6 +362,8 @@ def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int
                          candidates: Sequence[int] = (114, 118, 214, 124, 221, 222), verbose: bool = False):
     """Pick the fastest GEMM tile shape per launch by measuring each candidate on this
     GPU (HIP events on the launch stream).  Returns (phase_tiles, table)."""
+    if flags & _lib.FLAG_BF16_MFMA and all(c < 1000 for c in candidates):
+        candidates = [s * 1000 + c for c in candidates for s in (2, 3)]      # bf16 kernels: 2 or 3 LDS stages
     table = {}
     for cand in candidates:
         eng = TrainEngine(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags=flags,

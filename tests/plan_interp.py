@@ -35,7 +35,15 @@ class Task(C.Structure):
 
 
 class Phase(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "pad")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16")]
+
+
+def round_bf16(a):
+    """Round-to-nearest-even to bfloat16 precision (what v_cvt_pk_bf16_f32 does), returned in the input dtype."""
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).astype(a.dtype)
 
 
 _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", "flags",
@@ -159,7 +167,10 @@ class Interp:
                 A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
                 rowsum += A.sum(1)
                 Bm = self.operand(s.b_base, s.b_off, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)
-                acc += A @ Bm.T
+                if ph.bf16:      # TA3N_FLAG_BF16_MFMA: operands rounded to bf16, products and sums in the wide type
+                    acc += round_bf16(A) @ round_bf16(Bm).T
+                else:
+                    acc += A @ Bm.T
                 acc *= self.scale(s.scale_kind)
             v = acc
             m = np.arange(t.m0, t.m0 + nr)[:, None]

@@ -125,6 +125,47 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_proto(Gemm g) {
         if (MODE != 1) issue(c + NBUF - 1);        // refill the buffer stage c-1 used (MODE 1: compute-only ceiling)
         const float *sa = lds + (c % NBUF) * STAGE;
         const float *sb = sa + BM * BK;
+        if constexpr (MODE == 3 || MODE == 4) {
+            // MODE 3: fp32 stages, operands rounded to bf16 in registers, bf16 MFMA.  MODE 4: the stage bytes ARE bf16
+            // (timing probe of bf16 storage: K floats = 2K bf16, values meaningless).
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            static_assert(!AKM && !BKM, "bf16 probe: K-contiguous operands only");
+            float4 ta[GPW / 2], tb[GPW / 2];
+#pragma unroll
+            for (int q = 0; q < GPW / 2; ++q) {
+                const int G = wk * GPW + 2 * q + lh;
+                const int ra = wm * 32 + li, rb = wn * 32 + li;
+                ta[q] = *reinterpret_cast<const float4 *>(sa + ra * BK + ((G ^ (ra & 15)) << 2));
+                tb[q] = *reinterpret_cast<const float4 *>(sb + rb * BK + ((G ^ (rb & 15)) << 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto pk = [](float lo, float hi) { f32x2 v = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); };
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            if constexpr (MODE == 4) {
+#pragma unroll
+                for (int q = 0; q < GPW / 2; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[q]), __builtin_bit_cast(bf16x8, tb[q]), acc, 0, 0, 0);
+            } else if constexpr ((GPW / 2) % 2 == 0) {
+#pragma unroll
+                for (int q = 0; q < GPW / 2; q += 2) {
+                    const u32x4 a = {pk(ta[q].x, ta[q].y), pk(ta[q].z, ta[q].w), pk(ta[q + 1].x, ta[q + 1].y), pk(ta[q + 1].z, ta[q + 1].w)};
+                    const u32x4 b = {pk(tb[q].x, tb[q].y), pk(tb[q].z, tb[q].w), pk(tb[q + 1].x, tb[q + 1].y), pk(tb[q + 1].z, tb[q + 1].w)};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < GPW / 2; ++q) {
+                    const u32x2 a = {pk(ta[q].x, ta[q].y), pk(ta[q].z, ta[q].w)};
+                    const u32x2 b = {pk(tb[q].x, tb[q].y), pk(tb[q].z, tb[q].w)};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < GPW / 2; ++q) {
             const int G = wk * GPW + 2 * q + lh;   // this half-wave's k group: k = 4G .. 4G+3
@@ -660,15 +701,22 @@ int main() {
         }
         CK(hipFree(out));
     }
-    // shared-stage baseline vs a dedicated loader wave
-    run<1, 1, 4, 2, false, false>("NT F1", 1010, 512, 2048);
-    runl<4, 2, false, false>("NT F1", 1010, 512, 2048);
-    runl<4, 3, false, false>("NT F1", 1010, 512, 2048);
-    runl<4, 4, false, false>("NT F1", 1010, 512, 2048);
-    runl<8, 3, false, false>("NT F1", 1010, 512, 2048);
-    run<1, 1, 4, 2, true, true>("TN dWsh", 512, 2048, 1010);
-    runl<4, 3, true, true>("TN dWsh", 512, 2048, 1010);
-    runl<4, 4, true, true>("TN dWsh", 512, 2048, 1010);
-    runl<8, 3, true, true>("TN dWsh", 512, 2048, 1010);
+    // bf16-MFMA probes on the F1 shape: fp32 stages + in-register rounding (mode 3), bf16 stage bytes (mode 4, K halves)
+#define SWEEP(WM, WN, WK)                                                       \
+    run<WM, WN, WK, 2, false, false, 64, 3>("F1 cvt", 1010, 512, 2048);         \
+    run<WM, WN, WK, 3, false, false, 64, 3>("F1 cvt", 1010, 512, 2048);         \
+    run<WM, WN, WK, 4, false, false, 64, 3>("F1 cvt", 1010, 512, 2048);         \
+    run<WM, WN, WK, 2, false, false, 128, 3>("F1 cvt", 1010, 512, 2048);        \
+    run<WM, WN, WK, 2, false, false, 64, 4>("F1 bf16st", 1010, 512, 1024);      \
+    run<WM, WN, WK, 3, false, false, 64, 4>("F1 bf16st", 1010, 512, 1024);      \
+    run<WM, WN, WK, 4, false, false, 64, 4>("F1 bf16st", 1010, 512, 1024);      \
+    run<WM, WN, WK, 2, false, false, 128, 4>("F1 bf16st", 1010, 512, 1024);
+    SWEEP(1, 1, 4)
+    SWEEP(1, 2, 4)
+    SWEEP(2, 2, 2)
+    run<1, 1, 8, 2, false, false, 64, 3>("F1 cvt", 1010, 512, 2048);
+    run<1, 1, 8, 4, false, false, 64, 3>("F1 cvt", 1010, 512, 2048);
+    run<1, 1, 8, 2, false, false, 64, 4>("F1 bf16st", 1010, 512, 1024);
+    run<1, 1, 8, 4, false, false, 64, 4>("F1 bf16st", 1010, 512, 1024);
     return 0;
 }
