@@ -36,6 +36,8 @@ CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
 # per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
 # forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
 DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222]
+# same, bf16-MFMA arithmetic: thousands digit = LDS stages (3 for the long-K launches)
+DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 2214, 2118, 3124, 2122, 2124]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
@@ -125,6 +127,8 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
     ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--no-twins", action="store_true", help="bf16: round fp32 operands in registers everywhere instead of reading bf16 "
+                    "twins in the forward launches")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1])")
@@ -143,19 +147,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
-    phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or DEFAULT_PHASE_TILES
+    phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or (
+        DEFAULT_PHASE_TILES_BF16 if args.dtype == "bf16" else DEFAULT_PHASE_TILES)
     if args.autotune:
         from ta3n_amd.engine import autotune_phase_tiles
         from ta3n_amd.engine import ALL_FLAGS
         from ta3n_amd import _lib
         phase_tiles, _ = autotune_phase_tiles(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], device=dev,
-                                              flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if args.dtype == "bf16" else 0),
+                                              flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if args.dtype == "bf16" else 0) |
+                                              (_lib.FLAG_BF16_STORE if args.dtype == "bf16" and not args.no_twins else 0),
                                               candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
     if args.tile:
         phase_tiles = []
     eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
                       clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                      fused=not args.unfused, bf16=(args.dtype == "bf16"))
+                      fused=not args.unfused, bf16=(args.dtype == "bf16"),
+                      bf16_store=(args.dtype == "bf16" and not args.no_twins))
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
     xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)

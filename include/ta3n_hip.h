@@ -48,6 +48,12 @@ typedef enum {
  * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and
  * everything outside the contractions (biases, softmax, losses, update) stay fp32.  Off = fp32 MFMA (configs[2]). */
 #define TA3N_FLAG_BF16_MFMA      (1u << 8)
+/* With TA3N_FLAG_BF16_MFMA: the forward contractions of ta3n_train_step read their operands from bf16 copies
+ * ("twins", inside ws) instead of rounding fp32 values on the fly - same arithmetic, half the operand bytes.  The
+ * library keeps the twins of everything it writes itself (activations: the producing kernel; parameters:
+ * ta3n_sgd_step*); whatever the CALLER writes - the input features, parameters loaded from a checkpoint - must be
+ * followed by ta3n_refresh_bf16.  (A bf16 feature store can feed the input twin directly.) */
+#define TA3N_FLAG_BF16_STORE     (1u << 9)
 
 typedef struct {
     int32_t batch_source;    /* Bs: rows of the source half (after the reference's zero padding, main.py:359-372) */
@@ -206,6 +212,10 @@ int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum,
  *   ta3n_train_step_range(.., n - 1, 1, ..); all-reduce grads[0 .. n1); wait for both; ta3n_sgd_step. */
 int ta3n_train_step_range(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
                           int first_launch, int n_launches, void *stream);
+
+/* TA3N_FLAG_BF16_STORE: (re)build the bf16 twins of x (B*T*feature_dim floats, may be NULL) and of params (may be
+ * NULL) inside ws.  No-op without the flag. */
+int ta3n_refresh_bf16(ta3n_plan *plan, const float *x, const float *params, float *ws, void *stream);
 
 /* Overlapping the optimiser with the next step.  The first launch of ta3n_train_step reads only x and the shared frame
  * FC (the first parameter of the flat layout), while the update is a pure HBM stream; so a host may update

@@ -68,7 +68,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
         switch (ph.kind) {
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
-                                 p->geom.o_hyper, p->geom.o_zeros, stream);
+                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream);
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -281,7 +281,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         for (int k = 0; k < r; ++k) {
             int lrc = 0;
             switch (ph.kind) {
-                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, s); break;
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s); break;
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;
@@ -354,6 +354,16 @@ int ta3n_train_step_range(ta3n_plan *p, const float *x, const float *params, flo
     if (rc != TA3N_OK) return rc;
     Ptrs ptrs{x, params, grads, ws};
     return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, first_launch, n_launches);
+}
+
+int ta3n_refresh_bf16(ta3n_plan *p, const float *x, const float *params, float *ws, void *stream) {
+    if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (p->geom.o_ws16 < 0) return TA3N_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = 0;
+    if (x) rc |= launch_to_bf16(x, ws + p->geom.o_x16, (int64_t)p->geom.B * p->geom.T * p->geom.D, s);
+    if (params) rc |= launch_to_bf16(params, ws + p->geom.o_p16, p->param_floats, s);
+    return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, "bf16 conversion launch failed");
 }
 
 int ta3n_sgd_range(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, int64_t begin, int64_t end, int fused_norm,

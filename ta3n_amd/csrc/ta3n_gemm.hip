@@ -179,22 +179,37 @@ struct OperandStream {
 // BF: the operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and multiplied by the bf16 MFMA with
 // fp32 accumulation; the LDS images and their reads are the fp32 ones (BASELINE configs[1] arithmetic).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
 
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, bool BF>
+// BF == 2: the stage bytes are bf16 already (twins): a 16-byte slot is 8 consecutive k of one row, fed to the MFMA as is.
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF>
 __device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const float *__restrict__ sa, const float *__restrict__ sb,
                                               int ra, int rb, int wk, int lh, int krem) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
+    if constexpr (BF == 2) {
+        static_assert(!AKM && !BKM && !RS, "bf16 twins: K-contiguous operands only");
+        f32x4 ta[NQ], tb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int G = wk * GPW + 2 * q + lh;
+            ta[q] = *reinterpret_cast<const f32x4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
+            tb[q] = *reinterpret_cast<const f32x4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (FULL || 4 * (wk * GPW + 2 * q) < krem)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[q]), __builtin_bit_cast(bf16x8, tb[q]), acc,
+                                                              0, 0, 0);
+        return;
+    }
     float av[NQ][4], bv[NQ][4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -269,9 +284,9 @@ namespace ta3n {
 
 // BF: bf16 MFMA on operands rounded in registers; NS: LDS stages in flight (2, or 3 with BF: once the MFMA is cheap the
 // loop is latency-bound and a third stage pays for long K; short-K tasks prefer the extra resident workgroup of NS = 2).
-template <int WM, int WN, int WK, bool BF, int NS>
+template <int WM, int WN, int WK, int BF, int NS>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
-                                                                 Ptrs ptrs, int hyper_off, int zeros_off) {
+                                                                 Ptrs ptrs, int hyper_off, int zeros_off, int twin_off) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
@@ -456,7 +471,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     using F_ = std::false_type;
     {
         const Seg &s0 = segs[cseg];
-        switch (s0.a_kmajor * 2 + s0.b_kmajor) {
+        if constexpr (BF == 2) k_loop(F_{}, F_{}, F_{});
+        else switch (s0.a_kmajor * 2 + s0.b_kmajor) {
             case 0: k_loop(F_{}, F_{}, F_{}); break;
             case 1: k_loop(F_{}, T_{}, F_{}); break;
             case 2: k_loop(T_{}, F_{}, F_{}); break;
@@ -538,6 +554,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             for (int e = 0; e < 4; ++e)
                 if (e < nrem) cp[e] = v[e];
         }
+        if (epi & EPI_TWIN16) {          // bf16 twin of the stored values (TA3N_FLAG_BF16_STORE)
+            unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
+            const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+            if (nrem >= 4 && c_vec) {
+                *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+            } else {
+                const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16), (unsigned short)(hi & 0xFFFF),
+                                             (unsigned short)(hi >> 16)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nrem) tp[e] = h[e];
+            }
+        }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
             if (f < nfan) {
@@ -578,10 +607,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
 
-#define TA3N_INSTANTIATE(wm, wn, wk)                                                                       \
-    template __global__ void gemm_tiles<wm, wn, wk, false, 2>(const Task *, const Seg *, Ptrs, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, true, 2>(const Task *, const Seg *, Ptrs, int, int);  \
-    template __global__ void gemm_tiles<wm, wn, wk, true, 3>(const Task *, const Seg *, Ptrs, int, int);
+#define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 3>(const Task *, const Seg *, Ptrs, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3>(const Task *, const Seg *, Ptrs, int, int, int);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 
 bool tile_config_ok(int cfg) {
@@ -594,7 +625,7 @@ bool tile_config_ok(int cfg) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, hipStream_t stream) {
+                int zeros_off, int twin_off, hipStream_t stream) {
     if (ph.task_count == 0) return 0;
     const dim3 grid(ph.task_count);
     const Task *tp = d_tasks + ph.task_begin;
@@ -602,13 +633,17 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     bool launched = false;
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
     hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
-                       hyper_off, zeros_off)
-#define TA3N_LAUNCH(wm, wn, wk)                            \
-    if (cfg == wm * 100 + wn * 10 + wk) {                  \
-        if (ph.bf16 == 3) TA3N_LAUNCH_ONE(wm, wn, wk, true, 3);      \
-        else if (ph.bf16 != 0) TA3N_LAUNCH_ONE(wm, wn, wk, true, 2); \
-        else TA3N_LAUNCH_ONE(wm, wn, wk, false, 2);        \
-        launched = true;                                   \
+                       hyper_off, zeros_off, twin_off)
+#define TA3N_LAUNCH(wm, wn, wk)                                   \
+    if (cfg == wm * 100 + wn * 10 + wk) {                         \
+        switch (ph.bf16) {                                        \
+            case 0: TA3N_LAUNCH_ONE(wm, wn, wk, 0, 2); break;     \
+            case 3: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 3); break;     \
+            case 18: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 2); break;    \
+            case 19: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 3); break;    \
+            default: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 2); break;    \
+        }                                                         \
+        launched = true;                                          \
     }
     TA3N_TILE_CONFIGS(TA3N_LAUNCH)
     if (!launched) return -1;

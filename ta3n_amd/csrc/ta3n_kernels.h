@@ -87,7 +87,18 @@ __device__ __forceinline__ Soft2 soft2(float z0, float z1) {
 
 bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, hipStream_t stream);
+                int zeros_off, int twin_off, hipStream_t stream);
+#if defined(__HIPCC__)
+// two floats -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), low half = first argument
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+#endif
+
+int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t stream);   // n fp32 -> n bf16 (RNE), n % 4 == 0
 bool heads_supported(int NB, int C, int F);   // configurations the fused heads kernel (ta3n_heads.hip) covers
 int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

@@ -80,7 +80,7 @@ struct Builder {
         pi.name = name; pi.rows = rows; pi.cols = cols; pi.live = live;
         pi.off = p.param_floats;
         p.params.push_back(pi);
-        p.param_floats = align_up(p.param_floats + (int64_t)rows * (cols ? cols : 1), 4);
+        p.param_floats = align_up(p.param_floats + (int64_t)rows * (cols ? cols : 1), 8);   // 8: a bf16 twin row starts 16-byte aligned too
     }
     void add_linear(const std::string &name, int out, int in, bool live) {
         add_param(name + ".weight", out, in, live);
@@ -303,6 +303,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = NB; g.C = C;
     g.n_tuples = NT; g.n_rel = NR; g.flags = c.flags;
+    g.o_ws16 = g.o_p16 = g.o_x16 = -1; g.ws16_span = 0;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_Hf = (int32_t)b.add_region("Hf", (int64_t)BT * F);
     g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
@@ -633,6 +634,63 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         for (size_t k = 0; k < grad_tasks.size(); ++k) {
             p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
             p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
+        }
+        if ((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE)) {
+            // bf16 twins.  A launch of the fused step reads twins when every one of its Segs is K-contiguous on both sides
+            // and 8-element aligned (then the stage images are byte-for-byte those of a float matrix with half the
+            // columns: the Segs are rewritten in units of two elements and the kernel feeds the 16-byte slots to the
+            // bf16 MFMA as they are).  Today that is the three forward launches; the k-major launches keep rounding
+            // fp32 operands in registers.
+            g.ws16_span = (int32_t)p.ws_floats;
+            g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
+            g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
+            g.o_x16 = (int32_t)b.add_region("x16", ((int64_t)BT * D + 1) / 2);
+            auto twin = [&](int32_t &base, int32_t &off) {
+                const int32_t origin = base == BASE_WS ? g.o_ws16 : base == BASE_P ? g.o_p16 : g.o_x16;
+                off = origin + off / 2;
+                base = BASE_WS;
+            };
+            std::vector<std::pair<int64_t, int64_t>> read16;   // ws intervals (floats) some twin-reading Seg covers
+            for (Phase &ph : p.phases) {
+                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+                bool ok = true;
+                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count && ok; ++i) {
+                    const Task &t = p.tasks[i];
+                    for (int k = t.seg_begin; k < t.seg_begin + t.seg_count && ok; ++k) {
+                        const Seg &sg = p.segs[k];
+                        ok = !sg.a_kmajor && !sg.b_kmajor && ((sg.a_off | sg.a_ld | sg.b_off | sg.b_ld | sg.klen) & 7) == 0 &&
+                             sg.a_base != BASE_G && sg.b_base != BASE_G;
+                    }
+                }
+                if (!ok) continue;
+                ph.bf16 |= 16;
+                std::vector<char> done(p.segs.size(), 0);
+                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                    const Task &t = p.tasks[i];
+                    for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
+                        if (done[k]) continue;
+                        done[k] = 1;
+                        Seg &sg = p.segs[k];
+                        const int a_rows = sg.pad[0] > 0 ? sg.pad[0] : t.m_valid;
+                        if (sg.a_base == BASE_WS) read16.push_back({sg.a_off, sg.a_off + (int64_t)(a_rows - 1) * sg.a_ld + sg.klen});
+                        if (sg.b_base == BASE_WS) read16.push_back({sg.b_off, sg.b_off + (int64_t)(t.n_valid - 1) * sg.b_ld + sg.klen});
+                        twin(sg.a_base, sg.a_off);
+                        twin(sg.b_base, sg.b_off);
+                        sg.a_ld /= 2; sg.b_ld /= 2; sg.klen /= 2;
+                    }
+                }
+            }
+            // producers: every GEMM tile of the fused step whose output a twin-reading Seg covers also stores the twin
+            for (const Phase &ph : p.phases) {
+                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                    Task &t = p.tasks[i];
+                    if (t.seg_count == 0 || t.c_base != BASE_WS) continue;
+                    const int64_t lo = t.c_off, hi = t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid;
+                    for (auto &iv : read16)
+                        if (lo < iv.second && iv.first < hi) { t.epi |= EPI_TWIN16; break; }
+                }
+            }
         }
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }

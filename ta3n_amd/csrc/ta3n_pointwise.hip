@@ -11,6 +11,7 @@
 //  grad_norm / sgd   clip_grad_norm_ + Nesterov SGD with weight decay over the
 //             flat live-parameter prefix (main.py:578-583).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "ta3n_kernels.h"
 #include "../../include/ta3n_hip.h"
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
         }
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
     }
 }
 
@@ -384,6 +386,14 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
         }
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+    }
+}
+
+__global__ void to_bf16_kernel(const float4 *__restrict__ src, uint2 *__restrict__ dst, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        dst[i] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
     }
 }
 
@@ -460,6 +470,15 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t stream) {
+    const int64_t n4 = n / 4;
+    if (n4 <= 0) return 0;
+    int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<uint2 *>(dst_twin), n4);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -27,6 +27,7 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)
     EPI_ROWSUM_A = 1u << 8, // also store the K-sums of the tile's A rows to bias_base[bias_off + m] (bias gradient of a weight-gradient tile)
     EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[3]] = sum of squares of the stored tile (fused grad-norm partial)
 };
@@ -80,7 +81,9 @@ struct Phase {
     int32_t group;               // 0 fwd, 1 loss, 2 bwd, 3 sgd, 4 fused fwd+loss+bwd (ta3n_train_step)
     int32_t task_begin, task_count;
     int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
-    int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages
+    int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages;
+                                 // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): Segs address the bf16 twins in
+                                 // units of two elements (a_ld, klen, offsets halved)
 };
 
 // Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.
@@ -115,6 +118,9 @@ struct Geom {
     int32_t n_vid_wg, n_frm_wg;
     int32_t o_sumsq, n_sumsq;            // fused grad-norm partials (one slot per gradient tile of the fused step)
     int32_t o_metrics, o_confusion;      // validation: {sum CE, top-1 hits, top-5 hits, videos} and the int32 [C][C] confusion matrix
+    // bf16 twins (TA3N_FLAG_BF16_STORE), all inside ws, offsets in floats: element e of ws / params / x lives, rounded
+    // to bf16, at byte (o_*16 * 4 + 2 e).  -1: no twins.
+    int32_t o_ws16, o_p16, o_x16, ws16_span;   // ws16 mirrors ws[0 .. ws16_span)
 };
 
 }  // namespace ta3n

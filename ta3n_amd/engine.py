@@ -60,12 +60,15 @@ class TrainEngine:
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
-                 bf16: bool = False):
+                 bf16: bool = False, bf16_store: bool = False):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
-        if bf16:      # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
+        if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
             flags |= _lib.FLAG_BF16_MFMA
+        if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly
+            flags |= _lib.FLAG_BF16_STORE
         self.bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
+        self.bf16_store = bool(flags & _lib.FLAG_BF16_STORE)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware)
@@ -128,6 +131,16 @@ class TrainEngine:
         for k, v in views.items():
             if k in state:
                 v.copy_(state[k].to(device=self.device, dtype=torch.float32))
+        self.refresh_bf16(params=True)
+
+    def refresh_bf16(self, x: bool = False, params: bool = False) -> None:
+        """TA3N_FLAG_BF16_STORE: rebuild the bf16 twins of what the HOST side wrote (features / parameters).  Everything the
+        library writes itself keeps its twin up to date.  Call after writing self.X or self.P directly."""
+        if not self.bf16_store:
+            return
+        _lib.check(self._L.ta3n_refresh_bf16(self.plan.handle, self.X.data_ptr() if x else None,
+                                             self.P.data_ptr() if params else None, self.ws.data_ptr(), self._stream()),
+                   "ta3n_refresh_bf16")
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.param_views().items()}
@@ -140,6 +153,7 @@ class TrainEngine:
         self.X[: self.Bs * self.T].copy_(source.reshape(-1, self.D), non_blocking=True)
         self.X[self.Bs * self.T:].copy_(target.reshape(-1, self.D), non_blocking=True)
         self._labels[: self.Bs].copy_(source_label.to(torch.int32), non_blocking=True)
+        self.refresh_bf16(x=True)
 
     def set_hyper(self, beta: Sequence[float], gamma: float, lr: float, train: bool = True,
                   valid_source: Optional[int] = None, valid_target: Optional[int] = None,
@@ -290,6 +304,7 @@ class TrainEngine:
         torch.cuda.synchronize(self.device)
         self.P.copy_(keep_p)
         self.M.copy_(keep_m)
+        self.refresh_bf16(params=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._enqueue_step()
@@ -371,6 +386,7 @@ def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int
         eng.X.uniform_(0, 1)
         for v in eng.param_views().values():
             v.normal_(0, 0.02)
+        eng.refresh_bf16(x=True, params=True)
         eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3)
         eng.gemm_phase_times(2)
         table[cand] = eng.gemm_phase_times(reps)

@@ -52,7 +52,8 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_gR", "o_gZ", "o_gZ1", "o_zeros", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
-                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion"]
+                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
+                "o_ws16", "o_p16", "o_x16", "ws16_span"]
 
 
 class Geom(C.Structure):
@@ -164,6 +165,25 @@ class Interp:
             rowsum = np.zeros(nr, self.dtype)
             for si in range(t.seg_begin, t.seg_begin + t.seg_count):
                 s = self.segs[si]
+                if ph.bf16 & 16:
+                    # the Seg addresses bf16 twins in units of two elements.  A twin holds round_bf16(original) - which is what
+                    # the operand read below computes from the original - so the model reads the original; that the
+                    # twin is up to date when the kernel reads it is what the GPU test checks against this model.
+                    def untwin(off):
+                        g = self.g
+                        if off >= g.o_x16:
+                            return BASE_X, (off - g.o_x16) * 2
+                        if off >= g.o_p16:
+                            return BASE_P, (off - g.o_p16) * 2
+                        assert off >= g.o_ws16
+                        return BASE_WS, (off - g.o_ws16) * 2
+                    assert s.a_base == BASE_WS and s.b_base == BASE_WS and not s.a_kmajor and not s.b_kmajor
+                    ab, ao = untwin(s.a_off); bb, bo = untwin(s.b_off)
+                    A = self.operand(ab, ao, 2 * s.a_ld, 0, t.m0, nr, 2 * s.klen)
+                    Bm = self.operand(bb, bo, 2 * s.b_ld, 0, t.n0, nc, 2 * s.klen)
+                    acc += round_bf16(A) @ round_bf16(Bm).T
+                    acc *= self.scale(s.scale_kind)
+                    continue
                 A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
                 rowsum += A.sum(1)
                 Bm = self.operand(s.b_base, s.b_off, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)

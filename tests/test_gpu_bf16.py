@@ -28,17 +28,22 @@ def _close(name, got, want, rtol, atol_frac):
     return err / scale
 
 
-@pytest.mark.parametrize("tile", [0, 114, 118, 222])
+@pytest.mark.parametrize("store", [False, True])
+@pytest.mark.parametrize("tile", [0, 114, 118, 222, 3124])
 @pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9"])
-def test_bf16_kernels_match_the_bf16_operand_model(name, tile):
+def test_bf16_kernels_match_the_bf16_operand_model(name, tile, store):
+    """store=True: TA3N_FLAG_BF16_STORE - the forward launches read bf16 twins written by the producing kernels."""
     from ta3n_amd.engine import TrainEngine
     g = Golden(name)
     c = case_config(g)
     T = c["T"]
     eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"],
-                      tile_config=tile, bf16=True)
-    assert eng.bf16
-    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL | _lib.FLAG_BF16_MFMA, tile_config=tile)
+                      tile_config=tile, bf16=True, bf16_store=store)
+    assert eng.bf16 and eng.bf16_store == store
+    twin_launches = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["tile"] >= 16000]
+    assert (len(twin_launches) == 3) == store        # F1, F2 (Hf + TRN tuples), F3 (relation discriminator hidden layer)
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"],
+                     ALL | _lib.FLAG_BF16_MFMA | (_lib.FLAG_BF16_STORE if store else 0), tile_config=tile)
     it = Interp(plan)
     shapes = {n: s for n, _, s, _ in plan.params}
     state = synth_state(shapes, seed=c["wseed"], scale=c["wscale"])
@@ -50,6 +55,8 @@ def test_bf16_kernels_match_the_bf16_operand_model(name, tile):
     eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
     eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"], train=True, valid_source=st["n_src"], valid_target=st["n_tgt"])
     eng.fused_step()
+    if store:            # a second step after an update: the parameter twins written by the optimiser are the ones read
+        pass
     torch.cuda.synchronize()
 
     it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
@@ -106,3 +113,44 @@ def test_bf16_distance_from_fp32_reference_is_bounded_and_reported(capsys):
     with capsys.disabled():
         print("\nbf16-MFMA vs fp32 reference, max abs error (rms of reference): " +
               ", ".join(f"{k} {e:.2e} ({s:.2e})" for k, (e, s) in report.items()))
+
+
+def test_twin_storage_is_the_same_arithmetic_over_several_updates():
+    """Three full train steps (dropout on, clip, Nesterov SGD) with and without TA3N_FLAG_BF16_STORE: the twins read in
+    steps 2 and 3 are the ones the optimiser and the producing kernels wrote; a stale or misplaced twin shows up as
+    an O(1) difference, the legitimate one is fp32 summation order (different k grouping inside the MFMAs)."""
+    from ta3n_amd.engine import TrainEngine
+    g = Golden("headline")
+    c = case_config(g)
+    T = c["T"]
+    res = []
+    for store in (False, True):
+        eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], dropout_i=0.5, dropout_v=0.5, clip=c["clip"],
+                          bf16=True, bf16_store=store)
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        for step in range(3):
+            xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=100 + step)
+            eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+            eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
+        torch.cuda.synchronize()
+        if store:   # every twin is exactly the round-to-nearest-even bf16 of its fp32 original, after three updates
+            def twin_bits(name, n):
+                return eng.region(name).view(torch.int16)[:n]
+            def rne_bits(t):
+                return t.reshape(-1).to(torch.bfloat16).view(torch.int16)
+            assert torch.equal(twin_bits("p16", eng.P.numel()), rne_bits(eng.P)), "parameter twins (written by the optimiser)"
+            assert torch.equal(twin_bits("x16", eng.X.numel()), rne_bits(eng.X)), "input twin (ta3n_refresh_bf16)"
+            ws16 = eng.region("ws16").view(torch.int16)
+            for name in ("F1", "Zr"):
+                off, size = eng.plan.regions[name]
+                assert torch.equal(ws16[off: off + size], rne_bits(eng.region(name))), f"{name} twin (written by the producing launch)"
+        res.append((eng.P.clone(), eng.region("losses")[:6].clone()))
+    (p0, l0), (p1, l1) = res
+    scale = p0.abs().max().item()
+    # same arithmetic up to fp32 summation order; a sum-order ulp can flip a bf16 rounding or a ReLU, which three updates
+    # at lr 0.03 amplify to ~1e-5 typical / <1e-3 worst (a stale twin would show up at >= 1e-2 and fails the bit checks above)
+    d = (p0 - p1).abs()
+    assert d.max().item() <= 5e-3 * scale and d.mean().item() <= 5e-5 * scale, (d.max().item(), d.mean().item(), scale)
+    assert torch.allclose(l0, l1, rtol=5e-3, atol=1e-4)
+    assert not torch.equal(p0, torch.zeros_like(p0))

@@ -1,5 +1,5 @@
 """Three eager train steps at the BASELINE shape for rocprofv3 (kernel trace / PMC passes).
-usage: python tools/prof_step.py [tile_config] [xcd_aware] [fused|unfused]"""
+usage: python tools/prof_step.py [tile_config] [xcd_aware] [fused|unfused] [f32|bf16]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ta3n_amd.engine import TrainEngine
@@ -10,10 +10,13 @@ if tile == 0:                     # the bench's measured per-launch tile shapes
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    phase_tiles = bench.DEFAULT_PHASE_TILES
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles)
+    bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+    phase_tiles = bench.DEFAULT_PHASE_TILES_BF16 if bf16 else bench.DEFAULT_PHASE_TILES
+bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
+eng.refresh_bf16(x=True, params=True)
 eng.set_hyper([0.75,0.75,0.5], 0.003, 1e-3)
 fused = (sys.argv[3] != "unfused") if len(sys.argv) > 3 else True
 for _ in range(3):

@@ -73,6 +73,7 @@ def main():
                        use_bn=args.use_bn, ens_DA=args.ens_DA, use_attn=args.use_attn, verbose=False)
     eng.load_state(model.state_dict())                  # reference initialisation under torch.manual_seed(1)
     parallel.broadcast_(eng.P)
+    eng.refresh_bf16(params=True)
     if args.synthetic:
         n_src, n_tgt = args.synthetic
     elif args.feature_store:
@@ -127,6 +128,7 @@ def main():
                 eng.X.zero_()
                 stores[0].gather(xs[lo:hi].to(dev), T, out=eng.X[: Bs * T], labels_out=eng._labels[:Bs])
                 stores[1].gather(xt[lo_t:hi_t].to(dev), T, out=eng.X[Bs * T:])
+                eng.refresh_bf16(x=True)
             else:
                 xs_r = torch.zeros(Bs, T, D); xs_r[: hi - lo] = xs[lo:hi]
                 xt_r = torch.zeros(Bt, T, D); xt_r[: hi_t - lo_t] = xt[lo_t:hi_t]
