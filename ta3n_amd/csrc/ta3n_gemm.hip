@@ -116,7 +116,10 @@ __device__ __attribute__((noinline)) void issue_slow(const float *__restrict__ o
 // All branches are wave-uniform.
 constexpr int K_NEVER = 1 << 28;   // "k offset" of a lane whose row is out of range: never < remaining K
 
-template <int R, int NW>
+// TW: the operand is a bf16 twin (origin points into the twin region; ld, klen, rows in ELEMENTS).  The stage holds
+// 128 k: K-contiguous rows are 16 slots of 8 bf16, a k-major stage is [128][R] bf16 - the same bytes per stage, the
+// same number of 1 KiB pieces.  The plan only marks launches whose every operand moves 16 bytes at a time.
+template <int R, int NW, bool TW = false>
 struct OperandStream {
     static constexpr int NP = R / 4 / NW;   // 1 KiB pieces per wave per stage (16-byte path)
     static_assert((R / 4) % NW == 0, "pieces must divide over the waves");
@@ -131,6 +134,28 @@ struct OperandStream {
     __device__ __forceinline__ void setup(const float *__restrict__ origin_, int ld_, int kmajor_, int klen, int r0_, int rvalid_,
                                           int wave, int lane) {
         origin = origin_; ld = ld_; kmajor = kmajor_; r0 = r0_; rvalid = rvalid_;
+        if constexpr (TW) {
+            vec = true;
+            const int ldf = ld_ >> 1;                  // floats per row of the twin
+            step = kmajor_ ? 128 * ldf : BKC;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int q = wave + NW * i;
+                if (!kmajor_) {                        // piece = 4 rows x 256 B; slot s of row r holds k = 8 (s ^ (r & 15)) .. + 7
+                    const int row = q * 4 + (lane >> 4);
+                    const int slot = (lane & 15) ^ (row & 15);
+                    p[i] = origin_ + (size_t)(r0_ + row) * ldf + 4 * slot;
+                    kofs[i] = (r0_ + row < rvalid_) ? 8 * slot : K_NEVER;
+                } else {                               // [k][R] bf16: R/8 lanes (of 8 rows each) per k row
+                    constexpr int LPR = R / 8, KPP = 64 / LPR;
+                    const int k = q * KPP + lane / LPR;
+                    const int r = r0_ + (lane % LPR) * 8;
+                    p[i] = origin_ + (size_t)k * ldf + (r >> 1);
+                    kofs[i] = (r < rvalid_) ? k : K_NEVER;
+                }
+            }
+            return;
+        }
         // 16-byte movability (base pointers and Seg offsets of 16-byte aligned regions: API contract + plan builder)
         const int off_bits = (int)(reinterpret_cast<uintptr_t>(origin_) >> 2);
         vec = kmajor_ ? (((off_bits | ld_ | r0_ | rvalid_) & 3) == 0) : (((off_bits | ld_ | klen) & 3) == 0);
@@ -194,18 +219,39 @@ __device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const floa
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
     if constexpr (BF == 2) {
-        static_assert(!AKM && !BKM && !RS, "bf16 twins: K-contiguous operands only");
-        f32x4 ta[NQ], tb[NQ];
+        // stage of 128 k; slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): eight 2-byte reads.
+        u32x4 ta[NQ], tb[NQ];
+        const unsigned short *sa16 = reinterpret_cast<const unsigned short *>(sa);
+        const unsigned short *sb16 = reinterpret_cast<const unsigned short *>(sb);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int G = wk * GPW + 2 * q + lh;
-            ta[q] = *reinterpret_cast<const f32x4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
-            tb[q] = *reinterpret_cast<const f32x4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+            if (!AKM) {
+                ta[q] = *reinterpret_cast<const u32x4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ta[q][j] = (unsigned)sa16[(8 * G + 2 * j) * BM + ra] | ((unsigned)sa16[(8 * G + 2 * j + 1) * BM + ra] << 16);
+            }
+            if (!BKM) {
+                tb[q] = *reinterpret_cast<const u32x4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    tb[q][j] = (unsigned)sb16[(8 * G + 2 * j) * BN + rb] | ((unsigned)sb16[(8 * G + 2 * j + 1) * BN + rb] << 16);
+            }
+        }
+        if (RS) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rs += __builtin_bit_cast(float, ta[q][j] << 16) + __builtin_bit_cast(float, ta[q][j] & 0xFFFF0000u);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (FULL || 4 * (wk * GPW + 2 * q) < krem)
+            if (FULL || 8 * (wk * GPW + 2 * q) < krem)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[q]), __builtin_bit_cast(bf16x8, tb[q]), acc,
                                                               0, 0, 0);
         return;
@@ -290,6 +336,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
+    constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128)
+    constexpr bool TW = BF == 2;
     constexpr int EPI = NW * 32 * 36;                // epilogue staging (one padded 32x32 block per wave)
     constexpr int LDS_FLOATS = NS * STAGE > EPI ? NS * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
@@ -336,8 +384,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         if constexpr (NS == 2) {
             // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
             // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
-            OperandStream<BM, NW> oa;
-            OperandStream<BN, NW> ob;
+            OperandStream<BM, NW, TW> oa;
+            OperandStream<BN, NW, TW> ob;
             int klen = 0, scale = SK_ONE;
             auto open_seg = [&](int sidx) {            // wave-uniform: Seg fields live in SGPRs
                 const Seg &sg = segs[sidx];
@@ -360,17 +408,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             open_seg(cseg);
             issue(0, 0);
             for (;;) {
-                const int n_chunks = (klen + BKC - 1) / BKC;
+                const int n_chunks = (klen + CH - 1) / CH;
                 for (int c = 0; c < n_chunks - 1; ++c) {             // chunks whose successor is in the same Seg (all full)
                     stage_ready();
-                    issue(buf ^ 1, (c + 1) * BKC);
+                    issue(buf ^ 1, (c + 1) * CH);
                     const float *sa = lds + buf * STAGE;
-                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                     buf ^= 1;
                 }
                 // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
                 stage_ready();
-                const int krem = klen - (n_chunks - 1) * BKC, c_scale = scale;
+                const int krem = klen - (n_chunks - 1) * CH, c_scale = scale;
                 ++cseg;
                 if (cseg < seg_end) {
                     open_seg(cseg);
@@ -389,21 +437,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             } else {
             // Two cursors walk the task's Segs chunk by chunk: the issue cursor (per-lane DMA state) runs up to NS - 1
             // chunks ahead of the compute cursor (scalar state only).
-            OperandStream<BM, NW> oa;
-            OperandStream<BN, NW> ob;
-            constexpr int LPW = OperandStream<BM, NW>::NP + OperandStream<BN, NW>::NP;   // DMAs per lane and chunk (16-byte path;
+            OperandStream<BM, NW, TW> oa;
+            OperandStream<BN, NW, TW> ob;
+            constexpr int LPW = OperandStream<BM, NW, TW>::NP + OperandStream<BN, NW, TW>::NP;   // DMAs per lane and chunk (16-byte path;
                                                                                          // the 4-byte path issues more, never fewer)
             int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
             auto open_issue_seg = [&]() {            // wave-uniform: Seg fields live in SGPRs
                 const Seg &sg = segs[i_seg];
-                i_klen = sg.klen; i_nchunks = (sg.klen + BKC - 1) / BKC; i_chunk = 0;
+                i_klen = sg.klen; i_nchunks = (sg.klen + CH - 1) / CH; i_chunk = 0;
                 oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
                          wave, lane);
                 ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
             };
             auto issue_one = [&]() {                 // stream the chunk under the issue cursor, advance the cursor
                 const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
-                const int k0 = i_chunk * BKC;
+                const int k0 = i_chunk * CH;
                 oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
                 ob.issue(k0, i_klen - k0, st + BM * BKC * 4, wave, lane, zeros);
                 i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
@@ -427,19 +475,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             for (;;) {
                 const Seg &cs = segs[cseg];
                 const int klen = cs.klen, c_scale = cs.scale_kind;
-                const int n_chunks = (klen + BKC - 1) / BKC;
+                const int n_chunks = (klen + CH - 1) / CH;
                 int c = 0;
                 // interior of the Seg: both cursors inside it, NS - 1 chunks in flight, nothing to decide per chunk
                 if (i_seg == cseg) {
                     for (; c + (NS - 1) < n_chunks; ++c) {
                         wait_landed(NS - 2);
                         const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
-                        const int k0 = (c + NS - 1) * BKC;
+                        const int k0 = (c + NS - 1) * CH;
                         oa.issue(k0, klen - k0, st, wave, lane, zeros);
                         ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
                         i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                         const float *sa = lds + c_buf * STAGE;
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                         c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     }
                     // (issue cursor inside this Seg => NS - 1 of its chunks were in flight => the loop ran and sent its last chunk)
@@ -452,9 +500,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     if (i_seg < seg_end) issue_one();
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, BKC);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * BKC);
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH);
                     c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     --ahead;
                 }
@@ -471,8 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     using F_ = std::false_type;
     {
         const Seg &s0 = segs[cseg];
-        if constexpr (BF == 2) k_loop(F_{}, F_{}, F_{});
-        else switch (s0.a_kmajor * 2 + s0.b_kmajor) {
+        switch (s0.a_kmajor * 2 + s0.b_kmajor) {
             case 0: k_loop(F_{}, F_{}, F_{}); break;
             case 1: k_loop(F_{}, T_{}, F_{}); break;
             case 2: k_loop(T_{}, F_{}, F_{}); break;
@@ -572,9 +619,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             if (f < nfan) {
                 const float *mp = ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n;
                 float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (e < nrem && mp[e] > 0.f) ? v[e] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < nrem) op[e] = mp[e] > 0.f ? v[e] : 0.f;
+                    if (e < nrem) op[e] = ov[e];
+                if (epi & EPI_TWIN16_FAN) {
+                    unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) +
+                                         ((size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n);
+                    const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
+                    if (nrem >= 4 && ((t.fan_out_off[f] | t.fan_ld) & 3) == 0) {
+                        *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+                    } else {
+                        const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16),
+                                                     (unsigned short)(hi & 0xFFFF), (unsigned short)(hi >> 16)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (e < nrem) tp[e] = h[e];
+                    }
+                }
             }
         }
     }

@@ -636,11 +636,10 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
         }
         if ((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE)) {
-            // bf16 twins.  A launch of the fused step reads twins when every one of its Segs is K-contiguous on both sides
-            // and 8-element aligned (then the stage images are byte-for-byte those of a float matrix with half the
-            // columns: the Segs are rewritten in units of two elements and the kernel feeds the 16-byte slots to the
-            // bf16 MFMA as they are).  Today that is the three forward launches; the k-major launches keep rounding
-            // fp32 operands in registers.
+            // bf16 twins.  A launch of the fused step reads twins when every one of its operands can be moved 16 bytes (8
+            // elements) at a time and has a producer that keeps the twin current; its Segs are then re-addressed into the
+            // twin regions.  Launches with odd-shaped operands (the small head weight gradients) keep rounding fp32
+            // operands in registers.
             g.ws16_span = (int32_t)p.ws_floats;
             g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
             g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
@@ -650,45 +649,83 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
                 off = origin + off / 2;
                 base = BASE_WS;
             };
-            std::vector<std::pair<int64_t, int64_t>> read16;   // ws intervals (floats) some twin-reading Seg covers
+            typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
+            auto overlaps = [](const Span &a, const Span &b) { return a.first < b.second && b.first < a.second; };
+            // who keeps a twin up to date: GEMM tiles of the fused step (their C and their fan-out copies) and the heads
+            // kernel for gHf.  A launch may read twins only of such data (plus parameters and the input).
+            std::vector<Span> produced;
+            produced.push_back({g.o_gHf, g.o_gHf + (int64_t)BT * F});
+            for (const Phase &ph : p.phases) {
+                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                    const Task &t = p.tasks[i];
+                    if (t.seg_count == 0) continue;
+                    if (t.c_base == BASE_WS) produced.push_back({t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid});
+                    for (int f = 0; f < t.fan_count; ++f)
+                        produced.push_back({t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid});
+                }
+            }
+            std::vector<Span> read16;   // ws spans some twin-reading Seg covers
             for (Phase &ph : p.phases) {
                 if (ph.group != 4 || ph.kind != PH_GEMM) continue;
                 bool ok = true;
+                std::vector<Span> reads;
+                std::vector<char> seen(p.segs.size(), 0);
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count && ok; ++i) {
                     const Task &t = p.tasks[i];
                     for (int k = t.seg_begin; k < t.seg_begin + t.seg_count && ok; ++k) {
+                        if (seen[k]) continue;
+                        seen[k] = 1;
                         const Seg &sg = p.segs[k];
-                        ok = !sg.a_kmajor && !sg.b_kmajor && ((sg.a_off | sg.a_ld | sg.b_off | sg.b_ld | sg.klen) & 7) == 0 &&
-                             sg.a_base != BASE_G && sg.b_base != BASE_G;
+                        const int a_rows = sg.pad[0] > 0 ? sg.pad[0] : t.m_valid, b_rows = t.n_valid;
+                        auto side_ok = [&](int base, int off, int ld, int kmajor, int rows) {
+                            if (base == BASE_G) return false;
+                            if (((off | ld) & 7) != 0) return false;
+                            if ((kmajor ? rows : sg.klen) & 7) return false;      // the 16-byte pieces run along rows (k-major) or k
+                            if (base == BASE_WS) {
+                                const Span rd = kmajor ? Span{off, off + (int64_t)(sg.klen - 1) * ld + rows}
+                                                       : Span{off, off + (int64_t)(rows - 1) * ld + sg.klen};
+                                bool covered = false;
+                                for (auto &pr : produced) covered = covered || overlaps(rd, pr);
+                                if (!covered) return false;
+                                reads.push_back(rd);
+                            }
+                            return true;
+                        };
+                        ok = side_ok(sg.a_base, sg.a_off, sg.a_ld, sg.a_kmajor, a_rows) &&
+                             side_ok(sg.b_base, sg.b_off, sg.b_ld, sg.b_kmajor, b_rows);
                     }
                 }
                 if (!ok) continue;
                 ph.bf16 |= 16;
-                std::vector<char> done(p.segs.size(), 0);
+                read16.insert(read16.end(), reads.begin(), reads.end());
+                std::fill(seen.begin(), seen.end(), 0);
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
                     const Task &t = p.tasks[i];
                     for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
-                        if (done[k]) continue;
-                        done[k] = 1;
-                        Seg &sg = p.segs[k];
-                        const int a_rows = sg.pad[0] > 0 ? sg.pad[0] : t.m_valid;
-                        if (sg.a_base == BASE_WS) read16.push_back({sg.a_off, sg.a_off + (int64_t)(a_rows - 1) * sg.a_ld + sg.klen});
-                        if (sg.b_base == BASE_WS) read16.push_back({sg.b_off, sg.b_off + (int64_t)(t.n_valid - 1) * sg.b_ld + sg.klen});
-                        twin(sg.a_base, sg.a_off);
-                        twin(sg.b_base, sg.b_off);
-                        sg.a_ld /= 2; sg.b_ld /= 2; sg.klen /= 2;
+                        if (seen[k]) continue;
+                        seen[k] = 1;
+                        twin(p.segs[k].a_base, p.segs[k].a_off);
+                        twin(p.segs[k].b_base, p.segs[k].b_off);
                     }
                 }
             }
-            // producers: every GEMM tile of the fused step whose output a twin-reading Seg covers also stores the twin
+            // producers whose output some twin-reading Seg covers store the twin as well
             for (const Phase &ph : p.phases) {
                 if (ph.group != 4 || ph.kind != PH_GEMM) continue;
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
                     Task &t = p.tasks[i];
-                    if (t.seg_count == 0 || t.c_base != BASE_WS) continue;
-                    const int64_t lo = t.c_off, hi = t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid;
-                    for (auto &iv : read16)
-                        if (lo < iv.second && iv.first < hi) { t.epi |= EPI_TWIN16; break; }
+                    if (t.seg_count == 0) continue;
+                    if (t.c_base == BASE_WS) {
+                        const Span out{t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid};
+                        for (auto &rd : read16)
+                            if (overlaps(out, rd)) { t.epi |= EPI_TWIN16; break; }
+                    }
+                    for (int f = 0; f < t.fan_count; ++f) {
+                        const Span out{t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid};
+                        for (auto &rd : read16)
+                            if (overlaps(out, rd)) { t.epi |= EPI_TWIN16_FAN; break; }
+                    }
                 }
             }
         }

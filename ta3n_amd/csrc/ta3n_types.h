@@ -27,6 +27,7 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_TWIN16_FAN = 1u << 10,   // same for the fan-out copies (fan_out_off)
     EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)
     EPI_ROWSUM_A = 1u << 8, // also store the K-sums of the tile's A rows to bias_base[bias_off + m] (bias gradient of a weight-gradient tile)
     EPI_SUMSQ = 1u << 7,    // workgroup side job: ws[pad[3]] = sum of squares of the stored tile (fused grad-norm partial)
@@ -82,8 +83,8 @@ struct Phase {
     int32_t task_begin, task_count;
     int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
     int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages;
-                                 // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): Segs address the bf16 twins in
-                                 // units of two elements (a_ld, klen, offsets halved)
+                                 // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): the Segs' offsets address the
+                                 // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
 };
 
 // Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.

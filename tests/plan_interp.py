@@ -177,11 +177,12 @@ class Interp:
                             return BASE_P, (off - g.o_p16) * 2
                         assert off >= g.o_ws16
                         return BASE_WS, (off - g.o_ws16) * 2
-                    assert s.a_base == BASE_WS and s.b_base == BASE_WS and not s.a_kmajor and not s.b_kmajor
+                    assert s.a_base == BASE_WS and s.b_base == BASE_WS
                     ab, ao = untwin(s.a_off); bb, bo = untwin(s.b_off)
-                    A = self.operand(ab, ao, 2 * s.a_ld, 0, t.m0, nr, 2 * s.klen)
-                    Bm = self.operand(bb, bo, 2 * s.b_ld, 0, t.n0, nc, 2 * s.klen)
-                    acc += round_bf16(A) @ round_bf16(Bm).T
+                    A = round_bf16(self.operand(ab, ao, s.a_ld, s.a_kmajor, t.m0, nr, s.klen))
+                    Bm = round_bf16(self.operand(bb, bo, s.b_ld, s.b_kmajor, t.n0, nc, s.klen))
+                    rowsum += A.sum(1)          # the bias gradient of a twin-reading tile sums the rounded values
+                    acc += A @ Bm.T
                     acc *= self.scale(s.scale_kind)
                     continue
                 A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
