@@ -11,7 +11,9 @@ videos per GPU and step, 2048-d features, 12 classes, dropout 0.5/0.5).
 
 One "step" = forward + loss + backward + (RCCL all-reduce of the flat gradient
 buffer when N > 1) + clip + Nesterov SGD on synthetic features already resident
-in HBM.  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
+in HBM.  Default arithmetic: BASELINE configs[1] (bf16 MFMA operands, fp32
+accumulation and fp32 state); --dtype f32 is configs[2]'s.  At N = 1 the other
+arithmetic is timed in the same process and reported under "other_arithmetic".  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
 prints ONE JSON line; `roofline` is measured live with HIP events on the launch
 stream, `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
 CPU path) on a bounded sample on this host.
@@ -39,6 +41,7 @@ DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 11
 # same, bf16-MFMA arithmetic: thousands digit = LDS stages (3 for the long-K launches)
 DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 2214, 2118, 3124, 2122, 2124]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
 # profiles/r01_pmc_fused_step.txt: (sum FETCH_SIZE x 2 [gfx950 half-count correction] + sum WRITE_SIZE) KiB / 6
@@ -54,6 +57,21 @@ def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
     fwd = (2 * B * T * D * F + 2 * B * T * F * (F + 2) + 2 * B * NB * F * gathered +
            (T - 1) * 2 * B * NB * (NB + 2) + 2 * B * NB * C + 2 * B * NB * (NB + 2))
     return 3 * fwd - 2 * B * T * D * F
+
+
+def algorithmic_gemm_bytes_bf16(Bs, Bt, T, D, F, C, NB):
+    """SURVEY.md 8(d) bytes of the contraction launches with bf16 operands: the input once (2 B/element), every live
+    weight read twice as bf16 (forward + backward) and its fp32 gradient written once; activations are assumed to stay on
+    chip.  (The optimiser's 5 x 4 B/parameter belong to the SGD kernel, not to this one.)"""
+    from ta3n_amd import _lib
+    B = Bs + Bt
+    plan = _lib.Plan(Bs, Bt, T, D, F, C, 0x1F)
+    live = sum(int(torch.tensor(shape).prod()) for _, _, shape, lv in plan.params if lv)
+    return B * T * D * 2 + live * (2 + 2 + 4)
+
+
+# HBM-side bytes of one GEMM launch of the bf16 step (average over the six), profiles/r01_pmc_fused_step_bf16.txt
+GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 = (2 * 61289 + 29417) * 1024 / 6
 
 
 def cpu_baseline(seconds=12.0, max_steps=40):
@@ -128,8 +146,9 @@ def main():
     ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--no-twins", action="store_true", help="bf16: round fp32 operands in registers everywhere instead of reading bf16 "
-                    "twins in the forward launches")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    "twins")
+    ap.add_argument("--single-dtype", action="store_true", help="do not also time the other arithmetic (N = 1 runs both by default)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1])")
     ap.add_argument("--phase-reps", type=int, default=20)
@@ -147,99 +166,128 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
-    phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or (
-        DEFAULT_PHASE_TILES_BF16 if args.dtype == "bf16" else DEFAULT_PHASE_TILES)
-    if args.autotune:
-        from ta3n_amd.engine import autotune_phase_tiles
-        from ta3n_amd.engine import ALL_FLAGS
-        from ta3n_amd import _lib
-        phase_tiles, _ = autotune_phase_tiles(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], device=dev,
-                                              flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if args.dtype == "bf16" else 0) |
-                                              (_lib.FLAG_BF16_STORE if args.dtype == "bf16" and not args.no_twins else 0),
-                                              candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
-    if args.tile:
-        phase_tiles = []
-    eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
-                      clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                      fused=not args.unfused, bf16=(args.dtype == "bf16"),
-                      bf16_store=(args.dtype == "bf16" and not args.no_twins))
-    shapes = {n: s for n, _, s, _ in eng.plan.params}
-    eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
-    xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)
-    eng.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
-    lr0, gamma, beta = 3e-2, 0.003, [0.75, 0.75, 0.5]
-    total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
-    eng.set_hyper(beta, gamma, lr0)
-    if args.graph:
-        eng.capture()
-
-    def step(i):
-        if args.static_hyper and eng.graph is not None:
-            eng.graph.replay()
-            return
-        p = float(i % total_steps) / total_steps
-        lr = lr0 if i == 0 else lr_dann(lr0, p)
-        if deferred:
-            eng.train_step_deferred(beta, gamma, lr)
-        else:
-            eng.train_step(beta, gamma, lr)
-
-    deferred = eng.fused and not args.graph and args.overlap
-    for i in range(args.warmup):
-        step(i)
-    eng.flush()
-
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1 or selftest:
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    eng.flush()                                  # the K-th update is inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
-    ms_per_step = 1e3 * elapsed / args.steps
-    videos = (CFG["Bs"] + CFG["Bt"]) * world * args.steps
-    value = videos / elapsed
+    def run(dtype, steps, warmup):
+        """Build an engine for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
+        bf16 = dtype == "bf16"
+        twins = bf16 and not args.no_twins
+        phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or (DEFAULT_PHASE_TILES_BF16 if bf16 else DEFAULT_PHASE_TILES)
+        if args.autotune:
+            from ta3n_amd.engine import autotune_phase_tiles
+            from ta3n_amd.engine import ALL_FLAGS
+            from ta3n_amd import _lib
+            phase_tiles, _ = autotune_phase_tiles(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], device=dev,
+                                                  flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if bf16 else 0) |
+                                                  (_lib.FLAG_BF16_STORE if twins else 0),
+                                                  candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
+        if args.tile:
+            phase_tiles = []
+        eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
+                          clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
+                          fused=not args.unfused, bf16=bf16, bf16_store=twins)
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
+        xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)
+        eng.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
+        lr0, gamma, beta = 3e-2, 0.003, [0.75, 0.75, 0.5]
+        total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
+        eng.set_hyper(beta, gamma, lr0)
+        if args.graph:
+            eng.capture()
+        deferred = eng.fused and not args.graph and args.overlap
 
-    if rank == 0:
-        finite = bool(torch.isfinite(eng.P).all().item())
+        def step(i):
+            if args.static_hyper and eng.graph is not None:
+                eng.graph.replay()
+                return
+            p = float(i % total_steps) / total_steps
+            lr = lr0 if i == 0 else lr_dann(lr0, p)
+            if deferred:
+                eng.train_step_deferred(beta, gamma, lr)
+            else:
+                eng.train_step(beta, gamma, lr)
+
+        for i in range(warmup):
+            step(i)
+        eng.flush()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        eng.flush()                                  # the K-th update is inside the timed region
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = t.item()
+        res = {"ms_per_step": 1e3 * elapsed / steps, "value": (CFG["Bs"] + CFG["Bt"]) * world * steps / elapsed}
+        if rank != 0:
+            return res
+        res["finite"] = bool(torch.isfinite(eng.P).all().item())
+        res["deferred"] = deferred
+        res["fused"] = eng.fused
         # live per-launch timing of the dominant kernel (the tile-list GEMM), HIP events on the launch stream
         phases = eng.time_phases(args.phase_reps)
         gemm = [p for p in phases if p[0] == 0]
         gemm_ms = sum(p[3] for p in gemm)
         flops = algorithmic_gemm_flops(**CFG)
-        achieved = flops / (gemm_ms * 1e-3) / 1e12
+        tflops = flops / (gemm_ms * 1e-3) / 1e12
+        extra = {"kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step)", "launches": len(gemm),
+                 "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
+                 "all_kernels_us": 1e3 * sum(p[3] for p in phases),
+                 "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]}
+        if not bf16:       # fp32 MFMA: 95 FLOP/B against a machine balance of 25 -> MFMA-bound (SURVEY 8d)
+            res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tflops / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if eng.fused else None,
+                               "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step.txt)",
+                               **extra}
+        else:              # bf16 MFMA makes the math 16x cheaper than fp32's: the binding roofline is HBM (SURVEY 8d)
+            nbytes = algorithmic_gemm_bytes_bf16(**CFG)
+            gbs = nbytes / (gemm_ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 if (eng.fused and twins) else None,
+                               "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step_bf16.txt)",
+                               "bytes_per_launch": nbytes / max(len(gemm), 1),
+                               "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
+        res["phase_tiles"] = [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]
+        return res
+
+    main_res = run(args.dtype, args.steps, args.warmup)
+    other = None
+    if world == 1 and not args.single_dtype and not selftest:   # the other arithmetic, same process, for the record
+        other = run("f32" if args.dtype == "bf16" else "bf16", max(50, args.steps // 2), max(10, args.warmup // 2))
+
+    if rank == 0:
+        arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "
+                         "(BASELINE configs[1])",
+                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic)"}
         out = {
             "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N",
-            "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "value": main_res["value"], "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "UCF->HMDB_full TA3N train step: trn-m 5 segments, RevGrad x3, TransAttn, "
                                    "attentive entropy, 128 src + 74 tgt videos per GPU-step, 2048-d features, 12 classes, "
-                                   "dropout 0.5/0.5, clip 20, Nesterov SGD (BASELINE configs[2] arithmetic, fp32)",
+                                   "dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
                        "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
-                       "launch": "hipGraph" if args.graph else "eager", "finite": finite,
-                       "step": "fused (ta3n_train_step)" if eng.fused else "forward+loss+backward",
-                       "update": "deferred: overlaps the next step's first launch" if deferred else "end of step",
-                       "phase_tiles": [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if eng.fused else None,
-                         "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step.txt)",
-                         "kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step)",
-                         "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
-                         "launches": len(gemm), "all_kernels_us": 1e3 * sum(p[3] for p in phases),
-                         "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]},
+                       "launch": "hipGraph" if args.graph else "eager", "finite": main_res["finite"],
+                       "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",
+                       "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else "end of step",
+                       "phase_tiles": main_res["phase_tiles"]},
+            "roofline": main_res["roofline"],
         }
+        if other is not None:
+            o_dtype = "f32" if args.dtype == "bf16" else "bf16"
+            out["other_arithmetic"] = {"dtype": o_dtype, "what": arith[o_dtype], "value": other["value"], "unit": "videos/s",
+                                       "ms_per_step": other["ms_per_step"], "roofline": {k: other["roofline"][k] for k in
+                                                                                         ("bound", "achieved", "peak", "unit", "frac")}}
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

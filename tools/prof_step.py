@@ -13,7 +13,7 @@ if tile == 0:                     # the bench's measured per-launch tile shapes
     bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
     phase_tiles = bench.DEFAULT_PHASE_TILES_BF16 if bf16 else bench.DEFAULT_PHASE_TILES
 bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16)
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16, bf16_store=bf16)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
 eng.refresh_bf16(x=True, params=True)
