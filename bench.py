@@ -39,7 +39,7 @@ CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
 # forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
 DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222]
 # same, bf16-MFMA arithmetic: thousands digit = LDS stages (3 for the long-K launches)
-DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 2214, 2118, 3124, 2122, 2124]
+DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2124]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 HBM_PEAK_GBS = 8000.0

@@ -613,11 +613,15 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             gw.proto = proto(BASE_G, Wcd, 2 * F);
             s.push_back(gw);
             s.push_back(ones_bias_grad(g.o_fh_bpart, 2, 2, g.n_frm_wg, bcd));
-            push_frame_disc_wgrads(s);   // gHf is ready after the heads kernel: fills the CUs this short level leaves idle
+            // dWfd: gHf is ready after the heads kernel, so it can fill the CUs this short level leaves idle - unless the
+            // next launch reads bf16 twins and this one cannot (odd-shaped head gradients): then it is cheaper there
+            const bool twins = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
+            if (!twins) push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
         {
             std::vector<GemmSpec> s;
+            if ((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE)) push_frame_disc_wgrads(s);
             push_trn_level(s);
             b.add_gemm_phase(4, s);
         }

@@ -246,8 +246,17 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
                                                   float *__restrict__ mom, float *__restrict__ ws, int n4, int norm_off, int norm_n) {
     __shared__ float red[8];
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
+    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    // the first elements are requested before the norm partials are added up: every workgroup repeats that reduction
+    // (a fixed-order sum of a few thousand floats), and the stream should not wait behind it
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, gr = p;
+    if (i < n4) { p = p4[i]; m = m4[i]; gr = g4[i]; }
     float acc = 0.f;
-    for (int i = threadIdx.x; i < norm_n; i += blockDim.x) acc += ws[norm_off + i];
+    for (int k = threadIdx.x; k < norm_n; k += blockDim.x) acc += ws[norm_off + k];
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (hy->clip > 0.f) coef = fminf(hy->clip / (total + 1e-6f), 1.f);
@@ -256,12 +265,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
         ws[g.o_grad_norm + 1] = coef;
     }
     const float lr = hy->lr, mu = hy->momentum, wd = hy->weight_decay;
-    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
-    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
-    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        float4 p = p4[i], m = m4[i];
-        const float4 gr = g4[i];
+    while (i < n4) {
+        const int nxt = i + stride;
+        float4 pn = p, mn = m, gn = gr;
+        if (nxt < n4) { pn = p4[nxt]; mn = m4[nxt]; gn = g4[nxt]; }   // next element in flight while this one is updated
         float gg[4] = {gr.x, gr.y, gr.z, gr.w};
         float pp[4] = {p.x, p.y, p.z, p.w};
         float mm[4] = {m.x, m.y, m.z, m.w};
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
         if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+        i = nxt; p = pn; m = mn; gr = gn;
     }
 }
 
@@ -441,7 +449,7 @@ int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t s
 int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream, bool fused_norm) {
     const int n4 = g.live_floats / 4;
     int blocks = (n4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, n4,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks);
