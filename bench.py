@@ -144,6 +144,7 @@ def main():
                     "the ~9 us of HBM streaming they hide)")
     ap.add_argument("--unfused", action="store_true", help="forward / loss / backward as three calls (15 launches) instead of ta3n_train_step")
     ap.add_argument("--static-hyper", action="store_true", help="diagnostic: do not upload new per-step scalars between replays")
+    ap.add_argument("--no-pipeline", action="store_true", help="update at the end of each step + separate scalar upload (ta3n_set_hyper)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--no-twins", action="store_true", help="bf16: round fp32 operands in registers everywhere instead of reading bf16 "
                     "twins")
@@ -200,6 +201,9 @@ def main():
         if args.graph:
             eng.capture()
         deferred = eng.fused and not args.graph and args.overlap
+        # default: the update of step n is the first launch of step n+1 and carries that step's scalars (no per-step
+        # host-to-device copy); the timed region ends with flush(), so it contains exactly `steps` updates
+        pipelined = eng.fused and not args.graph and not deferred and not args.no_pipeline
 
         def step(i):
             if args.static_hyper and eng.graph is not None:
@@ -209,6 +213,8 @@ def main():
             lr = lr0 if i == 0 else lr_dann(lr0, p)
             if deferred:
                 eng.train_step_deferred(beta, gamma, lr)
+            elif pipelined:
+                eng.train_step_pipelined(beta, gamma, lr)
             else:
                 eng.train_step(beta, gamma, lr)
 
@@ -231,6 +237,7 @@ def main():
             return res
         res["finite"] = bool(torch.isfinite(eng.P).all().item())
         res["deferred"] = deferred
+        res["pipelined"] = pipelined
         res["fused"] = eng.fused
         # live per-launch timing of the dominant kernel (the tile-list GEMM), HIP events on the launch stream
         phases = eng.time_phases(args.phase_reps)
@@ -279,7 +286,8 @@ def main():
                        "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
                        "launch": "hipGraph" if args.graph else "eager", "finite": main_res["finite"],
                        "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",
-                       "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else "end of step",
+                       "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
+                       ("first launch of the next step, carrying its scalars (ta3n_sgd_step_next)" if main_res["pipelined"] else "end of step"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],
         }

@@ -213,6 +213,13 @@ int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum,
 int ta3n_train_step_range(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
                           int first_launch, int n_launches, void *stream);
 
+/* The whole-prefix update of step n with its scalars passed by value, which also leaves `next` - the per-step
+ * scalars of step n+1 - in the workspace: a loop that postpones each update to the start of the next step saves
+ * the separate ta3n_set_hyper upload (one host-to-device copy per step).  Arithmetic of ta3n_sgd_step[_fused]. */
+int ta3n_sgd_step_next(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                       float lr, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *next,
+                       void *stream);
+
 /* TA3N_FLAG_BF16_STORE: (re)build the bf16 twins of x (B*T*feature_dim floats, may be NULL) and of params (may be
  * NULL) inside ws.  No-op without the flag. */
 int ta3n_refresh_bf16(ta3n_plan *plan, const float *x, const float *params, float *ws, void *stream);

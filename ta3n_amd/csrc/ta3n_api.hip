@@ -379,7 +379,24 @@ int ta3n_sgd_range(ta3n_plan *p, float *params, float *grads, float *momentum, f
         if (launch_grad_norm(p->geom, grads, ws, static_cast<hipStream_t>(stream)) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
     }
     if (launch_sgd_range(p->geom, params, grads, momentum, ws, begin, end, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
-                         static_cast<hipStream_t>(stream)) != 0)
+                         nullptr, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("sgd launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
+int ta3n_sgd_step_next(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, int fused_norm, float lr,
+                       float momentum_coef, float weight_decay, float clip, const ta3n_hyper *next, void *stream) {
+    if (!p || !params || !grads || !momentum || !ws || !next) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (fused_norm && ta3n_has_fused_step(p) != 1) return fail(TA3N_ERR_INVALID, "no fused step for this configuration");
+    static_assert(sizeof(ta3n_hyper) == sizeof(Hyper), "ta3n_hyper and its device mirror differ");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (!fused_norm) {
+        if (launch_grad_norm(p->geom, grads, ws, static_cast<hipStream_t>(stream)) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+    }
+    if (launch_sgd_range(p->geom, params, grads, momentum, ws, 0, p->live_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                         reinterpret_cast<const Hyper *>(next), static_cast<hipStream_t>(stream)) != 0)
         return fail(TA3N_ERR_HIP, std::string("sgd launch failed: ") + hipGetErrorString(hipGetLastError()));
     return TA3N_OK;
 }

@@ -109,7 +109,7 @@ int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum
                bool fused_norm = false);
 int launch_fill(float *dst, float value, int64_t n, hipStream_t stream);
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
-                     bool fused_norm, float lr, float mu, float wd, float clip, hipStream_t stream);
+                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,

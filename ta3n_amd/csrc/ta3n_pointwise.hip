@@ -12,6 +12,7 @@
 //             flat live-parameter prefix (main.py:578-583).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 
 #include "ta3n_kernels.h"
 #include "../../include/ta3n_hip.h"
@@ -365,10 +366,17 @@ __global__ __launch_bounds__(1024) void eval_metrics_kernel(Geom g, float *__res
 // of this one on a second stream, and keeps it independent of a newer ta3n_set_hyper upload.
 __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
                                                         float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
-                                                        int norm_n, float lr, float mu, float wd, float clip) {
+                                                        int norm_n, float lr, float mu, float wd, float clip, Hyper next, int has_next) {
     __shared__ float red[8];
+    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
+    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    const int stride = gridDim.x * blockDim.x;
+    int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, gr = p;
+    if (i < i1) { p = p4[i]; m = m4[i]; gr = g4[i]; }      // in flight while the norm partials are added up
     float acc = 0.f;
-    for (int i = threadIdx.x; i < norm_n; i += blockDim.x) acc += ws[norm_off + i];
+    for (int k = threadIdx.x; k < norm_n; k += blockDim.x) acc += ws[norm_off + k];
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
@@ -376,12 +384,13 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
         ws[g.o_grad_norm] = total;
         ws[g.o_grad_norm + 1] = coef;
     }
-    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
-    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
-    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
-    for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += gridDim.x * blockDim.x) {
-        float4 p = p4[i], m = m4[i];
-        const float4 gr = g4[i];
+    // the per-step scalars of the NEXT step ride along (this kernel takes its own by value and never reads ws.hyper)
+    if (has_next && blockIdx.x == 0 && threadIdx.x < (int)(sizeof(Hyper) / 4))
+        reinterpret_cast<uint32_t *>(ws + g.o_hyper)[threadIdx.x] = reinterpret_cast<const uint32_t *>(&next)[threadIdx.x];
+    while (i < i1) {
+        const int nxt = i + stride;
+        float4 pn = p, mn = m, gn = gr;
+        if (nxt < i1) { pn = p4[nxt]; mn = m4[nxt]; gn = g4[nxt]; }
         float gg[4] = {gr.x, gr.y, gr.z, gr.w};
         float pp[4] = {p.x, p.y, p.z, p.w};
         float mm[4] = {m.x, m.y, m.z, m.w};
@@ -395,6 +404,7 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
         if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+        i = nxt; p = pn; m = mn; gr = gn;
     }
 }
 
@@ -471,13 +481,17 @@ int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t 
 }
 
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
-                     bool fused_norm, float lr, float mu, float wd, float clip, hipStream_t stream) {
+                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream) {
     const int i0 = (int)(begin / 4), i1 = (int)(end / 4);
     if (i1 <= i0) return 0;
     int blocks = (i1 - i0 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
+    Hyper nh;
+    std::memset(&nh, 0, sizeof(nh));
+    if (next) nh = *next;
     hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
-                       fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip);
+                       fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip, nh,
+                       next ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

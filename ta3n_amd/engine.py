@@ -158,7 +158,7 @@ class TrainEngine:
     def set_hyper(self, beta: Sequence[float], gamma: float, lr: float, train: bool = True,
                   valid_source: Optional[int] = None, valid_target: Optional[int] = None,
                   global_source: Optional[int] = None, global_target: Optional[int] = None,
-                  seed: Optional[int] = None) -> None:
+                  seed: Optional[int] = None, upload: bool = True) -> None:
         """Per-step scalars.  global_* are the job-wide valid video counts (all ranks):
         losses are means over the GLOBAL batch like the reference's DataParallel gather
         (main.py:446, 533; loss.py:24), so ranks divide by global counts and gradients are SUMMED."""
@@ -178,6 +178,8 @@ class TrainEngine:
         for k, v in parallel.loss_normalisers(gs, gt, self.T).items():
             setattr(h, k, v)
         h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))
+        if not upload:      # the caller delivers self._hyper another way (ta3n_sgd_step_next)
+            return
         _lib.check(self._L.ta3n_set_hyper(self.plan.handle, self.ws.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
 
     # ---- launches ----
@@ -288,6 +290,29 @@ class TrainEngine:
         _lib.check(self._L.ta3n_train_step_join(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                                 self.ws.data_ptr(), self._stream(), ev), "ta3n_train_step_join")
         self.all_reduce_grads()
+        self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
+        self.step_count += 1
+
+    def train_step_pipelined(self, beta: Sequence[float], gamma: float, lr: float, **hyper_kw) -> None:
+        """train_step whose optimiser update is postponed to the start of the next call, where ONE launch applies it and
+        leaves the next step's scalars in the workspace (ta3n_sgd_step_next): no per-step host-to-device copy.  Same
+        arithmetic as train_step; call flush() before reading parameters."""
+        if not self.fused:
+            raise _lib.Ta3nError("pipelined updates need the fused step")
+        first = self._pending is None
+        self.set_hyper(beta, gamma, lr, train=True, upload=first, **hyper_kw)
+        if not first:
+            lr_p, mu, wd, clip = self._pending
+            self._pending = None
+            fused_norm = int(self.world == 1 and not self._ddp_selftest)
+            _lib.check(self._L.ta3n_sgd_step_next(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                                                  self.ws.data_ptr(), fused_norm, lr_p, mu, wd, clip, C.byref(self._hyper),
+                                                  self._stream()), "ta3n_sgd_step_next")
+        if (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2:
+            self._fused_step_overlapped_allreduce()
+        else:
+            self.fused_step()
+            self.all_reduce_grads()
         self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self.step_count += 1
 

@@ -298,7 +298,7 @@ def test_deferred_overlapped_update_is_the_same_arithmetic():
     g = Golden("tiny_T5")
     c = case_config(g)
     results = []
-    for mode in ("plain", "deferred"):
+    for mode in ("plain", "deferred", "pipelined"):
         eng = _engine(c)
         _load(eng, c)
         for i in range(4):
@@ -306,9 +306,13 @@ def test_deferred_overlapped_update_is_the_same_arithmetic():
             eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
             if mode == "plain":
                 eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3 * (i + 1), seed=i)
-            else:
+            elif mode == "deferred":
                 eng.train_step_deferred([0.75, 0.75, 0.5], 0.003, 1e-3 * (i + 1), seed=i)
+            else:       # update of step s = first launch of step s+1, which also delivers that step's scalars (ta3n_sgd_step_next)
+                eng.train_step_pipelined([0.75, 0.75, 0.5], 0.003, 1e-3 * (i + 1), seed=i)
         eng.flush()
         torch.cuda.synchronize()
-        results.append((eng.P.clone(), eng.M.clone()))
-    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+        results.append((eng.P.clone(), eng.M.clone(), eng.region("losses")[:6].clone()))
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0]) and torch.equal(results[0][1], other[1])
+        assert torch.equal(results[0][2], other[2])
