@@ -156,3 +156,31 @@ def test_twin_storage_is_the_same_arithmetic_over_several_updates():
     assert d.max().item() <= 5e-3 * scale and d.mean().item() <= 5e-5 * scale, (d.max().item(), d.mean().item(), scale)
     assert torch.allclose(l0, l1, rtol=5e-3, atol=1e-4)
     assert not torch.equal(p0, torch.zeros_like(p0))
+
+
+@pytest.mark.parametrize("shape", [dict(Bs=64, Bt=64, T=9, D=2048, F=512, C=30), dict(Bs=32, Bt=32, T=12, D=1024, F=512, C=12)])
+def test_bf16_other_baseline_config_shapes(shape):
+    """BASELINE configs[3] / [4] geometry (T = 9 / C = 30; T = 12 / D = 1024) at a reduced batch: the bf16 step with twins
+    against the fp32 step of the same engine class, loose bound (bf16 rounding), and every GEMM launch but one reads twins."""
+    from ta3n_amd.engine import TrainEngine
+    outs = []
+    for bf16 in (False, True):
+        eng = TrainEngine(shape["Bs"], shape["Bt"], shape["T"], shape["D"], shape["F"], shape["C"], dropout_i=0.0, dropout_v=0.0,
+                          bf16=bf16, bf16_store=bf16)
+        assert eng.plan.has_fused_step
+        if bf16:
+            twin = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["tile"] >= 16000]
+            assert len(twin) == 5
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=11, scale="trained"))
+        xs, xt, ys, yt = synth_batch(shape["C"], shape["T"], shape["D"], shape["Bs"], shape["Bt"], seed=21)
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3)
+        torch.cuda.synchronize()
+        outs.append(({k: v.detach().cpu().double() for k, v in eng.outputs().items()}, eng.P.detach().cpu().double()))
+    (o32, p32), (o16, p16) = outs
+    for k in ("out", "pred_rel", "pred_vid", "pred_frm"):
+        rms = o32[k].pow(2).mean().sqrt().item()
+        assert (o32[k] - o16[k]).abs().max().item() <= 0.1 * rms + 1e-6, k
+    assert torch.isfinite(p16).all()
+    assert (p32 - p16).abs().max().item() <= 0.05 * p32.abs().max().item()
