@@ -100,7 +100,9 @@ class TrainEngine:
         self._side: Optional[torch.cuda.Stream] = None
         # TA3N_DDP_SELFTEST=1: take the N > 1 code path (split launches + RCCL buckets) in a 1-rank process group
         self._ddp_selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1"
-        self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "2"))      # 1: one all-reduce after the last launch
+        # 1 (default): one all-reduce after the last launch; 2: everything but the shared frame FC's gradient is reduced while
+        # the last launch runs (worth it only when that launch is longer than an extra collective's fixed cost)
+        self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1"))
         self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None

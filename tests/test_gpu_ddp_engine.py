@@ -46,7 +46,8 @@ def _run(eng, xs, xt, ys, steps, mode, **kw):
 
 
 def _worker(rank, world, port, out, mode):
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      TA3N_DDP_BUCKETS="2" if mode == "fused" else "1")      # cover both gradient bucketings
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ta3n_amd import parallel
