@@ -213,6 +213,13 @@ int ta3n_sgd_step(ta3n_plan *plan, float *params, float *grads, float *momentum,
 int ta3n_train_step_range(ta3n_plan *plan, const float *x, const float *params, float *grads, float *ws,
                           int first_launch, int n_launches, void *stream);
 
+/* ta3n_gather_segments straight into rows [first_video, first_video + n_videos) x num_segments of a plan's input
+ * buffer x - and, with TA3N_FLAG_BF16_STORE, into the input's bf16 twin in ws in the same pass, so no
+ * ta3n_refresh_bf16 is needed for the features. */
+int ta3n_gather_segments_into(ta3n_plan *plan, const float *store, const int64_t *first_row, const int32_t *num_frames,
+                              const int32_t *labels, const int32_t *video_ids, int n_videos, int first_video, float *x,
+                              float *ws, int32_t *labels_out, void *stream);
+
 /* The whole-prefix update of step n with its scalars passed by value, which also leaves `next` - the per-step
  * scalars of step n+1 - in the workspace: a loop that postpones each update to the start of the next step saves
  * the separate ta3n_set_hyper upload (one host-to-device copy per step).  Arithmetic of ta3n_sgd_step[_fused]. */

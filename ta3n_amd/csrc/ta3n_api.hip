@@ -316,7 +316,23 @@ int ta3n_gather_segments(const float *store, const int64_t *first_row, const int
     if (n_videos < 0 || num_segments <= 0 || feature_dim <= 0) return fail(TA3N_ERR_INVALID, "bad sizes");
     if ((feature_dim & 3) == 0 && (!aligned16(store) || !aligned16(out))) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
     if (launch_gather_segments(store, first_row, num_frames, labels, video_ids, n_videos, num_segments, feature_dim, out, labels_out,
-                               segment_ids_out, static_cast<hipStream_t>(stream)) != 0)
+                               segment_ids_out, nullptr, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
+int ta3n_gather_segments_into(ta3n_plan *p, const float *store, const int64_t *first_row, const int32_t *num_frames,
+                              const int32_t *labels, const int32_t *video_ids, int n_videos, int first_video, float *x, float *ws,
+                              int32_t *labels_out, void *stream) {
+    if (!p || !store || !first_row || !num_frames || !video_ids || !x || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (labels_out && !labels) return fail(TA3N_ERR_INVALID, "labels_out needs labels");
+    const Geom &g = p->geom;
+    if (n_videos < 0 || first_video < 0 || first_video + n_videos > g.B) return fail(TA3N_ERR_INVALID, "videos outside the batch");
+    if ((g.D & 3) != 0 || !aligned16(store) || !aligned16(x) || !aligned16(ws)) return fail(TA3N_ERR_INVALID, "feature_dim % 4 and 16-byte alignment required");
+    const size_t row0 = (size_t)first_video * g.T;
+    float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
+    if (launch_gather_segments(store, first_row, num_frames, labels, video_ids, n_videos, g.T, g.D, x + row0 * g.D, labels_out, nullptr,
+                               twin, static_cast<hipStream_t>(stream)) != 0)
         return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
     return TA3N_OK;
 }

@@ -113,6 +113,6 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
-                           hipStream_t stream);
+                           float *out_twin, hipStream_t stream);
 
 }  // namespace ta3n

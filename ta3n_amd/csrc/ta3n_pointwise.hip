@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
                                                               const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
                                                               const int32_t *__restrict__ video_ids, int T, int D,
                                                               float *__restrict__ out, int32_t *__restrict__ labels_out,
-                                                              int32_t *__restrict__ seg_out) {
+                                                              int32_t *__restrict__ seg_out, uint2 *__restrict__ out16) {
     const int row = blockIdx.x, v = row / T, x = row - v * T;
     const int vid = video_ids[v];
     const int nf = num_frames[vid];
@@ -314,7 +314,12 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
     if ((D & 3) == 0) {
         const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
         float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
-        for (int i = threadIdx.x; i < D / 4; i += 256) d4[i] = s4[i];
+        uint2 *__restrict__ t2 = out16 ? out16 + (size_t)row * (D / 4) : nullptr;   // bf16 twin row (TA3N_FLAG_BF16_STORE)
+        for (int i = threadIdx.x; i < D / 4; i += 256) {
+            const float4 v4 = s4[i];
+            d4[i] = v4;
+            if (t2) t2[i] = make_uint2(pack_bf16(v4.x, v4.y), pack_bf16(v4.z, v4.w));
+        }
     } else {
         for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
     }
@@ -468,10 +473,10 @@ int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum
 
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
-                           hipStream_t stream) {
+                           float *out_twin, hipStream_t stream) {
     if (n_videos <= 0) return 0;
     hipLaunchKernelGGL(gather_segments_kernel, dim3(n_videos * T), dim3(256), 0, stream, store, first_row, num_frames, labels, video_ids,
-                       T, D, out, labels_out, seg_out);
+                       T, D, out, labels_out, seg_out, reinterpret_cast<uint2 *>(out_twin));
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

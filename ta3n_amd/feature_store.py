@@ -87,3 +87,14 @@ class FeatureStore:
         _lib.check(self._L.ta3n_gather_segments(p(self.store), p(self.first_row), p(self.num_frames), p(self.labels), p(ids), n, T, D,
                                                 p(out), p(labels_out), p(segment_ids_out), stream), "ta3n_gather_segments")
         return out.view(-1)[: n * T * D].view(n, T, D), labels_out
+
+    def gather_into(self, engine, video_ids: torch.Tensor, first_video: int, labels_out: Optional[torch.Tensor] = None) -> None:
+        """Assemble videos [first_video, first_video + n) of a TrainEngine's input batch on the device: the fp32 rows of
+        engine.X and - when the engine reads bf16 twins - the input twin, in one pass (ta3n_gather_segments_into)."""
+        ids = video_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        assert engine.D == self.feature_dim
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._L.ta3n_gather_segments_into(engine.plan.handle, p(self.store), p(self.first_row), p(self.num_frames),
+                                                     p(self.labels), p(ids), ids.numel(), int(first_video), p(engine.X), p(engine.ws),
+                                                     p(labels_out), stream), "ta3n_gather_segments_into")

@@ -83,7 +83,37 @@ def test_gather_feeds_the_train_step_input_buffer(tmp_path):
 
 
 @pytest.mark.gpu
-def test_train_script_end_to_end_from_packed_stores(tmp_path):
+def test_gather_into_writes_the_input_and_its_bf16_twin(tmp_path):
+    """ta3n_gather_segments_into: the batch rows of engine.X bit-exact with the dataset AND, for a twin-reading engine,
+    the input twin = RNE_bf16 of those rows, in the same pass."""
+    from ta3n_amd.engine import TrainEngine
+    lst, D, lengths = _make_dataset(tmp_path, D=512)
+    prefix = str(tmp_path / "packed")
+    n, dim = feature_store.pack(lst, prefix)
+    fs = feature_store.FeatureStore(prefix, dim)
+    eng = TrainEngine(6, 4, 5, 512, 64, 7, dropout_i=0.0, dropout_v=0.0, bf16=True, bf16_store=True)
+    src = torch.tensor([0, 1, 2, 3, 4, 5], dtype=torch.int32, device="cuda")
+    tgt = torch.tensor([6, 7, 8, 9], dtype=torch.int32, device="cuda")
+    fs.gather_into(eng, src, 0, labels_out=eng._labels[:6])
+    fs.gather_into(eng, tgt, 6)
+    ds = TSNDataSet("", lst, num_dataload=n, num_segments=5, new_length=1, modality="RGB", test_mode=True)
+    ref = torch.cat([ds[i][0] for i in range(10)])
+    torch.cuda.synchronize()
+    assert torch.equal(eng.X.cpu(), ref)
+    assert eng._labels[:6].tolist() == [ds[i][1] for i in range(6)]
+    twin = eng.region("x16").view(torch.int16)[: eng.X.numel()].cpu()
+    assert torch.equal(twin, ref.reshape(-1).to(torch.bfloat16).view(torch.int16))
+    for v in eng.param_views().values():
+        v.normal_(0, 0.05)
+    eng.refresh_bf16(params=True)
+    eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.P).all() and eng.losses()["loss"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arithmetic", ["f32", "bf16"])
+def test_train_script_end_to_end_from_packed_stores(tmp_path, arithmetic):
     """train_ddp.py on one GPU: batches gathered on the device from packed stores, DANN schedules, device-side
     validation - the reference's train/validate loop (main.py:228-274) without its per-frame file reads."""
     import os
@@ -98,7 +128,7 @@ def test_train_script_end_to_end_from_packed_stores(tmp_path):
            "--add_fc", "1", "--fc_dim", "64", "-b", "6", "4", "6", "--epochs", "3", "--lr", "0.01", "--lr_adaptive", "dann",
            "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "TransAttn", "--add_loss_DA", "attentive_entropy",
            "--place_adv", "Y", "Y", "Y", "--beta", "0.75", "0.75", "0.5", "--gamma", "0.003", "--print_freq", "1",
-           "--feature_store", prefix, prefix, prefix]
+           "--feature_store", prefix, prefix, prefix, "--arithmetic", arithmetic]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("Train: [") >= 3 and r.stdout.count("Test: [") == 3, r.stdout[-2000:]

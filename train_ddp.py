@@ -129,9 +129,10 @@ def main():
             lo_t, hi_t = parallel.shard_range(xt.size(0), world, rank)
             if stores:                                                                # batch assembled on the device
                 eng.X.zero_()
-                stores[0].gather(xs[lo:hi].to(dev), T, out=eng.X[: Bs * T], labels_out=eng._labels[:Bs])
-                stores[1].gather(xt[lo_t:hi_t].to(dev), T, out=eng.X[Bs * T:])
-                eng.refresh_bf16(x=True)
+                if eng.bf16_store:
+                    eng.refresh_bf16(x=True)                                            # twin of the zeroed (padding) rows
+                stores[0].gather_into(eng, xs[lo:hi].to(dev), 0, labels_out=eng._labels[:Bs])   # features + their bf16 twin
+                stores[1].gather_into(eng, xt[lo_t:hi_t].to(dev), Bs)
             else:
                 xs_r = torch.zeros(Bs, T, D); xs_r[: hi - lo] = xs[lo:hi]
                 xt_r = torch.zeros(Bt, T, D); xt_r[: hi_t - lo_t] = xt[lo_t:hi_t]
