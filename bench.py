@@ -71,7 +71,7 @@ def algorithmic_gemm_bytes_bf16(Bs, Bt, T, D, F, C, NB):
 
 
 # HBM-side bytes of one GEMM launch of the bf16 step (average over the six), profiles/r01_pmc_fused_step_bf16.txt
-GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 = (2 * 61289 + 29417) * 1024 / 6
+GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 = (2 * 55748 + 29402) * 1024 / 6
 
 
 def cpu_baseline(seconds=12.0, max_steps=40):
