@@ -57,8 +57,6 @@ def test_bf16_kernels_match_the_bf16_operand_model(name, tile, store):
     eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
     eng.set_hyper([0.75, 0.75, 0.5], 0.003, st["lr"], train=True, valid_source=st["n_src"], valid_target=st["n_tgt"])
     eng.fused_step()
-    if store:            # a second step after an update: the parameter twins written by the optimiser are the ones read
-        pass
     torch.cuda.synchronize()
 
     it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
