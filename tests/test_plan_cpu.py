@@ -103,3 +103,44 @@ def test_param_table_matches_reference_state_dict():
     offs = [o for _, o, _, _ in plan.params]
     assert all(o % 4 == 0 for o in offs) and offs == sorted(offs)
     assert plan.live_floats % 4 == 0
+
+
+@pytest.mark.parametrize("store", [False, True])
+def test_bf16_plan_on_cpu(store):
+    """TA3N_FLAG_BF16_MFMA (+ _STORE): the numpy execution of the plan with bf16-rounded contraction operands stays within
+    bf16 rounding of the reference's fp32 goldens, and with twins every re-addressed Seg lands inside a twin region."""
+    name = "tiny_T5"
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    flags = ALL_FLAGS | _lib.FLAG_BF16_MFMA | (_lib.FLAG_BF16_STORE if store else 0)
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags)
+    assert plan.has_fused_step
+    it = Interp(plan)
+    twin_phases = [ph for ph in it.phases if ph.group == 4 and ph.kind == 0 and (ph.bf16 & 16)]
+    assert len(twin_phases) == (5 if store else 0)
+    if store:
+        geo = it.g
+        lo, hi = geo.o_ws16, geo.o_x16 + (c["Bs"] + c["Bt"]) * T * c["D"] // 2
+        assert 0 <= geo.o_ws16 < geo.o_p16 < geo.o_x16
+        for ph in twin_phases:
+            for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
+                t = it.tasks[ti]
+                for si in range(t.seg_begin, t.seg_begin + t.seg_count):
+                    s = it.segs[si]
+                    assert lo <= s.a_off < hi and lo <= s.b_off < hi and s.a_base == 3 and s.b_base == 3
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    st = step_schedule(c)[0]
+    xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+    xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+    it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+    it.labels[:c["Bs"]] = ys.numpy()
+    it.hy = make_hyper(c, st, T, st["lr"])
+    it.G[:] = 0
+    it.run_group(4)
+    B, Bs = c["Bs"] + c["Bt"], c["Bs"]
+    out = it.r(it.g.o_Y, (B, c["C"]))
+    for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+        rms = g.rms(f"fwd/out_{dom}")
+        g.check(f"fwd/out_{dom}", out[sl], 0.0, 0.1 * rms, "bf16 operands vs fp32 reference")
