@@ -99,6 +99,7 @@ class Config:
     place_adv: Tuple[str, str, str] = ("Y", "Y", "Y")   # opts.py:67
     add_loss_DA: str = "attentive_entropy"            # opts.py:54
     use_attn: str = "TransAttn"
+    frame_aggregation: str = "trn-m"                  # 'avgpool' = TemPooling (models.py:246, 421-433; BASELINE configs[0])
 
     @property
     def feat_dim(self) -> int:       # models.py:129
@@ -115,6 +116,18 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
         s[name + ".weight"] = (o, i)
         s[name + ".bias"] = (o,)
 
+    if cfg.frame_aggregation == "avgpool":          # feat_aggregated_dim = feat_shared_dim (models.py:246-247), no TRN, no relation discriminators
+        lin("fc_feature_shared_source", Fd, D)
+        lin("fc_feature_source", Fd, Fd)
+        lin("fc_feature_domain", Fd, Fd)
+        lin("fc_classifier_source", C, Fd)
+        lin("fc_classifier_domain", 2, Fd)
+        lin("fc_feature_video_source", Fd, Fd)
+        lin("fc_feature_video_source_2", Fd, Fd)
+        lin("fc_feature_domain_video", Fd, Fd)
+        lin("fc_classifier_video_source", C, Fd)
+        lin("fc_classifier_domain_video", 2, Fd)
+        return s
     lin("fc_feature_shared_source", Fd, D)          # models.py:141
     lin("fc_feature_source", Fd, Fd)                # :156  (never used in fwd)
     lin("fc_feature_domain", Fd, Fd)                # :161
@@ -201,6 +214,14 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
     # frame-level adversarial branch (:456-462, :606-610)
     h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2])))
     pred_frame = _linear(p, "fc_classifier_domain", h).view(B, T, 2)
+    if cfg.frame_aggregation == "avgpool":
+        # aggregate_frames, "1. averaging" (:421-433) without attention; attn is a placeholder column (:627-628)
+        v = feat_frame.mean(1)
+        vd = v * drop_v if drop_v is not None else v                                 # :679
+        y = _linear(p, "fc_classifier_video_source", vd)                             # :686
+        hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1])))
+        pred_video = _linear(p, "fc_classifier_domain_video", hv)
+        return dict(attn=v[:, 0], out=y, pred_domain=[pred_video, pred_video, pred_frame], feat=[y, v, feat_frame])
     # TRN (:632-636)
     rel = trn_multiscale(p, feat_frame, cfg)
     # relation discriminators (:472-488)

@@ -71,9 +71,10 @@ class _FakeDP:
 
 def build_model(case):
     torch.manual_seed(1)
-    m = RefVideoModel(case["C"], "video", "trn-m", "RGB", train_segments=case["T"], val_segments=case["T"],
+    avg = case.get("agg", "trn-m") == "avgpool"       # BASELINE configs[0]: TemPooling, source-only (script_train_val.sh:103-119)
+    m = RefVideoModel(case["C"], "video", "avgpool" if avg else "trn-m", "RGB", train_segments=case["T"], val_segments=case["T"],
                       base_model=case["arch"], add_fc=1, fc_dim=case["fc_dim"], dropout_i=0.0, dropout_v=0.0,
-                      partial_bn=False, use_bn="none", ens_DA="none", use_attn="TransAttn", n_attn=1,
+                      partial_bn=False, use_bn="none", ens_DA="none", use_attn="none" if avg else "TransAttn", n_attn=1,
                       use_attn_frame="none", verbose=False, share_params="Y")
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = m.state_dict()
@@ -109,6 +110,12 @@ def make_args(case):
     a.add_fc = 1
     a.momentum = 0.9
     a.weight_decay = 1e-4
+    if case.get("agg", "trn-m") == "avgpool":      # use_target none switches every DA option off (script_train_val.sh:103-119)
+        a.use_target = "none"
+        a.adv_DA = "none"
+        a.place_adv = ["N", "N", "N"]
+        a.add_loss_DA = "none"
+        a.use_attn = "none"
     return a
 
 
@@ -118,8 +125,9 @@ def run_case(name, case):
     model = build_model(case)
     D = model.feature_dim
     T, C = case["T"], case["C"]
-    beta = [0.75, 0.75, 0.5]
-    gamma = case.get("gamma", 0.003)
+    avg = case.get("agg", "trn-m") == "avgpool"
+    beta = [0.0, 0.0, 0.0] if avg else [0.75, 0.75, 0.5]
+    gamma = 0.0 if avg else case.get("gamma", 0.003)
 
     # ---- (1) plain forward through the reference model (train mode, dropout 0) ----
     xs, xt, ys, yt = synth_batch(C, T, D, case["Bs"], case["Bt"], seed=case["xseed"])
@@ -129,8 +137,9 @@ def run_case(name, case):
     attn_s, out_s, out_s2, pd_s, feat_s, attn_t, out_t, out_t2, pd_t, feat_t = out
     put(store, "fwd/attn_s", attn_s); put(store, "fwd/attn_t", attn_t)
     put(store, "fwd/out_s", out_s); put(store, "fwd/out_t", out_t)
-    for i, nm in enumerate(("rel", "vid", "frm")):
-        put(store, f"fwd/pd_s_{nm}", pd_s[i]); put(store, f"fwd/pd_t_{nm}", pd_t[i])
+    if not avg:      # (avgpool: the discriminators are forwarded but feed nothing in the source-only configuration)
+        for i, nm in enumerate(("rel", "vid", "frm")):
+            put(store, f"fwd/pd_s_{nm}", pd_s[i]); put(store, f"fwd/pd_t_{nm}", pd_t[i])
     for i, nm in enumerate(("y", "v", "f1")):
         put(store, f"fwd/feat_s_{nm}", feat_s[i]); put(store, f"fwd/feat_t_{nm}", feat_t[i])
 
@@ -208,6 +217,11 @@ CASES = {
     "headline_init": dict(arch="resnet101", fc_dim=512, T=5, C=12, Bs=128, Bt=74, wseed=7, wscale="init",
                           xseed=1234, steps=1),
     # config-5-like shape: T=12, single 1024-d stream is not expressible (no 1024-d arch); 2048-d used
+    # BASELINE configs[0] (hmdb_ucf_small, TemPooling, source-only): avgpool aggregation, every DA option off
+    "tiny_avgpool": dict(agg="avgpool", arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=13, wscale="trained", xseed=55,
+                         steps=3, short_last=(5, 3), lr=2e-3),
+    "config1_avgpool": dict(agg="avgpool", arch="resnet101", fc_dim=512, T=5, C=5, Bs=128, Bt=74, wseed=14, wscale="trained",
+                            xseed=66, steps=2, lr=2e-3),
     "mid_T12": dict(arch="resnet101", fc_dim=128, T=12, C=12, Bs=16, Bt=16, wseed=12, wscale="trained",
                     xseed=31, steps=1, lr=2e-3),
 }

@@ -8,6 +8,7 @@ import torch
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 N_SAMP = 64
 CASES = ["tiny_T5", "tiny_T3", "tiny_T9", "tiny_T2", "tiny_clip", "headline", "headline_init", "mid_T12"]
+AVG_CASES = ["tiny_avgpool", "config1_avgpool"]      # BASELINE configs[0]: TemPooling (avgpool), source-only, every DA option off
 ARCH_DIM = dict(resnet18=512, resnet34=512, resnet50=2048, resnet101=2048, resnet152=2048)
 
 
@@ -73,7 +74,8 @@ def case_config(g):
                 xseed=int(g.meta("xseed")), steps=int(g.meta("steps")) if g.has_meta("steps") else 1,
                 lr=float(g.meta("lr")) if g.has_meta("lr") else 3e-2,
                 clip=float(g.meta("clip")) if g.has_meta("clip") else 20.0,
-                short_last=tuple(int(v) for v in g.meta("short_last")) if g.has_meta("short_last") else None)
+                short_last=tuple(int(v) for v in g.meta("short_last")) if g.has_meta("short_last") else None,
+                agg=str(g.meta("agg")) if g.has_meta("agg") else "trn-m")
 
 
 def _has_meta(self, k):

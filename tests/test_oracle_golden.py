@@ -4,7 +4,7 @@ the clipped gradients / updated parameters / DANN LR of main.train."""
 import pytest
 import torch
 
-from golden_util import CASES, Golden, case_config, step_schedule
+from golden_util import AVG_CASES, CASES, Golden, case_config, step_schedule
 from oracle import ta3n_oracle as orc
 from ta3n_amd.synthetic import synth_batch, synth_state
 
@@ -64,3 +64,43 @@ def test_beta_schedule():
     # main.py:351
     assert orc.beta_dann(0.0) == 0.0
     assert abs(orc.beta_dann(1.0) - (2.0 / (1.0 + 2.718281828459045 ** -10) - 1)) < 1e-15
+
+
+# ---- BASELINE configs[0]: TemPooling (avgpool), source-only ----
+def _setup_avg(name):
+    g = Golden(name)
+    c = case_config(g)
+    assert c["agg"] == "avgpool"
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"], dropout_i=0.0, dropout_v=0.0,
+                     place_adv=("N", "N", "N"), add_loss_DA="none", use_attn="none", frame_aggregation="avgpool")
+    params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
+    return g, c, cfg, params
+
+
+@pytest.mark.parametrize("name", AVG_CASES)
+def test_avgpool_forward_and_train_steps_match_reference(name):
+    g, c, cfg, params = _setup_avg(name)
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    with torch.no_grad():
+        s = orc.forward_domain(params, xs, [0.0, 0.0, 0.0], cfg)
+        t = orc.forward_domain(params, xt, [0.0, 0.0, 0.0], cfg)
+    for dom, o in (("s", s), ("t", t)):
+        g.check(f"fwd/attn_{dom}", o["attn"], RTOL, ATOL)
+        g.check(f"fwd/out_{dom}", o["out"], RTOL, ATOL)
+        for i, nm in enumerate(("y", "v", "f1")):
+            g.check(f"fwd/feat_{dom}_{nm}", o["feat"][i], RTOL, ATOL)
+    state = orc.TrainState(params=params, lr=c["lr"])
+    live = set(str(k) for k in g.meta("live"))
+    assert live == {"fc_feature_shared_source.weight", "fc_feature_shared_source.bias",
+                    "fc_classifier_video_source.weight", "fc_classifier_video_source.bias"}
+    for si, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs = xs.clone(); xt = xt.clone()
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        state.lr = st["lr"]
+        res = orc.train_step(state, xs, xt, ys, [0.0, 0.0, 0.0], 0.0, cfg, clip=c["clip"], n_src=st["n_src"], n_tgt=st["n_tgt"])
+        assert set(res["clipped"]) == live
+        for k in params:
+            if k in live:
+                g.check(f"step{si}/clipped_grad/{k}", res["clipped"][k], 5e-5, 5e-6)
+            g.check(f"step{si}/param/{k}", state.params[k], 5e-5, 5e-6)
