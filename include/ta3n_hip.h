@@ -55,6 +55,14 @@ typedef enum {
  * followed by ta3n_refresh_bf16.  (A bf16 feature store can feed the input twin directly.) */
 #define TA3N_FLAG_BF16_STORE     (1u << 9)
 
+/* ta3n_config.aggregation */
+#define TA3N_AGG_TRN_M    0   /* 'trn-m': multi-scale TRN - the TA3N path (TRNmodule.py:27-86) */
+#define TA3N_AGG_AVGPOOL  1   /* 'avgpool' (TemPooling, models.py:246, 421-433) in the source-only configuration of
+                               * BASELINE configs[0] (script_train_val.sh:103-119: use_target none, every DA option off):
+                               * flags must carry no TA3N_FLAG_ADV_x / _ATTN_ENTROPY / _TRANS_ATTN bit.  The step is
+                               * F1 -> mean over segments -> dropout -> classifier -> CE on the source rows -> backward;
+                               * the discriminators (forwarded by the reference, feeding nothing) are not computed. */
+
 typedef struct {
     int32_t batch_source;    /* Bs: rows of the source half (after the reference's zero padding, main.py:359-372) */
     int32_t batch_target;    /* Bt */
@@ -67,7 +75,8 @@ typedef struct {
     int32_t tile_config;     /* 0 = auto; otherwise WM*100+WN*10+WK (114, 118, 212, 122, 214, 124, 221, 222) for every GEMM phase */
     int32_t phase_tiles[16]; /* per GEMM phase (in launch order) override of tile_config; 0 = use tile_config/auto */
     int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD */
-    int32_t reserved[6];
+    int32_t aggregation;     /* TA3N_AGG_*: frame aggregation (opts.py --frame_aggregation) */
+    int32_t reserved[5];
 } ta3n_config;
 
 /* Per-step scalars; lives in device memory inside ws (region "hyper").  The host

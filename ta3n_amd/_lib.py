@@ -24,6 +24,7 @@ FLAG_ATTN_ENTROPY = 1 << 3
 FLAG_TRANS_ATTN = 1 << 4
 FLAG_BF16_MFMA = 1 << 8
 FLAG_BF16_STORE = 1 << 9
+AGG_TRN_M, AGG_AVGPOOL = 0, 1
 
 # every symbol include/ta3n_hip.h declares (tests check the export list)
 SYMBOLS = [
@@ -40,7 +41,8 @@ class Config(C.Structure):
     _fields_ = [("batch_source", C.c_int32), ("batch_target", C.c_int32), ("num_segments", C.c_int32),
                 ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
                 ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
-                ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("aggregation", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class Hyper(C.Structure):
@@ -148,13 +150,14 @@ class Plan:
 
     def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
                  num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0,
-                 phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0):
+                 phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0, aggregation: int = 0):
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
         for i, t in enumerate(phase_tiles or []):
             self.cfg.phase_tiles[i] = int(t)
         self.cfg.xcd_aware = int(xcd_aware)
+        self.cfg.aggregation = int(aggregation)       # AGG_TRN_M / AGG_AVGPOOL
         h = C.c_void_p()
         check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
         self.handle = h

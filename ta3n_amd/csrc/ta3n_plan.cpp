@@ -215,6 +215,7 @@ struct Builder {
         ph.task_count = (int32_t)local.size();
         p.phases.push_back(ph);
     }
+    void sum8_pending(int dst, int src, int rows) { sum8[0] = dst; sum8[1] = src; sum8[2] = rows; }
     void add_simple_phase(int kind, int group) {
         Phase ph;
         std::memset(&ph, 0, sizeof(ph));
@@ -222,6 +223,223 @@ struct Builder {
         p.phases.push_back(ph);
     }
 };
+
+
+typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
+
+// bf16 twins (TA3N_FLAG_BF16_STORE).  extra_produced: ws spans whose twin a non-GEMM kernel of the fused step keeps current.
+void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std::vector<Span> &extra_produced) {
+    const ta3n_config &c = p.cfg;
+    if (!((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE))) return;
+    // bf16 twins.  A launch of the fused step reads twins when every one of its operands can be moved 16 bytes (8
+    // elements) at a time and has a producer that keeps the twin current; its Segs are then re-addressed into the
+    // twin regions.  Launches with odd-shaped operands (the small head weight gradients) keep rounding fp32
+    // operands in registers.
+    g.ws16_span = (int32_t)p.ws_floats;
+    g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
+    g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
+    g.o_x16 = (int32_t)b.add_region("x16", ((int64_t)BT * D + 1) / 2);
+    auto twin = [&](int32_t &base, int32_t &off) {
+        const int32_t origin = base == BASE_WS ? g.o_ws16 : base == BASE_P ? g.o_p16 : g.o_x16;
+        off = origin + off / 2;
+        base = BASE_WS;
+    };
+    auto overlaps = [](const Span &a, const Span &b) { return a.first < b.second && b.first < a.second; };
+    // who keeps a twin up to date: GEMM tiles of the fused step (their C and their fan-out copies) and the heads
+    // kernel for gHf.  A launch may read twins only of such data (plus parameters and the input).
+    std::vector<Span> produced;   // (Span = [first, last) in ws floats)
+    for (auto &sp : extra_produced) produced.push_back(sp);
+    for (const Phase &ph : p.phases) {
+        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+            const Task &t = p.tasks[i];
+            if (t.seg_count == 0) continue;
+            if (t.c_base == BASE_WS) produced.push_back({t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid});
+            for (int f = 0; f < t.fan_count; ++f)
+                produced.push_back({t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid});
+        }
+    }
+    std::vector<Span> read16;   // ws spans some twin-reading Seg covers
+    for (Phase &ph : p.phases) {
+        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        bool ok = true;
+        std::vector<Span> reads;
+        std::vector<char> seen(p.segs.size(), 0);
+        for (int i = ph.task_begin; i < ph.task_begin + ph.task_count && ok; ++i) {
+            const Task &t = p.tasks[i];
+            for (int k = t.seg_begin; k < t.seg_begin + t.seg_count && ok; ++k) {
+                if (seen[k]) continue;
+                seen[k] = 1;
+                const Seg &sg = p.segs[k];
+                const int a_rows = sg.pad[0] > 0 ? sg.pad[0] : t.m_valid, b_rows = t.n_valid;
+                auto side_ok = [&](int base, int off, int ld, int kmajor, int rows) {
+                    if (base == BASE_G) return false;
+                    if (((off | ld) & 7) != 0) return false;
+                    if ((kmajor ? rows : sg.klen) & 7) return false;      // the 16-byte pieces run along rows (k-major) or k
+                    if (base == BASE_WS) {
+                        const Span rd = kmajor ? Span{off, off + (int64_t)(sg.klen - 1) * ld + rows}
+                                               : Span{off, off + (int64_t)(rows - 1) * ld + sg.klen};
+                        bool covered = false;
+                        for (auto &pr : produced) covered = covered || overlaps(rd, pr);
+                        if (!covered) return false;
+                        reads.push_back(rd);
+                    }
+                    return true;
+                };
+                ok = side_ok(sg.a_base, sg.a_off, sg.a_ld, sg.a_kmajor, a_rows) &&
+                     side_ok(sg.b_base, sg.b_off, sg.b_ld, sg.b_kmajor, b_rows);
+            }
+        }
+        if (!ok) continue;
+        ph.bf16 |= 16;
+        read16.insert(read16.end(), reads.begin(), reads.end());
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+            const Task &t = p.tasks[i];
+            for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
+                if (seen[k]) continue;
+                seen[k] = 1;
+                twin(p.segs[k].a_base, p.segs[k].a_off);
+                twin(p.segs[k].b_base, p.segs[k].b_off);
+            }
+        }
+    }
+    // producers whose output some twin-reading Seg covers store the twin as well
+    for (const Phase &ph : p.phases) {
+        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+            Task &t = p.tasks[i];
+            if (t.seg_count == 0) continue;
+            if (t.c_base == BASE_WS) {
+                const Span out{t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid};
+                for (auto &rd : read16)
+                    if (overlaps(out, rd)) { t.epi |= EPI_TWIN16; break; }
+            }
+            for (int f = 0; f < t.fan_count; ++f) {
+                const Span out{t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid};
+                for (auto &rd : read16)
+                    if (overlaps(out, rd)) { t.epi |= EPI_TWIN16_FAN; break; }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TA3N_AGG_AVGPOOL: BASELINE configs[0] (TemPooling, source-only).  Reference: models.py:557-579 (shared frame FC),
+// 421-433 (aggregate_frames, "1. averaging"), 679-687 (dropout_v, classifier), main.py:439-451 (CE on the source rows),
+// 574-583 (backward, clip, SGD).  Launches: F1 GEMM, pool_cls kernel, {dWsh, dWcv} GEMM, SGD.  ta3n_forward runs the first
+// two, ta3n_loss nothing, ta3n_backward the third; ta3n_train_step all three.
+int build_plan_avgpool(ta3n_plan &p, std::string &err) {
+    const ta3n_config &c = p.cfg;
+    const int Bs = c.batch_source, Bt = c.batch_target, T = c.num_segments, D = c.feature_dim;
+    const int F = std::min(c.fc_dim, c.feature_dim), C = c.num_class;
+    const int B = Bs + Bt, BT = B * T;
+    const uint32_t da_flags = TA3N_FLAG_ADV_RELATION | TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_FRAME | TA3N_FLAG_ATTN_ENTROPY | TA3N_FLAG_TRANS_ATTN;
+    if (c.flags & da_flags) { err = "avgpool is built for the source-only configuration: no adversarial / attention flags (SURVEY 8f rank 4)"; return TA3N_ERR_INVALID; }
+    if (T < 1 || T > 64) { err = "num_segments must be in [1,64]"; return TA3N_ERR_INVALID; }
+    if (F % 4 != 0) { err = "avgpool: fc_dim must be a multiple of 4"; return TA3N_ERR_INVALID; }
+    p.n_tuples = 0;
+    p.tuple_first.assign(1, 0);
+    Builder b(p);
+    // live parameters first (the all-reduce / optimiser operand), then the rest of the reference's state_dict for this configuration
+    b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141
+    b.add_linear("fc_classifier_video_source", C, F, true);            // :272 (feat_aggregated_dim = F, :246-247)
+    p.live_floats = p.param_floats;
+    b.add_linear("fc_feature_source", F, F, false);
+    b.add_linear("fc_feature_domain", F, F, false);
+    b.add_linear("fc_classifier_source", C, F, false);
+    b.add_linear("fc_classifier_domain", 2, F, false);
+    b.add_linear("fc_feature_video_source", F, F, false);
+    b.add_linear("fc_feature_video_source_2", F, F, false);
+    b.add_linear("fc_feature_domain_video", F, F, false);
+    b.add_linear("fc_classifier_domain_video", 2, F, false);
+    const int64_t Wsh = p.poff("fc_feature_shared_source.weight"), bsh = p.poff("fc_feature_shared_source.bias");
+    const int64_t Wcv = p.poff("fc_classifier_video_source.weight"), bcv = p.poff("fc_classifier_video_source.bias");
+
+    Geom &g = p.geom;
+    std::memset(&g, 0, sizeof(g));
+    g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
+    g.flags = c.flags;
+    g.o_ws16 = g.o_p16 = g.o_x16 = -1;
+    g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
+    g.o_V = (int32_t)b.add_region("V", (int64_t)B * F);
+    g.o_Vd = (int32_t)b.add_region("Vd", (int64_t)B * F);
+    g.o_Y = (int32_t)b.add_region("Y", (int64_t)B * C);
+    g.o_gY = (int32_t)b.add_region("gY", (int64_t)B * C);
+    g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
+    g.o_zeros = (int32_t)b.add_region("zeros", 64);
+    g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);
+    if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
+    g.o_losses = (int32_t)b.add_region("losses", 8);
+    g.n_norm_blocks = 256;
+    g.o_norm_part = (int32_t)b.add_region("norm_part", g.n_norm_blocks);
+    g.o_grad_norm = (int32_t)b.add_region("grad_norm", 4);
+    g.o_hyper = (int32_t)b.add_region("hyper", 32);
+    g.o_labels = (int32_t)b.add_region("labels", B);
+    g.o_tuple_first = (int32_t)b.add_region("tuple_first", 1);
+    g.n_vid_wg = B; g.n_frm_wg = 0;
+    g.o_loss_part = (int32_t)b.add_region("loss_part", (int64_t)B * 8);
+    g.o_metrics = (int32_t)b.add_region("metrics", 8);
+    g.o_confusion = (int32_t)b.add_region("confusion", (int64_t)C * C);
+    g.live_floats = (int32_t)p.live_floats;
+    g.p_Wcv = (int32_t)Wcv; g.p_bcv = (int32_t)bcv;
+
+    auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
+        GemmSpec s;
+        s.M = BT; s.N = F;
+        s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        s.proto = proto(BASE_WS, g.o_F1, F);
+        with_bias(s.proto, bsh);
+        s.proto.epi |= EPI_RELU | EPI_DROP_I;
+        s.proto.gamma_kind = SK_INV_KEEP_I;
+        s.proto.drop_ld = F;
+        return s;
+    };
+    auto grads = [&]() {
+        std::vector<GemmSpec> s;
+        GemmSpec gw;             // dWsh = gZ1^T X, dbsh = column sums of gZ1
+        gw.M = F; gw.N = D;
+        gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ1, F), KM(BASE_X, 0, D), BT));
+        gw.proto = proto(BASE_G, Wsh, D);
+        gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bsh;
+        s.push_back(gw);
+        GemmSpec gc;             // dWcv = gY^T Vd, dbcv = column sums of gY
+        gc.M = C; gc.N = F;
+        gc.segs.push_back(mkseg(KM(BASE_WS, g.o_gY, C), KM(BASE_WS, g.o_Vd, F), B));
+        gc.proto = proto(BASE_G, Wcv, F);
+        gc.proto.epi |= EPI_ROWSUM_A; gc.proto.bias_base = BASE_G; gc.proto.bias_off = (int32_t)bcv;
+        s.push_back(gc);
+        return s;
+    };
+    for (int group : {0, 4}) {           // ta3n_forward / first part of ta3n_train_step
+        std::vector<GemmSpec> s{spec_F1()};
+        b.add_gemm_phase(group, s);
+        b.add_simple_phase(PH_POOL_CLS, group);
+        if (group == 4) b.sum8_pending(g.o_losses, g.o_loss_part, B);
+        if (group == 4) { auto q = grads(); b.add_gemm_phase(4, q); }
+    }
+    b.sum8_pending(g.o_losses, g.o_loss_part, B);
+    { auto q = grads(); b.add_gemm_phase(2, q); }   // ta3n_backward (also adds up the loss partials for logging)
+    b.add_simple_phase(PH_GRAD_NORM, 3);
+    b.add_simple_phase(PH_SGD, 3);
+    // fused grad-norm partials, as in the trn-m step
+    std::vector<size_t> grad_tasks;
+    for (const Phase &ph : p.phases)
+        if (ph.group == 4 && ph.kind == PH_GEMM)
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
+                if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
+    g.n_sumsq = (int32_t)grad_tasks.size();
+    g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
+    for (size_t k = 0; k < grad_tasks.size(); ++k) {
+        p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
+        p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
+    }
+    add_bf16_twins(p, b, g, BT, D, {Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F}});   // pool_cls keeps the twin of gZ1
+    if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
+    return TA3N_OK;
+}
 
 }  // namespace
 
@@ -231,6 +449,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     const int F = std::min(c.fc_dim, c.feature_dim);   // models.py:129
     const int NB = c.num_bottleneck, C = c.num_class;
     if (Bs < 0 || Bt < 0 || Bs + Bt <= 0) { err = "batch sizes must be non-negative and not both zero"; return TA3N_ERR_INVALID; }
+    if (c.aggregation != TA3N_AGG_TRN_M && c.aggregation != TA3N_AGG_AVGPOOL) { err = "aggregation must be TA3N_AGG_TRN_M or TA3N_AGG_AVGPOOL"; return TA3N_ERR_INVALID; }
     if (T < 2 || T > 64) { err = "num_segments must be in [2,64] for trn-m"; return TA3N_ERR_INVALID; }
     if (D <= 0 || F <= 0 || C <= 0) { err = "feature_dim, fc_dim and num_class must be positive"; return TA3N_ERR_INVALID; }
     if (NB <= 0 || NB % 64 != 0 || NB > 1024) { err = "num_bottleneck must be a multiple of 64 (<= 1024)"; return TA3N_ERR_INVALID; }
@@ -249,6 +468,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    if (c.aggregation == TA3N_AGG_AVGPOOL) return build_plan_avgpool(p, err);
 
     // ---- relation tuples ----
     p.n_tuples = ta3n_num_relation_tuples(T);
@@ -639,100 +859,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
             p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
         }
-        if ((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE)) {
-            // bf16 twins.  A launch of the fused step reads twins when every one of its operands can be moved 16 bytes (8
-            // elements) at a time and has a producer that keeps the twin current; its Segs are then re-addressed into the
-            // twin regions.  Launches with odd-shaped operands (the small head weight gradients) keep rounding fp32
-            // operands in registers.
-            g.ws16_span = (int32_t)p.ws_floats;
-            g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
-            g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
-            g.o_x16 = (int32_t)b.add_region("x16", ((int64_t)BT * D + 1) / 2);
-            auto twin = [&](int32_t &base, int32_t &off) {
-                const int32_t origin = base == BASE_WS ? g.o_ws16 : base == BASE_P ? g.o_p16 : g.o_x16;
-                off = origin + off / 2;
-                base = BASE_WS;
-            };
-            typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
-            auto overlaps = [](const Span &a, const Span &b) { return a.first < b.second && b.first < a.second; };
-            // who keeps a twin up to date: GEMM tiles of the fused step (their C and their fan-out copies) and the heads
-            // kernel for gHf.  A launch may read twins only of such data (plus parameters and the input).
-            std::vector<Span> produced;
-            produced.push_back({g.o_gHf, g.o_gHf + (int64_t)BT * F});
-            for (const Phase &ph : p.phases) {
-                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
-                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
-                    const Task &t = p.tasks[i];
-                    if (t.seg_count == 0) continue;
-                    if (t.c_base == BASE_WS) produced.push_back({t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid});
-                    for (int f = 0; f < t.fan_count; ++f)
-                        produced.push_back({t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid});
-                }
-            }
-            std::vector<Span> read16;   // ws spans some twin-reading Seg covers
-            for (Phase &ph : p.phases) {
-                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
-                bool ok = true;
-                std::vector<Span> reads;
-                std::vector<char> seen(p.segs.size(), 0);
-                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count && ok; ++i) {
-                    const Task &t = p.tasks[i];
-                    for (int k = t.seg_begin; k < t.seg_begin + t.seg_count && ok; ++k) {
-                        if (seen[k]) continue;
-                        seen[k] = 1;
-                        const Seg &sg = p.segs[k];
-                        const int a_rows = sg.pad[0] > 0 ? sg.pad[0] : t.m_valid, b_rows = t.n_valid;
-                        auto side_ok = [&](int base, int off, int ld, int kmajor, int rows) {
-                            if (base == BASE_G) return false;
-                            if (((off | ld) & 7) != 0) return false;
-                            if ((kmajor ? rows : sg.klen) & 7) return false;      // the 16-byte pieces run along rows (k-major) or k
-                            if (base == BASE_WS) {
-                                const Span rd = kmajor ? Span{off, off + (int64_t)(sg.klen - 1) * ld + rows}
-                                                       : Span{off, off + (int64_t)(rows - 1) * ld + sg.klen};
-                                bool covered = false;
-                                for (auto &pr : produced) covered = covered || overlaps(rd, pr);
-                                if (!covered) return false;
-                                reads.push_back(rd);
-                            }
-                            return true;
-                        };
-                        ok = side_ok(sg.a_base, sg.a_off, sg.a_ld, sg.a_kmajor, a_rows) &&
-                             side_ok(sg.b_base, sg.b_off, sg.b_ld, sg.b_kmajor, b_rows);
-                    }
-                }
-                if (!ok) continue;
-                ph.bf16 |= 16;
-                read16.insert(read16.end(), reads.begin(), reads.end());
-                std::fill(seen.begin(), seen.end(), 0);
-                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
-                    const Task &t = p.tasks[i];
-                    for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
-                        if (seen[k]) continue;
-                        seen[k] = 1;
-                        twin(p.segs[k].a_base, p.segs[k].a_off);
-                        twin(p.segs[k].b_base, p.segs[k].b_off);
-                    }
-                }
-            }
-            // producers whose output some twin-reading Seg covers store the twin as well
-            for (const Phase &ph : p.phases) {
-                if (ph.group != 4 || ph.kind != PH_GEMM) continue;
-                for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
-                    Task &t = p.tasks[i];
-                    if (t.seg_count == 0) continue;
-                    if (t.c_base == BASE_WS) {
-                        const Span out{t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid};
-                        for (auto &rd : read16)
-                            if (overlaps(out, rd)) { t.epi |= EPI_TWIN16; break; }
-                    }
-                    for (int f = 0; f < t.fan_count; ++f) {
-                        const Span out{t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid};
-                        for (auto &rd : read16)
-                            if (overlaps(out, rd)) { t.epi |= EPI_TWIN16_FAN; break; }
-                    }
-                }
-            }
-        }
+        add_bf16_twins(p, b, g, BT, D, {Span{g.o_gHf, g.o_gHf + (int64_t)BT * F}});   // the heads kernel keeps the twin of gHf
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }

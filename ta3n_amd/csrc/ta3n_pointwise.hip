@@ -287,6 +287,76 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
     }
 }
 
+
+// TA3N_AGG_AVGPOOL (BASELINE configs[0]): everything between F1 and gZ1 for one video per workgroup.
+//   V = mean_t F1[b,t,:]  (models.py:421-433, AvgPool2d over the segments);  Vd = dropout_v(V)  (:679);  Y = Wcv Vd + bcv  (:686)
+//   loss = CE(Y[source rows], label) / n_source  (main.py:446);  gY = (softmax - onehot) / n_source on valid source rows
+//   gVd = Wcv^T gY;  gV = dropout_v'(gVd);  gZ1[b,t,:] = gV / T * [F1[b,t,:] > 0] / keep_i   (dropout_i and ReLU of the frame FC)
+// Target rows are forwarded (Y is an output) and get zero gradients, as in the reference's source-only configuration.
+__global__ __launch_bounds__(256) void pool_cls_kernel(Geom g, Ptrs ptrs) {
+    extern __shared__ float sm[];                 // [F] Vd, then [F] mask_v/keep_v, [64] Y / gY
+    float *__restrict__ s_vd = sm, *__restrict__ s_mk = sm + g.F, *__restrict__ s_y = sm + 2 * g.F;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = g.F, C = g.C, T = g.T;
+    float *__restrict__ ws = ptrs.ws;
+    const float *__restrict__ P = ptrs.p;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const bool train = hy->train != 0;
+    const bool drop_v = train && hy->p_drop_v > 0.f;
+    const float inv_keep_v = hyper_scale(hy, SK_INV_KEEP_V), inv_keep_i = hyper_scale(hy, SK_INV_KEEP_I);
+    const float inv_T = 1.f / (float)T;
+    for (int k = tid; k < F; k += 256) {
+        float v = 0.f;
+        for (int t = 0; t < T; ++t) v += ws[g.o_F1 + ((size_t)b * T + t) * F + k];
+        v *= inv_T;
+        const float mk = drop_v ? keep_mask(hy->seed_v, (uint32_t)(b * F + k), hy->p_drop_v) * inv_keep_v : 1.f;
+        ws[g.o_V + (size_t)b * F + k] = v;
+        ws[g.o_Vd + (size_t)b * F + k] = v * mk;
+        s_vd[k] = v * mk;
+        s_mk[k] = mk;
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {           // one wave per class: dot(Wcv[c,:], Vd)
+        float acc = 0.f;
+        for (int k = lane; k < F; k += 64) acc = fmaf(P[g.p_Wcv + (size_t)c * F + k], s_vd[k], acc);
+        acc = wave_allreduce_sum(acc);
+        if (lane == 0) {
+            const float y = acc + P[g.p_bcv + c];
+            s_y[c] = y;
+            ws[g.o_Y + (size_t)b * C + c] = y;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                              // softmax cross-entropy on the C <= 64 logits
+        const bool on = b < g.Bs && b < hy->valid_source;
+        const int label = on ? reinterpret_cast<const int32_t *>(ws + g.o_labels)[b] : -1;
+        const float y = lane < C ? s_y[lane] : -INFINITY;
+        const float m = wave_allreduce_max(y);
+        const float e = lane < C ? expf(y - m) : 0.f;
+        const float ls = logf(wave_allreduce_sum(e));
+        const float lp = lane < C ? y - m - ls : 0.f;
+        const float gy = (on && lane < C) ? (expf(lp) - (lane == label ? 1.f : 0.f)) * hy->inv_n_cls : 0.f;
+        const float l = wave_allreduce_sum((on && lane == label) ? -lp * hy->inv_n_cls : 0.f);
+        if (lane < C) ws[g.o_gY + (size_t)b * C + lane] = gy;
+        if (lane < 8) ws[g.o_loss_part + (size_t)b * 8 + lane] = lane < 2 ? l : 0.f;   // {loss, loss_c, 0 ...}: losses region layout
+    }
+    __syncthreads();                               // s_y is free again: reuse it for gY
+    if (tid < 64) s_y[tid] = tid < C ? ws[g.o_gY + (size_t)b * C + tid] : 0.f;
+    __syncthreads();
+    unsigned short *__restrict__ twin = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) : nullptr;
+    for (int k = tid; k < F; k += 256) {
+        float gvd = 0.f;
+        for (int c = 0; c < C; ++c) gvd = fmaf(P[g.p_Wcv + (size_t)c * F + k], s_y[c], gvd);
+        const float gf = gvd * s_mk[k] * inv_T * (train ? inv_keep_i : 1.f);
+        for (int t = 0; t < T; ++t) {
+            const size_t idx = ((size_t)b * T + t) * F + k;
+            const float gz = ws[g.o_F1 + idx] > 0.f ? gf : 0.f;
+            ws[g.o_gZ1 + idx] = gz;
+            if (twin) twin[g.o_gZ1 + idx] = (unsigned short)pack_bf16(gz, 0.f);
+        }
+    }
+}
+
 // TSNDataSet.__getitem__ for a whole batch on the device (reference dataset.py:103-116, 128-144, new_length 1):
 // one workgroup per output row (video v, segment x).  The segment index is computed in float64 exactly as the
 // reference's Python does (tick = n / T; int(tick / 2.0 + tick * x)); clips shorter than T repeat their last frame.
@@ -452,6 +522,11 @@ int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     const int rows = g.B * (1 + g.n_rel + g.T);
     hipLaunchKernelGGL(loss_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_cls_kernel, dim3(g.B), dim3(256), (2 * g.F + 64) * sizeof(float), stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

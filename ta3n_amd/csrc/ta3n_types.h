@@ -71,6 +71,7 @@ enum PhaseKind : int32_t {
     PH_GRAD_NORM = 4,
     PH_SGD = 5,
     PH_HEADS = 6,            // fused video/frame heads: forward + loss + backward between Hr/Hf and gHr/gHf
+    PH_POOL_CLS = 7,         // TA3N_AGG_AVGPOOL: mean over segments, dropout, classifier, CE and the way back to gZ1
 };
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these

@@ -60,7 +60,7 @@ class TrainEngine:
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
-                 bf16: bool = False, bf16_store: bool = False):
+                 bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m"):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
@@ -70,8 +70,14 @@ class TrainEngine:
         self.bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
         self.bf16_store = bool(flags & _lib.FLAG_BF16_STORE)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if aggregation not in ("trn-m", "avgpool"):
+            raise NotImplementedError(f"frame_aggregation {aggregation!r} (built: 'trn-m', and 'avgpool' in the source-only configuration)")
+        self.aggregation = aggregation
+        if aggregation == "avgpool":     # BASELINE configs[0]: use_target none switches every DA option off (script_train_val.sh:103-119)
+            flags &= ~ALL_FLAGS
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
-                              tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware)
+                              tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
+                              aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M)
         self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
         self.B = batch_source + batch_target
         self.F = min(fc_dim, feature_dim)
@@ -389,6 +395,9 @@ class TrainEngine:
     # ---- results ----
     def outputs(self) -> Dict[str, torch.Tensor]:
         B, T, NR = self.B, self.T, self.T - 1
+        if self.aggregation == "avgpool":      # attn is a placeholder column in the reference (models.py:627-628)
+            v = self.region("V", (B, -1))
+            return dict(out=self.region("Y", (B, self.C)), attn=v[:, 0], feat_v=v, feat_f1=self.region("F1", (B, T, self.F)))
         return dict(out=self.region("Y", (B, self.C)), attn=self.region("attn", (B, NR)),
                     pred_rel=self.region("Pr", (B, NR, 2)), pred_vid=self.region("Pv", (B, 2)),
                     pred_frm=self.region("Pf", (B, T, 2)), feat_v=self.region("V", (B, -1)),

@@ -15,7 +15,7 @@ from ta3n_amd import _lib
 
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
-PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS = range(7)
+PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS = range(8)
 HEADS_RPW = 16
 
 
@@ -78,7 +78,8 @@ def plan_arrays(plan):
     phases = C.cast(ptrs[2], C.POINTER(Phase * ns[2].value)).contents
     geom = C.cast(ptrs[3], C.POINTER(Geom)).contents
     tf = np.ctypeslib.as_array(C.cast(ptrs[5], C.POINTER(C.c_int32)), shape=(geom.n_rel + 1,)).copy()
-    tup = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_int32)), shape=(geom.n_tuples, geom.T)).copy()
+    tup = (np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_int32)), shape=(geom.n_tuples, geom.T)).copy()
+           if geom.n_tuples > 0 else np.zeros((0, geom.T), np.int32))      # TA3N_AGG_AVGPOOL has no relation tuples
     return segs, tasks, phases, geom, tup, tf
 
 
@@ -258,6 +259,32 @@ class Interp:
             Vd = V * keep_mask(h["seed_v"], idx, h["p_drop_v"]) * self.scale(5)
         self.r(g.o_Vd, (B, NB))[:] = Vd
 
+    def run_pool_cls(self):
+        """TA3N_AGG_AVGPOOL: mean over segments, dropout_v, classifier, CE on the valid source rows and the way back to gZ1
+        (ta3n_pointwise.hip: pool_cls_kernel)."""
+        g, h = self.g, self.hy
+        B, T, F, Cn = g.B, g.T, g.F, g.C
+        F1 = self.r(g.o_F1, (B, T, F))
+        V = F1.mean(1)
+        mk = np.ones((B, F), self.dtype)
+        if h["train"] and h["p_drop_v"] > 0:
+            idx = np.arange(B)[:, None] * F + np.arange(F)[None, :]
+            mk = keep_mask(h["seed_v"], idx, h["p_drop_v"]) * self.scale(5)
+        Vd = V * mk
+        Wcv = self.P[g.p_Wcv:g.p_Wcv + Cn * F].reshape(Cn, F); bcv = self.P[g.p_bcv:g.p_bcv + Cn]
+        Y = Vd @ Wcv.T + bcv
+        self.r(g.o_V, (B, F))[:] = V; self.r(g.o_Vd, (B, F))[:] = Vd; self.r(g.o_Y, (B, Cn))[:] = Y
+        b = np.arange(B)
+        on = (b < g.Bs) & (b < h["valid_source"])
+        m = Y.max(1, keepdims=True); lp = Y - m - np.log(np.exp(Y - m).sum(1, keepdims=True)); p = np.exp(lp)
+        onehot = np.zeros_like(Y); onehot[b[on], self.labels[on]] = 1
+        gY = np.where(on[:, None], (p - onehot) * h["inv_n_cls"], 0.0)
+        self.r(g.o_gY, (B, Cn))[:] = gY
+        lpart = self.r(g.o_loss_part, (B, 8)); lpart[:] = 0
+        lpart[b[on], 0] = lpart[b[on], 1] = -lp[b[on], self.labels[on]] * h["inv_n_cls"]
+        gV = (gY @ Wcv) * mk / T * self.scale(4)
+        self.r(g.o_gZ1, (B, T, F))[:] = np.where(F1 > 0, gV[:, None, :], 0.0)
+
     def run_loss(self):
         g, h = self.g, self.hy
         B, NR, T, Cn = g.B, g.n_rel, g.T, g.C
@@ -380,5 +407,6 @@ class Interp:
             elif ph.kind == PH_LOSS: self.run_loss()
             elif ph.kind == PH_POOL_BWD: self.run_pool_bwd()
             elif ph.kind == PH_HEADS: self.run_heads()
+            elif ph.kind == PH_POOL_CLS: self.run_pool_cls()
             elif ph.kind == PH_GRAD_NORM: pass
             elif ph.kind == PH_SGD: self.run_sgd(fused_norm)

@@ -144,3 +144,49 @@ def test_bf16_plan_on_cpu(store):
     for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
         rms = g.rms(f"fwd/out_{dom}")
         g.check(f"fwd/out_{dom}", out[sl], 0.0, 0.1 * rms, "bf16 operands vs fp32 reference")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", ["tiny_avgpool"])
+def test_avgpool_plan_reproduces_reference(name, fused):
+    """BASELINE configs[0] (TemPooling / avgpool, source-only): the TA3N_AGG_AVGPOOL launch lists executed with numpy against
+    the fixture the reference produced."""
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], 0, aggregation=_lib.AGG_AVGPOOL)
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    assert live == set(str(k) for k in g.meta("live"))
+    with pytest.raises(ValueError):      # adversarial / attention options are not built for avgpool
+        _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS, aggregation=_lib.AGG_AVGPOOL)
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        it.run_group(4 if fused else 0)
+        if s == 0:
+            B, Bs = c["Bs"] + c["Bt"], c["Bs"]
+            geo = it.g
+            outs = dict(out=it.r(geo.o_Y, (B, c["C"])), v=it.r(geo.o_V, (B, geo.F)), f1=it.r(geo.o_F1, (B, T, geo.F)))
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", outs["out"][sl], 5e-5, 2e-5)
+                g.check(f"fwd/attn_{dom}", outs["v"][sl][:, 0], 5e-5, 2e-5)
+                g.check(f"fwd/feat_{dom}_v", outs["v"][sl], 5e-5, 2e-5)
+                g.check(f"fwd/feat_{dom}_f1", outs["f1"][sl], 5e-5, 2e-5)
+        if not fused:
+            it.run_group(1)
+            it.run_group(2)
+        raw = it.get_params(it.G)
+        it.run_group(3, fused_norm=fused)
+        coef = it.ws[it.g.o_grad_norm + 1]
+        new = it.get_params()
+        for k in shapes:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
