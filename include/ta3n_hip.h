@@ -72,7 +72,8 @@ typedef struct {
     int32_t num_bottleneck;  /* 256 for trn-m (models.py:223) */
     int32_t num_class;       /* C */
     uint32_t flags;          /* TA3N_FLAG_* */
-    int32_t tile_config;     /* 0 = auto; otherwise WM*100+WN*10+WK (114, 118, 212, 122, 214, 124, 221, 222) for every GEMM phase */
+    int32_t tile_config;     /* 0 = auto; otherwise WM*100+WN*10+WK (114, 118, 212, 122, 214, 124, 221, 222) for every GEMM phase;
+                              * + 2000 / 3000: LDS stages of the bf16 kernels (default: 3 when every tile streams K >= 1024) */
     int32_t phase_tiles[16]; /* per GEMM phase (in launch order) override of tile_config; 0 = use tile_config/auto */
     int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD */
     int32_t aggregation;     /* TA3N_AGG_*: frame aggregation (opts.py --frame_aggregation) */
