@@ -19,6 +19,7 @@ stream, `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
 CPU path) on a bounded sample on this host.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -221,6 +222,8 @@ def main():
         for i in range(warmup):
             step(i)
         eng.flush()
+        gc.collect()
+        gc.disable()                                 # eager launches: a collector pause on the host would show up as GPU idle time
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -228,6 +231,7 @@ def main():
         eng.flush()                                  # the K-th update is inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
