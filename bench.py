@@ -13,7 +13,8 @@ One "step" = forward + loss + backward + (RCCL all-reduce of the flat gradient
 buffer when N > 1) + clip + Nesterov SGD on synthetic features already resident
 in HBM.  Default arithmetic: BASELINE configs[1] (bf16 MFMA operands, fp32
 accumulation and fp32 state); --dtype f32 is configs[2]'s.  At N = 1 the other
-arithmetic is timed in the same process and reported under "other_arithmetic".  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
+arithmetic is timed in the same process and reported under "other_arithmetic" (at every N:
+with --gpus 8 that is configs[2], fp32 DDP).  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
 prints ONE JSON line; `roofline` is measured live with HIP events on the launch
 stream, `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
 CPU path) on a bounded sample on this host.
@@ -272,7 +273,7 @@ def main():
 
     main_res = run(args.dtype, args.steps, args.warmup)
     other = None
-    if world == 1 and not args.single_dtype and not selftest:   # the other arithmetic, same process, for the record
+    if not args.single_dtype and not selftest:   # the other arithmetic, same process (all ranks), for the record: at N > 1 the fp32 line is BASELINE configs[2]
         other = run("f32" if args.dtype == "bf16" else "bf16", max(50, args.steps // 2), max(10, args.warmup // 2))
 
     if rank == 0:
