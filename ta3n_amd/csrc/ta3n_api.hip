@@ -91,7 +91,7 @@ void ta3n::set_error(const std::string &msg) { g_err = msg; }
 extern "C" {
 
 const char *ta3n_last_error(void) { return g_err.c_str(); }
-const char *ta3n_version(void) { return "ta3n_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+const char *ta3n_version(void) { return "ta3n_hip 0.2 (gfx950, fp32 MFMA 32x32x2 | bf16 MFMA 32x32x16 with fp32 accumulation)"; }
 
 int ta3n_plan_create(const ta3n_config *cfg, ta3n_plan **out) {
     if (!cfg || !out) return fail(TA3N_ERR_INVALID, "null argument");
