@@ -268,7 +268,7 @@ def main():
                                "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step_bf16.txt)",
                                "bytes_per_launch": nbytes / max(len(gemm), 1),
                                "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
-        res["phase_tiles"] = [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0]
+        res["phase_tiles"] = [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] != 5]
         return res
 
     main_res = run(args.dtype, args.steps, args.warmup)

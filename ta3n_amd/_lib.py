@@ -32,7 +32,7 @@ SYMBOLS = [
     "ta3n_plan_destroy", "ta3n_num_params", "ta3n_param_info", "ta3n_param_floats", "ta3n_live_param_floats",
     "ta3n_workspace_floats", "ta3n_ws_offset", "ta3n_ws_size", "ta3n_plan_describe", "ta3n_set_hyper",
     "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step", "ta3n_eval_metrics",
-    "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_num_phases",
+    "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_last_error", "ta3n_version",
 ]
 
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
     L.ta3n_train_step_join.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.ta3n_train_step_range.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     L.ta3n_refresh_bf16.argtypes = [vp, vp, vp, vp, vp]
+    L.ta3n_has_pipelined_step.argtypes = [vp]
+    L.ta3n_train_step_after_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_gather_segments_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_sgd_step_next.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_num_phases.argtypes = [vp, C.c_int]
@@ -154,7 +156,7 @@ class Plan:
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
-        for i, t in enumerate(phase_tiles or []):
+        for i, t in enumerate((phase_tiles or [])[:16]):      # (launches past the 16th mirror an earlier one or use tile_config)
             self.cfg.phase_tiles[i] = int(t)
         self.cfg.xcd_aware = int(xcd_aware)
         self.cfg.aggregation = int(aggregation)       # AGG_TRN_M / AGG_AVGPOOL

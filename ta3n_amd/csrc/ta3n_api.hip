@@ -52,7 +52,8 @@ int ensure_uploaded(ta3n_plan *p) {
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream,
-              hipEvent_t join_after_first = nullptr, int first_launch = 0, int n_launches = 1 << 30) {
+              hipEvent_t join_after_first = nullptr, int first_launch = 0, int n_launches = 1 << 30,
+              const SgdSide *side = nullptr) {
     bool first = true;
     int index = -1;
     for (const Phase &ph : p->phases) {
@@ -68,7 +69,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
         switch (ph.kind) {
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
-                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream);
+                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side);
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -372,6 +373,38 @@ int ta3n_train_step_range(ta3n_plan *p, const float *x, const float *params, flo
     if (rc != TA3N_OK) return rc;
     Ptrs ptrs{x, params, grads, ws};
     return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, first_launch, n_launches);
+}
+
+int ta3n_has_pipelined_step(const ta3n_plan *p) {
+    if (!p) return TA3N_ERR_INVALID;
+    for (const Phase &ph : p->phases)
+        if (ph.group == 5) return 1;
+    return 0;
+}
+
+int ta3n_train_step_after_update(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws,
+                                 int fused_norm, float lr, float momentum_coef, float weight_decay, float clip,
+                                 const ta3n_hyper *next, void *stream) {
+    if (!p || !x || !params || !grads || !momentum || !ws || !next) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(momentum) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_pipelined_step(p) != 1) return fail(TA3N_ERR_INVALID, "no pipelined step for this configuration");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geom &g = p->geom;
+    if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+    // (1) the update of the shared frame FC - the only parameters the next launch reads - and the new step's scalars
+    if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                         reinterpret_cast<const Hyper *>(next), s) != 0)
+        return fail(TA3N_ERR_HIP, "sgd launch failed");
+    // (2) the new step's first launch, with the rest of the update as side tasks; (3) the other launches of the step
+    SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
+                 fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
+    Ptrs ptrs{x, params, grads, ws};
+    rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side);
+    if (rc != TA3N_OK) return rc;
+    return run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30);
 }
 
 int ta3n_refresh_bf16(ta3n_plan *p, const float *x, const float *params, float *ws, void *stream) {

@@ -35,6 +35,7 @@
 // The epilogue goes through LDS once more so the K-split partials are reduced
 // and the stores / bias / mask operands are row-contiguous float4s.
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <type_traits>
 
@@ -332,7 +333,7 @@ namespace ta3n {
 // loop is latency-bound and a third stage pays for long K; short-K tasks prefer the extra resident workgroup of NS = 2).
 template <int WM, int WN, int WK, int BF, int NS>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
-                                                                 Ptrs ptrs, int hyper_off, int zeros_off, int twin_off) {
+                                                                 Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
@@ -349,6 +350,37 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     const Task &t = tasks[blockIdx.x];
+    if (t.epi & EPI_SGD) {          // optimiser side job (uniform for the workgroup): arithmetic and summation order of sgd_range_kernel
+        if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
+        float part = 0.f;
+        if (tid < 256)
+            for (int k = tid; k < side.norm_n; k += 256) part += ptrs.ws[side.norm_off + k];
+        part = wave_allreduce_sum(part);
+        if (lane == 0 && wave < 4) lds[wave] = part;
+        __syncthreads();
+        const float total = sqrtf(((lds[0] + lds[1]) + lds[2]) + lds[3]);
+        float coef = 1.f;
+        if (side.clip > 0.f) coef = fminf(side.clip / (total + 1e-6f), 1.f);
+        float4 *__restrict__ p4 = reinterpret_cast<float4 *>(side.params);
+        float4 *__restrict__ m4 = reinterpret_cast<float4 *>(side.momentum);
+        const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(ptrs.g);
+        for (int i = t.pad[0] + tid; i < t.pad[1]; i += NT) {
+            const float4 p = p4[i], m = m4[i], gr = g4[i];
+            float gg[4] = {gr.x, gr.y, gr.z, gr.w}, pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = fmaf(side.wd, pp[e], gg[e] * coef);
+                mm[e] = fmaf(side.mu, mm[e], d);
+                d = fmaf(side.mu, mm[e], d);
+                pp[e] = fmaf(-side.lr, d, pp[e]);
+            }
+            p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            if (side.p16_off >= 0)
+                reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+        }
+        return;
+    }
     if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
     if (t.epi & EPI_SUMROWS8) {   // side job of one workgroup per fused step: add up the heads kernel's loss partials in a fixed order
         const float *__restrict__ src = ptrs.ws + t.pad[1];
@@ -672,11 +704,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
 
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
-    template __global__ void gemm_tiles<wm, wn, wk, 0, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 3>(const Task *, const Seg *, Ptrs, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 2>(const Task *, const Seg *, Ptrs, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 3>(const Task *, const Seg *, Ptrs, int, int, int);
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 3>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 
 bool tile_config_ok(int cfg) {
@@ -689,15 +721,19 @@ bool tile_config_ok(int cfg) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream) {
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side) {
     if (ph.task_count == 0) return 0;
+    SgdSide sd;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.p16_off = -1;
+    if (side) sd = *side;
     const dim3 grid(ph.task_count);
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
     hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
-                       hyper_off, zeros_off, twin_off)
+                       hyper_off, zeros_off, twin_off, sd)
 #define TA3N_LAUNCH(wm, wn, wk)                                   \
     if (cfg == wm * 100 + wn * 10 + wk) {                         \
         switch (ph.bf16) {                                        \

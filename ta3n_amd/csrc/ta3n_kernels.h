@@ -13,6 +13,16 @@ struct Ptrs {
     float *ws;        // BASE_WS workspace
 };
 
+// Side job of a GEMM launch (EPI_SGD tasks): the optimiser update of a parameter range, with its scalars by value.
+// ta3n_train_step_after_update puts the update of everything but the shared frame FC into the first launch of the
+// next step, whose own tiles only read the shared frame FC.
+struct SgdSide {
+    float *params, *momentum;
+    float lr, mu, wd, clip;
+    int32_t norm_off, norm_n;    // ws offsets of the squared-norm partials (fused per-tile slots or the grad_norm kernel's)
+    int32_t p16_off;             // ws offset of the parameter twins, -1: none
+};
+
 __device__ __forceinline__ float hyper_scale(const Hyper *__restrict__ hy, int kind) {
     switch (kind) {
         case SK_NEG_BETA_REL: return -hy->beta[0];
@@ -87,7 +97,7 @@ __device__ __forceinline__ Soft2 soft2(float z0, float z1) {
 
 bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream);
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side = nullptr);
 #if defined(__HIPCC__)
 // two floats -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), low half = first argument
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {

@@ -95,6 +95,7 @@ struct Builder {
     }
 
     int gemm_phase_index = 0;
+    int force_next = 0;         // tile code for the next add_gemm_phase only (a launch that mirrors an earlier one)
     bool mixed_kinds = false;   // a GEMM spec whose Segs differ in operand kinds (not supported by the kernel)
     int sum8[3] = {-1, 0, 0};   // {dst, src, rows}: when dst >= 0 the first workgroup of the next GEMM phase also sums an [rows][8] table
 
@@ -102,8 +103,13 @@ struct Builder {
     void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
         int wm = 1, wn = 1, wk = 4;
         int forced = p.cfg.tile_config;
-        if (gemm_phase_index < 16 && p.cfg.phase_tiles[gemm_phase_index] != 0) forced = p.cfg.phase_tiles[gemm_phase_index];
-        ++gemm_phase_index;
+        if (force_next != 0) {
+            forced = force_next;
+            force_next = 0;
+        } else {
+            if (gemm_phase_index < 16 && p.cfg.phase_tiles[gemm_phase_index] != 0) forced = p.cfg.phase_tiles[gemm_phase_index];
+            ++gemm_phase_index;
+        }
         const int forced_stages = forced / 1000;
         forced %= 1000;
         if (forced != 0) {
@@ -250,7 +256,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     std::vector<Span> produced;   // (Span = [first, last) in ws floats)
     for (auto &sp : extra_produced) produced.push_back(sp);
     for (const Phase &ph : p.phases) {
-        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
         for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
             const Task &t = p.tasks[i];
             if (t.seg_count == 0) continue;
@@ -261,7 +267,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     }
     std::vector<Span> read16;   // ws spans some twin-reading Seg covers
     for (Phase &ph : p.phases) {
-        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
         bool ok = true;
         std::vector<Span> reads;
         std::vector<char> seen(p.segs.size(), 0);
@@ -306,7 +312,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     }
     // producers whose output some twin-reading Seg covers store the twin as well
     for (const Phase &ph : p.phases) {
-        if (ph.group != 4 || ph.kind != PH_GEMM) continue;
+        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
         for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
             Task &t = p.tasks[i];
             if (t.seg_count == 0) continue;
@@ -846,6 +852,29 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             b.add_gemm_phase(4, s);
         }
         { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }
+        {   // group 5: the step's first launch once more, carrying the PREVIOUS step's optimiser update of every parameter
+            // it does not read itself (all but the shared frame FC) as EPI_SGD side tasks (ta3n_train_step_after_update)
+            const Phase *f1 = nullptr;
+            for (const Phase &ph : p.phases)
+                if (ph.group == 4 && ph.kind == PH_GEMM) { f1 = &ph; break; }
+            b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15);
+            std::vector<GemmSpec> s{spec_F1()};
+            b.add_gemm_phase(5, s);
+            p.first_floats = P("fc_feature_domain.weight");      // = end of fc_feature_shared_source.{weight,bias} (first in the layout)
+            const int64_t i0 = p.first_floats / 4, i1 = p.live_floats / 4;
+            const int n_side = 256;
+            const int64_t per = (i1 - i0 + n_side - 1) / n_side;
+            for (int k = 0; k < n_side; ++k) {
+                Task t;
+                std::memset(&t, 0, sizeof(t));
+                t.epi = EPI_SGD;
+                t.c_base = BASE_NONE; t.bias_base = BASE_NONE; t.aux_base = BASE_NONE; t.add_base = BASE_NONE;
+                t.pad[0] = (int32_t)std::min(i0 + per * k, i1);
+                t.pad[1] = (int32_t)std::min(i0 + per * (k + 1), i1);
+                p.tasks.push_back(t);
+            }
+            p.phases.back().task_count += n_side;
+        }
         // every gradient tile of the fused step leaves the sum of its squares in its own slot: the optimiser
         // (ta3n_sgd_step_fused) adds the slots in a fixed order instead of re-reading the gradient buffer
         std::vector<size_t> grad_tasks;

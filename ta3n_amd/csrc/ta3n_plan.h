@@ -24,6 +24,7 @@ struct ta3n_plan {
     ta3n::Geom geom;
     std::vector<ParamInfo> params;
     int64_t param_floats = 0, live_floats = 0;
+    int64_t first_floats = 0;   // size of the leading parameter block the step's first launch reads (shared frame FC weight + bias)
     std::vector<Region> regions;
     int64_t ws_floats = 0;
     std::vector<ta3n::Seg> segs;

@@ -27,6 +27,7 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_SGD = 1u << 11,     // not a tile: the workgroup applies the optimiser update to params[4 pad[0] .. 4 pad[1]) (SgdSide)
     EPI_TWIN16_FAN = 1u << 10,   // same for the fan-out copies (fan_out_off)
     EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)
     EPI_ROWSUM_A = 1u << 8, // also store the K-sums of the tile's A rows to bias_base[bias_off + m] (bias gradient of a weight-gradient tile)

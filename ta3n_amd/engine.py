@@ -106,6 +106,9 @@ class TrainEngine:
         self._side: Optional[torch.cuda.Stream] = None
         # TA3N_DDP_SELFTEST=1: take the N > 1 code path (split launches + RCCL buckets) in a 1-rank process group
         self._ddp_selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1"
+        # TA3N_SIDE_UPDATE=0: keep the pipelined update a launch of its own (ta3n_sgd_step_next)
+        self._side_update = (os.environ.get("TA3N_SIDE_UPDATE", "1") == "1" and
+                             self._L.ta3n_has_pipelined_step(self.plan.handle) == 1)
         # 1 (default): one all-reduce after the last launch; 2: everything but the shared frame FC's gradient is reduced while
         # the last launch runs (worth it only when that launch is longer than an extra collective's fixed cost)
         self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1"))
@@ -309,17 +312,28 @@ class TrainEngine:
             raise _lib.Ta3nError("pipelined updates need the fused step")
         first = self._pending is None
         self.set_hyper(beta, gamma, lr, train=True, upload=first, **hyper_kw)
+        two_buckets = (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2
+        stepped = False
         if not first:
             lr_p, mu, wd, clip = self._pending
             self._pending = None
             fused_norm = int(self.world == 1 and not self._ddp_selftest)
-            _lib.check(self._L.ta3n_sgd_step_next(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
-                                                  self.ws.data_ptr(), fused_norm, lr_p, mu, wd, clip, C.byref(self._hyper),
-                                                  self._stream()), "ta3n_sgd_step_next")
-        if (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2:
+            if self._side_update and not two_buckets:
+                # the update of everything but the shared frame FC rides in the new step's first launch
+                _lib.check(self._L.ta3n_train_step_after_update(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(),
+                                                                self.G.data_ptr(), self.M.data_ptr(), self.ws.data_ptr(), fused_norm,
+                                                                lr_p, mu, wd, clip, C.byref(self._hyper), self._stream()),
+                           "ta3n_train_step_after_update")
+                stepped = True
+            else:
+                _lib.check(self._L.ta3n_sgd_step_next(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                                                      self.ws.data_ptr(), fused_norm, lr_p, mu, wd, clip, C.byref(self._hyper),
+                                                      self._stream()), "ta3n_sgd_step_next")
+        if two_buckets:
             self._fused_step_overlapped_allreduce()
         else:
-            self.fused_step()
+            if not stepped:
+                self.fused_step()
             self.all_reduce_grads()
         self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self.step_count += 1

@@ -40,7 +40,7 @@ def test_bf16_kernels_match_the_bf16_operand_model(name, tile, store):
     eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"],
                       tile_config=tile, bf16=True, bf16_store=store)
     assert eng.bf16 and eng.bf16_store == store
-    twin_launches = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["tile"] >= 16000]
+    twin_launches = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] == 4 and ph["tile"] >= 16000]
     # F1, F2 (Hf + TRN tuples), F3 (relation discriminator hidden layer), TRN gradients, shared-FC weight gradient;
     # the launch with the small head weight gradients (odd shapes) keeps rounding fp32 operands
     assert len(twin_launches) == (5 if store else 0), [ph["tile"] for ph in eng.plan.description["phases"]]
@@ -132,7 +132,11 @@ def test_twin_storage_is_the_same_arithmetic_over_several_updates():
         for step in range(3):
             xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=100 + step)
             eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
-            eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
+            if store:      # the update rides in the next step's first launch (EPI_SGD side tasks write parameters AND twins)
+                eng.train_step_pipelined([0.75, 0.75, 0.5], 0.003, 0.03)
+            else:
+                eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
+        eng.flush()
         torch.cuda.synchronize()
         if store:   # every twin is exactly the round-to-nearest-even bf16 of its fp32 original, after three updates
             def twin_bits(name, n):
@@ -167,7 +171,7 @@ def test_bf16_other_baseline_config_shapes(shape):
                           bf16=bf16, bf16_store=bf16)
         assert eng.plan.has_fused_step
         if bf16:
-            twin = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["tile"] >= 16000]
+            twin = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] == 4 and ph["tile"] >= 16000]
             assert len(twin) == 5
         shapes = {n: s for n, _, s, _ in eng.plan.params}
         eng.load_state(synth_state(shapes, seed=11, scale="trained"))
