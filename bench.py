@@ -292,7 +292,8 @@ def main():
                        "launch": "hipGraph" if args.graph else "eager", "finite": main_res["finite"],
                        "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",
                        "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
-                       ("first launch of the next step, carrying its scalars (ta3n_sgd_step_next)" if main_res["pipelined"] else "end of step"),
+                       ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "
+                        "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],
         }
