@@ -186,3 +186,43 @@ def test_bf16_other_baseline_config_shapes(shape):
         assert (o32[k] - o16[k]).abs().max().item() <= 0.1 * rms + 1e-6, k
     assert torch.isfinite(p16).all()
     assert (p32 - p16).abs().max().item() <= 0.05 * p32.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [dict(Bs=3, Bt=2, T=4, D=100, F=36, C=7), dict(Bs=5, Bt=0, T=3, D=72, F=40, C=3),
+                                   dict(Bs=2, Bt=7, T=6, D=64, F=64, C=12)])
+def test_bf16_twins_fall_back_per_launch_on_odd_shapes(shape):
+    """Dimensions that are not multiples of 8: the launches whose operands cannot move 16 bytes at a time keep rounding fp32
+    operands in registers, the others read twins - and the whole step still matches the bf16-operand model of its plan."""
+    from ta3n_amd.engine import TrainEngine
+    eng = TrainEngine(shape["Bs"], shape["Bt"], shape["T"], shape["D"], shape["F"], shape["C"], dropout_i=0.0, dropout_v=0.0,
+                      bf16=True, bf16_store=True)
+    plan = _lib.Plan(shape["Bs"], shape["Bt"], shape["T"], shape["D"], shape["F"], shape["C"], ALL | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE)
+    it = Interp(plan)
+    T, B = shape["T"], shape["Bs"] + shape["Bt"]
+    shapes = {n: s for n, _, s, _ in plan.params}
+    state = synth_state(shapes, seed=5, scale="trained")
+    eng.load_state(state)
+    it.set_params(state)
+    xs, xt, ys, yt = synth_batch(shape["C"], T, shape["D"], shape["Bs"], shape["Bt"], seed=17)
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3, train=True)
+    eng.fused_step()
+    torch.cuda.synchronize()
+    n_s, n_t = shape["Bs"], shape["Bt"]
+    it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+    it.labels[:n_s] = ys.numpy()
+    it.hy = dict(beta=[0.75, 0.75, 0.5], gamma=0.003, lr=1e-3, momentum=0.9, weight_decay=1e-4, clip=20.0, p_drop_i=0.0, p_drop_v=0.0,
+                 seed_i=1, seed_v=2, inv_n_cls=1.0 / max(n_s, 1), inv_n_rel=1.0 / ((n_s + n_t) * (T - 1)), inv_n_vid=1.0 / (n_s + n_t),
+                 inv_n_frm=1.0 / ((n_s + n_t) * T), inv_n_ent=1.0 / (n_s + n_t), valid_source=n_s, valid_target=n_t, train=1)
+    it.G[:] = 0
+    it.run_group(4)
+    o = {k: v.detach().cpu().numpy() for k, v in eng.outputs().items()}
+    geo = it.g
+    want = dict(out=it.r(geo.o_Y, (B, shape["C"])), pred_rel=it.r(geo.o_Pr, (B, T - 1, 2)), pred_vid=it.r(geo.o_Pv, (B, 2)),
+                pred_frm=it.r(geo.o_Pf, (B, T, 2)), feat_v=it.r(geo.o_V, (B, 256)))
+    for k, w in want.items():
+        _close(f"fwd/{k}", o[k].reshape(w.shape), w, 2e-4, 2e-5)
+    got_g = {k: v.cpu().numpy() for k, v in eng.param_views(eng.G).items()}
+    want_g = it.get_params(it.G)
+    for k in eng.live_names():
+        _close(f"grad/{k}", got_g[k], want_g[k].reshape(got_g[k].shape), 2e-3, 2e-4)
