@@ -17,6 +17,15 @@ Parity pin: ``tests/golden/*.npz`` were produced by running the reference's own
 module against every fixture.  The reference ships no tests or golden vectors
 of its own.
 
+Two arithmetics (``Config.arithmetic``):
+  * ``"fp32"`` - the reference's own arithmetic (ATen CPU fp32); pinned by the goldens.
+  * ``"bf16"`` - BASELINE configs[1]: the SAME graph, but every contraction the HIP path runs on the bf16 matrix cores
+    rounds BOTH operands to bf16 (round to nearest even) and multiplies / accumulates in fp32 (``_MatmulBf16``).
+    Which contractions those are is the arithmetic contract of the bf16 configuration, written down per reference layer
+    in ``BF16_POLICY`` (and in DESIGN.md section 5); parameters, biases, softmax / entropy / losses, GradReverse scales and the
+    optimiser stay fp32.  This mode is independent of the product's launch descriptors: it is derived from the reference's
+    layer structure only, and it is what tests/test_gpu_bf16.py compares the HIP bf16 path with.
+
 Scope: frame_aggregation='trn-m', baseline_type='video', share_params='Y',
 use_bn='none', use_attn='TransAttn', add_fc=1, adv_DA='RevGrad' - the
 UCF->HMDB_full TA3N configuration of script_train_val.sh.
@@ -100,6 +109,9 @@ class Config:
     add_loss_DA: str = "attentive_entropy"            # opts.py:54
     use_attn: str = "TransAttn"
     frame_aggregation: str = "trn-m"                  # 'avgpool' = TemPooling (models.py:246, 421-433; BASELINE configs[0])
+    arithmetic: str = "fp32"                          # 'bf16': BASELINE configs[1] (bf16 MFMA operands, fp32 accumulation)
+    bf16_twins: bool = True                           # bf16 only: operands are read from bf16 copies (TA3N_FLAG_BF16_STORE), so a bias
+                                                      # gradient made by a weight-gradient launch sums ROUNDED values (BF16_POLICY bias16)
 
     @property
     def feat_dim(self) -> int:       # models.py:129
@@ -174,24 +186,125 @@ class _GradReverse(torch.autograd.Function):
         return g.neg() * ctx.beta, None
 
 
-def _linear(p, name, x):
-    return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+def rne_bf16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest-even bf16 -> fp32 (what v_cvt_pk_bf16_f32 / a bf16 store does)."""
+    return t.to(torch.bfloat16).to(torch.float32)
 
 
-def trn_multiscale(p, x, cfg: Config):
-    """TRNmodule.py:58-82.  x [B,T,F] -> [B,T-1,256]."""
+class _MatmulBf16(torch.autograd.Function):
+    """x W^T of an nn.Linear (and its two backward products) with the operands of the flagged contractions rounded
+    to bf16; products and sums are fp32 (a bf16 x bf16 product is exact in fp32; the summation order differs from the
+    matrix core's, which is fp32 round-off).  fwd / dgrad / wgrad: which of  x W^T,  g W,  g^T x  round their operands.
+    The bias is added (and its gradient summed) outside, in fp32; bias16: the bias gradient is the column sum of
+    the ROUNDED g (a weight-gradient launch that reads bf16 copies only has those)."""
+
+    @staticmethod
+    def forward(ctx, x, w, fwd, dgrad, wgrad):
+        ctx.save_for_backward(x, w)
+        ctx.flags = (dgrad, wgrad)
+        return rne_bf16(x) @ rne_bf16(w).t() if fwd else x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dgrad, wgrad = ctx.flags
+        g16 = rne_bf16(g)
+        gx = g16 @ rne_bf16(w) if dgrad else g @ w
+        gw = g16.t() @ rne_bf16(x) if wgrad else g.t() @ x
+        return gx, gw, None, None, None
+
+
+class _BiasBf16Sum(torch.autograd.Function):
+    """y = h + b whose bias gradient is the column sum of bf16-rounded upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, h, b):
+        return h + b
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, rne_bf16(g).sum(0)
+
+
+class _SegSumMatmulBf16(torch.autograd.Function):
+    """(sum_t z_t) W^T computed as sum_t bf16(z_t) bf16(W)^T: the relation discriminator's hidden layer reads the
+    tuple activations of its scale as separate K segments (each rounded on its own), never their sum.  Backward:
+    every z_t receives bf16(g) bf16(W); dW = bf16(g)^T bf16(sum_t z_t) (the weight-gradient launch reads R_j)."""
+
+    @staticmethod
+    def forward(ctx, w, *zs):
+        ctx.save_for_backward(w, *zs)
+        w16 = rne_bf16(w)
+        out = None
+        for z in zs:
+            y = rne_bf16(z) @ w16.t()
+            out = y if out is None else out + y
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, *zs = ctx.saved_tensors
+        g16 = rne_bf16(g)
+        gz = g16 @ rne_bf16(w)
+        r = zs[0]
+        for z in zs[1:]:
+            r = r + z
+        return (g16.t() @ rne_bf16(r),) + tuple(gz for _ in zs)
+
+
+# The arithmetic contract of the bf16 configuration, per reference layer: which of (forward x W^T, input gradient g W,
+# weight gradient g^T x) run on the bf16 matrix cores, and whether the bias gradient sums rounded values.  Everything
+# else - the 2-wide / C-wide output layers and the 256x256 video-discriminator layer inside the fused heads kernel,
+# all softmax / entropy / loss math, the optimiser - is fp32.
+BF16_POLICY = {
+    # layer prefix:                        (fwd,   dgrad, wgrad, bias16)
+    "fc_feature_shared_source":            (True,  False, True,  True),    # models.py:565-566 (no input gradient: features are data)
+    "fc_feature_domain":                   (True,  True,  True,  True),    # :458-459
+    "fc_classifier_domain":                (False, False, False, False),   # :460   heads kernel, fp32
+    "TRN.fc_fusion_scales":                (True,  True,  True,  True),    # TRNmodule.py:60-79
+    "relation_domain_classifier_all.*.0":  (True,  True,  True,  False),   # models.py:475-479 (forward: _SegSumMatmulBf16)
+    "relation_domain_classifier_all.*.2":  (False, False, True,  False),   # :479   2-wide output layer: fp32 except dW
+    "fc_feature_domain_video":             (False, False, True,  False),   # :466-467 heads kernel fp32; dW on the matrix cores
+    "fc_classifier_video_source":          (False, False, True,  False),   # :686
+    "fc_classifier_domain_video":          (False, False, True,  False),   # :468
+}
+
+
+def _policy(name: str):
+    """BF16_POLICY entry of a layer name ('*' stands for the scale / relation index)."""
+    import re
+    for k, v in BF16_POLICY.items():
+        if re.fullmatch(re.escape(k).replace("\\*", "[0-9]+") + "(\\.[0-9]+\\.1)?", name):
+            return v
+    raise KeyError(f"no bf16 policy for layer {name!r}")
+
+
+def _linear(p, name, x, cfg: Optional["Config"] = None):
+    if cfg is None or cfg.arithmetic == "fp32":
+        return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+    fwd, dgrad, wgrad, bias16 = _policy(name)
+    h = _MatmulBf16.apply(x, p[name + ".weight"], fwd, dgrad, wgrad)
+    return _BiasBf16Sum.apply(h, p[name + ".bias"]) if (bias16 and cfg.bf16_twins) else h + p[name + ".bias"]
+
+
+def trn_multiscale(p, x, cfg: Config, with_tuples: bool = False):
+    """TRNmodule.py:58-82.  x [B,T,F] -> [B,T-1,256] (with_tuples: also the per-scale lists of tuple activations)."""
     rel = selected_relations(cfg.num_segments)
     B = x.size(0)
-    acts = []
+    acts, parts = [], []
     for sid, tuples in enumerate(rel):
         scale = len(tuples[0])
         acc = None
+        zs = []
         for tup in tuples:
             a = x[:, list(tup), :].reshape(B, scale * cfg.feat_dim)
-            a = F.relu(_linear(p, f"TRN.fc_fusion_scales.{sid}.1", F.relu(a)))
+            a = F.relu(_linear(p, f"TRN.fc_fusion_scales.{sid}.1", F.relu(a), cfg))
+            zs.append(a)
             acc = a if acc is None else acc + a
         acts.append(acc.unsqueeze(1))
-    return torch.cat(acts, 1)
+        parts.append(zs)
+    out = torch.cat(acts, 1)
+    return (out, parts) if with_tuples else out
 
 
 def trans_attn(pred_domain):
@@ -207,29 +320,34 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
     ([B*T,F] and [B,256]); None means dropout off (eval or p=0).
     Returns dict with the reference's per-domain outputs."""
     B, T = x.size(0), cfg.num_segments
-    f = F.relu(_linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1))))   # :557-572
+    f = F.relu(_linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1)), cfg))   # :557-572
     if drop_i is not None:
         f = f * drop_i                                                               # :574-575
     feat_frame = f.view(B, T, -1)                                                    # :578
     # frame-level adversarial branch (:456-462, :606-610)
-    h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2])))
-    pred_frame = _linear(p, "fc_classifier_domain", h).view(B, T, 2)
+    h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2]), cfg))
+    pred_frame = _linear(p, "fc_classifier_domain", h, cfg).view(B, T, 2)
     if cfg.frame_aggregation == "avgpool":
         # aggregate_frames, "1. averaging" (:421-433) without attention; attn is a placeholder column (:627-628)
         v = feat_frame.mean(1)
         vd = v * drop_v if drop_v is not None else v                                 # :679
-        y = _linear(p, "fc_classifier_video_source", vd)                             # :686
-        hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1])))
-        pred_video = _linear(p, "fc_classifier_domain_video", hv)
+        y = _linear(p, "fc_classifier_video_source", vd, cfg)                        # :686
+        hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg))
+        pred_video = _linear(p, "fc_classifier_domain_video", hv, cfg)
         return dict(attn=v[:, 0], out=y, pred_domain=[pred_video, pred_video, pred_frame], feat=[y, v, feat_frame])
     # TRN (:632-636)
-    rel = trn_multiscale(p, feat_frame, cfg)
+    rel, rel_parts = trn_multiscale(p, feat_frame, cfg, with_tuples=True)
     # relation discriminators (:472-488)
     preds = []
     for i in range(T - 1):
-        r = _GradReverse.apply(rel[:, i, :], beta[0])
-        hr = F.relu(_linear(p, f"relation_domain_classifier_all.{i}.0", r))
-        preds.append(_linear(p, f"relation_domain_classifier_all.{i}.2", hr).view(-1, 1, 2))
+        if cfg.arithmetic == "bf16":      # hidden layer on the scale's tuple activations as separate (separately rounded) K segments
+            name = f"relation_domain_classifier_all.{i}.0"
+            zs = [_GradReverse.apply(z, beta[0]) for z in rel_parts[i]]
+            hr = F.relu(_SegSumMatmulBf16.apply(p[name + ".weight"], *zs) + p[name + ".bias"])
+        else:
+            r = _GradReverse.apply(rel[:, i, :], beta[0])
+            hr = F.relu(_linear(p, f"relation_domain_classifier_all.{i}.0", r))
+        preds.append(_linear(p, f"relation_domain_classifier_all.{i}.2", hr, cfg).view(-1, 1, 2))
     pred_rel = torch.cat(preds, 1).view(-1, 2)
     # transferable attention (:379-388, :643-645)
     if cfg.use_attn == "TransAttn":
@@ -240,9 +358,9 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
         rel_attn, attn = rel, rel[:, :, 0]
     v = torch.sum(rel_attn, 1)                                                       # :651
     vd = v * drop_v if drop_v is not None else v                                     # :679
-    y = _linear(p, "fc_classifier_video_source", vd)                                 # :686
-    hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1])))  # :464-470
-    pred_video = _linear(p, "fc_classifier_domain_video", hv)
+    y = _linear(p, "fc_classifier_video_source", vd, cfg)                            # :686
+    hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg))  # :464-470
+    pred_video = _linear(p, "fc_classifier_domain_video", hv, cfg)
     return dict(attn=attn, out=y,
                 pred_domain=[pred_rel.view(B, T - 1, 2), pred_video, pred_frame],   # :697-707, :722 reversed
                 feat=[y, v, feat_frame])                                             # :578, :675, :690, :722

@@ -381,6 +381,28 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         }
         return;
     }
+    if (t.epi & EPI_COLSUM) {       // exact column sums of a [rows][ld] table of partials (uniform for the workgroup)
+        float *__restrict__ dst = const_cast<float *>(base_ptr(ptrs, t.c_base)) + (size_t)t.c_off;
+        const float *__restrict__ src = ptrs.ws + t.pad[0];
+        float sq = 0.f;
+        for (int n = t.n0 + tid; n < t.n_valid; n += NT) {
+            float v = 0.f;
+            for (int r = 0; r < t.pad[1]; ++r) v += src[(size_t)r * t.pad[2] + n];
+            dst[n] = v;
+            sq = fmaf(v, v, sq);
+        }
+        if (t.epi & EPI_SUMSQ) {
+            sq = wave_allreduce_sum(sq);
+            if (lane == 0) lds[wave] = sq;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f;
+                for (int i = 0; i < NW; ++i) tot += lds[i];
+                ptrs.ws[t.pad[3]] = tot;
+            }
+        }
+        return;
+    }
     if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
     if (t.epi & EPI_SUMROWS8) {   // side job of one workgroup per fused step: add up the heads kernel's loss partials in a fixed order
         const float *__restrict__ src = ptrs.ws + t.pad[1];

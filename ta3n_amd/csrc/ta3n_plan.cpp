@@ -98,6 +98,21 @@ struct Builder {
     int force_next = 0;         // tile code for the next add_gemm_phase only (a launch that mirrors an earlier one)
     bool mixed_kinds = false;   // a GEMM spec whose Segs differ in operand kinds (not supported by the kernel)
     int sum8[3] = {-1, 0, 0};   // {dst, src, rows}: when dst >= 0 the first workgroup of the next GEMM phase also sums an [rows][8] table
+    std::vector<Task> side_tasks;   // non-tile tasks (EPI_COLSUM) appended to the next GEMM phase
+
+    // exact fp32 column sums of a [rows][ld] table of per-workgroup partials -> gradient entries dst[0 .. n): one task per 256 columns
+    void colsum_pending(int64_t src, int rows, int ld, int n, int64_t dst) {
+        for (int n0 = 0; n0 < n; n0 += 256) {
+            Task t;
+            std::memset(&t, 0, sizeof(t));
+            t.epi = EPI_COLSUM;
+            t.c_base = BASE_G; t.c_off = (int32_t)dst; t.c_ld = n;
+            t.bias_base = BASE_NONE; t.aux_base = BASE_NONE; t.add_base = BASE_NONE;
+            t.m_valid = 1; t.n0 = n0; t.n_valid = std::min(n, n0 + 256);
+            t.pad[0] = (int32_t)src; t.pad[1] = rows; t.pad[2] = ld;
+            side_tasks.push_back(t);
+        }
+    }
 
     // expand GEMM specs into tile tasks of one phase
     void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
@@ -217,6 +232,8 @@ struct Builder {
             local[0].pad[0] = sum8[0]; local[0].pad[1] = sum8[1]; local[0].pad[2] = sum8[2];
             sum8[0] = -1;
         }
+        for (auto &t : side_tasks) local.push_back(t);
+        side_tasks.clear();
         for (auto &t : local) p.tasks.push_back(t);
         ph.task_count = (int32_t)local.size();
         p.phases.push_back(ph);
@@ -434,7 +451,7 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     for (const Phase &ph : p.phases)
         if (ph.group == 4 && ph.kind == PH_GEMM)
             for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
-                if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
+                if ((p.tasks[i].seg_count > 0 || (p.tasks[i].epi & EPI_COLSUM)) && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
     g.n_sumsq = (int32_t)grad_tasks.size();
     g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
     for (size_t k = 0; k < grad_tasks.size(); ++k) {
@@ -586,13 +603,6 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     auto tau = [&](int t, int pos) { return p.tuples[(size_t)t * T + pos]; };
 
     // ---- GEMM specs (one per affine contraction of the step) ----
-    auto ones_bias_grad = [&](int64_t gsrc_off, int gsrc_ld, int n, int klen, int64_t dst) {
-        GemmSpec gb;   // column sums as ones^T * G
-        gb.M = 1; gb.N = n;
-        gb.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, gsrc_off, gsrc_ld), klen, SK_ONE, 4));
-        gb.proto = proto(BASE_G, dst, n);
-        return gb;
-    };
     auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
         GemmSpec s;
         s.M = BT; s.N = F;
@@ -833,12 +843,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             push_relation_level(s);
             push_video_head_wgrads(s);
             push_video_disc_wgrads(s);
-            GemmSpec gw;   // dWcd = sum over frame workgroups of their partial sums (deterministic order)
-            gw.M = 1; gw.N = 2 * F;
-            gw.segs.push_back(mkseg(KM(BASE_WS, g.o_ones, 4), KM(BASE_WS, g.o_fh_part, 2 * F), g.n_frm_wg, SK_ONE, 4));
-            gw.proto = proto(BASE_G, Wcd, 2 * F);
-            s.push_back(gw);
-            s.push_back(ones_bias_grad(g.o_fh_bpart, 2, 2, g.n_frm_wg, bcd));
+            // dWcd, dbcd = sums over the frame workgroups of their partial sums: exact fp32 column sums in a fixed order
+            b.colsum_pending(g.o_fh_part, g.n_frm_wg, 2 * F, 2 * F, Wcd);
+            b.colsum_pending(g.o_fh_bpart, g.n_frm_wg, 2, 2, bcd);
             // dWfd: gHf is ready after the heads kernel, so it can fill the CUs this short level leaves idle - unless the
             // next launch reads bf16 twins and this one cannot (odd-shaped head gradients): then it is cheaper there
             const bool twins = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
@@ -881,7 +888,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         for (const Phase &ph : p.phases)
             if (ph.group == 4 && ph.kind == PH_GEMM)
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
-                    if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
+                    if ((p.tasks[i].seg_count > 0 || (p.tasks[i].epi & EPI_COLSUM)) && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
         g.n_sumsq = (int32_t)grad_tasks.size();
         g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
         for (size_t k = 0; k < grad_tasks.size(); ++k) {

@@ -27,6 +27,9 @@ enum EpiFlags : uint32_t {
     EPI_DROP_I = 1u << 4,   // v *= keep_i(m*drop_ld + n)   (dropout_i stream)
     EPI_DROP_V = 1u << 5,   // v *= keep_v(...)
     EPI_SUMROWS8 = 1u << 6, // workgroup side job: ws[pad[0] + c] = sum_r ws[pad[1] + 8 r + c], r < pad[2], c < 8 (loss scalars of the fused step)
+    EPI_COLSUM = 1u << 12,  // not a tile: c[n] = sum_{r < pad[1]} ws[pad[0] + r * pad[2] + n] for n in [n0, n_valid), rows added in order by
+                            // one thread per column - exact fp32 reduction of per-workgroup partial sums (never through the MFMA,
+                            // which would round the partials to bf16 in the bf16 configuration); honours EPI_SUMSQ
     EPI_SGD = 1u << 11,     // not a tile: the workgroup applies the optimiser update to params[4 pad[0] .. 4 pad[1]) (SgdSide)
     EPI_TWIN16_FAN = 1u << 10,   // same for the fan-out copies (fan_out_off)
     EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)
@@ -61,7 +64,8 @@ struct Task {
     int32_t fan_mask_off[3];
     int32_t fan_out_off[3];
     int32_t cost;                        // sum of klen (for ordering / balance)
-    int32_t pad[4];                      // EPI_SUMROWS8: [0..2] = {dst, src, rows} (ws offsets); EPI_SUMSQ: [3] = ws offset of the slot
+    int32_t pad[4];                      // EPI_SUMROWS8: [0..2] = {dst, src, rows} (ws offsets); EPI_SUMSQ: [3] = ws offset of the slot;
+                                         // EPI_COLSUM: [0..2] = {src ws offset, rows, row stride}
 };
 
 enum PhaseKind : int32_t {

@@ -15,6 +15,7 @@ from ta3n_amd import _lib
 
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_COLSUM = 1 << 12
 PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS = range(8)
 HEADS_RPW = 16
 
@@ -155,6 +156,14 @@ class Interp:
         BM, BN = 32 * ph.wm, 32 * ph.wn
         for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
             t = self.tasks[ti]
+            if t.epi & EPI_COLSUM:       # exact column sums of a table of per-workgroup partials
+                src, rows, ld = t.pad[0], t.pad[1], t.pad[2]
+                n = np.arange(t.n0, t.n_valid)
+                v = self.ws[src + np.arange(rows)[:, None] * ld + n[None, :]].sum(0)
+                self.buf(t.c_base)[t.c_off + n] = v
+                if t.epi & EPI_SUMSQ:
+                    self.ws[t.pad[3]] = float((v * v).sum())
+                continue
             if t.seg_count == 0:
                 continue
             if t.epi & EPI_SUMROWS8:

@@ -1,16 +1,22 @@
 """bf16-MFMA arithmetic (TA3N_FLAG_BF16_MFMA, BASELINE.json configs[1]) on a real MI355X.
 
-Two statements, kept apart as SURVEY.md 8(d) asks:
- (a) the kernels compute exactly the arithmetic the header states - every contraction on operands rounded to
-     bf16 (round to nearest even), products and sums in fp32 - checked against the numpy execution of the SAME
-     launch plan with the same rounding (tests/plan_interp.py), tight tolerance;
- (b) the distance of that arithmetic from the reference's fp32 results (the committed goldens) is reported and
-     bounded loosely; bf16 cannot meet the 1e-3 logit bound, which is the fp32 path's claim."""
+Three statements, kept apart as SURVEY.md 8(d) asks:
+ (a) PARITY GATE of the bf16 configuration: the HIP path against the INDEPENDENT bf16-operand oracle
+     (oracle/ta3n_oracle.py, arithmetic="bf16": the reference's graph with the operands of the matrix-core contractions
+     rounded to bf16, written against the reference's layer structure - not against the product's launch descriptors):
+     logits within 2e-3 x rms, gradients and updated parameters within 2e-3 of their scale, at the headline shape, the
+     small goldens' shapes, T = 12 and the BASELINE configs[3] / [4] shapes;
+ (b) wiring: the kernels against the numpy execution of the SAME launch plan with the same rounding
+     (tests/plan_interp.py) - catches a kernel bug, cannot catch a plan bug (that is what (a) and the CPU test
+     tests/test_oracle_bf16.py are for);
+ (c) the distance of the bf16 arithmetic from the reference's fp32 results (the committed goldens) is reported and bounded
+     at 1.5e-2 x rms; bf16 cannot meet the 1e-3 logit bound, which is the fp32 path's claim."""
 import numpy as np
 import pytest
 import torch
 
 from golden_util import Golden, case_config, step_schedule
+from oracle import ta3n_oracle as orc
 from plan_interp import Interp
 from ta3n_amd import _lib
 from ta3n_amd.synthetic import synth_batch, synth_state
@@ -86,12 +92,13 @@ def test_bf16_kernels_match_the_bf16_operand_model(name, tile, store):
 
 def test_bf16_distance_from_fp32_reference_is_bounded_and_reported(capsys):
     """Trained-scale weights (logits O(1..10)): report max |bf16 path - reference fp32| per output, relative to the
-    output's rms.  Bound: 0.1 x rms of the reference tensor."""
+    output's rms.  Bound: 1.5e-2 x rms of the reference tensor (measured: 0.3 - 0.7 %)."""
     from ta3n_amd.engine import TrainEngine
     g = Golden("headline")
     c = case_config(g)
     T = c["T"]
-    eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"], bf16=True)
+    eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"], bf16=True,
+                      bf16_store=True)
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
     st = step_schedule(c)[0]
@@ -108,7 +115,7 @@ def test_bf16_distance_from_fp32_reference_is_bounded_and_reported(capsys):
         for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
             rec = "fwd/" + gk.format(dom)
             rms = g.rms(rec)
-            err = g.check(rec, o[key][sl], 0.0, 0.1 * rms, "bf16 vs fp32 reference")
+            err = g.check(rec, o[key][sl], 0.0, 1.5e-2 * rms, "bf16 vs fp32 reference")
             report[f"{key}_{dom}"] = (err, rms)
     with capsys.disabled():
         print("\nbf16-MFMA vs fp32 reference, max abs error (rms of reference): " +
@@ -226,3 +233,78 @@ def test_bf16_twins_fall_back_per_launch_on_odd_shapes(shape):
     want_g = it.get_params(it.G)
     for k in eng.live_names():
         _close(f"grad/{k}", got_g[k], want_g[k].reshape(got_g[k].shape), 2e-3, 2e-4)
+
+
+# ---- (a) the parity gate: HIP bf16 path vs the independent bf16-operand oracle ----
+def _oracle_gate(shape, wseed, wscale, xseed, lr, clip, n_src=None, n_tgt=None, store=True, steps=1):
+    from ta3n_amd.engine import TrainEngine
+    Bs, Bt, T, D, Fc, Cn = shape["Bs"], shape["Bt"], shape["T"], shape["D"], shape["F"], shape["C"]
+    n_src = Bs if n_src is None else n_src
+    n_tgt = Bt if n_tgt is None else n_tgt
+    cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, arithmetic="bf16",
+                     bf16_twins=store)
+    params = synth_state(orc.param_shapes(cfg), seed=wseed, scale=wscale)
+    eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=clip, bf16=True, bf16_store=store)
+    eng.load_state(params)
+    state = orc.TrainState(params={k: v.clone() for k, v in params.items()}, lr=lr)
+    report = {}
+    for step in range(steps):
+        xs, xt, ys, yt = synth_batch(Cn, T, D, Bs, Bt, seed=xseed + 100 * step)
+        xs[n_src:] = 0; xt[n_tgt:] = 0
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, lr, valid_source=n_src, valid_target=n_tgt)
+        torch.cuda.synchronize()
+        prev = {k: v.clone() for k, v in state.params.items()}
+        res = orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, clip=clip, n_src=n_src, n_tgt=n_tgt)
+        o = {k: v.detach().cpu().double() for k, v in eng.outputs().items()}
+        B = Bs + Bt
+        for key, pick in (("out", lambda r: r["out"]), ("pred_rel", lambda r: r["pred_domain"][0]),
+                          ("pred_vid", lambda r: r["pred_domain"][1]), ("pred_frm", lambda r: r["pred_domain"][2]),
+                          ("feat_v", lambda r: r["feat"][1]), ("attn", lambda r: r["attn"])):
+            want = torch.cat((pick(res["src"]), pick(res["tgt"])), 0).detach().double()
+            got = o[key].reshape(want.shape)
+            rms = want.pow(2).mean().sqrt().item()
+            err = (got - want).abs().max().item()
+            report[f"s{step}/{key}"] = err / (rms + 1e-30)
+            assert err <= 2e-3 * rms + 1e-7, f"step {step} {key}: max err {err:.3e} at rms {rms:.3e}"
+        got_g = {k: v.cpu().double() for k, v in eng.param_views(eng.G).items()}
+        for k, w in res["grads"].items():       # unclipped gradients of the step (the engine's G holds them before the update scales them)
+            w = w.double()
+            scale = w.abs().max().item() + 1e-30
+            err = (got_g[k] - w).abs().max().item()
+            report[f"s{step}/grad/{k}"] = err / scale
+            assert err <= 2e-3 * scale, f"step {step} grad {k}: max err {err:.3e} at scale {scale:.3e}"
+        got_p = {k: v.cpu().double() for k, v in eng.param_views().items()}
+        for k, w in state.params.items():       # the UPDATE (new - old parameter) within 2e-3 of its own scale
+            w = w.double()
+            upd = (w - prev[k].double()).abs().max().item()
+            err = (got_p[k] - w).abs().max().item()
+            assert err <= 2e-3 * upd + 2e-7 * (w.abs().max().item() + 1e-30), f"step {step} param {k}: max err {err:.3e} (update scale {upd:.3e})"
+    return report
+
+
+@pytest.mark.parametrize("store", [True, False])
+@pytest.mark.parametrize("name", ["headline", "tiny_T5", "tiny_T9", "mid_T12"])
+def test_bf16_path_matches_the_independent_bf16_oracle(name, store, capsys):
+    if not store and name not in ("headline", "tiny_T5"):
+        pytest.skip("register-rounding variant checked on two cases")
+    g = Golden(name)
+    c = case_config(g)
+    st = step_schedule(c)[0]
+    shape = dict(Bs=c["Bs"], Bt=c["Bt"], T=c["T"], D=c["D"], F=c["fc_dim"], C=c["C"])
+    rep = _oracle_gate(shape, c["wseed"], c["wscale"], st["xseed"], st["lr"], c["clip"], st["n_src"], st["n_tgt"], store=store,
+                       steps=2 if name == "headline" else 1)
+    with capsys.disabled():
+        worst = sorted(rep.items(), key=lambda kv: -kv[1])[:4]
+        print(f"\n[bf16 vs bf16-oracle] {name} store={store}: worst relative errors " + ", ".join(f"{k} {v:.1e}" for k, v in worst))
+
+
+@pytest.mark.parametrize("shape", [dict(Bs=512, Bt=512, T=9, D=2048, F=512, C=30), dict(Bs=128, Bt=128, T=12, D=1024, F=512, C=12)],
+                         ids=["configs3_T9_C30_b512", "configs4_T12_D1024"])
+def test_bf16_oracle_gate_at_the_other_baseline_config_shapes(shape, capsys):
+    """BASELINE configs[3] (30 classes, 9 segments, 512+512 videos) and one stream of configs[4] (1024-d, 12 segments,
+    128+128 videos) at FULL size, trained-scale weights."""
+    rep = _oracle_gate(shape, wseed=11, wscale="trained", xseed=21, lr=1e-3, clip=20.0)
+    with capsys.disabled():
+        worst = sorted(rep.items(), key=lambda kv: -kv[1])[:4]
+        print(f"\n[bf16 vs bf16-oracle] {shape}: worst relative errors " + ", ".join(f"{k} {v:.1e}" for k, v in worst))
