@@ -164,8 +164,9 @@ int64_t ta3n_plan_describe(const ta3n_plan *plan, char *buf, int64_t cap);
 
 /* ---- per-step entry points (enqueue only) ------------------------------------- */
 
-/* Uploads the per-step scalars into ws["hyper"] (async copy from an internal
- * pinned staging ring; safe to call every step before ta3n_forward). */
+/* Writes the per-step scalars into ws["hyper"]: a one-thread kernel that receives *h BY VALUE as its launch argument, in
+ * stream order.  The values are captured when the call returns, so it is safe to call it any number of steps ahead of the
+ * device (no staging buffer to fence).  Call every step before ta3n_forward / ta3n_train_step. */
 int ta3n_set_hyper(ta3n_plan *plan, float *ws, const ta3n_hyper *h, void *stream);
 
 /* One-time initialisation of constant workspace regions (ones vector). */

@@ -23,7 +23,6 @@ static_assert(sizeof(ta3n_hyper) <= 32 * sizeof(float), "hyper region is 32 floa
 
 namespace {
 thread_local std::string g_err;
-constexpr int kHyperSlots = 64;
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -44,7 +43,6 @@ int ensure_uploaded(ta3n_plan *p) {
     HIP_TRY(hipMalloc(&p->d_tasks, p->tasks.size() * sizeof(Task)));
     HIP_TRY(hipMemcpy(p->d_segs, p->segs.data(), p->segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->d_tasks, p->tasks.data(), p->tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
-    HIP_TRY(hipHostMalloc(&p->h_hyper, kHyperSlots * sizeof(ta3n_hyper), hipHostMallocDefault));
     p->uploaded = true;
     return TA3N_OK;
 }
@@ -114,7 +112,6 @@ void ta3n_plan_destroy(ta3n_plan *p) {
     if (p->uploaded) {
         (void)hipFree(p->d_segs);
         (void)hipFree(p->d_tasks);
-        (void)hipHostFree(p->h_hyper);
     }
     delete p;
 }
@@ -226,11 +223,12 @@ int ta3n_set_hyper(ta3n_plan *p, float *ws, const ta3n_hyper *h, void *stream) {
     if (!p || !ws || !h) return fail(TA3N_ERR_INVALID, "null argument");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    ta3n_hyper *slot = static_cast<ta3n_hyper *>(p->h_hyper) + p->hyper_slot;
-    p->hyper_slot = (p->hyper_slot + 1) % kHyperSlots;
-    *slot = *h;
-    HIP_TRY(hipMemcpyAsync(ws + p->geom.o_hyper, slot, sizeof(ta3n_hyper), hipMemcpyHostToDevice,
-                           static_cast<hipStream_t>(stream)));
+    // by kernel argument: the values are captured when the launch is enqueued, so the host may run any number of steps
+    // ahead of the stream (a pinned staging ring would need an event per slot before reuse)
+    Hyper hv;
+    std::memcpy(&hv, h, sizeof(hv));
+    if (launch_set_hyper(ws + p->geom.o_hyper, hv, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("set_hyper launch failed: ") + hipGetErrorString(hipGetLastError()));
     return TA3N_OK;
 }
 

@@ -119,6 +119,7 @@ int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t s
 int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum, float *ws, hipStream_t stream,
                bool fused_norm = false);
 int launch_fill(float *dst, float value, int64_t n, hipStream_t stream);
+int launch_set_hyper(float *ws_hyper, const Hyper &h, hipStream_t stream);   // scalars by kernel argument (no staging copy)
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
                      bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);

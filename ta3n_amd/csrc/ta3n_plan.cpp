@@ -506,19 +506,35 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
 
     Builder b(p);
     // ---- parameters: live first (they form the all-reduce / optimiser operand) ----
-    b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141
-    b.add_linear("fc_feature_domain", F, F, true);                     // :161
-    b.add_linear("fc_classifier_domain", 2, F, true);                  // :170
+    // Which discriminators receive a gradient depends on the options, as in the reference, where a parameter whose
+    // output feeds no loss keeps grad None and is skipped by SGD (no weight decay either): the frame discriminator is
+    // live only with its adversarial loss (place_adv[2], main.py:508-538), the video discriminator with its loss
+    // (attentive entropy needs it too, and the plan requires ADV_VIDEO for it), the relation discriminators with their
+    // loss OR the transferable attention, whose weights are not detached (models.py:351-357, 379-388).
+    const bool live_frm = (c.flags & TA3N_FLAG_ADV_FRAME) != 0;
+    const bool live_vid = (c.flags & TA3N_FLAG_ADV_VIDEO) != 0;
+    const bool live_rel = (c.flags & (TA3N_FLAG_ADV_RELATION | TA3N_FLAG_TRANS_ATTN)) != 0;
+    struct Lin { std::string name; int out, in; };
+    std::vector<Lin> dead;
+    auto lin = [&](const std::string &name, int out, int in, bool live) {
+        if (live) b.add_linear(name, out, in, true);
+        else dead.push_back(Lin{name, out, in});
+    };
+    b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141 (first: ta3n_train_step_after_update relies on it)
+    p.first_floats = p.param_floats;
+    lin("fc_feature_domain", F, F, live_frm);                          // :161
+    lin("fc_classifier_domain", 2, F, live_frm);                       // :170
     for (int j = 0; j < NR; ++j)                                       // TRNmodule.py:44-54
         b.add_linear("TRN.fc_fusion_scales." + std::to_string(j) + ".1", NB, (T - j) * F, true);
     for (int j = 0; j < NR; ++j) {                                     // models.py:286-294
-        b.add_linear("relation_domain_classifier_all." + std::to_string(j) + ".0", NB, NB, true);
-        b.add_linear("relation_domain_classifier_all." + std::to_string(j) + ".2", 2, NB, true);
+        lin("relation_domain_classifier_all." + std::to_string(j) + ".0", NB, NB, live_rel);
+        lin("relation_domain_classifier_all." + std::to_string(j) + ".2", 2, NB, live_rel);
     }
-    b.add_linear("fc_feature_domain_video", NB, NB, true);             // :267
+    lin("fc_feature_domain_video", NB, NB, live_vid);                  // :267
     b.add_linear("fc_classifier_video_source", C, NB, true);           // :272
-    b.add_linear("fc_classifier_domain_video", 2, NB, true);           // :281
+    lin("fc_classifier_domain_video", 2, NB, live_vid);                // :281
     p.live_floats = p.param_floats;
+    for (auto &d : dead) b.add_linear(d.name, d.out, d.in, false);     // computed (zero or unused) gradients land past the live prefix
     // never receive a gradient in this configuration: kept for state_dict compatibility
     b.add_linear("fc_feature_source", F, F, false);                    // :156
     b.add_linear("fc_classifier_source", C, F, false);                 // :166 (dead for baseline_type 'video')
@@ -867,7 +883,6 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15);
             std::vector<GemmSpec> s{spec_F1()};
             b.add_gemm_phase(5, s);
-            p.first_floats = P("fc_feature_domain.weight");      // = end of fc_feature_shared_source.{weight,bias} (first in the layout)
             const int64_t i0 = p.first_floats / 4, i1 = p.live_floats / 4;
             const int n_side = 256;
             const int64_t per = (i1 - i0 + n_side - 1) / n_side;

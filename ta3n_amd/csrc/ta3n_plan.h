@@ -35,8 +35,6 @@ struct ta3n_plan {
     // device copies (created lazily by the launcher)
     void *d_segs = nullptr;
     void *d_tasks = nullptr;
-    void *h_hyper = nullptr;   // pinned staging ring for ta3n_set_hyper
-    int hyper_slot = 0;
     bool uploaded = false;
     int device = -1;
 

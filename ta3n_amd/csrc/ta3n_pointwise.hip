@@ -490,6 +490,12 @@ __global__ void to_bf16_kernel(const float4 *__restrict__ src, uint2 *__restrict
     }
 }
 
+// The per-step scalars travel as a kernel argument (copied at launch time): no staging buffer whose reuse would have to be
+// fenced against the copy, however far the host runs ahead of the stream.
+__global__ void set_hyper_kernel(Hyper *__restrict__ dst, Hyper h) {
+    if (threadIdx.x == 0) *dst = h;
+}
+
 __global__ void fill_kernel(float *__restrict__ dst, float v, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
 }
@@ -581,6 +587,11 @@ int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t str
     int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
     hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(src),
                        reinterpret_cast<uint2 *>(dst_twin), n4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_set_hyper(float *ws_hyper, const Hyper &h, hipStream_t stream) {
+    hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<Hyper *>(ws_hyper), h);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

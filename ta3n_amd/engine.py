@@ -50,6 +50,15 @@ def lr_dann(lr0: float, p: float) -> float:
     return lr0 / (1.0 + 10 * p) ** 0.75
 
 
+def dropout_seeds(step: int, rank: int = 0):
+    """(seed_i, seed_v) of one step on one rank.  The kernels key a mask element by its LOCAL row index, so the rank has
+    to be part of the seed: the reference's DataParallel replicas draw independent masks for their shards (nn.Dropout,
+    models.py:574-575, 679-680), two ranks must not share one."""
+    s = int(step)
+    r = (0xC2B2AE3D * int(rank)) & 0xFFFFFFFF
+    return ((0x9E3779B1 * (2 * s + 1)) ^ r) & 0xFFFFFFFF, ((0x85EBCA77 * (2 * s + 2)) ^ ((r * 0x27D4EB2F) & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
 class TrainEngine:
     """Device-resident state of one rank: flat parameters / gradients / momentum,
     workspace, static input buffers.  Source rows come first in every batch
@@ -84,9 +93,10 @@ class TrainEngine:
         self.dropout_i, self.dropout_v = dropout_i, dropout_v
         self.momentum, self.weight_decay, self.clip = momentum, weight_decay, clip
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
         p = self.plan
         with torch.cuda.device(self.device):
             self.P = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
@@ -183,9 +193,7 @@ class TrainEngine:
         h.momentum, h.weight_decay = float(self.momentum), float(self.weight_decay)
         h.clip = float(self.clip) if self.clip is not None else 0.0
         h.p_drop_i, h.p_drop_v = float(self.dropout_i), float(self.dropout_v)
-        s = self.step_count if seed is None else seed
-        h.seed_i = (0x9E3779B1 * (2 * s + 1)) & 0xFFFFFFFF
-        h.seed_v = (0x85EBCA77 * (2 * s + 2)) & 0xFFFFFFFF
+        h.seed_i, h.seed_v = dropout_seeds(self.step_count if seed is None else seed, self.rank)
         for k, v in parallel.loss_normalisers(gs, gt, self.T).items():
             setattr(h, k, v)
         h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))

@@ -82,6 +82,7 @@ class _HipForward(torch.autograd.Function):
         ctx.mark_non_differentiable(v, f1)
         if not model._attn_on:
             ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)      # an output that feeds no loss arrives as None in backward (see there)
         return attn, y, pr, pv, pf, v, f1
 
     @staticmethod
@@ -103,9 +104,18 @@ class _HipForward(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
                                    stream), "ta3n_backward")
+        # A discriminator whose logits feed no loss (place_adv 'N', use_target none, ...) keeps grad None in the reference,
+        # so torch.optim.SGD skips it - no weight decay either (main.py:508-538).  Same here: None, not zeros.
+        unused = []
+        if g_pf is None:
+            unused += ["fc_feature_domain.", "fc_classifier_domain."]
+        if g_pv is None:
+            unused += ["fc_feature_domain_video.", "fc_classifier_domain_video."]
+        if g_pr is None and (g_attn is None or not model._attn_on):
+            unused += ["relation_domain_classifier_all."]
         out: List[Optional[torch.Tensor]] = []
         for name, off, shape, live in plan.params:
-            if not live:
+            if not live or name.startswith(tuple(unused)):
                 out.append(None)            # never receives a gradient in the reference either
                 continue
             n = 1
@@ -212,8 +222,10 @@ class VideoModel(nn.Module):
 
     # ---- plumbing ----
     def _flags(self) -> int:
-        # the loss flags are irrelevant on this path (losses are assembled by the caller, main.py:439-562)
-        return _lib.FLAG_TRANS_ATTN if self._attn_on else 0
+        # losses are assembled by the caller (main.py:439-562), so every discriminator has to be able to receive a gradient:
+        # the adversarial flags only decide the plan's live parameter set here (the loss kernel is not used on this path)
+        return (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME |
+                (_lib.FLAG_TRANS_ATTN if self._attn_on else 0))
 
     def _plan(self, Bs: int, Bt: int) -> _lib.Plan:
         key = (Bs, Bt)

@@ -190,3 +190,25 @@ def test_avgpool_plan_reproduces_reference(name, fused):
             if k in live:
                 g.check(f"step{s}/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
             g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("place_adv,use_attn", [(("Y", "Y", "Y"), "TransAttn"), (("Y", "Y", "N"), "TransAttn"), (("N", "Y", "Y"), "TransAttn"),
+                                                (("N", "N", "N"), "TransAttn"), (("N", "N", "Y"), "none"), (("Y", "N", "N"), "none"),
+                                                (("N", "N", "N"), "none")])
+def test_live_parameter_set_follows_the_options_like_autograd_does(place_adv, use_attn):
+    """A discriminator whose output feeds no loss keeps grad None in the reference, so SGD skips it (no weight decay either).
+    The plan's live prefix (= the all-reduce and optimiser operand) must be exactly the set autograd gives a gradient."""
+    from oracle import ta3n_oracle as orc
+    from ta3n_amd.engine import flags_from_options
+    ent = "attentive_entropy" if (use_attn != "none" and place_adv[0] == "Y" and place_adv[1] == "Y") else "none"
+    flags = flags_from_options(place_adv, ent, use_attn, "RevGrad", "uSv")
+    plan = _lib.Plan(3, 2, 4, 32, 16, 5, flags)
+    live = {n for n, _, _, lv in plan.params if lv}
+    offs = [off for _, off, _, lv in plan.params if lv]
+    assert max(offs) < plan.live_floats and all(off >= plan.live_floats for _, off, _, lv in plan.params if not lv)
+    cfg = orc.Config(num_class=5, num_segments=4, feature_dim=32, fc_dim=16, dropout_i=0.0, dropout_v=0.0, place_adv=place_adv,
+                     add_loss_DA=ent, use_attn=use_attn)
+    params = synth_state(orc.param_shapes(cfg), seed=3)
+    xs, xt, ys, yt = synth_batch(5, 4, 32, 3, 2, seed=4)
+    res = orc.train_step(orc.TrainState(params=params), xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg)
+    assert live == set(res["grads"].keys())
