@@ -191,6 +191,15 @@ def rne_bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def _mm16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16(a) @ bf16(b) with "fp32 accumulation": the products of bf16 values are exact in fp32; their sum is formed in
+    fp64 and rounded to fp32 once, i.e. the correctly rounded value every fp32 summation order approximates.  (Summing
+    in fp32 here would add this machine's BLAS summation order to the comparison: ~1e-6 relative noise that flips the
+    bf16 rounding of downstream operands and a few ReLU units - measured 5e-4 .. 7e-3 relative L2 on gradient tensors
+    depending on the host CPU, against 4e-6 .. 4e-4 for the HIP kernels versus an fp64-accumulating model.)"""
+    return (rne_bf16(a).double() @ rne_bf16(b).double()).float()
+
+
 class _MatmulBf16(torch.autograd.Function):
     """x W^T of an nn.Linear (and its two backward products) with the operands of the flagged contractions rounded
     to bf16; products and sums are fp32 (a bf16 x bf16 product is exact in fp32; the summation order differs from the
@@ -202,15 +211,14 @@ class _MatmulBf16(torch.autograd.Function):
     def forward(ctx, x, w, fwd, dgrad, wgrad):
         ctx.save_for_backward(x, w)
         ctx.flags = (dgrad, wgrad)
-        return rne_bf16(x) @ rne_bf16(w).t() if fwd else x @ w.t()
+        return _mm16(x, w.t()) if fwd else x @ w.t()
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dgrad, wgrad = ctx.flags
-        g16 = rne_bf16(g)
-        gx = g16 @ rne_bf16(w) if dgrad else g @ w
-        gw = g16.t() @ rne_bf16(x) if wgrad else g.t() @ x
+        gx = _mm16(g, w) if dgrad else g @ w
+        gw = _mm16(g.t(), x) if wgrad else g.t() @ x
         return gx, gw, None, None, None
 
 
@@ -234,22 +242,21 @@ class _SegSumMatmulBf16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, *zs):
         ctx.save_for_backward(w, *zs)
-        w16 = rne_bf16(w)
+        w16 = rne_bf16(w).double().t()
         out = None
         for z in zs:
-            y = rne_bf16(z) @ w16.t()
+            y = rne_bf16(z).double() @ w16
             out = y if out is None else out + y
-        return out
+        return out.float()
 
     @staticmethod
     def backward(ctx, g):
         w, *zs = ctx.saved_tensors
-        g16 = rne_bf16(g)
-        gz = g16 @ rne_bf16(w)
+        gz = _mm16(g, w)
         r = zs[0]
         for z in zs[1:]:
             r = r + z
-        return (g16.t() @ rne_bf16(r),) + tuple(gz for _ in zs)
+        return (_mm16(g.t(), r),) + tuple(gz for _ in zs)
 
 
 # The arithmetic contract of the bf16 configuration, per reference layer: which of (forward x W^T, input gradient g W,

@@ -169,6 +169,18 @@ class TrainEngine:
     def live_names(self):
         return [n for n, _, _, live in self.plan.params if live]
 
+    def momentum_views(self) -> Dict[str, torch.Tensor]:
+        """Momentum buffers of the live parameters (views into the flat buffer; zero = "no update yet", which is what
+        torch.optim.SGD's lazily created buffer amounts to: buf = g on first use = mu * 0 + g)."""
+        out = {}
+        for name, off, shape, live in self.plan.params:
+            if live:
+                n = 1
+                for s in shape:
+                    n *= s
+                out[name] = self.M[off:off + n].view(shape)
+        return out
+
     def set_batch(self, source: torch.Tensor, target: torch.Tensor, source_label: torch.Tensor) -> None:
         """[Bs,T,D], [Bt,T,D] float features and int labels into the static device buffers."""
         self.X[: self.Bs * self.T].copy_(source.reshape(-1, self.D), non_blocking=True)

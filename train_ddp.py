@@ -10,7 +10,9 @@ opts.py flags, driven by torchrun:
 `-b Bs Bt Bv` are GLOBAL batch sizes (as in the reference); each rank takes a contiguous
 shard of every batch, zero-padded to a static per-rank size.  Loss means use global row
 counts and gradients are summed by one RCCL all-reduce per step (ta3n_amd/parallel.py).
-Schedules follow main.py: beta (main.py:350-352), DANN learning rate (main.py:620-621)."""
+Schedules follow main.py: beta (main.py:350-352), learning rate (DANN main.py:620-621, step decay :236-237), the
+list-repeat rule of --copy_list (main.py:145-153), checkpoints in the reference's format (ta3n_amd/checkpoint.py).
+Every option value the engine does not implement is REJECTED at start-up (validate_options) instead of being ignored."""
 import os
 import sys
 import time
@@ -21,24 +23,81 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from ta3n_amd import checkpoint as ckpt  # noqa: E402
 from ta3n_amd import parallel  # noqa: E402
 from ta3n_amd.engine import TrainEngine, beta_dann, flags_from_options, lr_dann  # noqa: E402
 from ta3n_amd.models import ARCH_FEATURE_DIM  # noqa: E402
 from ta3n_amd.opts import parser  # noqa: E402
 
 
+def validate_options(args) -> None:
+    """The engine implements the TA3N hot path and BASELINE configs[0]; every behaviour-changing value
+    outside it stops the run here - a silently ignored flag would train a different model than the command line says."""
+    bad = []
+
+    def need(cond, msg):
+        if not cond:
+            bad.append(msg)
+    need(args.baseline_type == "video", f"--baseline_type {args.baseline_type} (built: video)")
+    need(args.frame_aggregation in ("trn-m", "avgpool"), f"--frame_aggregation {args.frame_aggregation} (built: trn-m, avgpool)")
+    if args.frame_aggregation == "avgpool":
+        need(args.use_target == "none" and args.adv_DA == "none",
+             "avgpool is built in the source-only configuration (--use_target none --adv_DA none; BASELINE configs[0])")
+    need(args.optimizer == "SGD", f"--optimizer {args.optimizer} (built: SGD with Nesterov momentum, main.py:83)")
+    need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses are not built)")
+    need(args.ens_DA == "none", f"--ens_DA {args.ens_DA}")
+    need(args.use_bn == "none", f"--use_bn {args.use_bn}")
+    need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
+    need(args.use_target in ("none", "uSv"), f"--use_target {args.use_target} (target labels in the classification loss are not built)")
+    need(args.weighted_class_loss == "N", "--weighted_class_loss Y")
+    need(args.weighted_class_loss_DA == "N", "--weighted_class_loss_DA Y")
+    need(args.pred_normalize == "N", "--pred_normalize Y")
+    need(not args.pretrain_source, "--pretrain_source")
+    need(args.lr_adaptive in ("dann", "none"), f"--lr_adaptive {args.lr_adaptive} (built: dann, none with --lr_steps/--lr_decay)")
+    need(args.use_attn in ("TransAttn", "none"), f"--use_attn {args.use_attn}")
+    need(args.use_attn_frame == "none", f"--use_attn_frame {args.use_attn_frame}")
+    need(args.share_params == "Y", "--share_params N")
+    need(args.add_fc == 1, f"--add_fc {args.add_fc}")
+    need(args.modality == "RGB", f"modality {args.modality} (pre-extracted RGB features)")
+    need(args.mu == 0, f"--mu {args.mu} (only used by the discrepancy losses)")
+    need(len(args.beta) == 3 and len(args.place_adv) == 3, "--beta and --place_adv take three values [relation, video, frame]")
+    need(len(args.batch_size) >= 2, "-b needs at least the source and target batch sizes")
+    need(args.arch in ARCH_FEATURE_DIM, f"--arch {args.arch}")
+    if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none":
+        need(args.place_adv[0] == "Y" and args.place_adv[1] == "Y",
+             "attentive_entropy indexes pred_domain_all[1] (main.py:559-562): needs --place_adv Y Y *")
+    if bad:
+        raise SystemExit("train_ddp.py: unsupported option value(s):\n  " + "\n  ".join(bad))
+
+
+def train_list_sizes(num_source: int, num_target: int, batch_size, copy_list):
+    """main.py:145-153: the shorter list is repeated (--copy_list Y) so that both loaders run the same number of
+    iterations.  Returns (num_source_train, num_target_train)."""
+    num_iter_source = num_source / batch_size[0]
+    num_iter_target = num_target / batch_size[1]
+    num_max_iter = max(num_iter_source, num_iter_target)
+    ns = round(num_max_iter * batch_size[0]) if copy_list[0] == "Y" else num_source
+    nt = round(num_max_iter * batch_size[1]) if copy_list[1] == "Y" else num_target
+    return ns, nt
+
+
+def n_batches(n: int, batch: int) -> int:
+    return max(-(-n // batch), 1)        # DataLoader(drop_last=False)
+
+
 def synthetic_loader(n_videos, batch, T, D, C, seed):
     """Batches of half-normal features [b,T,D] + labels, like TSNDataSet items stacked by a DataLoader."""
     g = torch.Generator().manual_seed(seed)
-    n_steps = max(n_videos // batch, 1)
-    for _ in range(n_steps):
-        yield torch.randn(batch, T, D, generator=g).abs_(), torch.randint(0, C, (batch,), generator=g)
+    left = n_videos
+    while left > 0:
+        b = min(batch, left)
+        yield torch.randn(b, T, D, generator=g).abs_(), torch.randint(0, C, (b,), generator=g)
+        left -= b
 
 
-def list_loader(list_file, batch, T, seed):
+def list_loader(list_file, n_load, batch, T, seed):
     from ta3n_amd.dataset import TSNDataSet
-    n = sum(1 for _ in open(list_file))
-    ds = TSNDataSet("", list_file, num_dataload=n, num_segments=T, new_length=1, modality="RGB", random_shift=False,
+    ds = TSNDataSet("", list_file, num_dataload=n_load, num_segments=T, new_length=1, modality="RGB", random_shift=False,
                     test_mode=True)
     g = torch.Generator().manual_seed(seed)             # same permutation on every rank: shards are disjoint slices
     sampler = torch.utils.data.RandomSampler(ds, generator=g)
@@ -55,19 +114,19 @@ def main():
     parser.add_argument("--feature_store", type=str, nargs="+", default=None, metavar="PREFIX",
                         help="packed feature stores (ta3n_amd.feature_store.pack): SRC TGT [VAL]; batches are assembled on the GPU")
     args = parser.parse_args()
+    validate_options(args)
     rank, local_rank, world = parallel.init_distributed()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     num_class = len([x for x in open(args.class_file)]) if os.path.exists(args.class_file) else 12
     T, D = args.num_segments, ARCH_FEATURE_DIM[args.arch]
-    if args.frame_aggregation != "trn-m" or args.baseline_type != "video":
-        raise SystemExit("train_ddp.py implements the TA3N hot path: --frame_aggregation trn-m --baseline_type video")
     Bs_g, Bt_g = args.batch_size[0], args.batch_size[1]
     Bs, Bt = parallel.padded_shard_size(Bs_g, world), parallel.padded_shard_size(Bt_g, world)
     flags = flags_from_options(args.place_adv, args.add_loss_DA, args.use_attn, args.adv_DA, args.use_target)
     eng = TrainEngine(Bs, Bt, T, D, args.fc_dim, num_class, flags=flags, dropout_i=args.dropout_i,
                       dropout_v=args.dropout_v, momentum=args.momentum, weight_decay=args.weight_decay,
-                      clip=args.clip_gradient, device=dev, bf16=(args.arithmetic == "bf16"), bf16_store=(args.arithmetic == "bf16"))
+                      clip=args.clip_gradient, device=dev, bf16=(args.arithmetic == "bf16"), bf16_store=(args.arithmetic == "bf16"),
+                      aggregation=args.frame_aggregation)
     from ta3n_amd.models import VideoModel
     torch.manual_seed(1)
     model = VideoModel(num_class, args.baseline_type, args.frame_aggregation, args.modality, train_segments=T,
@@ -75,54 +134,67 @@ def main():
                        dropout_i=args.dropout_i, dropout_v=args.dropout_v, partial_bn=not args.no_partialbn,
                        use_bn=args.use_bn, ens_DA=args.ens_DA, use_attn=args.use_attn, verbose=False)
     eng.load_state(model.state_dict())                  # reference initialisation under torch.manual_seed(1)
+    start_epoch, best_prec1, lr_resumed = 1, 0.0, None
+    if args.resume:                                      # main.py:94-106
+        if not os.path.isfile(args.resume):
+            raise SystemExit(f"=> no checkpoint found at '{args.resume}'")
+        st = ckpt.load_into_engine(eng, model, torch.load(args.resume, map_location="cpu", weights_only=False), args.resume_hp)
+        start_epoch, best_prec1, lr_resumed = st["start_epoch"], st["best_prec1"], st["lr"]
+        if rank == 0:
+            print(f"=> loaded checkpoint '{args.resume}' (epoch {start_epoch - 1})", flush=True)
     parallel.broadcast_(eng.P)
+    parallel.broadcast_(eng.M)
     eng.refresh_bf16(params=True)
-    if args.synthetic:
-        n_src, n_tgt = args.synthetic
-    elif args.feature_store:
-        n_src, n_tgt = 1, 1                              # set from the stores below
-    else:
-        n_src, n_tgt = sum(1 for _ in open(args.train_source_list)), sum(1 for _ in open(args.train_target_list))
-    steps_per_epoch = max(n_src // Bs_g, 1)
-    total_steps = args.epochs * steps_per_epoch
-    captured = False
     stores = None
     if args.feature_store:
         from ta3n_amd.feature_store import FeatureStore
         stores = [FeatureStore(pfx, D, dev) for pfx in args.feature_store]
         n_src, n_tgt = len(stores[0]), len(stores[1])
-        steps_per_epoch = max(n_src // Bs_g, 1)
-        total_steps = args.epochs * steps_per_epoch
+    elif args.synthetic:
+        n_src, n_tgt = args.synthetic
+    else:
+        n_src, n_tgt = sum(1 for _ in open(args.train_source_list)), sum(1 for _ in open(args.train_target_list))
+    n_src_train, n_tgt_train = train_list_sizes(n_src, n_tgt, args.batch_size, args.copy_list)
+    len_source_loader = n_batches(n_src_train, Bs_g)                      # main.py:334-335 use len(source_loader)
+    steps_per_epoch = min(len_source_loader, n_batches(n_tgt_train, Bt_g))   # zip() stops at the shorter loader (main.py:348)
+    captured = False
 
-    def store_loader(n_videos, batch, seed):
-        """Video ids of one epoch: a seeded permutation (RandomSampler, main.py:176-190), identical on every rank."""
-        perm = torch.randperm(n_videos, generator=torch.Generator().manual_seed(seed))
-        for b in range(max(n_videos // batch, 1)):
+    def store_loader(n_videos, n_load, batch, seed):
+        """Video ids of one epoch: a seeded permutation of the list repeated to n_load entries (dataset.py:69-74 +
+        RandomSampler, main.py:176-190), identical on every rank."""
+        ids = torch.arange(n_load) % n_videos
+        perm = ids[torch.randperm(n_load, generator=torch.Generator().manual_seed(seed))]
+        for b in range(n_batches(n_load, batch)):
             yield perm[b * batch:(b + 1) * batch].to(torch.int32)
 
     def validate(epoch):
-        """main.validate (main.py:669-761) on rank 0: eval-mode forward + device-side CE / top-k / confusion matrix."""
+        """main.validate (main.py:669-761): eval-mode forward + device-side CE / top-k / confusion matrix (same on every rank)."""
         val = stores[2]
         for b0 in range(0, len(val), Bs):
             ids = torch.arange(b0, min(b0 + Bs, len(val)), dtype=torch.int32, device=dev)
             x, y = val.gather(ids, T)
             eng.evaluate_batch(x, y, reset=(b0 == 0))
         r = eng.eval_results()
-        print(f"Test: [{epoch}] Prec@1 {r['prec1']:.3f} Prec@5 {r['prec5']:.3f} Loss {r['loss']:.5f} ({r['n']} videos)", flush=True)
+        if rank == 0:
+            print(f"Test: [{epoch}] Prec@1 {r['prec1']:.3f} Prec@5 {r['prec5']:.3f} Loss {r['loss']:.5f} ({r['n']} videos)", flush=True)
+        return r["prec1"]
 
+    lr = args.lr if lr_resumed is None else lr_resumed
     t_start = time.time()
-    for epoch in range(1, args.epochs + 1):
+    for epoch in range(start_epoch, args.epochs + 1):
+        if args.lr_adaptive == "none" and epoch in args.lr_steps:                     # main.py:236-237, 790-793
+            lr /= args.lr_decay
         if stores:
-            src = ((ids, None) for ids in store_loader(n_src, Bs_g, 1000 + epoch))
-            tgt = ((ids, None) for ids in store_loader(max(n_tgt, 1), Bt_g, 2000 + epoch))
+            src = ((ids, None) for ids in store_loader(n_src, n_src_train, Bs_g, 1000 + epoch))
+            tgt = ((ids, None) for ids in store_loader(max(n_tgt, 1), n_tgt_train, Bt_g, 2000 + epoch))
         elif args.synthetic:
-            src = synthetic_loader(n_src, Bs_g, T, D, num_class, 1000 + epoch)
-            tgt = synthetic_loader(max(n_tgt, Bt_g * steps_per_epoch), Bt_g, T, D, num_class, 2000 + epoch)
+            src = synthetic_loader(n_src_train, Bs_g, T, D, num_class, 1000 + epoch)
+            tgt = synthetic_loader(n_tgt_train, Bt_g, T, D, num_class, 2000 + epoch)
         else:
-            src = list_loader(args.train_source_list, Bs_g, T, 1000 + epoch)
-            tgt = list_loader(args.train_target_list, Bt_g, T, 2000 + epoch)
+            src = list_loader(args.train_source_list, n_src_train, Bs_g, T, 1000 + epoch)
+            tgt = list_loader(args.train_target_list, n_tgt_train, Bt_g, T, 2000 + epoch)
         for i, ((xs, ys), (xt, _)) in enumerate(zip(src, tgt)):
-            p = float(i + epoch * steps_per_epoch) / total_steps                      # main.py:350
+            p = float(i + epoch * len_source_loader) / (args.epochs * len_source_loader)   # main.py:334-335, 350
             bd = beta_dann(p)
             beta = [bd if b < 0 else b for b in args.beta]                            # main.py:352
             lo, hi = parallel.shard_range(xs.size(0), world, rank)                    # this rank's videos
@@ -138,30 +210,35 @@ def main():
                 xt_r = torch.zeros(Bt, T, D); xt_r[: hi_t - lo_t] = xt[lo_t:hi_t]
                 ys_r = torch.zeros(Bs, dtype=torch.long); ys_r[: hi - lo] = ys[lo:hi]
                 eng.set_batch(xs_r.to(dev, non_blocking=True), xt_r.to(dev, non_blocking=True), ys_r.to(dev))
-            lr = args.lr if (epoch == 1 and i == 0) or args.lr_adaptive != "dann" else eng._lr_next
             if not captured and args.graph:
                 eng.set_hyper(beta, args.gamma, lr)
                 eng.capture()
                 captured = True
             eng.train_step(beta, args.gamma, lr, valid_source=hi - lo, valid_target=hi_t - lo_t,
                            global_source=xs.size(0), global_target=xt.size(0))
-            eng._lr_next = lr_dann(args.lr, p) if args.lr_adaptive == "dann" else lr   # main.py:620-621
-            if rank == 0 and i % max(args.print_freq, 1) == 0:
-                L = eng.losses()          # one host sync every print_freq steps (the reference syncs 5-6x per step)
-                print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr:.5f} loss {L['loss']:.4f} loss_c {L['loss_c']:.4f} "
-                      f"loss_a {L['loss_adv_rel'] + L['loss_adv_vid'] + L['loss_adv_frm']:.4f} loss_e {L['loss_e']:.4f} "
-                      f"beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
-        if stores and len(stores) > 2 and rank == 0:
-            validate(epoch)
+            lr_used = lr
+            if args.lr_adaptive == "dann":
+                lr = lr_dann(args.lr, p)                                              # main.py:620-621 (takes effect at the next step)
+            if i % max(args.print_freq, 1) == 0:
+                # one host sync every print_freq steps (the reference syncs 5-6x per step).  A rank's loss scalars are its
+                # shard's sums divided by the GLOBAL counts: the job's losses are their sum over ranks.
+                scal = eng.region("losses")[:6].clone()
+                if world > 1:
+                    torch.distributed.all_reduce(scal)
+                if rank == 0:
+                    v = scal.tolist()
+                    print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
+                          f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
+        if epoch % max(args.eval_freq, 1) == 0 or epoch == args.epochs:                   # main.py:252-274
+            prec1 = validate(epoch) if (stores and len(stores) > 2) else 0.0
+            is_best = prec1 > best_prec1
+            best_prec1 = max(prec1, best_prec1)
+            if rank == 0 and args.save_model and args.exp_path:
+                ckpt.save_checkpoint(ckpt.engine_checkpoint(eng, model, epoch, args.arch, lr, best_prec1, prec1), is_best,
+                                     os.path.join(args.exp_path, args.modality))
     torch.cuda.synchronize(dev)
     if rank == 0:
         print(f"total training time: {time.time() - t_start:.1f}s")
-        if args.save_model and args.exp_path:
-            os.makedirs(args.exp_path, exist_ok=True)
-            sd = {"module." + k: v.cpu() for k, v in eng.state_dict().items()}        # DataParallel-style keys (main.py:270)
-            for k, v in model.state_dict().items():
-                sd.setdefault("module." + k, v)                                       # BatchNorm buffers
-            torch.save({"epoch": args.epochs, "arch": args.arch, "state_dict": sd}, os.path.join(args.exp_path, "checkpoint.pth.tar"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
