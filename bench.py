@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1])")
+    ap.add_argument("--wgrads-late", action="store_true", help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -192,7 +193,7 @@ def main():
             phase_tiles = []
         eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
                           clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                          fused=not args.unfused, bf16=bf16, bf16_store=twins)
+                          fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late)
         shapes = {n: s for n, _, s, _ in eng.plan.params}
         eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
         xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)

@@ -77,7 +77,13 @@ typedef struct {
     int32_t phase_tiles[16]; /* per GEMM phase (in launch order) override of tile_config; 0 = use tile_config/auto */
     int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD */
     int32_t aggregation;     /* TA3N_AGG_*: frame aggregation (opts.py --frame_aggregation) */
-    int32_t reserved[5];
+    int32_t wgrads_late;     /* fused step, 0 (default): the TRN / frame-discriminator weight gradients share the launch of the
+                              * gradient at the frame features; 1: that launch holds only the (critical-path) gradient at the frame
+                              * features and the weight gradients nobody waits for ride in the LAST launch, beside the shared-FC
+                              * weight gradient.  Measured slower at the headline shape (17.0 + 19.5 us against 22.1 + 9.3 us: a
+                              * long-K tile alone on a compute unit is bound by the latency of its two LDS stages, not by the
+                              * load path it no longer shares); kept for other shapes and A/B runs. */
+    int32_t reserved[4];
 } ta3n_config;
 
 /* Per-step scalars; lives in device memory inside ws (region "hyper").  The host

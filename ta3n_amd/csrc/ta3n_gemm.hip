@@ -150,7 +150,10 @@ struct OperandStream {
                 } else {                               // [k][R] bf16: R/8 lanes (of 8 rows each) per k row
                     constexpr int LPR = R / 8, KPP = 64 / LPR;
                     const int k = q * KPP + lane / LPR;
-                    const int r = r0_ + (lane % LPR) * 8;
+                    // R = 64: image rows k with (k >> 1) & 1 hold their 16-byte chunks swapped by four (the transpose reads of
+                    // compute_stage then touch every LDS bank once); R = 32 rows are 64 bytes and need no swizzle
+                    const int chunk = (lane % LPR) ^ (R == 64 ? ((k >> 1) & 1) << 2 : 0);
+                    const int r = r0_ + chunk * 8;
                     p[i] = origin_ + (size_t)k * ldf + (r >> 1);
                     kofs[i] = (r < rvalid_) ? k : K_NEVER;
                 }
@@ -220,26 +223,40 @@ __device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const floa
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
     if constexpr (BF == 2) {
-        // stage of 128 k; slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): eight 2-byte reads.
+        // stage of 128 k; slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): two transpose
+        // reads (ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 rows] block, 8 contiguous bytes per lane, and lane i
+        // receives row i's four k) - k 8G .. 8G+3 and 8G+4 .. 8G+7 of this lane's row.  For R = 64 the 16-byte chunks of image
+        // rows k with (k >> 1) & 1 are stored swapped by 4 chunks (OperandStream::setup), which makes the reads conflict-free.
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
         u32x4 ta[NQ], tb[NQ];
+        const int lane = lh * 32 + (ra & 31);
+        const int trow = 8 * lh + ((lane >> 2) & 3);                              // k row of this lane inside the 16-k block of one MFMA
+        const int tcol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3));                 // first of this lane's 4 contiguous rows of the block
         const unsigned short *sa16 = reinterpret_cast<const unsigned short *>(sa);
         const unsigned short *sb16 = reinterpret_cast<const unsigned short *>(sb);
+        const int acol = ((ra & ~31) + tcol) ^ (BM == 64 ? 32 * ((lane >> 3) & 1) : 0);
+        const int bcol = ((rb & ~31) + tcol) ^ (BN == 64 ? 32 * ((lane >> 3) & 1) : 0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int G = wk * GPW + 2 * q + lh;
             if (!AKM) {
                 ta[q] = *reinterpret_cast<const u32x4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    ta[q][j] = (unsigned)sa16[(8 * G + 2 * j) * BM + ra] | ((unsigned)sa16[(8 * G + 2 * j + 1) * BM + ra] << 16);
+                const int k0 = 8 * (wk * GPW + 2 * q) + trow;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + k0 * BM + acol));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + (k0 + 4) * BM + acol));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                ta[q] = u32x4{l2[0], l2[1], h2[0], h2[1]};
             }
             if (!BKM) {
                 tb[q] = *reinterpret_cast<const u32x4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    tb[q][j] = (unsigned)sb16[(8 * G + 2 * j) * BN + rb] | ((unsigned)sb16[(8 * G + 2 * j + 1) * BN + rb] << 16);
+                const int k0 = 8 * (wk * GPW + 2 * q) + trow;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + k0 * BN + bcol));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + (k0 + 4) * BN + bcol));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                tb[q] = u32x4{l2[0], l2[1], h2[0], h2[1]};
             }
         }
         if (RS) {
@@ -327,6 +344,13 @@ __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
 
 }  // namespace
 
+#ifdef TA3N_GEMM_STAMPS
+__device__ unsigned long long ta3n_dbg_stamps[8192 * 8];
+#define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ta3n_dbg_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 namespace ta3n {
 
 // BF: bf16 MFMA on operands rounded in registers; NS: LDS stages in flight (2, or 3 with BF: once the MFMA is cheap the
@@ -349,6 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const int li = lane & 31, lh = lane >> 5;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
+    GSTAMP(0);
     const Task &t = tasks[blockIdx.x];
     if (t.epi & EPI_SGD) {          // optimiser side job (uniform for the workgroup): arithmetic and summation order of sgd_range_kernel
         if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
@@ -419,10 +444,27 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
     const float *__restrict__ zeros = ptrs.ws + zeros_off;   // 64 floats that are never written
+    // What the epilogue needs that does not depend on the accumulators is fetched NOW, under the K loop: the per-step
+    // scalars and this thread's four bias entries (its column group is the same in every epilogue iteration).
+    const uint32_t epi = t.epi;
+    const float alpha = hyper_scale(hy, t.alpha_kind);
+    const float gamma = hyper_scale(hy, t.gamma_kind);
+    const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && hy->train != 0;
+    const uint32_t dseed = (epi & EPI_DROP_I) ? hy->seed_i : hy->seed_v;
+    const float dp = (epi & EPI_DROP_I) ? hy->p_drop_i : hy->p_drop_v;
+    float ebias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi & EPI_BIAS) {
+        const float *__restrict__ bias = base_ptr(ptrs, t.bias_base) + t.bias_off;
+        const int n = t.n0 + (tid % (BN / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < t.n_valid) ebias[e] = bias[n + e];
+    }
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    GSTAMP(1);
 
     const int m0 = t.m0, n0 = t.n0, m_valid = t.m_valid, n_valid = t.n_valid;
     const int seg_end = t.seg_begin + t.seg_count;
@@ -441,8 +483,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             OperandStream<BM, NW, TW> oa;
             OperandStream<BN, NW, TW> ob;
             int klen = 0, scale = SK_ONE;
+            // The descriptor of the NEXT Seg is fetched while the current one streams (scalar loads, consumed at the next
+            // open): opening a Seg used to start with a dependent global load between "stage landed" and "next DMA issued" -
+            // pure load-path idle time, once per Seg, and the gradient-at-F1 tiles have a Seg every two chunks.
+            Seg nx = t.seg0;
             auto open_seg = [&](int sidx) {            // wave-uniform: Seg fields live in SGPRs
-                const Seg &sg = segs[sidx];
+                const Seg sg = nx;
+                if (sidx + 1 < seg_end) nx = segs[sidx + 1];
                 klen = sg.klen; scale = sg.scale_kind;
                 oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
                          wave, lane);
@@ -496,8 +543,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             constexpr int LPW = OperandStream<BM, NW, TW>::NP + OperandStream<BN, NW, TW>::NP;   // DMAs per lane and chunk (16-byte path;
                                                                                          // the 4-byte path issues more, never fewer)
             int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
+            Seg nx = t.seg0;                         // descriptor of the Seg the issue cursor opens next, fetched one Seg ahead
             auto open_issue_seg = [&]() {            // wave-uniform: Seg fields live in SGPRs
-                const Seg &sg = segs[i_seg];
+                const Seg sg = nx;
+                if (i_seg + 1 < seg_end) nx = segs[i_seg + 1];
                 i_klen = sg.klen; i_nchunks = (sg.klen + CH - 1) / CH; i_chunk = 0;
                 oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
                          wave, lane);
@@ -526,9 +575,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             for (int sidx = 0; sidx < NS - 1 && i_seg < seg_end; ++sidx) issue_one();
 
             int c_buf = 0;
+            int c_klen_nx = t.seg0.klen, c_scale_nx = t.seg0.scale_kind;   // compute cursor: the same one-ahead fetch of (klen, scale)
             for (;;) {
-                const Seg &cs = segs[cseg];
-                const int klen = cs.klen, c_scale = cs.scale_kind;
+                const int klen = c_klen_nx, c_scale = c_scale_nx;
+                if (cseg + 1 < seg_end) { c_klen_nx = segs[cseg + 1].klen; c_scale_nx = segs[cseg + 1].scale_kind; }
                 const int n_chunks = (klen + CH - 1) / CH;
                 int c = 0;
                 // interior of the Seg: both cursors inside it, NS - 1 chunks in flight, nothing to decide per chunk
@@ -572,7 +622,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     using T_ = std::true_type;
     using F_ = std::false_type;
     {
-        const Seg &s0 = segs[cseg];
+        const Seg &s0 = t.seg0;
         switch (s0.a_kmajor * 2 + s0.b_kmajor) {
             case 0: k_loop(F_{}, F_{}, F_{}); break;
             case 1: k_loop(F_{}, T_{}, F_{}); break;
@@ -585,6 +635,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
 
     // ---- epilogue: accumulators -> LDS (reduces the K split, makes rows contiguous) ----
+    GSTAMP(2);
     __syncthreads();
     {
         float *cs = lds + wave * (32 * 36);
@@ -596,48 +647,54 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
     __syncthreads();
 
-    const uint32_t epi = t.epi;
-    const float alpha = hyper_scale(hy, t.alpha_kind);
-    const float gamma = hyper_scale(hy, t.gamma_kind);
-    const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && hy->train != 0;
-    const uint32_t dseed = (epi & EPI_DROP_I) ? hy->seed_i : hy->seed_v;
-    const float dp = (epi & EPI_DROP_I) ? hy->p_drop_i : hy->p_drop_v;
     float *__restrict__ cbase = const_cast<float *>(base_ptr(ptrs, t.c_base)) + (size_t)t.c_off;
-    // Operand reads are address-selected (absent / out-of-range -> a block of zeros, or of
-    // ones for the mask) so that all of a thread's epilogue loads issue together.
-    const float *__restrict__ ones = zeros + 64;   // region "ones" follows region "zeros" (plan builder)
-    const float *__restrict__ bias = (epi & EPI_BIAS) ? base_ptr(ptrs, t.bias_base) + t.bias_off : nullptr;
     const float *__restrict__ aux = (epi & EPI_MASK) ? base_ptr(ptrs, t.aux_base) + t.aux_off : nullptr;
     const float *__restrict__ add = (epi & EPI_ADD) ? base_ptr(ptrs, t.add_base) + t.add_off : nullptr;
     const bool c_vec = ((t.c_off | t.c_ld) & 3) == 0;
+    const bool aux_vec = ((t.aux_off | t.aux_ld) & 3) == 0, add_vec = ((t.add_off | t.add_ld) & 3) == 0;
     const int nfan = t.fan_count;
     float sumsq = 0.f;   // EPI_SUMSQ: this thread's share of the tile's sum of squares
-
-    for (int idx = tid; idx < BM * BN / 4; idx += NT) {
+    // Every flag test below is workgroup-uniform: a tile without bias / mask / residual issues no load for it (the
+    // bias and the per-step scalars were fetched before the K loop, so the first dependent global access of a plain
+    // tile is its store).
+    constexpr int ITER = (BM * BN / 4 + NT - 1) / NT;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * NT;
+        if (idx >= BM * BN / 4) break;
         const int r = idx / (BN / 4);
-        const int c4 = (idx % (BN / 4)) * 4;
+        const int c4 = (idx % (BN / 4)) * 4;        // == ec4 for every iteration: NT is a multiple of BN / 4
         const int tile = (r >> 5) * WN + (c4 >> 5);
+        const int m = m0 + r, n = n0 + c4;
+        const bool row_ok = m < m_valid;
+        const int nrem = row_ok ? n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
+        float av[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (add != nullptr && nrem > 0) {           // issued first: their latency overlaps the LDS reads below
+            const float *ap = add + (size_t)m * t.add_ld + n;
+            if (nrem >= 4 && add_vec) { const float4 q4 = *reinterpret_cast<const float4 *>(ap); av[0] = q4.x; av[1] = q4.y; av[2] = q4.z; av[3] = q4.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nrem) av[e] = ap[e];
+            }
+        }
+        if (aux != nullptr && nrem > 0) {
+            const float *xp = aux + (size_t)m * t.aux_ld + n;
+            if (nrem >= 4 && aux_vec) { const float4 q4 = *reinterpret_cast<const float4 *>(xp); mv[0] = q4.x; mv[1] = q4.y; mv[2] = q4.z; mv[3] = q4.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nrem) mv[e] = xp[e];
+            }
+        }
         float4 v4 = zero4();
 #pragma unroll
         for (int q = 0; q < WK; ++q) {
             const float4 part = *reinterpret_cast<const float4 *>(&lds[(tile * WK + q) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
             v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
         }
-        const int m = m0 + r, n = n0 + c4;
-        const bool row_ok = m < m_valid;
-        const int nrem = row_ok ? n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        float bv[4], av[4], mv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool ok = e < nrem;
-            bv[e] = *((ok && bias) ? bias + n + e : zeros);
-            av[e] = *((ok && add) ? add + (size_t)m * t.add_ld + n + e : zeros);
-            mv[e] = *((ok && aux) ? aux + (size_t)m * t.aux_ld + n + e : ones);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = (v[e] + bv[e]) * alpha + av[e];
+            float x = (v[e] + ebias[e]) * alpha + av[e];
             if (epi & EPI_RELU) x = fmaxf(x, 0.f);
             x = mv[e] > 0.f ? x : 0.f;
             if (drop_on) x *= keep_mask(dseed, (uint32_t)(m * t.drop_ld + n + e), dp);
@@ -668,29 +725,47 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     if (e < nrem) tp[e] = h[e];
             }
         }
+        if (nfan > 0) {
+            const bool fan_vec = nrem >= 4 && (t.fan_ld & 3) == 0;
+            float fm[3][4];
 #pragma unroll
-        for (int f = 0; f < 3; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
-            if (f < nfan) {
-                const float *mp = ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n;
-                float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
-                float ov[4];
+            for (int f = 0; f < 3; ++f) {   // all mask loads first
+                if (f < nfan) {
+                    const float *mp = ptrs.ws + (size_t)t.fan_mask_off[f] + (size_t)m * t.fan_ld + n;
+                    if (fan_vec && (t.fan_mask_off[f] & 3) == 0) { const float4 q4 = *reinterpret_cast<const float4 *>(mp); fm[f][0] = q4.x; fm[f][1] = q4.y; fm[f][2] = q4.z; fm[f][3] = q4.w; }
+                    else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = (e < nrem && mp[e] > 0.f) ? v[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) fm[f][e] = e < nrem ? mp[e] : 0.f;
+                    }
+                }
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nrem) op[e] = ov[e];
-                if (epi & EPI_TWIN16_FAN) {
-                    unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) +
-                                         ((size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n);
-                    const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
-                    if (nrem >= 4 && ((t.fan_out_off[f] | t.fan_ld) & 3) == 0) {
-                        *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+            for (int f = 0; f < 3; ++f) {   // same value through several ReLU masks (TRN tuples of one scale)
+                if (f < nfan) {
+                    float *op = ptrs.ws + (size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n;
+                    float ov[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (e < nrem && fm[f][e] > 0.f) ? v[e] : 0.f;
+                    if (fan_vec && (t.fan_out_off[f] & 3) == 0) {
+                        *reinterpret_cast<float4 *>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
                     } else {
-                        const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16),
-                                                     (unsigned short)(hi & 0xFFFF), (unsigned short)(hi >> 16)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (e < nrem) tp[e] = h[e];
+                            if (e < nrem) op[e] = ov[e];
+                    }
+                    if (epi & EPI_TWIN16_FAN) {
+                        unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) +
+                                             ((size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n);
+                        const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
+                        if (nrem >= 4 && ((t.fan_out_off[f] | t.fan_ld) & 3) == 0) {
+                            *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+                        } else {
+                            const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16),
+                                                         (unsigned short)(hi & 0xFFFF), (unsigned short)(hi >> 16)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (e < nrem) tp[e] = h[e];
+                        }
                     }
                 }
             }
@@ -710,6 +785,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             }
         }
     }
+    GSTAMP(3);
+#ifdef TA3N_GEMM_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { ta3n_dbg_stamps[blockIdx.x * 8 + 4] = (unsigned long long)t.cost; ta3n_dbg_stamps[blockIdx.x * 8 + 5] = (unsigned long long)t.seg_count; ta3n_dbg_stamps[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(( (4-1) << 11) | (0 << 6) | 20); }
+#endif
     if (epi & EPI_SUMSQ) {   // wave-uniform: fixed-order block sum -> this tile's slot (fused grad-norm partial)
         __syncthreads();
         sumsq = wave_allreduce_sum(sumsq);
@@ -732,6 +811,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     template __global__ void gemm_tiles<wm, wn, wk, 2, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
     template __global__ void gemm_tiles<wm, wn, wk, 2, 3>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
+
+#ifdef TA3N_GEMM_STAMPS
+extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ta3n_dbg_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 bool tile_config_ok(int cfg) {
     const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice)

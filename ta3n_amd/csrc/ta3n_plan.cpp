@@ -232,7 +232,8 @@ struct Builder {
             local[0].pad[0] = sum8[0]; local[0].pad[1] = sum8[1]; local[0].pad[2] = sum8[2];
             sum8[0] = -1;
         }
-        for (auto &t : side_tasks) local.push_back(t);
+        // the short side tasks go right behind the first tile: they finish under the tiles instead of extending the launch's tail
+        local.insert(local.begin() + (local.empty() ? 0 : 1), side_tasks.begin(), side_tasks.end());
         side_tasks.clear();
         for (auto &t : local) p.tasks.push_back(t);
         ph.task_count = (int32_t)local.size();
@@ -461,6 +462,8 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     add_bf16_twins(p, b, g, BT, D, {Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F}});   // pool_cls keeps the twin of gZ1
     if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
+    for (auto &t : p.tasks)      // (after the twin re-addressing: the copies must be the final Segs)
+        if (t.seg_count > 0) t.seg0 = p.segs[t.seg_begin];
     return TA3N_OK;
 }
 
@@ -758,7 +761,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j)));
         }
     };
-    auto push_trn_level = [&](std::vector<GemmSpec> &s) {   // TRN weight grads + gradient at F1
+    auto push_trn_wgrads = [&](std::vector<GemmSpec> &s) {   // TRN weight (and bias) gradients
         for (int j = 0; j < NR; ++j) {
             const int sl = T - j;
             for (int pos = 0; pos < sl; ++pos) {   // dW_j[:, pos*F:(pos+1)*F] = sum_t gZ_t^T F1[:, tau_t[pos]]
@@ -772,6 +775,8 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
                 s.push_back(gw);
             }
         }
+    };
+    auto push_f1_grad = [&](std::vector<GemmSpec> &s) {   // gradient at the frame features (TRN input gradient + frame discriminator's, reversed)
         for (int f = 0; f < T; ++f) {   // gZ1[:, f] = ( -beta2 gHf[:, f] Wfd + sum_{(t,pos): tau_t[pos]==f} gZ_t W_j[:, pos] ) * [F1>0] / keep
             GemmSpec gz;
             gz.M = B; gz.N = F;
@@ -789,6 +794,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             s.push_back(gz);
         }
     };
+    auto push_trn_level = [&](std::vector<GemmSpec> &s) { push_trn_wgrads(s); push_f1_grad(s); };
     auto push_shared_fc_wgrad = [&](std::vector<GemmSpec> &s) {   // shared frame FC weight grad (no input gradient: the features are data)
         GemmSpec gw;
         gw.M = F; gw.N = D;
@@ -868,13 +874,27 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             if (!twins) push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
+        // The critical path of the backward pass is  relation level -> gradient at F1 -> shared-FC weight gradient; the TRN
+        // weight gradients and dWfd feed nothing but the optimiser, so they may ride with either of the last two launches
+        // (ta3n_config.wgrads_late, default 0 = with the gradient at F1: measured faster at the headline shape, ta3n_hip.h).
+        const bool twins_on = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
+        const bool late = c.wgrads_late != 0;
         {
             std::vector<GemmSpec> s;
-            if ((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE)) push_frame_disc_wgrads(s);
-            push_trn_level(s);
+            if (twins_on && !late) push_frame_disc_wgrads(s);
+            if (!late) push_trn_wgrads(s);
+            push_f1_grad(s);
             b.add_gemm_phase(4, s);
         }
-        { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(4, s); }
+        {
+            std::vector<GemmSpec> s;
+            push_shared_fc_wgrad(s);
+            if (late) {
+                push_trn_wgrads(s);
+                if (twins_on) push_frame_disc_wgrads(s);
+            }
+            b.add_gemm_phase(4, s);
+        }
         {   // group 5: the step's first launch once more, carrying the PREVIOUS step's optimiser update of every parameter
             // it does not read itself (all but the shared frame FC) as EPI_SGD side tasks (ta3n_train_step_after_update)
             const Phase *f1 = nullptr;
@@ -914,5 +934,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
+    for (auto &t : p.tasks)      // (after the twin re-addressing: the copies must be the final Segs)
+        if (t.seg_count > 0) t.seg0 = p.segs[t.seg_begin];
     return TA3N_OK;
 }

@@ -63,6 +63,8 @@ struct Task {
     int32_t fan_ld;
     int32_t fan_mask_off[3];
     int32_t fan_out_off[3];
+    Seg seg0;                            // copy of segs[seg_begin]: arrives with the Task, so the first DMA is one dependent
+                                         // scalar load away from kernel entry instead of two
     int32_t cost;                        // sum of klen (for ordering / balance)
     int32_t pad[4];                      // EPI_SUMROWS8: [0..2] = {dst, src, rows} (ws offsets); EPI_SUMSQ: [3] = ws offset of the slot;
                                          // EPI_COLSUM: [0..2] = {src ws offset, rows, row stride}

@@ -31,7 +31,7 @@ class Task(C.Structure):
                 [(n, C.c_int32) for n in ("alpha_kind", "gamma_kind", "c_base", "c_off", "c_ld", "bias_base", "bias_off",
                                           "aux_base", "aux_off", "aux_ld", "add_base", "add_off", "add_ld", "drop_ld",
                                           "fan_count", "fan_ld")] +
-                [("fan_mask_off", C.c_int32 * 3), ("fan_out_off", C.c_int32 * 3), ("cost", C.c_int32),
+                [("fan_mask_off", C.c_int32 * 3), ("fan_out_off", C.c_int32 * 3), ("seg0", Seg), ("cost", C.c_int32),
                  ("pad", C.c_int32 * 4)])
 
 

@@ -212,3 +212,16 @@ def test_live_parameter_set_follows_the_options_like_autograd_does(place_adv, us
     xs, xt, ys, yt = synth_batch(5, 4, 32, 3, 2, seed=4)
     res = orc.train_step(orc.TrainState(params=params), xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg)
     assert live == set(res["grads"].keys())
+
+
+def test_every_task_carries_a_copy_of_its_first_segment():
+    """Task.seg0 (what the kernel opens its K loop with) must be the final - twin-re-addressed - segs[seg_begin]."""
+    import ctypes as C
+    for flags in (ALL_FLAGS, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE):
+        it = Interp(_lib.Plan(6, 4, 5, 512, 64, 12, flags))
+        n = 0
+        for t in it.tasks:
+            if t.seg_count > 0:
+                assert bytes(t.seg0) == bytes(it.segs[t.seg_begin])
+                n += 1
+        assert n > 100

@@ -26,7 +26,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 struct Gemm {
     const unsigned short *A, *B;   // bf16 [M][K], [N][K]
     float *C;
-    int M, N, K;
+    int M, N, K, ld;               // ld: row stride of A and B in elements (>= K)
     unsigned long long *stamps;    // [grid][4]
     const unsigned short *zeros;
 };
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_bf16(Gemm g) {
         const int total = (BM + BN) * lines_per_row;
         for (int i = tid; i < total; i += 64 * NW) {
             const int row = i / lines_per_row, ln = i % lines_per_row;
-            const unsigned short *p = row < BM ? g.A + (size_t)min(m0 + row, g.M - 1) * g.K + ln * 64
-                                               : g.B + (size_t)min(n0 + row - BM, g.N - 1) * g.K + ln * 64;
+            const unsigned short *p = row < BM ? g.A + (size_t)min(m0 + row, g.M - 1) * g.ld + ln * 64
+                                               : g.B + (size_t)min(n0 + row - BM, g.N - 1) * g.ld + ln * 64;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(p), "s"(lds_base + (unsigned)LDS_B) : "memory");
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_bf16(Gemm g) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int q = wave + NW * i, row = q * 4 + (lane >> 4), s = (lane & 15) ^ (row & 15);
-        pa[i] = (m0 + row < g.M) ? reinterpret_cast<const unsigned char *>(g.A + (size_t)(m0 + row) * g.K) + 16 * s
+        pa[i] = (m0 + row < g.M) ? reinterpret_cast<const unsigned char *>(g.A + (size_t)(m0 + row) * g.ld) + 16 * s
                                  : reinterpret_cast<const unsigned char *>(g.zeros);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int q = wave + NW * i, row = q * 4 + (lane >> 4), s = (lane & 15) ^ (row & 15);
-        pb[i] = (n0 + row < g.N) ? reinterpret_cast<const unsigned char *>(g.B + (size_t)(n0 + row) * g.K) + 16 * s
+        pb[i] = (n0 + row < g.N) ? reinterpret_cast<const unsigned char *>(g.B + (size_t)(n0 + row) * g.ld) + 16 * s
                                  : reinterpret_cast<const unsigned char *>(g.zeros);
     }
     const bool a_ok[1] = {true};
@@ -231,12 +231,18 @@ int main(int argc, char **argv) {
             }
     }
     Gemm g;
+    const int pad = argc > 2 ? atoi(argv[2]) : 0;          // extra elements per row
+    const int ld = K + pad;
+    std::vector<unsigned short> ap((size_t)M * ld, 0), bp((size_t)N * ld, 0);
+    for (int m = 0; m < M; ++m) memcpy(&ap[(size_t)m * ld], &a[(size_t)m * K], K * 2);
+    for (int n = 0; n < N; ++n) memcpy(&bp[(size_t)n * ld], &b[(size_t)n * K], K * 2);
     unsigned short *dA, *dB, *dZ; float *dC; unsigned long long *dS;
-    CK(hipMalloc(&dA, a.size() * 2)); CK(hipMalloc(&dB, b.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    CK(hipMalloc(&dA, ap.size() * 2)); CK(hipMalloc(&dB, bp.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMalloc(&dS, 4096 * 4 * 8)); CK(hipMalloc(&dZ, 4096)); CK(hipMemset(dZ, 0, 4096));
-    CK(hipMemcpy(dA, a.data(), a.size() * 2, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dB, b.data(), b.size() * 2, hipMemcpyHostToDevice));
-    g.A = dA; g.B = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.stamps = dS; g.zeros = dZ;
+    CK(hipMemcpy(dA, ap.data(), ap.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, bp.data(), bp.size() * 2, hipMemcpyHostToDevice));
+    g.A = dA; g.B = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.ld = ld; g.stamps = dS; g.zeros = dZ;
+    printf("row stride %d elements (%d bytes)\n", ld, ld * 2);
     const int R = 50;
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const int which = argc > 1 ? atoi(argv[1]) : -1;
