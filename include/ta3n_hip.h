@@ -278,6 +278,33 @@ int ta3n_train_step_join(ta3n_plan *plan, const float *x, const float *params, f
 int ta3n_sgd_step_fused(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                         void *stream);
 
+/* ---- data parallelism: RCCL from the C ABI (replaces nn.DataParallel's per-step broadcast / gather / reduce, main.py:79) ----
+ * One process per GPU.  Rank 0 makes a 128-byte id (ta3n_comm_unique_id), the launcher hands it to every rank (any
+ * channel: torch.distributed store, MPI, a file), every rank calls ta3n_comm_create on its device - a collective over
+ * `world` ranks (ncclCommInitRank).  RCCL is dlopen'ed at the first of these calls; a process that never calls them
+ * never loads it. */
+typedef struct ta3n_comm ta3n_comm;
+int ta3n_comm_unique_id(char *id128);
+int ta3n_comm_create(const char *id128, int rank, int world, ta3n_comm **out);
+void ta3n_comm_destroy(ta3n_comm *comm);
+int ta3n_comm_world(const ta3n_comm *comm);
+
+/* In-place SUM all-reduce of buf[0 .. count) over the communicator, enqueued on `stream` (ncclAllReduce).
+ * scratch_bf16 == NULL: fp32 transport (exact sum of the ranks' fp32 gradients up to the reduction order).
+ * scratch_bf16 != NULL (count * 2 bytes, count % 4 == 0): bf16 transport - every rank's values are rounded to bf16
+ * (nearest even), summed in bf16 and widened back: half the bytes over xGMI, bf16 precision of the summed gradient. */
+int ta3n_all_reduce_sum(ta3n_comm *comm, float *buf, int64_t count, void *scratch_bf16, void *stream);
+
+/* ta3n_train_step followed by the all-reduce of the live gradient prefix - the data-parallel step up to the optimiser
+ * (continue with ta3n_sgd_step, whose norm pass reads the reduced gradients).  Losses must be normalised by GLOBAL row
+ * counts (ta3n_hyper.inv_n_*), so the summed gradients are the global-batch gradients.
+ * comm_stream == NULL or == stream: everything on one stream, ONE collective after the last launch (no events).
+ * comm_stream != stream: the gradients of everything but the shared frame FC (complete before the last launch) are
+ * reduced on comm_stream while the last launch runs, the shared frame FC's afterwards; `stream` continues after
+ * both (three event edges, all inside this call; capturable into one hipGraph with the kernels). */
+int ta3n_train_step_ddp(ta3n_plan *plan, ta3n_comm *comm, const float *x, const float *params, float *grads, float *ws,
+                        void *scratch_bf16, void *stream, void *comm_stream);
+
 /* Measurement aid: per-launch durations (ms) of every phase of one train step,
  * taken with HIP events recorded on `stream`; GEMM/pool/loss phases are repeated
  * `reps` times back to back.  kind_out[i]: 0 GEMM, 1 pool fwd, 2 loss, 3 pool bwd,

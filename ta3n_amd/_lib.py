@@ -34,6 +34,7 @@ SYMBOLS = [
     "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step", "ta3n_eval_metrics",
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_last_error", "ta3n_version",
+    "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
 ]
 
 
@@ -110,6 +111,13 @@ def lib() -> C.CDLL:
                                    C.c_int]
     L.ta3n_debug_arrays.argtypes = [vp] + [C.POINTER(vp), C.POINTER(i64)] * 3 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ta3n_debug_struct_sizes.argtypes = [C.POINTER(i32)] * 5
+    L.ta3n_comm_unique_id.argtypes = [C.c_char_p]
+    L.ta3n_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ta3n_comm_destroy.argtypes = [vp]
+    L.ta3n_comm_destroy.restype = None
+    L.ta3n_comm_world.argtypes = [vp]
+    L.ta3n_all_reduce_sum.argtypes = [vp, vp, i64, vp, vp]
+    L.ta3n_train_step_ddp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ta3n_last_error.restype = C.c_char_p
     L.ta3n_version.restype = C.c_char_p
     _LIB = L

@@ -368,6 +368,7 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     Builder b(p);
     // live parameters first (the all-reduce / optimiser operand), then the rest of the reference's state_dict for this configuration
     b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141
+    p.first_floats = p.param_floats;
     b.add_linear("fc_classifier_video_source", C, F, true);            // :272 (feat_aggregated_dim = F, :246-247)
     p.live_floats = p.param_floats;
     b.add_linear("fc_feature_source", F, F, false);

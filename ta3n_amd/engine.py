@@ -124,6 +124,17 @@ class TrainEngine:
         # the last launch runs (worth it only when that launch is longer than an extra collective's fixed cost)
         self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1"))
         self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
+        # N > 1 (or the 1-rank self-test): RCCL straight from the C ABI on the step's streams (TA3N_DDP_NATIVE=0: through
+        # torch.distributed instead).  Gradient transport: fp32, or bf16 (half the xGMI bytes) - default for the bf16
+        # arithmetic, whose contractions see the gradients' operands in bf16 anyway; TA3N_DDP_BF16=0/1 overrides.
+        self.comm = None
+        self._g16 = None
+        self._comm_stream: Optional[torch.cuda.Stream] = None
+        rccl_group = self.world == 1 or torch.distributed.get_backend(self.pg) == "nccl"     # gloo (CPU / shared-GPU tests): torch path
+        if (self.world > 1 or self._ddp_selftest) and rccl_group and os.environ.get("TA3N_DDP_NATIVE", "1") == "1":
+            self.comm = parallel.NativeComm(self.pg if self.world > 1 else None, self.device)
+            if os.environ.get("TA3N_DDP_BF16", "1" if self.bf16 else "0") == "1":
+                self._g16 = torch.zeros(p.live_floats, dtype=torch.bfloat16, device=self.device)
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._hyper = _lib.Hyper()
@@ -227,7 +238,11 @@ class TrainEngine:
                                          self.ws.data_ptr(), self._stream()), "ta3n_backward")
 
     def all_reduce_grads(self) -> None:
-        if self.world > 1:
+        if self.comm is not None:      # RCCL on the step's stream, enqueued by the library
+            _lib.check(self._L.ta3n_all_reduce_sum(self.comm.handle, self.G.data_ptr(), self.plan.live_floats,
+                                                   self._g16.data_ptr() if self._g16 is not None else None, self._stream()),
+                       "ta3n_all_reduce_sum")
+        elif self.world > 1:
             parallel.all_reduce_sum_(self.G[: self.plan.live_floats], self.pg)
         elif self._ddp_selftest:
             w = parallel.all_reduce_sum_async(self.G[: self.plan.live_floats], self.pg, True)
@@ -252,6 +267,14 @@ class TrainEngine:
         """N > 1: the all-reduce of every gradient but the shared frame FC's (the last launch's output, 4.2 of the
         13.9 MB) starts before that launch and runs beside it over xGMI; the rest follows; both are joined before
         the update.  Same collectives in the same order on every rank."""
+        if self.comm is not None:      # the same schedule inside the library: two HIP streams, three event edges, no framework
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.device)
+            _lib.check(self._L.ta3n_train_step_ddp(self.plan.handle, self.comm.handle, self.X.data_ptr(), self.P.data_ptr(),
+                                                   self.G.data_ptr(), self.ws.data_ptr(),
+                                                   self._g16.data_ptr() if self._g16 is not None else None, self._stream(),
+                                                   C.c_void_p(self._comm_stream.cuda_stream)), "ta3n_train_step_ddp")
+            return
         n = self._L.ta3n_num_phases(self.plan.handle, 4)
         args = (self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(), self.ws.data_ptr())
         _lib.check(self._L.ta3n_train_step_range(*args, 0, n - 1, self._stream()), "ta3n_train_step_range")

@@ -90,3 +90,38 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+class NativeComm:
+    """RCCL communicator owned by libta3n_hip.so (include/ta3n_hip.h: ta3n_comm_*): the step's collectives are enqueued by
+    the library on the step's own HIP streams.  The 128-byte id travels over the existing torch.distributed group (any
+    backend); without a group (world 1: the single-rank self-test) it stays local."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.ta3n_comm_unique_id(buf), "ta3n_comm_unique_id")
+        ids = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = C.c_void_p()
+        if device is not None:
+            torch.cuda.set_device(device)
+        _lib.check(L.ta3n_comm_create(C.c_char_p(ids[0]), rank, world, C.byref(h)), "ta3n_comm_create")
+        self.handle, self.world, self.rank, self._L = h, world, rank, L
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.ta3n_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
