@@ -112,6 +112,8 @@ int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t str
 bool heads_supported(int NB, int C, int F);   // configurations the fused heads kernel (ta3n_heads.hip) covers
 int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream);   // TA3N_AGG_AVGPOOL: between F1 and gZ1
+int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

@@ -468,6 +468,221 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     return TA3N_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TA3N_AGG_AVGPOOL, general: TemPooling with the adversarial branches (the "RevGrad" rows of the paper's TemPooling table;
+// also what the module path uses for every avgpool model, because there the caller assembles the loss).  Reference:
+// models.py:557-579 (shared frame FC), 456-462 (frame discriminator), 421-433 (averaging), 679-687 (dropout_v, classifier),
+// 464-470 (video discriminator; feat_aggregated_dim = F, :246-247), 697-708 (pred_domain = [video again, video, frame]),
+// main.py:439-451, 508-538 (losses), 574-583.  Every Linear is a tile-list GEMM; the three small kernels are the
+// averaging, the losses (the trn-m loss kernel with zero relation rows) and the way back through the averaging.
+// Launches of one step (ta3n_forward / ta3n_loss / ta3n_backward, or all of them as ta3n_train_step): F1 | Hf | mean |
+// {Y, Hv} | {Pv, Pf} | losses | {gHv, gHf, small weight gradients} | {gVt, dWdv, dWfd} | spread | gZ1 | dWsh.
+int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
+    const ta3n_config &c = p.cfg;
+    const int Bs = c.batch_source, Bt = c.batch_target, T = c.num_segments, D = c.feature_dim;
+    const int F = std::min(c.fc_dim, c.feature_dim), C = c.num_class;
+    const int B = Bs + Bt, BT = B * T;
+    if (c.flags & (TA3N_FLAG_ATTN_ENTROPY | TA3N_FLAG_TRANS_ATTN)) {
+        err = "avgpool: attention / attentive entropy are not built (the reference's script switches them off with use_attn none)";
+        return TA3N_ERR_INVALID;
+    }
+    if (T < 1 || T > 64) { err = "num_segments must be in [1,64]"; return TA3N_ERR_INVALID; }
+    if (F % 4 != 0) { err = "avgpool: fc_dim must be a multiple of 4"; return TA3N_ERR_INVALID; }
+    const bool live_frm = (c.flags & TA3N_FLAG_ADV_FRAME) != 0;
+    // the video discriminator also serves the relation slot (models.py:707-708), see loss_kernel
+    const bool live_vid = (c.flags & (TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_RELATION)) != 0;
+    p.n_tuples = 0;
+    p.tuple_first.assign(1, 0);
+    Builder b(p);
+    struct Lin { std::string name; int out, in; };
+    std::vector<Lin> dead;
+    auto lin = [&](const std::string &name, int out, int in, bool live) {
+        if (live) b.add_linear(name, out, in, true);
+        else dead.push_back(Lin{name, out, in});
+    };
+    b.add_linear("fc_feature_shared_source", F, D, true);              // models.py:141
+    p.first_floats = p.param_floats;
+    lin("fc_feature_domain", F, F, live_frm);                          // :161
+    lin("fc_classifier_domain", 2, F, live_frm);                       // :170
+    lin("fc_feature_domain_video", F, F, live_vid);                    // :267 (feat_aggregated_dim = F)
+    b.add_linear("fc_classifier_video_source", C, F, true);            // :272
+    lin("fc_classifier_domain_video", 2, F, live_vid);                 // :281
+    p.live_floats = p.param_floats;
+    for (auto &d : dead) b.add_linear(d.name, d.out, d.in, false);
+    b.add_linear("fc_feature_source", F, F, false);
+    b.add_linear("fc_classifier_source", C, F, false);
+    b.add_linear("fc_feature_video_source", F, F, false);
+    b.add_linear("fc_feature_video_source_2", F, F, false);
+    auto P = [&](const std::string &n) { return p.poff(n); };
+    const int64_t Wsh = P("fc_feature_shared_source.weight"), bsh = P("fc_feature_shared_source.bias");
+    const int64_t Wfd = P("fc_feature_domain.weight"), bfd = P("fc_feature_domain.bias");
+    const int64_t Wcd = P("fc_classifier_domain.weight"), bcd = P("fc_classifier_domain.bias");
+    const int64_t Wdv = P("fc_feature_domain_video.weight"), bdv = P("fc_feature_domain_video.bias");
+    const int64_t Wcv = P("fc_classifier_video_source.weight"), bcv = P("fc_classifier_video_source.bias");
+    const int64_t Wcdv = P("fc_classifier_domain_video.weight"), bcdv = P("fc_classifier_domain_video.bias");
+
+    Geom &g = p.geom;
+    std::memset(&g, 0, sizeof(g));
+    g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
+    g.n_tuples = 0; g.n_rel = 0; g.flags = c.flags;
+    g.o_ws16 = g.o_p16 = g.o_x16 = -1;
+    g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
+    g.o_Hf = (int32_t)b.add_region("Hf", live_frm ? (int64_t)BT * F : 4);
+    g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
+    g.o_V = (int32_t)b.add_region("V", (int64_t)B * F);
+    g.o_Vd = (int32_t)b.add_region("Vd", (int64_t)B * F);
+    g.o_Y = (int32_t)b.add_region("Y", (int64_t)B * C);
+    g.o_Hv = (int32_t)b.add_region("Hv", live_vid ? (int64_t)B * F : 4);
+    g.o_Pv = (int32_t)b.add_region("Pv", (int64_t)B * 2);
+    g.o_Pr = (int32_t)b.add_region("Pr", 4);            // no relation rows
+    g.o_gY = (int32_t)b.add_region("gY", (int64_t)B * C);
+    g.o_gPv = (int32_t)b.add_region("gPv", (int64_t)B * 2);
+    g.o_gPr = (int32_t)b.add_region("gPr", 4);
+    g.o_gPf = (int32_t)b.add_region("gPf", (int64_t)BT * 2);
+    g.o_gHv = (int32_t)b.add_region("gHv", live_vid ? (int64_t)B * F : 4);
+    const int64_t o_gHf = b.add_region("gHf", live_frm ? (int64_t)BT * F : 4);
+    g.o_gHf = live_frm ? (int32_t)o_gHf : -1;           // -1: pool_avg_bwd writes gZ1 directly
+    g.o_gVt = (int32_t)b.add_region("gVt", (int64_t)B * F);
+    g.o_gRa = (int32_t)b.add_region("gRa", live_frm ? (int64_t)BT * F : 4);   // gVt / T spread over the segments
+    g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
+    g.o_attn = (int32_t)b.add_region("attn", 4); g.o_gattn = (int32_t)b.add_region("g_attn", 4);
+    g.o_zeros = (int32_t)b.add_region("zeros", 64);
+    g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);
+    if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
+    g.o_losses = (int32_t)b.add_region("losses", 8);
+    g.n_norm_blocks = 256;
+    g.o_norm_part = (int32_t)b.add_region("norm_part", g.n_norm_blocks);
+    g.o_grad_norm = (int32_t)b.add_region("grad_norm", 4);
+    g.o_hyper = (int32_t)b.add_region("hyper", 32);
+    g.o_labels = (int32_t)b.add_region("labels", B);
+    g.o_tuple_first = (int32_t)b.add_region("tuple_first", 1);
+    g.o_loss_part = (int32_t)b.add_region("loss_part", 8);
+    g.o_metrics = (int32_t)b.add_region("metrics", 8);
+    g.o_confusion = (int32_t)b.add_region("confusion", (int64_t)C * C);
+    g.live_floats = (int32_t)p.live_floats;
+    g.p_Wcv = (int32_t)Wcv; g.p_bcv = (int32_t)bcv;
+
+    auto fwd = [&](int M, int N, int K, int64_t x_off, int64_t w, int64_t bias, int64_t y_off, bool relu) {   // Y = act(X W^T + b)
+        GemmSpec s;
+        s.M = M; s.N = N;
+        s.segs.push_back(mkseg(KC(BASE_WS, x_off, K), KC(BASE_P, w, K), K));
+        s.proto = proto(BASE_WS, y_off, N);
+        with_bias(s.proto, bias);
+        if (relu) s.proto.epi |= EPI_RELU;
+        return s;
+    };
+    auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
+        GemmSpec s;
+        s.M = BT; s.N = F;
+        s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        s.proto = proto(BASE_WS, g.o_F1, F);
+        with_bias(s.proto, bsh);
+        s.proto.epi |= EPI_RELU | EPI_DROP_I;
+        s.proto.gamma_kind = SK_INV_KEEP_I;
+        s.proto.drop_ld = F;
+        return s;
+    };
+    auto masked_back = [&](int M, int N, int64_t g_off, int64_t w, int64_t mask_off, int64_t out_off) {   // (G W) * [H > 0], G two logits wide
+        GemmSpec s;
+        s.M = M; s.N = N;
+        s.segs.push_back(mkseg(KC(BASE_WS, g_off, 2), KM(BASE_P, w, N), 2));
+        s.proto = proto(BASE_WS, out_off, N);
+        with_mask(s.proto, mask_off, N);
+        return s;
+    };
+    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int base_x, int64_t x_off, int x_ld, int64_t dst, int64_t bias_dst) {
+        GemmSpec gw;
+        gw.M = M; gw.N = N;
+        gw.segs.push_back(mkseg(KM(BASE_WS, g_off, g_ld), KM(base_x, x_off, x_ld), K));
+        gw.proto = proto(BASE_G, dst, N);
+        gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bias_dst;
+        return gw;
+    };
+    auto forward = [&](int group) {
+        { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(group, s); }
+        if (live_frm) { std::vector<GemmSpec> s{fwd(BT, F, F, g.o_F1, Wfd, bfd, g.o_Hf, true)}; b.add_gemm_phase(group, s); }   // models.py:458-459
+        b.add_simple_phase(PH_POOL_AVG_FWD, group);
+        {
+            std::vector<GemmSpec> s{fwd(B, C, F, g.o_Vd, Wcv, bcv, g.o_Y, false)};                                 // :686
+            if (live_vid) s.push_back(fwd(B, F, F, g.o_Vd, Wdv, bdv, g.o_Hv, true));                                // :466-467
+            b.add_gemm_phase(group, s);
+        }
+        if (live_vid || live_frm) {
+            std::vector<GemmSpec> s;
+            if (live_vid) s.push_back(fwd(B, 2, F, g.o_Hv, Wcdv, bcdv, g.o_Pv, false));                             // :468
+            if (live_frm) s.push_back(fwd(BT, 2, F, g.o_Hf, Wcd, bcd, g.o_Pf, false));                              // :460
+            b.add_gemm_phase(group, s);
+        }
+    };
+    auto backward = [&](int group) {
+        {   // what depends only on the logit gradients
+            std::vector<GemmSpec> s;
+            if (live_vid) {
+                s.push_back(masked_back(B, F, g.o_gPv, Wcdv, g.o_Hv, g.o_gHv));
+                s.push_back(wgrad(2, F, B, g.o_gPv, 2, BASE_WS, g.o_Hv, F, Wcdv, bcdv));
+            }
+            if (live_frm) {
+                s.push_back(masked_back(BT, F, g.o_gPf, Wcd, g.o_Hf, g.o_gHf));
+                s.push_back(wgrad(2, F, BT, g.o_gPf, 2, BASE_WS, g.o_Hf, F, Wcd, bcd));
+            }
+            s.push_back(wgrad(C, F, B, g.o_gY, C, BASE_WS, g.o_Vd, F, Wcv, bcv));
+            b.add_gemm_phase(group, s);
+        }
+        {   // gVt = dropout_v'( -beta1 * gHv Wdv + gY Wcv ), first-layer weight gradients of the discriminators
+            std::vector<GemmSpec> s;
+            GemmSpec gv;
+            gv.M = B; gv.N = F;
+            if (live_vid) gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gHv, F), KM(BASE_P, Wdv, F), F, SK_NEG_BETA_VID));
+            gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY, C), KM(BASE_P, Wcv, F), C));
+            gv.proto = proto(BASE_WS, g.o_gVt, F);
+            gv.proto.epi |= EPI_DROP_V; gv.proto.gamma_kind = SK_INV_KEEP_V; gv.proto.drop_ld = F;
+            s.push_back(gv);
+            if (live_vid) s.push_back(wgrad(F, F, B, g.o_gHv, F, BASE_WS, g.o_Vd, F, Wdv, bdv));
+            if (live_frm) s.push_back(wgrad(F, F, BT, g.o_gHf, F, BASE_WS, g.o_F1, F, Wfd, bfd));
+            b.add_gemm_phase(group, s);
+        }
+        b.add_simple_phase(PH_POOL_AVG_BWD, group);
+        if (live_frm) {   // gZ1 = ( -beta2 gHf Wfd + gVt / T ) * [F1 > 0] / keep_i
+            GemmSpec gz;
+            gz.M = BT; gz.N = F;
+            gz.segs.push_back(mkseg(KC(BASE_WS, g.o_gHf, F), KM(BASE_P, Wfd, F), F, SK_NEG_BETA_FRM));
+            gz.proto = proto(BASE_WS, g.o_gZ1, F);
+            with_add(gz.proto, g.o_gRa, F);
+            with_mask(gz.proto, g.o_F1, F);
+            gz.proto.gamma_kind = SK_INV_KEEP_I;
+            std::vector<GemmSpec> s{gz};
+            b.add_gemm_phase(group, s);
+        }
+        { std::vector<GemmSpec> s{wgrad(F, D, BT, g.o_gZ1, F, BASE_X, 0, D, Wsh, bsh)}; b.add_gemm_phase(group, s); }
+    };
+    forward(0);
+    b.add_simple_phase(PH_LOSS, 1);
+    backward(2);
+    b.add_simple_phase(PH_GRAD_NORM, 3);
+    b.add_simple_phase(PH_SGD, 3);
+    forward(4);                           // ta3n_train_step: the same launches as one sequence
+    b.add_simple_phase(PH_LOSS, 4);
+    backward(4);
+    std::vector<size_t> grad_tasks;
+    for (const Phase &ph : p.phases)
+        if (ph.group == 4 && ph.kind == PH_GEMM)
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
+                if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
+    g.n_sumsq = (int32_t)grad_tasks.size();
+    g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
+    for (size_t k = 0; k < grad_tasks.size(); ++k) {
+        p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
+        p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
+    }
+    // (no bf16 twins on this path: the small kernels between the launches do not maintain them; the contractions still
+    // round their operands in registers with TA3N_FLAG_BF16_MFMA)
+    if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
+    for (auto &t : p.tasks)
+        if (t.seg_count > 0) t.seg0 = p.segs[t.seg_begin];
+    return TA3N_OK;
+}
+
 }  // namespace
 
 int ta3n::build_plan(ta3n_plan &p, std::string &err) {
@@ -495,7 +710,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
-    if (c.aggregation == TA3N_AGG_AVGPOOL) return build_plan_avgpool(p, err);
+    if (c.aggregation == TA3N_AGG_AVGPOOL)      // source-only: the fused fast path (BASELINE configs[0]); with adversarial branches: the general one
+        return (c.flags & (TA3N_FLAG_ADV_RELATION | TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_FRAME)) ? build_plan_avgpool_general(p, err)
+                                                                                                 : build_plan_avgpool(p, err);
 
     // ---- relation tuples ----
     p.n_tuples = ta3n_num_relation_tuples(T);

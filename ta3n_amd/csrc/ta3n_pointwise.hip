@@ -180,11 +180,14 @@ __global__ __launch_bounds__(256) void loss_kernel(Geom g, Ptrs ptrs) {
             gy[i] = gi;
         }
         float g0 = 0.f, g1 = 0.f;
-        if ((g.flags & TA3N_FLAG_ADV_VIDEO) && valid) {                              // main.py:508-538, l = 1
+        // Without relation features (avgpool) the reference's relation slot of pred_domain holds the VIDEO logits once more
+        // ("add dummy tensors", models.py:707-708), so place_adv[0] = 'Y' adds the video-level CE a second time.
+        const float vmult = ((g.flags & TA3N_FLAG_ADV_VIDEO) ? 1.f : 0.f) + ((NR == 0 && (g.flags & TA3N_FLAG_ADV_RELATION)) ? 1.f : 0.f);
+        if (vmult > 0.f && valid) {                                                  // main.py:508-538, l = 1 (and l = 0 for avgpool)
             const int d = is_src ? 0 : 1;
-            l_vid = -(d ? s.lp1 : s.lp0) * hy->inv_n_vid;
-            g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_vid;
-            g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_vid;
+            l_vid = -(d ? s.lp1 : s.lp0) * hy->inv_n_vid * vmult;
+            g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_vid * vmult;
+            g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_vid * vmult;
         }
         if (ent_on) {
             g0 += ce * Hc * (-s.p0 * (s.lp0 + s.H));
@@ -354,6 +357,39 @@ __global__ __launch_bounds__(256) void pool_cls_kernel(Geom g, Ptrs ptrs) {
             ws[g.o_gZ1 + idx] = gz;
             if (twin) twin[g.o_gZ1 + idx] = (unsigned short)pack_bf16(gz, 0.f);
         }
+    }
+}
+
+// TA3N_AGG_AVGPOOL, general (TemPooling with or without the adversarial branches): aggregate_frames "1. averaging"
+// (models.py:421-433: AvgPool2d over the segments) and dropout_v (:679).  One workgroup per video.
+__global__ __launch_bounds__(256) void pool_avg_fwd_kernel(Geom g, Ptrs ptrs) {
+    float *__restrict__ ws = ptrs.ws;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int b = blockIdx.x, F = g.F, T = g.T;
+    const bool drop_v = hy->train != 0 && hy->p_drop_v > 0.f;
+    const float inv_keep_v = hyper_scale(hy, SK_INV_KEEP_V), inv_T = 1.f / (float)T;
+    if (blockIdx.x == 0 && threadIdx.x < 8) ws[g.o_losses + threadIdx.x] = 0.f;   // the loss kernel accumulates into them
+    for (int k = threadIdx.x; k < F; k += 256) {
+        float v = 0.f;
+        for (int t = 0; t < T; ++t) v += ws[g.o_F1 + ((size_t)b * T + t) * F + k];
+        v *= inv_T;
+        ws[g.o_V + (size_t)b * F + k] = v;
+        ws[g.o_Vd + (size_t)b * F + k] = drop_v ? v * keep_mask(hy->seed_v, (uint32_t)(b * F + k), hy->p_drop_v) * inv_keep_v : v;
+    }
+}
+
+// Backward of the averaging: every segment of video b receives gVt[b] / T (gVt already carries dropout_v's mask and scale,
+// it is the epilogue of the launch that made it).  With a live frame discriminator that is the additive operand ("gRa"
+// region) of the launch that forms gZ1 = (-beta2 gHf Wfd + base) * [F1 > 0] / keep_i; without one it IS gZ1 after the mask.
+__global__ __launch_bounds__(256) void pool_avg_bwd_kernel(Geom g, Ptrs ptrs, int direct) {
+    float *__restrict__ ws = ptrs.ws;
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int row = blockIdx.x, b = row / g.T, F = g.F;
+    const float inv_T = 1.f / (float)g.T, inv_keep_i = hyper_scale(hy, SK_INV_KEEP_I);
+    for (int k = threadIdx.x; k < F; k += 256) {
+        const float base = ws[g.o_gVt + (size_t)b * F + k] * inv_T;
+        if (direct) ws[g.o_gZ1 + (size_t)row * F + k] = ws[g.o_F1 + (size_t)row * F + k] > 0.f ? base * inv_keep_i : 0.f;
+        else ws[g.o_gRa + (size_t)row * F + k] = base;
     }
 }
 
@@ -528,6 +564,16 @@ int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     const int rows = g.B * (1 + g.n_rel + g.T);
     hipLaunchKernelGGL(loss_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_avg_fwd_kernel, dim3(g.B), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_avg_bwd_kernel, dim3(g.B * g.T), dim3(256), 0, stream, g, ptrs, g.o_gHf < 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -78,7 +78,9 @@ enum PhaseKind : int32_t {
     PH_GRAD_NORM = 4,
     PH_SGD = 5,
     PH_HEADS = 6,            // fused video/frame heads: forward + loss + backward between Hr/Hf and gHr/gHf
-    PH_POOL_CLS = 7,         // TA3N_AGG_AVGPOOL: mean over segments, dropout, classifier, CE and the way back to gZ1
+    PH_POOL_CLS = 7,         // TA3N_AGG_AVGPOOL, source-only fused: mean over segments, dropout, classifier, CE and the way back to gZ1
+    PH_POOL_AVG_FWD = 8,     // TA3N_AGG_AVGPOOL, general: V = mean over the segments of F1, Vd = dropout_v(V)
+    PH_POOL_AVG_BWD = 9,     // TA3N_AGG_AVGPOOL, general: gradient at V spread back over the segments (-> gZ1 or its additive base)
 };
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these

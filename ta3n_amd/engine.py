@@ -82,8 +82,9 @@ class TrainEngine:
         if aggregation not in ("trn-m", "avgpool"):
             raise NotImplementedError(f"frame_aggregation {aggregation!r} (built: 'trn-m', and 'avgpool' in the source-only configuration)")
         self.aggregation = aggregation
-        if aggregation == "avgpool":     # BASELINE configs[0]: use_target none switches every DA option off (script_train_val.sh:103-119)
-            flags &= ~ALL_FLAGS
+        if aggregation == "avgpool":     # TemPooling: no relation features, no attention (use_attn none in the reference's script); with
+            # use_target none (BASELINE configs[0]) the caller passes no adversarial flag either (flags_from_options)
+            flags &= ~(_lib.FLAG_ATTN_ENTROPY | _lib.FLAG_TRANS_ATTN)
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
@@ -455,7 +456,10 @@ class TrainEngine:
         B, T, NR = self.B, self.T, self.T - 1
         if self.aggregation == "avgpool":      # attn is a placeholder column in the reference (models.py:627-628)
             v = self.region("V", (B, -1))
-            return dict(out=self.region("Y", (B, self.C)), attn=v[:, 0], feat_v=v, feat_f1=self.region("F1", (B, T, self.F)))
+            out = dict(out=self.region("Y", (B, self.C)), attn=v[:, 0], feat_v=v, feat_f1=self.region("F1", (B, T, self.F)))
+            if "Pv" in self.plan.regions:      # general variant: video- / frame-level domain logits (the relation slot repeats the video's)
+                out.update(pred_vid=self.region("Pv", (B, 2)), pred_frm=self.region("Pf", (B, T, 2)))
+            return out
         return dict(out=self.region("Y", (B, self.C)), attn=self.region("attn", (B, NR)),
                     pred_rel=self.region("Pr", (B, NR, 2)), pred_vid=self.region("Pv", (B, 2)),
                     pred_frm=self.region("Pf", (B, T, 2)), feat_v=self.region("V", (B, -1)),

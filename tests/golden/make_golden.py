@@ -116,6 +116,10 @@ def make_args(case):
         a.place_adv = ["N", "N", "N"]
         a.add_loss_DA = "none"
         a.use_attn = "none"
+        if case.get("place_adv"):                  # TemPooling + RevGrad (the DA rows of the paper's TemPooling table): no attention
+            a.use_target = "uSv"
+            a.adv_DA = "RevGrad"
+            a.place_adv = list(case["place_adv"])
     return a
 
 
@@ -126,7 +130,8 @@ def run_case(name, case):
     D = model.feature_dim
     T, C = case["T"], case["C"]
     avg = case.get("agg", "trn-m") == "avgpool"
-    beta = [0.0, 0.0, 0.0] if avg else [0.75, 0.75, 0.5]
+    avg_da = avg and bool(case.get("place_adv"))
+    beta = [0.0, 0.0, 0.0] if (avg and not avg_da) else [0.75, 0.75, 0.5]
     gamma = 0.0 if avg else case.get("gamma", 0.003)
 
     # ---- (1) plain forward through the reference model (train mode, dropout 0) ----
@@ -137,8 +142,8 @@ def run_case(name, case):
     attn_s, out_s, out_s2, pd_s, feat_s, attn_t, out_t, out_t2, pd_t, feat_t = out
     put(store, "fwd/attn_s", attn_s); put(store, "fwd/attn_t", attn_t)
     put(store, "fwd/out_s", out_s); put(store, "fwd/out_t", out_t)
-    if not avg:      # (avgpool: the discriminators are forwarded but feed nothing in the source-only configuration)
-        for i, nm in enumerate(("rel", "vid", "frm")):
+    if not avg or avg_da:      # (avgpool source-only: the discriminators are forwarded but feed nothing)
+        for i, nm in enumerate(("rel", "vid", "frm")):       # avgpool: "rel" is the video logits once more (models.py:707-708)
             put(store, f"fwd/pd_s_{nm}", pd_s[i]); put(store, f"fwd/pd_t_{nm}", pd_t[i])
     for i, nm in enumerate(("y", "v", "f1")):
         put(store, f"fwd/feat_s_{nm}", feat_s[i]); put(store, f"fwd/feat_t_{nm}", feat_t[i])
@@ -224,6 +229,16 @@ CASES = {
                             xseed=66, steps=2, lr=2e-3),
     "mid_T12": dict(arch="resnet101", fc_dim=128, T=12, C=12, Bs=16, Bt=16, wseed=12, wscale="trained",
                     xseed=31, steps=1, lr=2e-3),
+    # TemPooling + RevGrad: avgpool with the video- and frame-level adversarial branches; with
+    # place_adv[0] = 'Y' the reference counts the video-level loss twice (its relation slot holds the video logits)
+    "tiny_avgpool_da": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=15,
+                            wscale="trained", xseed=57, steps=3, short_last=(5, 3), lr=2e-3),
+    "tiny_avgpool_da3": dict(agg="avgpool", place_adv=("Y", "Y", "Y"), arch="resnet18", fc_dim=64, T=3, C=7, Bs=4, Bt=5, wseed=16,
+                             wscale="trained", xseed=58, steps=2, lr=2e-3),
+    "tiny_avgpool_dav": dict(agg="avgpool", place_adv=("N", "Y", "N"), arch="resnet18", fc_dim=32, T=4, C=5, Bs=5, Bt=3, wseed=17,
+                             wscale="trained", xseed=59, steps=2, lr=2e-3),
+    "tempooling_da": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet101", fc_dim=512, T=5, C=12, Bs=128, Bt=74, wseed=18,
+                          wscale="trained", xseed=60, steps=2, lr=2e-3),
 }
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 N_SAMP = 64
 CASES = ["tiny_T5", "tiny_T3", "tiny_T9", "tiny_T2", "tiny_clip", "headline", "headline_init", "mid_T12"]
 AVG_CASES = ["tiny_avgpool", "config1_avgpool"]      # BASELINE configs[0]: TemPooling (avgpool), source-only, every DA option off
+AVG_DA_CASES = ["tiny_avgpool_da", "tiny_avgpool_da3", "tiny_avgpool_dav", "tempooling_da"]   # TemPooling + RevGrad (place_adv in the fixture)
 ARCH_DIM = dict(resnet18=512, resnet34=512, resnet50=2048, resnet101=2048, resnet152=2048)
 
 
@@ -75,7 +76,8 @@ def case_config(g):
                 lr=float(g.meta("lr")) if g.has_meta("lr") else 3e-2,
                 clip=float(g.meta("clip")) if g.has_meta("clip") else 20.0,
                 short_last=tuple(int(v) for v in g.meta("short_last")) if g.has_meta("short_last") else None,
-                agg=str(g.meta("agg")) if g.has_meta("agg") else "trn-m")
+                agg=str(g.meta("agg")) if g.has_meta("agg") else "trn-m",
+                place_adv=tuple(str(v) for v in g.meta("place_adv")) if g.has_meta("place_adv") else None)
 
 
 def _has_meta(self, k):

@@ -16,7 +16,7 @@ from ta3n_amd import _lib
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_COLSUM = 1 << 12
-PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS = range(8)
+PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS, PH_POOL_AVG_FWD, PH_POOL_AVG_BWD = range(10)
 HEADS_RPW = 16
 
 
@@ -294,6 +294,29 @@ class Interp:
         gV = (gY @ Wcv) * mk / T * self.scale(4)
         self.r(g.o_gZ1, (B, T, F))[:] = np.where(F1 > 0, gV[:, None, :], 0.0)
 
+    def run_pool_avg_fwd(self):
+        """TA3N_AGG_AVGPOOL, general: V = mean over the segments, Vd = dropout_v(V) (ta3n_pointwise.hip: pool_avg_fwd_kernel)."""
+        g, h = self.g, self.hy
+        B, T, F = g.B, g.T, g.F
+        V = self.r(g.o_F1, (B, T, F)).mean(1)
+        mk = np.ones((B, F), self.dtype)
+        if h["train"] and h["p_drop_v"] > 0:
+            idx = np.arange(B)[:, None] * F + np.arange(F)[None, :]
+            mk = keep_mask(h["seed_v"], idx, h["p_drop_v"]) * self.scale(5)
+        self.r(g.o_V, (B, F))[:] = V
+        self.r(g.o_Vd, (B, F))[:] = V * mk
+        self.ws[g.o_losses:g.o_losses + 8] = 0
+
+    def run_pool_avg_bwd(self):
+        """gVt / T spread over the segments: gZ1 directly (no frame discriminator) or the additive base of its launch."""
+        g = self.g
+        B, T, F = g.B, g.T, g.F
+        base = np.repeat(self.r(g.o_gVt, (B, F)) / T, T, axis=0)
+        if g.o_gHf < 0:
+            self.r(g.o_gZ1, (B * T, F))[:] = np.where(self.r(g.o_F1, (B * T, F)) > 0, base * self.scale(4), 0.0)
+        else:
+            self.r(g.o_gRa, (B * T, F))[:] = base
+
     def run_loss(self):
         g, h = self.g, self.hy
         B, NR, T, Cn = g.B, g.n_rel, g.T, g.C
@@ -310,9 +333,11 @@ class Interp:
         q, lq, Hd = self.soft2(Pv)
         gPv = np.zeros_like(Pv); l_vid = 0.0; l_ent = 0.0
         oh2 = np.zeros_like(Pv); oh2[b, d] = 1
-        if g.flags & _lib.FLAG_ADV_VIDEO:
-            gPv += np.where(valid[:, None], (q - oh2) * h["inv_n_vid"], 0)
-            l_vid = float((-lq[b, d] * valid).sum() * h["inv_n_vid"])
+        # avgpool (no relation rows): the relation slot of pred_domain is the video logits once more (models.py:707-708)
+        vmult = (1 if g.flags & _lib.FLAG_ADV_VIDEO else 0) + (1 if (NR == 0 and g.flags & _lib.FLAG_ADV_RELATION) else 0)
+        if vmult:
+            gPv += np.where(valid[:, None], (q - oh2) * h["inv_n_vid"] * vmult, 0)
+            l_vid = float((-lq[b, d] * valid).sum() * h["inv_n_vid"] * vmult)
         if g.flags & _lib.FLAG_ATTN_ENTROPY:
             ce = h["gamma"] * h["inv_n_ent"]
             l_ent = float(((1 + Hd) * Hc * valid).sum() * h["inv_n_ent"])
@@ -417,5 +442,7 @@ class Interp:
             elif ph.kind == PH_POOL_BWD: self.run_pool_bwd()
             elif ph.kind == PH_HEADS: self.run_heads()
             elif ph.kind == PH_POOL_CLS: self.run_pool_cls()
+            elif ph.kind == PH_POOL_AVG_FWD: self.run_pool_avg_fwd()
+            elif ph.kind == PH_POOL_AVG_BWD: self.run_pool_avg_bwd()
             elif ph.kind == PH_GRAD_NORM: pass
             elif ph.kind == PH_SGD: self.run_sgd(fused_norm)

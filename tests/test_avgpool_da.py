@@ -1,0 +1,153 @@
+"""TemPooling + RevGrad (first item): frame_aggregation 'avgpool' with the video- and frame-level
+adversarial branches, against fixtures produced by the reference itself (tests/golden/make_golden.py: adv_DA RevGrad,
+use_target uSv, use_attn none, the fixture's place_adv) - oracle on the CPU, the launch plan executed with numpy on the
+CPU, the HIP path on the GPU.  With place_adv[0] = 'Y' the reference counts the video-level loss twice (without relation
+features its relation slot holds the video logits again, models.py:707-708): reproduced, and covered by tiny_avgpool_da3."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import AVG_DA_CASES, Golden, case_config, step_schedule
+from oracle import ta3n_oracle as orc
+from plan_interp import Interp
+from ta3n_amd import _lib
+from ta3n_amd.engine import flags_from_options
+from ta3n_amd.synthetic import synth_batch, synth_state
+from test_plan_cpu import make_hyper
+
+RTOL, ATOL = 2e-5, 2e-6
+BETA = [0.75, 0.75, 0.5]
+
+
+def _setup(name):
+    g = Golden(name)
+    c = case_config(g)
+    assert c["agg"] == "avgpool" and c["place_adv"] is not None
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"], dropout_i=0.0, dropout_v=0.0,
+                     place_adv=c["place_adv"], add_loss_DA="none", use_attn="none", frame_aggregation="avgpool")
+    params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
+    flags = flags_from_options(c["place_adv"], "none", "none", "RevGrad", "uSv")
+    return g, c, cfg, params, flags
+
+
+@pytest.mark.parametrize("name", AVG_DA_CASES)
+def test_oracle_matches_reference(name):
+    g, c, cfg, params, _ = _setup(name)
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    with torch.no_grad():
+        s = orc.forward_domain(params, xs, BETA, cfg)
+        t = orc.forward_domain(params, xt, BETA, cfg)
+    for dom, o in (("s", s), ("t", t)):
+        g.check(f"fwd/out_{dom}", o["out"], RTOL, ATOL)
+        for i, nm in enumerate(("rel", "vid", "frm")):
+            g.check(f"fwd/pd_{dom}_{nm}", o["pred_domain"][i], RTOL, ATOL)
+        for i, nm in enumerate(("y", "v", "f1")):
+            g.check(f"fwd/feat_{dom}_{nm}", o["feat"][i], RTOL, ATOL)
+    state = orc.TrainState(params=params, lr=c["lr"])
+    live = set(str(k) for k in g.meta("live"))
+    for si, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        state.lr = st["lr"]
+        res = orc.train_step(state, xs, xt, ys, BETA, 0.0, cfg, clip=c["clip"], n_src=st["n_src"], n_tgt=st["n_tgt"])
+        assert set(res["clipped"]) == live
+        for k in params:
+            if k in live:
+                g.check(f"step{si}/clipped_grad/{k}", res["clipped"][k], 5e-5, 5e-6)
+            g.check(f"step{si}/param/{k}", state.params[k], 5e-5, 5e-6)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", [n for n in AVG_DA_CASES if n.startswith("tiny")])
+def test_plan_reproduces_reference_on_cpu(name, fused):
+    g, c, _, _, flags = _setup(name)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, aggregation=_lib.AGG_AVGPOOL)
+    assert plan.has_fused_step
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    assert live == set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.hy["gamma"] = 0.0
+        it.G[:] = 0
+        if fused:
+            it.run_group(4)
+        else:
+            it.run_group(0); it.run_group(1); it.run_group(2)
+        if s == 0:
+            B, Bs = c["Bs"] + c["Bt"], c["Bs"]
+            geo = it.g
+            outs = dict(out=it.r(geo.o_Y, (B, c["C"])), vid=it.r(geo.o_Pv, (B, 2)), frm=it.r(geo.o_Pf, (B, T, 2)), v=it.r(geo.o_V, (B, geo.F)))
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", outs["out"][sl], 5e-5, 2e-5)
+                g.check(f"fwd/feat_{dom}_v", outs["v"][sl], 5e-5, 2e-5)
+                if c["place_adv"][1] == "Y" or c["place_adv"][0] == "Y":
+                    g.check(f"fwd/pd_{dom}_vid", outs["vid"][sl], 5e-5, 2e-5)
+                    g.check(f"fwd/pd_{dom}_rel", outs["vid"][sl], 5e-5, 2e-5)     # the relation slot IS the video logits
+                if c["place_adv"][2] == "Y":
+                    g.check(f"fwd/pd_{dom}_frm", outs["frm"][sl], 5e-5, 2e-5)
+        raw = it.get_params(it.G)
+        it.run_group(3, fused_norm=fused)
+        coef = it.ws[it.g.o_grad_norm + 1]
+        new = it.get_params()
+        for k in shapes:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", AVG_DA_CASES)
+def test_hip_path_matches_reference_golden(name, fused):
+    from ta3n_amd.engine import TrainEngine
+    g, c, _, _, flags = _setup(name)
+    eng = TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], flags=flags, dropout_i=0.0, dropout_v=0.0, clip=c["clip"],
+                      aggregation="avgpool", fused=fused)
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = set(eng.live_names())
+    assert live == set(str(k) for k in g.meta("live"))
+    B, Bs, T = c["Bs"] + c["Bt"], c["Bs"], c["T"]
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.set_hyper(BETA, 0.0, st["lr"], train=True, valid_source=st["n_src"], valid_target=st["n_tgt"])
+        if fused:
+            eng.fused_step()
+        else:
+            eng.forward(); eng.loss(); eng.backward()
+        if s == 0:
+            o = {k: v.detach().cpu() for k, v in eng.outputs().items()}
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", o["out"][sl], 0, 1e-3, "class logits")          # the north-star bound
+                g.check(f"fwd/feat_{dom}_v", o["feat_v"][sl], 2e-4, 5e-5)
+                if c["place_adv"][1] == "Y" or c["place_adv"][0] == "Y":
+                    g.check(f"fwd/pd_{dom}_vid", o["pred_vid"][sl], 0, 1e-3, "video domain logits")
+                if c["place_adv"][2] == "Y":
+                    g.check(f"fwd/pd_{dom}_frm", o["pred_frm"][sl], 0, 1e-3, "frame domain logits")
+        raw = {k: v.clone() for k, v in eng.param_views(eng.G).items()}
+        if fused:
+            eng.sgd_step_fused()
+        else:
+            eng.sgd_step()
+        torch.cuda.synchronize()
+        coef = eng.region("grad_norm")[1].item()
+        new = eng.param_views()
+        for k in new:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 0.15)
+            g.check(f"step{s}/param/{k}", new[k].cpu(), 2e-4, 5e-5)
+    last = [ln for ln in str(g.meta("log")).strip().splitlines() if "Loss" in ln][-1]       # the reference's own log line
+    ref_loss = float(last.split("Loss")[1].split()[0])
+    ref_a = float(last.split("loss_a")[1].split()[0])
+    L = eng.losses()
+    assert abs(L["loss"] - ref_loss) < 3e-3 and abs(L["loss_adv_vid"] + L["loss_adv_frm"] + L["loss_adv_rel"] - ref_a) < 3e-3
