@@ -1,0 +1,333 @@
+#!/usr/bin/env python
+"""The reference's training program on the MI355X path: same command line (opts.py), same functions
+(main / train / validate / save_checkpoint / accuracy / removeDummy / adjust_learning_rate*), same log files and
+checkpoint format, written fresh against ta3n_amd.models.VideoModel - every arithmetic op of forward and backward is a
+HIP kernel of libta3n_hip.so, the loss assembly below is the reference's (main.py:439-562) on the returned logits.
+
+    python main.py <class_file> RGB <train_source_list> <train_target_list> <val_list> --baseline_type video \
+        --frame_aggregation trn-m --use_target uSv --adv_DA RevGrad --use_attn TransAttn --add_loss_DA attentive_entropy ...
+
+This is the single-process path the reference has (one GPU; main.py:79 wraps the model in nn.DataParallel, which for
+one device is a pass-through and is kept so that checkpoints carry the `module.` prefix).  The multi-GPU path is
+train_ddp.py (one process per GPU, RCCL).  Options outside the supported configurations are rejected at start-up
+(train_ddp.validate_options), never ignored.  Reference line numbers cite cmhungsteve/TA3N main.py."""
+import math
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.parallel
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ta3n_amd.dataset import TSNDataSet  # noqa: E402
+from ta3n_amd.loss import attentive_entropy  # noqa: E402
+from ta3n_amd.models import VideoModel  # noqa: E402
+from ta3n_amd.opts import parser  # noqa: E402
+from train_ddp import train_list_sizes, validate_options  # noqa: E402
+
+best_prec1 = 0
+gpu_count = 1
+args = None
+
+
+def main():
+    global args, best_prec1
+    args = parser.parse_args()
+    validate_options(args)
+    print("Baseline:", args.baseline_type, " Frame aggregation method:", args.frame_aggregation)
+    print("target data usage:", args.use_target)
+    if args.use_target == "none":                                                       # :41-43
+        print("no Domain Adaptation")
+    num_class = len([x for x in open(args.class_file)])                                # :56-57
+    path_exp = os.path.join(args.exp_path, args.modality) + "/"                         # :60-62
+    os.makedirs(path_exp, exist_ok=True)
+
+    val_segments = args.val_segments if args.val_segments > 0 else args.num_segments
+    model = VideoModel(num_class, args.baseline_type, args.frame_aggregation, args.modality,   # :69-77
+                       train_segments=args.num_segments, val_segments=val_segments, base_model=args.arch,
+                       path_pretrained=args.pretrained, add_fc=args.add_fc, fc_dim=args.fc_dim, dropout_i=args.dropout_i,
+                       dropout_v=args.dropout_v, partial_bn=not args.no_partialbn,
+                       use_bn=args.use_bn if args.use_target != "none" else "none",
+                       ens_DA=args.ens_DA if args.use_target != "none" else "none", n_rnn=args.n_rnn, rnn_cell=args.rnn_cell,
+                       n_directions=args.n_directions, n_ts=args.n_ts, use_attn=args.use_attn, n_attn=args.n_attn,
+                       use_attn_frame=args.use_attn_frame, verbose=args.verbose, share_params=args.share_params)
+    model = torch.nn.DataParallel(model, [0]).cuda()                                    # :79 (one device: a pass-through wrapper)
+    optimizer = torch.optim.SGD(model.parameters(), args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
+                                nesterov=True)                                          # :83
+
+    start_epoch = 1
+    if args.resume:                                                                     # :94-106
+        if os.path.isfile(args.resume):
+            checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+            start_epoch = checkpoint["epoch"] + 1
+            best_prec1 = checkpoint["best_prec1"]
+            model.load_state_dict(checkpoint["state_dict"])
+            print("=> loaded checkpoint '{}' (epoch {})".format(args.resume, checkpoint["epoch"]))
+            if args.resume_hp:
+                print("=> loaded checkpoint hyper-parameters")
+                optimizer.load_state_dict(checkpoint["optimizer"])
+        else:
+            print("=> no checkpoint found at '{}'".format(args.resume))
+
+    mode = "a" if args.resume else "w"                                                  # :111-131
+    if not args.evaluate:
+        train_file, train_short_file = open(path_exp + "train.log", mode), open(path_exp + "train_short.log", mode)
+        val_file, val_short_file = open(path_exp + "val.log", mode), open(path_exp + "val_short.log", mode)
+        if args.resume:
+            for f in (train_file, train_short_file, val_file, val_short_file):
+                f.write("========== start: " + str(start_epoch) + "\n")
+        val_best_file = open(args.save_best_log, "a")
+    else:
+        test_short_file, test_file = open(path_exp + "test_short.log", "w"), open(path_exp + "test.log", "w")
+
+    # === data (:139-200) === #
+    num_source = sum(1 for _ in open(args.train_source_list))
+    num_target = sum(1 for _ in open(args.train_target_list))
+    num_val = sum(1 for _ in open(args.val_list))
+    num_source_train, num_target_train = train_list_sizes(num_source, num_target, args.batch_size, args.copy_list)   # :145-153
+
+    def dataset(list_file, n, segments):
+        return TSNDataSet("", list_file, num_dataload=n, num_segments=segments, new_length=1, modality=args.modality,
+                          image_tmpl="img_{:05d}.t7", random_shift=False, test_mode=True)
+
+    val_loader = torch.utils.data.DataLoader(dataset(args.val_list, num_val, val_segments), batch_size=args.batch_size[2],
+                                             shuffle=False, num_workers=args.workers, pin_memory=True)
+    criterion = torch.nn.CrossEntropyLoss().cuda()                                      # :204-206 (class weights: rejected options)
+    criterion_domain = torch.nn.CrossEntropyLoss().cuda()
+    if args.evaluate:                                                                   # :208-212
+        prec1 = validate(val_loader, model, criterion, num_class, 0, test_file)
+        test_short_file.write("%.3f\n" % prec1)
+        return
+    source_set = dataset(args.train_source_list, num_source_train, args.num_segments)
+    target_set = dataset(args.train_target_list, num_target_train, args.num_segments)
+    source_loader = torch.utils.data.DataLoader(source_set, batch_size=args.batch_size[0], shuffle=False,
+                                                sampler=torch.utils.data.sampler.RandomSampler(source_set),
+                                                num_workers=args.workers, pin_memory=True)
+    target_loader = torch.utils.data.DataLoader(target_set, batch_size=args.batch_size[1], shuffle=False,
+                                                sampler=torch.utils.data.sampler.RandomSampler(target_set),
+                                                num_workers=args.workers, pin_memory=True)
+
+    # === training (:215-274) === #
+    start_train = time.time()
+    beta, gamma, mu = args.beta, args.gamma, args.mu
+    for epoch in range(start_epoch, args.epochs + 1):
+        alpha = 2 / (1 + math.exp(-1 * epoch / args.epochs)) - 1 if args.alpha < 0 else args.alpha      # :231
+        if args.lr_adaptive == "none" and epoch in args.lr_steps:                       # :236-237
+            adjust_learning_rate(optimizer, args.lr_decay)
+        train(num_class, source_loader, target_loader, model, criterion, criterion_domain, optimizer, epoch, train_file,
+              train_short_file, alpha, beta, gamma, mu)
+        if epoch % args.eval_freq == 0 or epoch == args.epochs:                         # :252-274
+            prec1 = validate(val_loader, model, criterion, num_class, epoch, val_file)
+            is_best = prec1 > best_prec1
+            print("Best score {} vs current score {}".format(best_prec1, prec1) + (" ==> updating the best accuracy" if is_best else ""))
+            val_short_file.write("%.3f\n" % prec1)
+            best_prec1 = max(prec1, best_prec1)
+            if args.save_model:
+                save_checkpoint({"epoch": epoch, "arch": args.arch, "state_dict": model.state_dict(),
+                                 "optimizer": optimizer.state_dict(), "best_prec1": best_prec1, "prec1": prec1}, is_best, path_exp)
+    end_train = time.time()
+    print("total training time:", end_train - start_train)
+    val_best_file.write("%.3f\n" % best_prec1)
+    line_time = "total time: {:.3f} ".format(end_train - start_train)
+    for f in (train_file, train_short_file, val_file, val_short_file):
+        f.write(line_time)
+        f.close()
+    val_best_file.close()
+
+
+def _pad(data, n):
+    """:359-372: zero rows up to the nominal batch size (and to a multiple of gpu_count): shapes stay static."""
+    if data.size(0) < n:
+        data = torch.cat((data, torch.zeros((n - data.size(0),) + tuple(data.size()[1:]), dtype=data.dtype)))
+    if data.size(0) % gpu_count != 0:
+        extra = gpu_count - data.size(0) % gpu_count
+        data = torch.cat((data, torch.zeros((extra,) + tuple(data.size()[1:]), dtype=data.dtype)))
+    return data
+
+
+def train(num_class, source_loader, target_loader, model, criterion, criterion_domain, optimizer, epoch, log, log_short, alpha, beta,
+          gamma, mu):
+    """:309-667 for the supported options: RevGrad adversarial losses on the enabled levels and attentive entropy."""
+    batch_time, data_time = AverageMeter(), AverageMeter()
+    losses_a, losses_e, losses_c, losses = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    top1, top5 = AverageMeter(), AverageMeter()
+    model.module.partialBN(not args.no_partialbn)                                       # :321-324
+    model.train()
+    end = time.time()
+    start_steps = epoch * len(source_loader)                                            # :334-335
+    total_steps = args.epochs * len(source_loader)
+    attn_epoch_source, attn_epoch_target = torch.Tensor(), torch.Tensor()
+    for i, ((source_data, source_label), (target_data, target_label)) in enumerate(zip(source_loader, target_loader)):   # :348
+        p = float(i + start_steps) / total_steps                                        # :350-352
+        beta_dann = 2. / (1. + np.exp(-10 * p)) - 1
+        beta_new = [beta_dann if beta[k] < 0 else beta[k] for k in range(len(beta))]
+        source_size_ori, target_size_ori = source_data.size(), target_data.size()       # :354-372
+        batch_source_ori, batch_target_ori = source_size_ori[0], target_size_ori[0]
+        source_data, target_data = _pad(source_data, args.batch_size[0]), _pad(target_data, args.batch_size[1])
+        data_time.update(time.time() - end)
+        source_label = source_label.cuda(non_blocking=True)                             # :377-378
+        target_label = target_label.cuda(non_blocking=True)
+        label_source = source_label
+        attn_source, out_source, out_source_2, pred_domain_source, feat_source, attn_target, out_target, out_target_2, \
+            pred_domain_target, feat_target = model(source_data, target_data, beta_new, mu, is_train=True, reverse=False)   # :418
+        attn_source, out_source, out_source_2, pred_domain_source, feat_source = removeDummy(
+            attn_source, out_source, out_source_2, pred_domain_source, feat_source, batch_source_ori)       # :421-422
+        attn_target, out_target, out_target_2, pred_domain_target, feat_target = removeDummy(
+            attn_target, out_target, out_target_2, pred_domain_target, feat_target, batch_target_ori)
+        out, label = out_source, label_source                                           # :439-451 (use_target uSv / none: source labels only)
+        loss_classification = criterion(out, label)
+        losses_c.update(loss_classification.item(), out_source.size(0))
+        loss = loss_classification
+        if args.adv_DA != "none" and args.use_target != "none":                         # :508-538
+            loss_adversarial = 0
+            pred_domain_all, pred_domain_target_all = [], []
+            for l in range(len(args.place_adv)):
+                if args.place_adv[l] == "Y":
+                    pred_domain_source_single = pred_domain_source[l].view(-1, pred_domain_source[l].size()[-1])
+                    pred_domain_target_single = pred_domain_target[l].view(-1, pred_domain_target[l].size()[-1])
+                    source_domain_label = torch.zeros(pred_domain_source_single.size(0)).long()
+                    target_domain_label = torch.ones(pred_domain_target_single.size(0)).long()
+                    domain_label = torch.cat((source_domain_label, target_domain_label), 0).cuda(non_blocking=True)
+                    pred_domain = torch.cat((pred_domain_source_single, pred_domain_target_single), 0)
+                    pred_domain_all.append(pred_domain)
+                    pred_domain_target_all.append(pred_domain_target_single)
+                    loss_adversarial = loss_adversarial + criterion_domain(pred_domain, domain_label)
+            losses_a.update(loss_adversarial.item(), pred_domain.size(0))
+            loss = loss + loss_adversarial
+        if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none":   # :559-562
+            loss_entropy = attentive_entropy(torch.cat((out_source, out_target), 0), pred_domain_all[1])
+            losses_e.update(loss_entropy.item(), out_target.size(0))
+            loss = loss + gamma * loss_entropy
+        prec1, prec5 = accuracy(out.data, label, topk=(1, min(5, num_class)))           # :567-571
+        losses.update(loss.item())
+        top1.update(prec1.item(), out_source.size(0))
+        top5.update(prec5.item(), out_source.size(0))
+        optimizer.zero_grad()                                                           # :574-583
+        loss.backward()
+        if args.clip_gradient is not None:
+            total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_gradient)
+            if total_norm > args.clip_gradient and args.verbose:
+                print("clipping gradient: {} with coef {}".format(total_norm, args.clip_gradient / total_norm))
+        optimizer.step()
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % args.print_freq == 0:                                                    # :589-617
+            line = ("Train: [{0}][{1}/{2}], lr: {lr:.5f}\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t"
+                    "Prec@1 {t1.val:.3f} ({t1.avg:.3f})\tPrec@5 {t5.val:.3f} ({t5.avg:.3f})\tLoss {ls.val:.4f} ({ls.avg:.4f})   "
+                    "loss_c {lc.avg:.4f}\t").format(epoch, i, len(source_loader), bt=batch_time, dt=data_time, t1=top1, t5=top5,
+                                                    ls=losses, lc=losses_c, lr=optimizer.param_groups[0]["lr"])
+            if args.adv_DA != "none" and args.use_target != "none":
+                line += "beta {:.3f}, {:.3f}, {:.3f}  loss_a {:.4f}\t".format(beta_new[0], beta_new[1], beta_new[2], losses_a.avg)
+            if args.add_loss_DA != "none" and args.use_target != "none":
+                line += "gamma {:.6f}  loss_e {:.4f}\t".format(gamma, losses_e.avg)
+            print(line)
+            log.write("%s\n" % line)
+        if args.lr_adaptive == "dann":                                                  # :620-621
+            adjust_learning_rate_dann(optimizer, p)
+        if args.save_attention >= 0:                                                    # :624-628
+            attn_epoch_source = torch.cat((attn_epoch_source, attn_source.detach().cpu()))
+            attn_epoch_target = torch.cat((attn_epoch_target, attn_target.detach().cpu()))
+    log_short.write("%s\n" % line)                                                      # :666
+    return losses_c.avg, attn_epoch_source.mean(0) if attn_epoch_source.numel() else attn_epoch_source, \
+        attn_epoch_target.mean(0) if attn_epoch_target.numel() else attn_epoch_target
+
+
+def validate(val_loader, model, criterion, num_class, epoch, log):
+    """:669-761: eval-mode forward of the validation data in both slots (beta = 0), CE + top-k on the target-slot outputs."""
+    batch_time, losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    end = time.time()
+    line = ""
+    with torch.no_grad():
+        for i, (val_data, val_label) in enumerate(val_loader):
+            val_size_ori = val_data.size()
+            batch_val_ori = val_size_ori[0]
+            val_data = _pad(val_data, args.batch_size[2])                              # :691-698
+            val_label = val_label.cuda(non_blocking=True)
+            _, _, _, _, _, attn_val, out_val, out_val_2, pred_domain_val, feat_val = model(val_data, val_data, [0] * len(args.beta), 0,
+                                                                                          is_train=False, reverse=False)    # :707
+            attn_val, out_val, out_val_2, pred_domain_val, feat_val = removeDummy(attn_val, out_val, out_val_2, pred_domain_val, feat_val,
+                                                                                  batch_val_ori)
+            loss = criterion(out_val, val_label)
+            prec1, prec5 = accuracy(out_val.data, val_label, topk=(1, min(5, num_class)))
+            losses.update(loss.item(), out_val.size(0))
+            top1.update(prec1.item(), out_val.size(0))
+            top5.update(prec5.item(), out_val.size(0))
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0:
+                line = ("Test: [{0}][{1}/{2}]\tTime {bt.val:.3f} ({bt.avg:.3f})\tLoss {ls.val:.4f} ({ls.avg:.4f})\t"
+                        "Prec@1 {t1.val:.3f} ({t1.avg:.3f})\tPrec@5 {t5.val:.3f} ({t5.avg:.3f})\t").format(
+                            epoch, i, len(val_loader), bt=batch_time, ls=losses, t1=top1, t5=top5)
+                if args.verbose:
+                    print(line)
+                log.write("%s\n" % line)
+    print("Testing Results: Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f} Loss {loss.avg:.5f}".format(top1=top1, top5=top5, loss=losses))
+    log.write("Testing Results: Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f} Loss {loss.avg:.5f}\n".format(top1=top1, top5=top5, loss=losses))
+    return top1.avg
+
+
+def save_checkpoint(state, is_best, path_exp, filename="checkpoint.pth.tar"):
+    """:764-770."""
+    path_file = path_exp + filename
+    torch.save(state, path_file)
+    if is_best:
+        shutil.copyfile(path_file, path_exp + "model_best.pth.tar")
+
+
+class AverageMeter(object):
+    """:772-787."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def adjust_learning_rate(optimizer, decay):
+    """:789-792."""
+    for param_group in optimizer.param_groups:
+        param_group["lr"] /= decay
+
+
+def adjust_learning_rate_dann(optimizer, p):
+    """:800-802."""
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = args.lr / (1. + 10 * p) ** 0.75
+
+
+def accuracy(output, target, topk=(1,)):
+    """:809-822 (with .reshape where the reference's .view fails on a non-contiguous slice with torch >= 1.7)."""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    res = []
+    for k in topk:
+        correct_k = correct[:k].reshape(-1).float().sum(0)
+        res.append(correct_k.mul_(100.0 / batch_size))
+    return res
+
+
+def removeDummy(attn, out_1, out_2, pred_domain, feat, batch_size):
+    """:825-832."""
+    return attn[:batch_size], out_1[:batch_size], out_2[:batch_size], [pred[:batch_size] for pred in pred_domain], \
+        [f[:batch_size] for f in feat]
+
+
+if __name__ == "__main__":
+    main()

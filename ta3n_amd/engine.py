@@ -65,13 +65,15 @@ class TrainEngine:
     tensor (rows [0, Bs) source, [Bs, Bs+Bt) target)."""
 
     def __init__(self, batch_source: int, batch_target: int, num_segments: int = 5, feature_dim: int = 2048,
-                 fc_dim: int = 512, num_class: int = 12, flags: int = ALL_FLAGS, dropout_i: float = 0.5,
+                 fc_dim: int = 512, num_class: int = 12, flags: Optional[int] = None, dropout_i: float = 0.5,
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
+        if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
+            flags = ALL_FLAGS if aggregation == "trn-m" else 0
         if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
             flags |= _lib.FLAG_BF16_MFMA
         if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly

@@ -7,9 +7,10 @@ all of that works here, with every arithmetic op of forward and backward execute
 by the HIP kernels (no eager-PyTorch or CPU fallback: calling forward without the
 HIP library or without a GPU raises).
 
-Supported configuration = the TA3N hot path:
-frame_aggregation='trn-m', baseline_type='video', share_params='Y', use_bn='none',
-add_fc=1, ens_DA='none', use_attn in {'TransAttn','none'}, use_attn_frame='none'.
+Supported configurations = the TA3N hot path and TemPooling:
+frame_aggregation='trn-m' (use_attn in {'TransAttn','none'}) or 'avgpool' (use_attn 'none': BASELINE configs[0] and the
+TemPooling + RevGrad rows), baseline_type='video', share_params='Y', use_bn='none', add_fc=1, ens_DA='none',
+use_attn_frame='none'.
 Anything else raises NotImplementedError at construction (several of those
 branches are broken in the reference itself).
 """
@@ -125,6 +126,72 @@ class _HipForward(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+class _HipForwardAvg(torch.autograd.Function):
+    """frame_aggregation='avgpool' (TemPooling, models.py:421-433): forward = ta3n_forward of the general avgpool plan
+    (F1 | Hf | mean | {Y, Hv} | {Pv, Pf}), backward = ta3n_backward from the caller's logit gradients."""
+
+    @staticmethod
+    def forward(ctx, model, xs, xt, beta, train, *params):
+        dev = model._flat.device
+        Bs, Bt = xs.shape[0], xt.shape[0]
+        plan = model._plan(Bs, Bt)
+        T = model.train_segments
+        x = torch.cat((xs.reshape(Bs * T, -1), xt.reshape(Bt * T, -1)), 0).to(device=dev, dtype=torch.float32).contiguous()
+        ws = model._ws_template(plan).clone()
+        h = _lib.Hyper()
+        h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
+        h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,))
+        h.seed_i, h.seed_v = int(seeds[0]), int(seeds[1])
+        h.valid_source, h.valid_target, h.train = Bs, Bt, int(bool(train))
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
+        _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
+        ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
+        B, Cn = Bs + Bt, model.num_class
+
+        def reg(name, shape):
+            off, n = plan.region(name)
+            return ws[off:off + n].view(shape).clone()
+
+        y, pv, pf = reg("Y", (B, Cn)), reg("Pv", (B, 2)), reg("Pf", (B, T, 2))
+        v, f1 = reg("V", (B, -1)), reg("F1", (B, T, -1))
+        ctx.mark_non_differentiable(v, f1)
+        ctx.set_materialize_grads(False)
+        return y, pv, pf, v, f1
+
+    @staticmethod
+    def backward(ctx, g_y, g_pv, g_pf, g_v, g_f1):
+        model, plan, ws = ctx.model, ctx.plan, ctx.ws
+        dev = ws.device
+        for name, g in (("gY", g_y), ("gPv", g_pv), ("gPf", g_pf)):
+            off, n = plan.region(name)
+            if g is None:
+                ws[off:off + n].zero_()
+            else:
+                ws[off:off + n].copy_(g.reshape(-1))
+        grads = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
+                                            stream), "ta3n_backward")
+        unused = []                               # a discriminator that feeds no loss keeps grad None (see _HipForward.backward)
+        if g_pf is None:
+            unused += ["fc_feature_domain.", "fc_classifier_domain."]
+        if g_pv is None:
+            unused += ["fc_feature_domain_video.", "fc_classifier_domain_video."]
+        out: List[Optional[torch.Tensor]] = []
+        for name, off, shape, live in plan.params:
+            if not live or name.startswith(tuple(unused)):
+                out.append(None)
+                continue
+            n = 1
+            for s_ in shape:
+                n *= s_
+            out.append(grads[off:off + n].view(shape))
+        return (None, None, None, None, None, *out)
+
+
 class VideoModel(nn.Module):
     def __init__(self, num_class, baseline_type, frame_aggregation, modality,
                  train_segments=5, val_segments=25,
@@ -137,7 +204,9 @@ class VideoModel(nn.Module):
                  share_params='Y'):
         super().__init__()
         unsupported = []
-        if frame_aggregation != 'trn-m': unsupported.append(f"frame_aggregation={frame_aggregation!r}")
+        if frame_aggregation not in ('trn-m', 'avgpool'): unsupported.append(f"frame_aggregation={frame_aggregation!r}")
+        if frame_aggregation == 'avgpool' and use_attn != 'none':
+            unsupported.append("frame_aggregation='avgpool' with use_attn (the reference's script runs TemPooling with use_attn none)")
         if baseline_type != 'video': unsupported.append(f"baseline_type={baseline_type!r}")
         if share_params != 'Y': unsupported.append("share_params='N'")
         if use_bn != 'none': unsupported.append(f"use_bn={use_bn!r}")
@@ -165,6 +234,7 @@ class VideoModel(nn.Module):
         self.new_length = (1 if modality == "RGB" else 5) if new_length is None else new_length
         self.num_class = num_class
         self._attn_on = use_attn == 'TransAttn'
+        self._avg = frame_aggregation == 'avgpool'
         if verbose:
             print(f"Initializing TSN with base model: {base_model}. input_modality: {modality}, "
                   f"num_segments: {train_segments}, new_length: {self.new_length}")
@@ -187,16 +257,21 @@ class VideoModel(nn.Module):
         self.fc_classifier_source = lin(F_, num_class)                   # :166 (dead for baseline_type='video')
         self.fc_classifier_domain = lin(F_, 2)                           # :170
         self.num_bottleneck = NB
-        self.TRN = RelationModuleMultiScale(F_, NB, train_segments, verbose=verbose)   # :224 (default nn.Linear init)
-        self.bn_trn_S = nn.BatchNorm1d(NB)                               # :225-226 (unused with use_bn='none')
-        self.bn_trn_T = nn.BatchNorm1d(NB)
-        self.fc_feature_video_source = lin(NB, NB)                       # :258 (unused)
-        self.fc_feature_video_source_2 = lin(NB, NB)                     # :262 (unused)
-        self.fc_feature_domain_video = lin(NB, NB)                       # :267
-        self.fc_classifier_video_source = lin(NB, num_class)             # :272
-        self.fc_classifier_domain_video = lin(NB, 2)                     # :281
-        self.relation_domain_classifier_all = nn.ModuleList(             # :286-294 (default init)
-            nn.Sequential(nn.Linear(NB, NB), nn.ReLU(), nn.Linear(NB, 2)) for _ in range(train_segments - 1))
+        if self._avg:                                                    # feat_aggregated_dim = feat_shared_dim (models.py:246-247)
+            A = F_
+        else:
+            A = NB
+            self.TRN = RelationModuleMultiScale(F_, NB, train_segments, verbose=verbose)   # :224 (default nn.Linear init)
+            self.bn_trn_S = nn.BatchNorm1d(NB)                           # :225-226 (unused with use_bn='none')
+            self.bn_trn_T = nn.BatchNorm1d(NB)
+        self.fc_feature_video_source = lin(A, A)                         # :258 (unused)
+        self.fc_feature_video_source_2 = lin(A, A)                       # :262 (unused)
+        self.fc_feature_domain_video = lin(A, A)                         # :267
+        self.fc_classifier_video_source = lin(A, num_class)              # :272
+        self.fc_classifier_domain_video = lin(A, 2)                      # :281
+        if not self._avg:
+            self.relation_domain_classifier_all = nn.ModuleList(         # :286-294 (default init)
+                nn.Sequential(nn.Linear(NB, NB), nn.ReLU(), nn.Linear(NB, 2)) for _ in range(train_segments - 1))
         self.alpha = torch.ones(1)                                       # :314 plain attribute
         self.relu = nn.ReLU(inplace=True)
         self.dropout_i = nn.Dropout(p=dropout_i)                         # kept as attributes; the HIP kernels apply them
@@ -224,6 +299,8 @@ class VideoModel(nn.Module):
     def _flags(self) -> int:
         # losses are assembled by the caller (main.py:439-562), so every discriminator has to be able to receive a gradient:
         # the adversarial flags only decide the plan's live parameter set here (the loss kernel is not used on this path)
+        if self._avg:
+            return _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME
         return (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME |
                 (_lib.FLAG_TRANS_ATTN if self._attn_on else 0))
 
@@ -231,7 +308,7 @@ class VideoModel(nn.Module):
         key = (Bs, Bt)
         if key not in self._plans:
             self._plans[key] = _lib.Plan(Bs, Bt, self.train_segments, self.feature_dim, self._feat_dim_F, self.num_class,
-                                         self._flags())
+                                         self._flags(), aggregation=_lib.AGG_AVGPOOL if self._avg else _lib.AGG_TRN_M)
         return self._plans[key]
 
     def _ws_template(self, plan: _lib.Plan) -> torch.Tensor:
@@ -284,7 +361,7 @@ class VideoModel(nn.Module):
             raise NotImplementedError("reverse=True is only used by ens_DA='MCD' (main.py:549)")
         num_segments = self.train_segments if is_train else self.val_segments
         if num_segments != self.train_segments:
-            raise ValueError("TRN needs val_segments == num_segments (models.py:222)")
+            raise ValueError("val_segments must equal num_segments (static launch plans; TRN needs it anyway, models.py:222)")
         if input_source.dim() != 3 or input_target.dim() != 3 or input_source.size(1) != num_segments or \
                 input_source.size(2) != self.feature_dim or input_target.size(2) != self.feature_dim:
             raise ValueError("inputs must be [B, num_segments, feature_dim]")
@@ -295,10 +372,16 @@ class VideoModel(nn.Module):
         plan = self._plan(Bs, Bt)
         self._ensure_flat(plan, device)
         params = [p for _, _, _, p in self._named_flat_params(plan)]
+        s, t = slice(0, Bs), slice(Bs, Bs + Bt)
+        if self._avg:
+            with torch.cuda.device(device):
+                y, pv, pf, v, f1 = _HipForwardAvg.apply(self, input_source, input_target, list(beta), self.training, *params)
+            # models.py:627-628 (attn placeholder = first feature column), :697-708 (the relation slot repeats the video logits)
+            return (v[s][:, 0], y[s], y[s], [pv[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
+                    v[t][:, 0], y[t], y[t], [pv[t], pv[t], pf[t]], [y[t], v[t], f1[t]])
         with torch.cuda.device(device):
             attn, y, pr, pv, pf, v, f1 = _HipForward.apply(self, input_source, input_target, list(beta),
                                                             self.training, *params)
-        s, t = slice(0, Bs), slice(Bs, Bs + Bt)
         out_s, out_t = y[s], y[t]
         return (attn[s], out_s, out_s, [pr[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
                 attn[t], out_t, out_t, [pr[t], pv[t], pf[t]], [y[t], v[t], f1[t]])

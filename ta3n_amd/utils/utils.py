@@ -4,11 +4,10 @@ import torch
 
 
 def randSelectBatch(input, num):
-    """utils/utils.py:8-11."""
-    id_all = torch.randperm(input.size(0))
-    if input.is_cuda:
-        id_all = id_all.to(input.device)
-    return input[id_all[:num]]
+    """utils/utils.py:8-11: (ids, input[ids]) for `num` random rows."""
+    id_all = torch.randperm(input.size(0)).to(input.device)
+    id = id_all[:num]
+    return id, input[id]
 
 
 def plot_confusion_matrix(*args, **kwargs):

@@ -1,0 +1,103 @@
+"""The drop-in claims of SURVEY.md 8(b), executed:
+
+ * GPU: the repo's own main.py (the reference's program structure on the HIP-backed modules) trains on a dataset in the
+   reference's on-disk format for two epochs - the TA3N configuration and BASELINE configs[0] (TemPooling, source-only) and
+   TemPooling + RevGrad - writes the reference's log files and checkpoint, resumes from it, and the checkpoint loads
+   the way test_models.py loads it;
+ * build container only (needs /root/reference; skipped elsewhere): the REFERENCE's own main.py source, unmodified,
+   imports and starts with compat/ first on sys.path - parser, VideoModel constructor, DataParallel wrap, optimizer,
+   data loaders, train() up to the first forward, where the HIP path refuses to run without a GPU (no CPU fallback)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from fixture_t7 import make_dataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TA3N = ["--baseline_type", "video", "--frame_aggregation", "trn-m", "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "TransAttn",
+        "--add_loss_DA", "attentive_entropy", "--beta", "0.75", "0.75", "0.5", "--gamma", "0.003", "--lr_adaptive", "dann"]
+CONFIGS0 = ["--baseline_type", "video", "--frame_aggregation", "avgpool", "--use_target", "none", "--adv_DA", "none", "--use_attn", "none",
+            "--add_loss_DA", "none", "--beta", "0", "0", "0", "--gamma", "0", "--place_adv", "N", "N", "N"]
+TEMPOOL_DA = ["--baseline_type", "video", "--frame_aggregation", "avgpool", "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "none",
+              "--add_loss_DA", "none", "--beta", "0.75", "0.75", "0.5", "--place_adv", "N", "Y", "Y", "--lr_adaptive", "dann"]
+COMMON = ["--arch", "resnet18", "--num_segments", "5", "--fc_dim", "64", "--dropout_i", "0.5", "--dropout_v", "0.5", "-b", "8", "6", "8",
+          "--lr", "0.03", "--epochs", "2", "-j", "0", "--print_freq", "1", "--save_model", "--no_partialbn"]
+
+
+def _run(script, data, exp, flags, extra=()):
+    cmd = [sys.executable, script, data[0], "RGB", data[1], data[2], data[3], "--exp_path", exp + "/", *flags, *COMMON, *extra]
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", [("ta3n", TA3N), ("configs0", CONFIGS0), ("tempooling_da", TEMPOOL_DA)])
+def test_own_main_trains_logs_checkpoints_and_resumes(tmp_path, name, flags):
+    data = make_dataset(str(tmp_path / "data"))
+    exp = str(tmp_path / "exp")
+    r = _run(os.path.join(ROOT, "main.py"), data, exp, flags, ["--save_best_log", str(tmp_path / "best.log")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = exp + "/RGB/"
+    for f in ("train.log", "train_short.log", "val.log", "val_short.log", "checkpoint.pth.tar", "model_best.pth.tar"):
+        assert os.path.exists(out + f), f
+    train_lines = [ln for ln in open(out + "train.log") if ln.startswith("Train:")]
+    assert len(train_lines) == 2 * 3                                     # 2 epochs x ceil(24 / 8) steps, print_freq 1
+    first, last = (float(ln.split("loss_c")[1].split()[0]) for ln in (train_lines[0], train_lines[-1]))
+    assert last < first, (first, last)                                    # it learns (running average of the classification loss drops)
+    if name != "configs0":
+        assert "loss_a" in train_lines[-1]
+    assert "Testing Results: Prec@1" in open(out + "val.log").read()
+    ck = torch.load(out + "checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "arch", "state_dict", "optimizer", "best_prec1", "prec1"} and ck["epoch"] == 2
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    # test_models.py:85-90
+    from ta3n_amd.models import VideoModel
+    agg = "trn-m" if name == "ta3n" else "avgpool"
+    net = VideoModel(5, "video", agg, "RGB", train_segments=5, val_segments=5, base_model="resnet18", fc_dim=64,
+                     use_attn="TransAttn" if name == "ta3n" else "none", verbose=False)
+    net.load_state_dict({'.'.join(k.split('.')[1:]): v for k, v in list(ck['state_dict'].items())})
+    # --resume --resume_hp continues at epoch 3
+    r2 = _run(os.path.join(ROOT, "main.py"), data, exp, flags, ["--resume", out + "checkpoint.pth.tar", "--resume_hp", "--epochs", "3",
+                                                                   "--save_best_log", str(tmp_path / "best.log")])
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    assert "(epoch 2)" in r2.stdout and "Train: [3][0/3]" in r2.stdout and "Train: [2]" not in r2.stdout
+
+
+_REF_DRIVER = r"""
+import sys, types, builtins, torch
+sys.path.insert(0, {compat!r}); sys.path.insert(1, {root!r})
+col = types.ModuleType('colorama'); col.init = lambda **k: None
+class _C:
+    def __getattr__(self, k): return ''
+col.Fore = col.Back = col.Style = _C(); sys.modules['colorama'] = col
+tbx = types.ModuleType('tensorboardX'); tbx.SummaryWriter = object; sys.modules['tensorboardX'] = tbx
+torch.Tensor.cuda = lambda self, *a, **k: self; torch.nn.Module.cuda = lambda self, *a, **k: self    # no GPU here
+torch.cuda.device_count = lambda: 1
+import importlib.util                       # the reference's main.py SOURCE FILE, unmodified (the repo has a main.py of its own)
+spec = importlib.util.spec_from_file_location('main', '/root/reference/main.py')
+ref_main = importlib.util.module_from_spec(spec); sys.modules['main'] = ref_main
+spec.loader.exec_module(ref_main)          # its imports - models / TRNmodule / loss / opts / dataset / utils - resolve to compat/
+import models, opts, dataset, loss, TRNmodule
+assert models.__file__.startswith({compat!r}) and opts.__file__.startswith({compat!r}) and dataset.__file__.startswith({compat!r})
+assert ref_main.__file__.startswith('/root/reference')
+sys.argv = ['main.py'] + {argv!r}
+try:
+    ref_main.main()
+except Exception as e:
+    print('STOPPED', type(e).__name__, str(e)[:200])
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
+@pytest.mark.parametrize("flags", [TA3N, CONFIGS0])
+def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path, flags):
+    data = make_dataset(str(tmp_path / "data"), videos=(8, 6, 4))
+    argv = [data[0], "RGB", data[1], data[2], data[3], "--exp_path", str(tmp_path / "exp") + "/", *flags, *COMMON]
+    code = _REF_DRIVER.format(compat=os.path.join(ROOT, "compat"), root=ROOT, argv=argv)
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # everything before the first forward ran on the reference's own code: parser, ctor, DataParallel, SGD, loaders, train()
+    assert "start training" in r.stdout, r.stdout[-2000:]
+    assert "STOPPED Ta3nError" in r.stdout and "HIP device" in r.stdout, r.stdout[-2000:]      # loud: no CPU fallback

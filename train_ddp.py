@@ -40,9 +40,9 @@ def validate_options(args) -> None:
             bad.append(msg)
     need(args.baseline_type == "video", f"--baseline_type {args.baseline_type} (built: video)")
     need(args.frame_aggregation in ("trn-m", "avgpool"), f"--frame_aggregation {args.frame_aggregation} (built: trn-m, avgpool)")
-    if args.frame_aggregation == "avgpool":
-        need(args.use_target == "none" and args.adv_DA == "none",
-             "avgpool is built in the source-only configuration (--use_target none --adv_DA none; BASELINE configs[0])")
+    if args.frame_aggregation == "avgpool":      # TemPooling: source-only (BASELINE configs[0]) or with the RevGrad branches; no attention
+        need(args.use_attn == "none" and (args.add_loss_DA == "none" or args.use_target == "none"),
+             "avgpool is built without attention / attentive entropy (--use_attn none --add_loss_DA none, as the reference's script runs it)")
     need(args.optimizer == "SGD", f"--optimizer {args.optimizer} (built: SGD with Nesterov momentum, main.py:83)")
     need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses are not built)")
     need(args.ens_DA == "none", f"--ens_DA {args.ens_DA}")
