@@ -151,3 +151,41 @@ def test_hip_path_matches_reference_golden(name, fused):
     ref_a = float(last.split("loss_a")[1].split()[0])
     L = eng.losses()
     assert abs(L["loss"] - ref_loss) < 3e-3 and abs(L["loss_adv_vid"] + L["loss_adv_frm"] + L["loss_adv_rel"] - ref_a) < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("place_adv", [("N", "Y", "Y"), ("Y", "Y", "Y"), ("N", "N", "N")])
+def test_module_path_avgpool_matches_oracle(place_adv):
+    """VideoModel(frame_aggregation='avgpool'): forward 10-tuple and, with the loss assembled by the CALLER as main.train does
+    (main.py:439-451, 508-538), every parameter gradient - against the oracle; unused discriminators keep grad None."""
+    import torch.nn.functional as Fn
+    from ta3n_amd.models import VideoModel
+    C_, T, D, Fc, Bs, Bt = 7, 4, 512, 64, 6, 5
+    cfg = orc.Config(num_class=C_, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, place_adv=place_adv,
+                     add_loss_DA="none", use_attn="none", frame_aggregation="avgpool")
+    params = synth_state(orc.param_shapes(cfg), seed=21)
+    xs, xt, ys, yt = synth_batch(C_, T, D, Bs, Bt, seed=22)
+    res = orc.train_step(orc.TrainState(params={k: v.clone() for k, v in params.items()}), xs, xt, ys, BETA, 0.0, cfg, clip=None)
+    m = VideoModel(C_, "video", "avgpool", "RGB", train_segments=T, val_segments=T, base_model="resnet18", fc_dim=Fc, dropout_i=0.0,
+                   dropout_v=0.0, use_attn="none", verbose=False)
+    sd = m.state_dict(); sd.update(params); m.load_state_dict(sd)
+    m = m.cuda(); m.train()
+    out = m(xs, xt, BETA, 0, True, False)
+    attn_s, out_s, out_s2, pd_s, feat_s, attn_t, out_t, out_t2, pd_t, feat_t = out
+    assert torch.allclose(out_s.cpu(), res["src"]["out"], atol=1e-3) and torch.allclose(out_t.cpu(), res["tgt"]["out"], atol=1e-3)
+    assert torch.allclose(pd_s[1].cpu(), res["src"]["pred_domain"][1], atol=1e-3) and torch.equal(pd_s[0], pd_s[1])
+    assert torch.allclose(pd_t[2].cpu(), res["tgt"]["pred_domain"][2], atol=1e-3)
+    assert torch.allclose(attn_s.cpu(), res["src"]["attn"], atol=1e-4) and torch.allclose(feat_s[1].cpu(), res["src"]["feat"][1], atol=1e-4)
+    loss = Fn.cross_entropy(out_s, ys.cuda())
+    for l in range(3):
+        if place_adv[l] == "Y":
+            ps, pt = pd_s[l].reshape(-1, 2), pd_t[l].reshape(-1, 2)
+            lab = torch.cat((torch.zeros(ps.size(0)), torch.ones(pt.size(0)))).long().cuda()
+            loss = loss + Fn.cross_entropy(torch.cat((ps, pt)), lab)
+    loss.backward()
+    assert abs(loss.item() - res["loss"].item()) < 2e-4
+    named = dict(m.named_parameters())
+    assert {k for k, v in named.items() if v.grad is not None} == set(res["grads"])
+    for k, w in res["grads"].items():
+        got = named[k].grad.cpu()
+        assert torch.allclose(got, w, rtol=2e-3, atol=2e-4 * w.abs().max().item() + 1e-7), (k, (got - w).abs().max().item(), w.abs().max().item())
