@@ -3,7 +3,10 @@
 
 Metric (BASELINE.json): src+tgt videos/sec per train step, UCF->HMDB_full 5-seg
 TA3N (trn-m, RevGrad x3, TransAttn, attentive entropy; 128 source + 74 target
-videos per GPU and step, 2048-d features, 12 classes, dropout 0.5/0.5).
+videos per GPU and step, 2048-d features, 12 classes, dropout 0.5/0.5).  --config N
+times another BASELINE configuration (1: TemPooling source-only, 3: the headline in
+fp32, 4: 30 classes / 9 segments / 512+512 videos, 5: two-stream 1024-d / 12 segments);
+`config.workload` names it.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -37,6 +40,20 @@ from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
 
 # BASELINE config 2/3 (script_train_val.sh: bS=128, bS_2=128*840/1438=74, 5 segments, fc_dim 512, 12 classes)
 CFG = dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12, NB=256)
+# --config N (SURVEY.md 8d numbering = BASELINE.json configs[N-1]); 2 with --dtype bf16 is the headline, 3 is the same shape in fp32
+CONFIGS = {
+    1: dict(shape=dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=5, NB=256), agg="avgpool", streams=1, dtype="f32",
+            name="hmdb_ucf_small shape, TemPooling (avgpool), source-only, 128 src + 74 tgt videos (target forwarded), 5 classes"),
+    2: dict(shape=CFG, agg="trn-m", streams=1, dtype="bf16",
+            name="UCF->HMDB_full TA3N train step: trn-m 5 segments, RevGrad x3, TransAttn, attentive entropy, 128 src + 74 tgt videos per "
+                 "GPU-step, 2048-d features, 12 classes"),
+    3: dict(shape=CFG, agg="trn-m", streams=1, dtype="f32", name="UCF->HMDB_full TA3N (same as config 2), fp32"),
+    4: dict(shape=dict(Bs=512, Bt=512, T=9, D=2048, F=512, C=30, NB=256), agg="trn-m", streams=1, dtype="bf16",
+            name="synthetic Kinetics->Gameplay shape: TA3N, 30 classes, 9 segments, 512 src + 512 tgt videos per GPU-step, 2048-d features"),
+    5: dict(shape=dict(Bs=128, Bt=128, T=12, D=1024, F=512, C=12, NB=256), agg="trn-m", streams=2, dtype="bf16",
+            name="two-stream RGB+Flow: two TA3N models on 1024-d I3D-shaped features, 12 segments, attentive entropy on, 128 src + 128 tgt "
+                 "videos per stream and GPU-step, class logits summed (ta3n_amd/two_stream.py)"),
+}
 # per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
 # forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
 DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222]
@@ -45,9 +62,25 @@ DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 HBM_PEAK_GBS = 8000.0
-# HBM-side bytes of one GEMM launch (average over the six of a fused step), from the committed PMC passes
-# profiles/r01_pmc_fused_step.txt: (sum FETCH_SIZE x 2 [gfx950 half-count correction] + sum WRITE_SIZE) KiB / 6
-GEMM_TRAFFIC_BYTES_PER_LAUNCH = (2 * 99698 + 26270) * 1024 / 6
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "gemm_traffic.json")   # written by tools/measure_traffic.py from rocprofv3 PMC passes
+
+
+def measured_traffic(dtype):
+    """HBM-side bytes per GEMM launch (FETCH_SIZE x 2 [gfx950 half-count correction] + WRITE_SIZE, average over the GEMM
+    launches of a fused step) of the headline configuration, as measured by tools/measure_traffic.py on a GPU box and
+    committed under profiles/ together with the raw counter tables.  PMC collection needs its own rocprofv3 passes (it
+    cannot run inside the timed loop), so the line carries the number of the LAST measurement plus the hash of the kernel
+    sources it was taken on and whether that is still the tree's hash: a stale number is visible as such."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        from ta3n_amd.build import source_hash
+        e = t[dtype]
+        return e["bytes_per_gemm_launch"], {"file": "profiles/gemm_traffic.json", "measured_on_sources": t.get("source_hash"),
+                                            "current_sources": source_hash(), "fresh": t.get("source_hash") == source_hash(),
+                                            "passes": e.get("passes")}
+    except Exception as ex:      # no measurement committed for this arithmetic
+        return None, {"file": None, "error": str(ex)[:80]}
 
 
 def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
@@ -61,35 +94,50 @@ def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
     return 3 * fwd - 2 * B * T * D * F
 
 
-def algorithmic_gemm_bytes_bf16(Bs, Bt, T, D, F, C, NB):
+def algorithmic_gemm_bytes_bf16(Bs, Bt, T, D, F, C, NB, agg="trn-m"):
     """SURVEY.md 8(d) bytes of the contraction launches with bf16 operands: the input once (2 B/element), every live
     weight read twice as bf16 (forward + backward) and its fp32 gradient written once; activations are assumed to stay on
     chip.  (The optimiser's 5 x 4 B/parameter belong to the SGD kernel, not to this one.)"""
     from ta3n_amd import _lib
     B = Bs + Bt
-    plan = _lib.Plan(Bs, Bt, T, D, F, C, 0x1F)
+    plan = _lib.Plan(Bs, Bt, T, D, F, C, 0x1F if agg == "trn-m" else 0, aggregation=_lib.AGG_TRN_M if agg == "trn-m" else _lib.AGG_AVGPOOL)
     live = sum(int(torch.tensor(shape).prod()) for _, _, shape, lv in plan.params if lv)
     return B * T * D * 2 + live * (2 + 2 + 4)
 
 
-# HBM-side bytes of one GEMM launch of the bf16 step (average over the six), profiles/r01_pmc_fused_step_bf16.txt
-GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 = (2 * 55748 + 29402) * 1024 / 6
 
 
-def cpu_baseline(seconds=12.0, max_steps=40):
+def algorithmic_flops(cfg):
+    """GEMM FLOPs of one train step of a CONFIGS entry (per stream)."""
+    sh = cfg["shape"]
+    if cfg["agg"] == "avgpool":      # shared FC (fwd + wgrad, no input gradient) + classifier (fwd, dgrad, wgrad)
+        B = sh["Bs"] + sh["Bt"]
+        return 2 * (2 * B * sh["T"] * sh["D"] * sh["F"]) + 3 * (2 * B * sh["F"] * sh["C"])
+    return algorithmic_gemm_flops(**sh)
+
+
+def cpu_baseline(conf=None, seconds=12.0, max_steps=40):
     """The CPU path on this host: oracle train step (same ATen CPU kernels the
-    reference dispatches), dropout on, all cores."""
+    reference dispatches, including the frame classifier it computes and never uses), dropout on, a bounded sample."""
     from oracle import ta3n_oracle as orc
-    cfg = orc.Config(num_class=CFG["C"], num_segments=CFG["T"], feature_dim=CFG["D"], fc_dim=CFG["F"])
+    conf = conf or CONFIGS[2]
+    CFG = conf["shape"]
+    avg = conf["agg"] == "avgpool"
+    cfg = orc.Config(num_class=CFG["C"], num_segments=CFG["T"], feature_dim=CFG["D"], fc_dim=CFG["F"], frame_aggregation=conf["agg"],
+                     place_adv=("N", "N", "N") if avg else ("Y", "Y", "Y"), add_loss_DA="none" if avg else "attentive_entropy",
+                     use_attn="none" if avg else "TransAttn", compute_dead_branches=True)
     params = synth_state(orc.param_shapes(cfg), seed=7, scale="init")
     xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234)
     state = orc.TrainState(params=params, lr=3e-2)
+    vdim = cfg.feat_dim if avg else 256
+    beta, gamma = ([0.0, 0.0, 0.0], 0.0) if avg else ([0.75, 0.75, 0.5], 0.003)
 
     def one():
         keep_i, keep_v = 1 - cfg.dropout_i, 1 - cfg.dropout_v
         di = [torch.bernoulli(torch.full((n * CFG["T"], cfg.feat_dim), keep_i)) / keep_i for n in (CFG["Bs"], CFG["Bt"])]
-        dv = [torch.bernoulli(torch.full((n, 256), keep_v)) / keep_v for n in (CFG["Bs"], CFG["Bt"])]
-        orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, drop_i=di, drop_v=dv)
+        dv = [torch.bernoulli(torch.full((n, vdim), keep_v)) / keep_v for n in (CFG["Bs"], CFG["Bt"])]
+        for _ in range(conf["streams"]):
+            orc.train_step(state, xs, xt, ys, beta, gamma, cfg, drop_i=di, drop_v=dv)
 
     # thread count: the CPU path is many small ATen ops; on a many-core host (or under a
     # cgroup CPU quota) all hardware threads is far slower than a moderate count, so probe a
@@ -123,7 +171,7 @@ def cpu_baseline(seconds=12.0, max_steps=40):
     except OSError:
         pass
     return dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port",
-                sample=f"{n} full train steps (128+74 videos, fp32, dropout 0.5) of oracle/ta3n_oracle.py on {cores} "
+                sample=f"{n} full train steps ({CFG['Bs']}+{CFG['Bt']} videos, fp32, dropout 0.5" + (", both streams" if conf["streams"] > 1 else "") + f") of oracle/ta3n_oracle.py on {cores} "
                        f"torch threads (best of a bounded probe; {avail} hw threads visible) of '{model}' = "
                        f"{1e3 * dt / n:.1f} ms/step",
                 ms_per_step=1e3 * dt / n)
@@ -134,6 +182,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE configuration (SURVEY.md 8d numbering); 2 = headline")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of eager launches (eager is "
                     "faster here: 8 launches of 10-70 us each keep the host ahead, a replay adds ~5 us of GPU idle time per step)")
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
@@ -151,12 +200,18 @@ def main():
     ap.add_argument("--no-twins", action="store_true", help="bf16: round fp32 operands in registers everywhere instead of reading bf16 "
                     "twins")
     ap.add_argument("--single-dtype", action="store_true", help="do not also time the other arithmetic (N = 1 runs both by default)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="bf16",
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
-                         "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1])")
+                         "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1]); default: the configuration's")
     ap.add_argument("--wgrads-late", action="store_true", help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    SH = conf["shape"]
+    if args.dtype is None:
+        args.dtype = conf["dtype"]
+    headline = args.config in (2, 3)
+    n_streams = conf["streams"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -177,60 +232,69 @@ def main():
             torch.cuda.synchronize(dev)
 
     def run(dtype, steps, warmup):
-        """Build an engine for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
+        """Build the engine(s) for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
         bf16 = dtype == "bf16"
         twins = bf16 and not args.no_twins
-        phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or (DEFAULT_PHASE_TILES_BF16 if bf16 else DEFAULT_PHASE_TILES)
+        phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v]
+        if not phase_tiles and headline:
+            phase_tiles = DEFAULT_PHASE_TILES_BF16 if bf16 else DEFAULT_PHASE_TILES
         if args.autotune:
-            from ta3n_amd.engine import autotune_phase_tiles
-            from ta3n_amd.engine import ALL_FLAGS
+            from ta3n_amd.engine import ALL_FLAGS, autotune_phase_tiles
             from ta3n_amd import _lib
-            phase_tiles, _ = autotune_phase_tiles(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], device=dev,
+            phase_tiles, _ = autotune_phase_tiles(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], device=dev,
                                                   flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if bf16 else 0) |
                                                   (_lib.FLAG_BF16_STORE if twins else 0),
                                                   candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
         if args.tile:
             phase_tiles = []
-        eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], dropout_i=0.5, dropout_v=0.5,
-                          clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                          fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late)
-        shapes = {n: s for n, _, s, _ in eng.plan.params}
-        eng.load_state(synth_state(shapes, seed=7, scale="init"))           # reference init: N(0, 0.001), zero bias
-        xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234 + rank)
-        eng.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
-        lr0, gamma, beta = 3e-2, 0.003, [0.75, 0.75, 0.5]
+        engs = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
+                            clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
+                            fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"])
+                for _ in range(n_streams)]
+        eng = engs[0]
+        for k, e in enumerate(engs):
+            shapes = {n: s for n, _, s, _ in e.plan.params}
+            e.load_state(synth_state(shapes, seed=7 + k, scale="init"))       # reference init: N(0, 0.001), zero bias
+            xs, xt, ys, yt = synth_batch(SH["C"], SH["T"], SH["D"], SH["Bs"], SH["Bt"], seed=1234 + rank + 100 * k)
+            e.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
+        avg = conf["agg"] == "avgpool"
+        lr0, gamma, beta = 3e-2, (0.0 if avg else 0.003), ([0.0, 0.0, 0.0] if avg else [0.75, 0.75, 0.5])
         total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
-        eng.set_hyper(beta, gamma, lr0)
+        for e in engs:
+            e.set_hyper(beta, gamma, lr0)
         if args.graph:
-            eng.capture()
+            for e in engs:
+                e.capture()
         deferred = eng.fused and not args.graph and args.overlap
         # default: the update of step n is the first launch of step n+1 and carries that step's scalars (no per-step
         # host-to-device copy); the timed region ends with flush(), so it contains exactly `steps` updates
         pipelined = eng.fused and not args.graph and not deferred and not args.no_pipeline
 
         def step(i):
-            if args.static_hyper and eng.graph is not None:
-                eng.graph.replay()
-                return
             p = float(i % total_steps) / total_steps
             lr = lr0 if i == 0 else lr_dann(lr0, p)
-            if deferred:
-                eng.train_step_deferred(beta, gamma, lr)
-            elif pipelined:
-                eng.train_step_pipelined(beta, gamma, lr)
-            else:
-                eng.train_step(beta, gamma, lr)
+            for e in engs:                                                 # two-stream: both models step, one after the other
+                if args.static_hyper and e.graph is not None:
+                    e.graph.replay()
+                elif deferred:
+                    e.train_step_deferred(beta, gamma, lr)
+                elif pipelined:
+                    e.train_step_pipelined(beta, gamma, lr)
+                else:
+                    e.train_step(beta, gamma, lr)
 
         for i in range(warmup):
             step(i)
-        eng.flush()
+        for e in engs:
+            e.flush()
         gc.collect()
         gc.disable()                                 # eager launches: a collector pause on the host would show up as GPU idle time
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
-        eng.flush()                                  # the K-th update is inside the timed region
+        for e in engs:
+            e.flush()                                # the K-th update is inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
         gc.enable()
@@ -238,10 +302,11 @@ def main():
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = t.item()
-        res = {"ms_per_step": 1e3 * elapsed / steps, "value": (CFG["Bs"] + CFG["Bt"]) * world * steps / elapsed}
+        # a two-stream step processes each video through both models: videos/s counts videos, not model passes
+        res = {"ms_per_step": 1e3 * elapsed / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / elapsed}
         if rank != 0:
             return res
-        res["finite"] = bool(torch.isfinite(eng.P).all().item())
+        res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
         res["deferred"] = deferred
         res["pipelined"] = pipelined
         res["fused"] = eng.fused
@@ -249,24 +314,22 @@ def main():
         phases = eng.time_phases(args.phase_reps)
         gemm = [p for p in phases if p[0] == 0]
         gemm_ms = sum(p[3] for p in gemm)
-        flops = algorithmic_gemm_flops(**CFG)
+        flops = algorithmic_flops(conf)
         tflops = flops / (gemm_ms * 1e-3) / 1e12
-        extra = {"kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step)", "launches": len(gemm),
+        traffic, traffic_src = measured_traffic(dtype) if (headline and eng.fused and (twins or not bf16)) else (None, {"file": None})
+        extra = {"kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step" + (" and stream)" if n_streams > 1 else ")"), "launches": len(gemm),
                  "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
-                 "all_kernels_us": 1e3 * sum(p[3] for p in phases),
+                 "all_kernels_us": 1e3 * sum(p[3] for p in phases), "traffic": traffic,
+                 "traffic_unit": "bytes per GEMM launch: rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (tools/measure_traffic.py)",
+                 "traffic_source": traffic_src,
                  "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases]}
         if not bf16:       # fp32 MFMA: 95 FLOP/B against a machine balance of 25 -> MFMA-bound
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tflops / PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH if eng.fused else None,
-                               "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step.txt)",
-                               **extra}
+                               "frac": tflops / PEAK_FP32_MFMA_TFLOPS, **extra}
         else:              # bf16 MFMA makes the math 16x cheaper than fp32's: the binding roofline is HBM
-            nbytes = algorithmic_gemm_bytes_bf16(**CFG)
+            nbytes = algorithmic_gemm_bytes_bf16(**SH, agg=conf["agg"])
             gbs = nbytes / (gemm_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": GEMM_TRAFFIC_BYTES_PER_LAUNCH_BF16 if (eng.fused and twins) else None,
-                               "traffic_unit": "bytes per launch, rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (profiles/r01_pmc_fused_step_bf16.txt)",
                                "bytes_per_launch": nbytes / max(len(gemm), 1),
                                "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
         res["phase_tiles"] = [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] != 5]
@@ -274,37 +337,43 @@ def main():
 
     main_res = run(args.dtype, args.steps, args.warmup)
     other = None
-    if not args.single_dtype and not selftest:   # the other arithmetic, same process (all ranks), for the record: at N > 1 the fp32 line is BASELINE configs[2]
+    if headline and not args.single_dtype and not selftest:   # the other arithmetic, same process (all ranks): at N > 1 the fp32 line is BASELINE configs[2]
         other = run("f32" if args.dtype == "bf16" else "bf16", max(50, args.steps // 2), max(10, args.warmup // 2))
 
     if rank == 0:
         arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "
-                         "(BASELINE configs[1])",
-                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic)"}
+                         "(BASELINE configs[1]); parity gate: tests/test_gpu_bf16.py against the bf16-operand oracle",
+                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within 1e-3 of the reference's CPU path"}
         out = {
-            "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N",
+            "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N" if headline else
+                      "src+tgt videos/sec per train step (BASELINE configs[%d])" % (args.config - 1),
             "value": main_res["value"], "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "UCF->HMDB_full TA3N train step: trn-m 5 segments, RevGrad x3, TransAttn, "
-                                   "attentive entropy, 128 src + 74 tgt videos per GPU-step, 2048-d features, 12 classes, "
-                                   "dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
-                       "global_batch": (CFG["Bs"] + CFG["Bt"]) * world, "parallelism": f"dp{world}",
+            "config": {"workload": conf["name"] + ", dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
+                       "baseline_config": args.config - 1,
+                       "global_batch": (SH["Bs"] + SH["Bt"]) * world, "parallelism": f"dp{world}",
                        "launch": "hipGraph" if args.graph else "eager", "finite": main_res["finite"],
                        "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",
                        "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
                        ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "
                         "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
+                       "gradient_exchange": None if world == 1 else
+                       ("RCCL ncclAllReduce from the C ABI on the step's stream, " + ("bf16" if args.dtype == "bf16" else "fp32") + " transport"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],
         }
         if other is not None:
             o_dtype = "f32" if args.dtype == "bf16" else "bf16"
-            out["other_arithmetic"] = {"dtype": o_dtype, "what": arith[o_dtype], "value": other["value"], "unit": "videos/s",
-                                       "ms_per_step": other["ms_per_step"], "roofline": {k: other["roofline"][k] for k in
-                                                                                         ("bound", "achieved", "peak", "unit", "frac")}}
+            o = {"dtype": o_dtype, "what": arith[o_dtype], "value": other["value"], "unit": "videos/s", "ms_per_step": other["ms_per_step"],
+                 "roofline": {k: other["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                                "per_phase_us")}}
+            out["other_arithmetic"] = o
+            # the same numbers inside `roofline`, so that the parity-qualified fp32 figure travels with the headline line
+            out["roofline"]["other_arithmetic"] = {"dtype": o_dtype, "value": other["value"], "ms_per_step": other["ms_per_step"],
+                                                   **{k: other["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)
     if world > 1 or selftest:
         torch.distributed.barrier()

@@ -110,6 +110,8 @@ class Config:
     use_attn: str = "TransAttn"
     frame_aggregation: str = "trn-m"                  # 'avgpool' = TemPooling (models.py:246, 421-433; BASELINE configs[0])
     arithmetic: str = "fp32"                          # 'bf16': BASELINE configs[1] (bf16 MFMA operands, fp32 accumulation)
+    compute_dead_branches: bool = False              # also evaluate what the reference computes and never uses (the frame classifier,
+                                                      # models.py:617-618): for timing the CPU path fairly, no effect on any output
     bf16_twins: bool = True                           # bf16 only: operands are read from bf16 copies (TA3N_FLAG_BF16_STORE), so a bias
                                                       # gradient made by a weight-gradient launch sums ROUNDED values (BF16_POLICY bias16)
 
@@ -334,6 +336,8 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
     # frame-level adversarial branch (:456-462, :606-610)
     h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2]), cfg))
     pred_frame = _linear(p, "fc_classifier_domain", h, cfg).view(B, T, 2)
+    if cfg.compute_dead_branches:
+        _ = F.linear(f, p["fc_classifier_source.weight"], p["fc_classifier_source.bias"])       # :617-618, dead for baseline_type 'video'
     if cfg.frame_aggregation == "avgpool":
         # aggregate_frames, "1. averaging" (:421-433) without attention; attn is a placeholder column (:627-628)
         v = feat_frame.mean(1)

@@ -22,6 +22,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel / plan sources and headers: identifies the binary a measurement was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -1,0 +1,48 @@
+"""Two-stream (RGB + Flow) training: BASELINE configs[4].
+
+The reference cannot express it (SURVEY.md 8d "Config 5": one modality per run, no fusion code), so this is the
+shape-only synthetic the survey defines: two independent VideoModel-equivalents - one TrainEngine per feature stream, same
+TA3N options - stepped on their own features, with the class logits SUMMED for reporting (late fusion).  Each stream is a
+complete train step of the hot path (its own parameters, gradients, optimiser state and, under data parallelism, its own
+all-reduce); the two steps are enqueued back to back on one HIP stream, so a "step" of this wrapper is two engine steps."""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+
+from .engine import TrainEngine
+
+
+class TwoStreamEngine:
+    def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dims: Sequence[int] = (1024, 1024),
+                 fc_dim: int = 512, num_class: int = 12, **engine_kw):
+        self.streams: List[TrainEngine] = [TrainEngine(batch_source, batch_target, num_segments, d, fc_dim, num_class, **engine_kw)
+                                           for d in feature_dims]
+        self.Bs, self.Bt, self.C = batch_source, batch_target, num_class
+
+    def set_batch(self, sources: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], source_label: torch.Tensor) -> None:
+        for e, xs, xt in zip(self.streams, sources, targets):
+            e.set_batch(xs, xt, source_label)
+
+    def train_step(self, beta, gamma, lr, pipelined: bool = True, **kw) -> None:
+        for e in self.streams:
+            (e.train_step_pipelined if (pipelined and e.fused) else e.train_step)(beta, gamma, lr, **kw)
+
+    def flush(self) -> None:
+        for e in self.streams:
+            e.flush()
+
+    def logits(self) -> torch.Tensor:
+        """Summed class logits of the streams, [Bs + Bt, C] (what a two-stream evaluation reports)."""
+        out = self.streams[0].outputs()["out"].clone()
+        for e in self.streams[1:]:
+            out += e.outputs()["out"]
+        return out
+
+    def losses(self) -> Dict[str, float]:
+        tot: Dict[str, float] = {}
+        for e in self.streams:
+            for k, v in e.losses().items():
+                tot[k] = tot.get(k, 0.0) + v
+        return tot
