@@ -237,6 +237,13 @@ int ta3n_gather_segments_into(ta3n_plan *plan, const float *store, const int64_t
                               const int32_t *labels, const int32_t *video_ids, int n_videos, int first_video, float *x,
                               float *ws, int32_t *labels_out, void *stream);
 
+/* The same from a bf16 packed store (raw bf16 [total_frames, feature_dim], feature_dim % 8 == 0): the rows are copied
+ * into the input's bf16 twin as they are; x may be NULL when the plan reads twins (TA3N_FLAG_BF16_STORE) - then nothing
+ * fp32 is written: 2 bytes in and 2 bytes out per element instead of 4 + 4 + 2.  With x the rows are also widened. */
+int ta3n_gather_segments_bf16_into(ta3n_plan *plan, const void *store16, const int64_t *first_row, const int32_t *num_frames,
+                                   const int32_t *labels, const int32_t *video_ids, int n_videos, int first_video, float *x,
+                                   float *ws, int32_t *labels_out, void *stream);
+
 /* The whole-prefix update of step n with its scalars passed by value, which also leaves `next` - the per-step
  * scalars of step n+1 - in the workspace: a loop that postpones each update to the start of the next step saves
  * the separate ta3n_set_hyper upload (one host-to-device copy per step).  Arithmetic of ta3n_sgd_step[_fused]. */

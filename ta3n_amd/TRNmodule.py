@@ -40,9 +40,57 @@ class RelationModuleMultiScale(nn.Module):
         return list(itertools.combinations(range(num_frames), num_frames_relation))
 
     def forward(self, input):
-        raise NotImplementedError(
-            "RelationModuleMultiScale runs inside ta3n_amd.models.VideoModel as a grouped HIP GEMM; a standalone "
-            "forward is not part of the TA3N train-step path (SURVEY.md 8)")
+        """TRNmodule.py:58-82 on its own: input [B, T, D] -> [B, T-1, bottleneck].  Runs the SAME grouped tile-list launch the
+        train step uses for the tuple GEMMs (gather + concat folded into the operand addressing, bias + ReLU in the
+        epilogue; csrc/ta3n_plan.cpp: spec_Z) on a plan of B source videos; the per-scale sum of the (at most 3) tuple
+        activations is the only thing done here.  Inference only: inside VideoModel the module trains through the fused
+        step, a standalone autograd backward is not provided (raises if a gradient is required)."""
+        import ctypes as C
+        if not torch.cuda.is_available():
+            raise _lib.Ta3nError("RelationModuleMultiScale.forward needs a HIP device; there is no CPU fallback")
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("standalone RelationModuleMultiScale.forward is forward-only: call it under torch.no_grad() "
+                                      "(it trains inside ta3n_amd.models.VideoModel)")
+        if input.dim() != 3 or input.size(1) != self.num_frames or input.size(2) != self.img_feature_dim:
+            raise ValueError("input must be [B, num_frames, img_feature_dim]")
+        B, T, D = input.shape
+        NB = self.fc_fusion_scales[0][1].out_features
+        if NB != 256:
+            raise NotImplementedError("the fused launch sequence exists for num_bottleneck = 256 (TA3N's value, models.py:223)")
+        dev = input.device if input.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        key = (B, str(dev))
+        cache = self.__dict__.setdefault("_hip_cache", {})
+        if key not in cache:
+            plan = _lib.Plan(B, 0, T, D, D, 1, 0, num_bottleneck=NB)
+            with torch.cuda.device(dev):
+                ws = torch.zeros(plan.ws_floats, dtype=torch.float32, device=dev)
+                _lib.check(_lib.lib().ta3n_init_workspace(plan.handle, ws.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                           "ta3n_init_workspace")
+            cache[key] = (plan, ws, torch.zeros(plan.param_floats, dtype=torch.float32, device=dev),
+                          torch.zeros(plan.param_floats, dtype=torch.float32, device=dev), torch.zeros(B * T, D, dtype=torch.float32, device=dev))
+        plan, ws, flat, grads, x = cache[key]
+        offs = {n: (o, sh) for n, o, sh, _ in plan.params}
+        for j, seq in enumerate(self.fc_fusion_scales):
+            for nm, t in (("weight", seq[1].weight), ("bias", seq[1].bias)):
+                o, sh = offs[f"TRN.fc_fusion_scales.{j}.1.{nm}"]
+                flat[o:o + t.numel()].copy_(t.detach().reshape(-1))
+        o_f1, n_f1 = plan.region("F1")
+        # the reference applies a ReLU to the gathered frames first (TRNmodule.py:49): the launch reads F1 as stored, so it is applied here
+        ws[o_f1:o_f1 + n_f1].copy_(torch.relu(input.detach().to(dev, torch.float32)).reshape(-1))
+        L = _lib.lib()
+        h = _lib.Hyper()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
+            _lib.check(L.ta3n_train_step_range(plan.handle, x.data_ptr(), flat.data_ptr(), grads.data_ptr(), ws.data_ptr(), 1, 1, stream),
+                       "ta3n_train_step_range")      # launch 1 of the fused sequence: the tuple GEMMs (+ the frame discriminator's hidden layer)
+        o_z, n_z = plan.region("Zr")
+        z = ws[o_z:o_z + n_z].view(B, -1, NB)
+        out, t0 = [], 0
+        for tuples in self.relations_selected:            # sum of the scale's tuple activations (TRNmodule.py:73-79)
+            out.append(z[:, t0:t0 + len(tuples)].sum(1, keepdim=True))
+            t0 += len(tuples)
+        return torch.cat(out, 1)
 
 
 class RelationModule(nn.Module):

@@ -342,6 +342,23 @@ int ta3n_gather_segments_into(ta3n_plan *p, const float *store, const int64_t *f
     return TA3N_OK;
 }
 
+int ta3n_gather_segments_bf16_into(ta3n_plan *p, const void *store16, const int64_t *first_row, const int32_t *num_frames,
+                                   const int32_t *labels, const int32_t *video_ids, int n_videos, int first_video, float *x, float *ws,
+                                   int32_t *labels_out, void *stream) {
+    if (!p || !store16 || !first_row || !num_frames || !video_ids || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    if (labels_out && !labels) return fail(TA3N_ERR_INVALID, "labels_out needs labels");
+    const Geom &g = p->geom;
+    if (n_videos < 0 || first_video < 0 || first_video + n_videos > g.B) return fail(TA3N_ERR_INVALID, "videos outside the batch");
+    if ((g.D & 7) != 0 || !aligned16(store16) || (x && !aligned16(x)) || !aligned16(ws)) return fail(TA3N_ERR_INVALID, "feature_dim % 8 and 16-byte alignment required");
+    if (!x && g.o_x16 < 0) return fail(TA3N_ERR_INVALID, "a plan without bf16 twins needs the fp32 input rows (x)");
+    const size_t row0 = (size_t)first_video * g.T;
+    float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
+    if (launch_gather_segments_bf16(store16, first_row, num_frames, labels, video_ids, n_videos, g.T, g.D, x ? x + row0 * g.D : nullptr, labels_out,
+                                    twin, static_cast<hipStream_t>(stream)) != 0)
+        return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return TA3N_OK;
+}
+
 int ta3n_eval_metrics(ta3n_plan *p, float *ws, int n_videos, int reset, void *stream) {
     if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     if (n_videos < 0 || n_videos > p->geom.Bs) return fail(TA3N_ERR_INVALID, "n_videos must be in [0, batch_source]");

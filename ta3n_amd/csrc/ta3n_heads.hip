@@ -34,6 +34,8 @@
 // results are bitwise reproducible and no atomics are used.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/ta3n_hip.h"
 #include "ta3n_kernels.h"
 
@@ -541,11 +543,11 @@ __global__ __launch_bounds__(256) void heads_kernel(Geom g, Ptrs ptrs) {
 template <int FQ>
 int launch_fq(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     static_assert(8 * FQ * 64 + 16 <= S_LOSS, "the frame partials must stay below the loss slots");
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
-    if (!attr_set) {
+    static std::once_flag attr_once;   // > 64 KiB of dynamic LDS needs the opt-in once per process; callers may be DataParallel's
+                                       // one-thread-per-replica workers (re-entrancy), hence call_once and no plain flag
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(heads_kernel<FQ>, dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)S_TOTAL * sizeof(float), stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -129,4 +129,8 @@ int launch_gather_segments(const float *store, const int64_t *first_row, const i
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
                            float *out_twin, hipStream_t stream);
 
+int launch_gather_segments_bf16(const void *store16, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
+                                const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, float *out_twin,
+                                hipStream_t stream);
+
 }  // namespace ta3n

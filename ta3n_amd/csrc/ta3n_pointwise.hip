@@ -431,6 +431,38 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
     }
 }
 
+// The same batch assembly from a bf16 packed store ("fp16/bf16 memory-mapped blob"): a quarter of the
+// bytes of the fp32 store + twin path when the step reads bf16 twins (2 B in, 2 B out per element; the fp32 rows are
+// written only if the caller wants them).  One workgroup per output row; D % 8 == 0.
+__global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *__restrict__ store, const int64_t *__restrict__ first_row,
+                                                                   const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                                                   const int32_t *__restrict__ video_ids, int T, int D,
+                                                                   float4 *__restrict__ out, int32_t *__restrict__ labels_out,
+                                                                   uint4 *__restrict__ out16) {
+    const int row = blockIdx.x, v = row / T, x = row - v * T;
+    const int vid = video_ids[v];
+    const int nf = num_frames[vid];
+    int off;
+    if (nf >= T) {
+        const double tick = (double)nf / (double)T;             // dataset.py:103-116, float64 like the reference's Python
+        off = (int)(tick / 2.0 + tick * (double)x);
+    } else {
+        off = x < nf ? x : nf - 1;
+    }
+    if (threadIdx.x == 0 && labels_out && x == 0) labels_out[v] = labels[vid];
+    const uint4 *__restrict__ src = store + (size_t)(first_row[vid] + off) * (D / 8);
+    for (int i = threadIdx.x; i < D / 8; i += 256) {
+        const uint4 q = src[i];
+        if (out16) out16[(size_t)row * (D / 8) + i] = q;
+        if (out) {
+            out[(size_t)row * (D / 4) + 2 * i] = make_float4(__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xFFFF0000u),
+                                                             __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xFFFF0000u));
+            out[(size_t)row * (D / 4) + 2 * i + 1] = make_float4(__builtin_bit_cast(float, q.z << 16), __builtin_bit_cast(float, q.z & 0xFFFF0000u),
+                                                                 __builtin_bit_cast(float, q.w << 16), __builtin_bit_cast(float, q.w & 0xFFFF0000u));
+        }
+    }
+}
+
 // Validation metrics of main.validate / test_models.py (reference main.py:707-735, 809-822; test_models.py:155-198)
 // over the first n source rows of Y: cross-entropy sum, top-1 / top-5 hits (torch.topk order: ties go to the lower
 // class index) and the confusion matrix (rows = label, cols = argmax), ACCUMULATED into ws["metrics"] / ws["confusion"]
@@ -604,6 +636,15 @@ int launch_gather_segments(const float *store, const int64_t *first_row, const i
     if (n_videos <= 0) return 0;
     hipLaunchKernelGGL(gather_segments_kernel, dim3(n_videos * T), dim3(256), 0, stream, store, first_row, num_frames, labels, video_ids,
                        T, D, out, labels_out, seg_out, reinterpret_cast<uint2 *>(out_twin));
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gather_segments_bf16(const void *store16, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
+                                const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, float *out_twin,
+                                hipStream_t stream) {
+    if (n_videos <= 0) return 0;
+    hipLaunchKernelGGL(gather_segments_bf16_kernel, dim3(n_videos * T), dim3(256), 0, stream, static_cast<const uint4 *>(store16), first_row,
+                       num_frames, labels, video_ids, T, D, reinterpret_cast<float4 *>(out), labels_out, reinterpret_cast<uint4 *>(out_twin));
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -133,3 +133,52 @@ def test_train_script_end_to_end_from_packed_stores(tmp_path, arithmetic):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("Train: [") >= 3 and r.stdout.count("Test: [") == 3, r.stdout[-2000:]
     assert "nan" not in r.stdout.lower()
+
+
+def test_pack_bf16_layout(tmp_path):
+    """dtype='bf16': the same rows rounded to bf16 (nearest even), raw 2-byte elements."""
+    lst, D, lengths = _make_dataset(tmp_path)
+    n, dim = feature_store.pack(lst, str(tmp_path / "p32"))
+    n2, dim2 = feature_store.pack(lst, str(tmp_path / "p16"), dtype="bf16")
+    assert (n, dim) == (n2, dim2)
+    b32 = torch.from_numpy(np.fromfile(str(tmp_path / "p32.f32"), dtype=np.float32))
+    b16 = torch.from_numpy(np.fromfile(str(tmp_path / "p16.bf16"), dtype=np.int16))
+    assert torch.equal(b16, b32.to(torch.bfloat16).view(torch.int16))
+    assert np.array_equal(np.load(str(tmp_path / "p16.idx.npy")), np.load(str(tmp_path / "p32.idx.npy")))
+
+
+@pytest.mark.gpu
+def test_bf16_store_feeds_the_input_twin_directly(tmp_path):
+    """A bf16 store assembles the batch into the input's bf16 twin without touching fp32 (2 B in + 2 B out per element): the
+    twin equals the one the fp32 store + conversion path builds, bit for bit, and a train step from either is the same step."""
+    from ta3n_amd.engine import TrainEngine
+    lst, D, lengths = _make_dataset(tmp_path, D=64)
+    feature_store.pack(lst, str(tmp_path / "p32"))
+    feature_store.pack(lst, str(tmp_path / "p16"), dtype="bf16")
+    s32 = feature_store.FeatureStore(str(tmp_path / "p32"), D)
+    s16 = feature_store.FeatureStore(str(tmp_path / "p16"), D)
+    assert s16.bf16 and not s32.bf16
+    T, Bs, Bt = 5, 6, 5
+    ids = torch.arange(len(lengths), dtype=torch.int32)
+    res = []
+    for store in (s32, s16):
+        eng = TrainEngine(Bs, Bt, T, D, 32, 7, dropout_i=0.0, dropout_v=0.0, bf16=True, bf16_store=True)
+        for v in eng.param_views().values():
+            v.normal_(0, 0.05, generator=torch.Generator(device="cuda").manual_seed(1))
+        eng.refresh_bf16(params=True)
+        store.gather_into(eng, ids[:Bs].cuda(), 0, labels_out=eng._labels[:Bs])
+        store.gather_into(eng, ids[Bs:Bs + Bt].cuda(), Bs)
+        eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-2)
+        torch.cuda.synchronize()
+        res.append((eng.region("x16").clone(), eng.P.clone(), eng._labels[:Bs].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][1], res[1][1]) and res[0][1].abs().max().item() > 0
+    # the host-side gather of a bf16 store widens the same rows
+    f32, lab32 = s32.gather(ids[:4].cuda(), T)
+    f16, lab16 = s16.gather(ids[:4].cuda(), T)
+    assert torch.equal(f16, f32.to(torch.bfloat16).to(torch.float32)) and torch.equal(lab32, lab16)
+    # an engine that does NOT read twins gets widened fp32 rows from the bf16 store
+    eng = TrainEngine(Bs, Bt, T, D, 32, 7, dropout_i=0.0, dropout_v=0.0)
+    s16.gather_into(eng, ids[:Bs].cuda(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.X[: Bs * T].view(Bs, T, D), s16.gather(ids[:Bs].cuda(), T)[0])

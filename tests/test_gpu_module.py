@@ -110,3 +110,29 @@ def test_validation_metrics_match_reference_accuracy():
     for p_, l_ in zip(out.argmax(1).tolist(), lab.tolist()):
         conf[l_, p_] += 1
     assert torch.equal(res["confusion"], conf)
+
+
+def test_standalone_relation_module_forward_matches_reference_math():
+    """TRNmodule.RelationModuleMultiScale.forward on its own (north_star names it first): against the reference's formula
+    (TRNmodule.py:58-82) written with torch ops on the CPU - ReLU, gather + concat of each selected tuple, Linear, ReLU, per-scale sum."""
+    import torch.nn.functional as Fn
+    from ta3n_amd.TRNmodule import RelationModuleMultiScale
+    torch.manual_seed(3)
+    for T, D, B in ((5, 128, 7), (9, 64, 4), (3, 512, 33)):
+        m = RelationModuleMultiScale(D, 256, T, verbose=False)
+        x = torch.randn(B, T, D)
+        want = []
+        for j, tuples in enumerate(m.relations_selected):
+            lin = m.fc_fusion_scales[j][1]
+            acc = 0
+            for tup in tuples:
+                a = torch.relu(x[:, list(tup), :]).reshape(B, -1)
+                acc = acc + torch.relu(Fn.linear(a, lin.weight, lin.bias))
+            want.append(acc.unsqueeze(1))
+        want = torch.cat(want, 1).detach()
+        with torch.no_grad():
+            got = m(x.cuda()).cpu()
+        assert got.shape == (B, T - 1, 256)
+        assert torch.allclose(got, want, rtol=2e-4, atol=2e-5), (got - want).abs().max()
+    with pytest.raises(NotImplementedError):
+        m(x.cuda())          # gradients required: forward-only
