@@ -444,14 +444,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + hyper_off);
     const float *__restrict__ zeros = ptrs.ws + zeros_off;   // 64 floats that are never written
-    // What the epilogue needs that does not depend on the accumulators is fetched NOW, under the K loop: the per-step
-    // scalars and this thread's four bias entries (its column group is the same in every epilogue iteration).
+    // What the epilogue needs that does not depend on the accumulators is REQUESTED now and consumed after the K loop:
+    // the per-step scalars (one unconditional block load, independent of the Task - it travels beside the descriptor
+    // instead of behind it; which of them the tile uses is decided in the epilogue) and this thread's four bias entries
+    // (its column group is the same in every epilogue iteration).
     const uint32_t epi = t.epi;
-    const float alpha = hyper_scale(hy, t.alpha_kind);
-    const float gamma = hyper_scale(hy, t.gamma_kind);
-    const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && hy->train != 0;
-    const uint32_t dseed = (epi & EPI_DROP_I) ? hy->seed_i : hy->seed_v;
-    const float dp = (epi & EPI_DROP_I) ? hy->p_drop_i : hy->p_drop_v;
+    struct HyperHead { float beta[3], gamma, lr, momentum, weight_decay, clip, p_drop_i, p_drop_v; uint32_t seed_i, seed_v; };
+    const HyperHead hh = *reinterpret_cast<const HyperHead *>(hy);      // first 12 dwords of Hyper (ta3n_types.h)
+    const int h_train = hy->train;
+    auto scale_of = [&](int kind) -> float {
+        switch (kind) {
+            case SK_NEG_BETA_REL: return -hh.beta[0];
+            case SK_NEG_BETA_VID: return -hh.beta[1];
+            case SK_NEG_BETA_FRM: return -hh.beta[2];
+            case SK_INV_KEEP_I: return (h_train && hh.p_drop_i > 0.f) ? (hh.p_drop_i < 1.f ? 1.f / (1.f - hh.p_drop_i) : 0.f) : 1.f;
+            case SK_INV_KEEP_V: return (h_train && hh.p_drop_v > 0.f) ? (hh.p_drop_v < 1.f ? 1.f / (1.f - hh.p_drop_v) : 0.f) : 1.f;
+            default: return 1.f;
+        }
+    };
     float ebias[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi & EPI_BIAS) {
         const float *__restrict__ bias = base_ptr(ptrs, t.bias_base) + t.bias_off;
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 const float *sa = lds + buf * STAGE;
                 compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
                 if (c_scale != SK_ONE) {
-                    const float sc = hyper_scale(hy, c_scale);
+                    const float sc = scale_of(c_scale);
     #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] *= sc;
                 }
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     --ahead;
                 }
                 if (c_scale != SK_ONE) {
-                    const float sc = hyper_scale(hy, c_scale);
+                    const float sc = scale_of(c_scale);
     #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] *= sc;
                 }
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     // ---- epilogue: accumulators -> LDS (reduces the K split, makes rows contiguous) ----
     GSTAMP(2);
     __syncthreads();
+    GSTAMP(3);
     {
         float *cs = lds + wave * (32 * 36);
 #pragma unroll
@@ -646,7 +657,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         }
     }
     __syncthreads();
+    GSTAMP(4);
 
+    const float alpha = scale_of(t.alpha_kind);
+    const float gamma = scale_of(t.gamma_kind);
+    const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && h_train != 0;
+    const uint32_t dseed = (epi & EPI_DROP_I) ? hh.seed_i : hh.seed_v;
+    const float dp = (epi & EPI_DROP_I) ? hh.p_drop_i : hh.p_drop_v;
     float *__restrict__ cbase = const_cast<float *>(base_ptr(ptrs, t.c_base)) + (size_t)t.c_off;
     const float *__restrict__ aux = (epi & EPI_MASK) ? base_ptr(ptrs, t.aux_base) + t.aux_off : nullptr;
     const float *__restrict__ add = (epi & EPI_ADD) ? base_ptr(ptrs, t.add_base) + t.add_off : nullptr;
@@ -705,7 +722,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         for (int e = 0; e < 4; ++e)
             if (e < nrem) sumsq = fmaf(v[e], v[e], sumsq);
         float *cp = cbase + (size_t)m * t.c_ld + n;
-        if (nrem >= 4 && c_vec) {
+        if (epi & EPI_TWIN_ONLY) {
+            // every consumer of this tile reads its bf16 twin: the fp32 copy is not written (a third of the store burst)
+        } else if (nrem >= 4 && c_vec) {
             *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
@@ -746,7 +765,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     float ov[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = (e < nrem && fm[f][e] > 0.f) ? v[e] : 0.f;
-                    if (fan_vec && (t.fan_out_off[f] & 3) == 0) {
+                    if (epi & EPI_TWIN_ONLY_FAN) {
+                    } else if (fan_vec && (t.fan_out_off[f] & 3) == 0) {
                         *reinterpret_cast<float4 *>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
                     } else {
 #pragma unroll
@@ -785,9 +805,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             }
         }
     }
-    GSTAMP(3);
+    GSTAMP(5);
 #ifdef TA3N_GEMM_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192) { ta3n_dbg_stamps[blockIdx.x * 8 + 4] = (unsigned long long)t.cost; ta3n_dbg_stamps[blockIdx.x * 8 + 5] = (unsigned long long)t.seg_count; ta3n_dbg_stamps[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(( (4-1) << 11) | (0 << 6) | 20); }
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { ta3n_dbg_stamps[blockIdx.x * 8 + 6] = (unsigned long long)t.cost; ta3n_dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)t.seg_count; }
 #endif
     if (epi & EPI_SUMSQ) {   // wave-uniform: fixed-order block sum -> this tile's slot (fused grad-norm partial)
         __syncthreads();

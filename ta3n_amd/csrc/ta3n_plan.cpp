@@ -252,7 +252,8 @@ struct Builder {
 typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
 
 // bf16 twins (TA3N_FLAG_BF16_STORE).  extra_produced: ws spans whose twin a non-GEMM kernel of the fused step keeps current.
-void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std::vector<Span> &extra_produced) {
+void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std::vector<Span> &extra_produced,
+                    const std::vector<Span> &gemm_only = {}) {
     const ta3n_config &c = p.cfg;
     if (!((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE))) return;
     // bf16 twins.  A launch of the fused step reads twins when every one of its operands can be moved 16 bytes (8
@@ -343,6 +344,60 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
                 const Span out{t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid};
                 for (auto &rd : read16)
                     if (overlaps(out, rd)) { t.epi |= EPI_TWIN16_FAN; break; }
+            }
+        }
+    }
+    // gemm_only: workspace regions that only GEMM launches read (no pointwise kernel, no API output).  If every launch
+    // that reads such a region reads its twin, the producers skip the fp32 store (EPI_TWIN_ONLY): the fp32 region then
+    // holds nothing meaningful in this configuration.
+    for (const Span &reg : gemm_only) {
+        bool fp32_reader = false;
+        for (const Phase &ph : p.phases) {
+            if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM || (ph.bf16 & 16)) continue;
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                const Task &t = p.tasks[i];
+                for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
+                    const Seg &sg = p.segs[k];
+                    auto hit = [&](int base, int off, int ld, int kmajor, int rows) {
+                        if (base != BASE_WS) return false;
+                        const Span rd = kmajor ? Span{off, off + (int64_t)(sg.klen - 1) * ld + rows} : Span{off, off + (int64_t)(rows - 1) * ld + sg.klen};
+                        return overlaps(rd, reg);
+                    };
+                    fp32_reader = fp32_reader || hit(sg.a_base, sg.a_off, sg.a_ld, sg.a_kmajor, sg.pad[0] > 0 ? sg.pad[0] : t.m_valid) ||
+                                  hit(sg.b_base, sg.b_off, sg.b_ld, sg.b_kmajor, t.n_valid);
+                }
+                if ((t.epi & (EPI_MASK | EPI_ADD)) && t.seg_count > 0) {     // epilogue operands are read in fp32
+                    if (t.aux_base == BASE_WS && (t.epi & EPI_MASK) && overlaps(Span{t.aux_off, t.aux_off + (int64_t)(t.m_valid - 1) * t.aux_ld + t.n_valid}, reg)) fp32_reader = true;
+                    if (t.add_base == BASE_WS && (t.epi & EPI_ADD) && overlaps(Span{t.add_off, t.add_off + (int64_t)(t.m_valid - 1) * t.add_ld + t.n_valid}, reg)) fp32_reader = true;
+                }
+            }
+        }
+        // (twin launches read masks / residuals in fp32 too)
+        for (const Phase &ph : p.phases) {
+            if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM || !(ph.bf16 & 16)) continue;
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                const Task &t = p.tasks[i];
+                if (t.seg_count == 0) continue;
+                if ((t.epi & EPI_MASK) && t.aux_base == BASE_WS && overlaps(Span{t.aux_off, t.aux_off + (int64_t)(t.m_valid - 1) * t.aux_ld + t.n_valid}, reg)) fp32_reader = true;
+                if ((t.epi & EPI_ADD) && t.add_base == BASE_WS && overlaps(Span{t.add_off, t.add_off + (int64_t)(t.m_valid - 1) * t.add_ld + t.n_valid}, reg)) fp32_reader = true;
+                for (int f = 0; f < t.fan_count; ++f)
+                    if (overlaps(Span{t.fan_mask_off[f], t.fan_mask_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid}, reg)) fp32_reader = true;
+            }
+        }
+        if (fp32_reader) continue;
+        for (const Phase &ph : p.phases) {
+            if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                Task &t = p.tasks[i];
+                if (t.seg_count == 0) continue;
+                if ((t.epi & EPI_TWIN16) && t.c_base == BASE_WS &&
+                    overlaps(Span{t.c_off, t.c_off + (int64_t)(t.m_valid - 1) * t.c_ld + t.n_valid}, reg)) t.epi |= EPI_TWIN_ONLY;
+                if (t.epi & EPI_TWIN16_FAN) {
+                    bool all_in = t.fan_count > 0;
+                    for (int f = 0; f < t.fan_count; ++f)
+                        all_in = all_in && overlaps(Span{t.fan_out_off[f], t.fan_out_off[f] + (int64_t)(t.m_valid - 1) * t.fan_ld + t.n_valid}, reg);
+                    if (all_in) t.epi |= EPI_TWIN_ONLY_FAN;
+                }
             }
         }
     }
@@ -1148,7 +1203,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
             p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
         }
-        add_bf16_twins(p, b, g, BT, D, {Span{g.o_gHf, g.o_gHf + (int64_t)BT * F}});   // the heads kernel keeps the twin of gHf
+        // (the heads kernel keeps the twin of gHf; gZ and gZ1 are read by GEMM launches only: twin-only when those read twins)
+        add_bf16_twins(p, b, g, BT, D, {Span{g.o_gHf, g.o_gHf + (int64_t)BT * F}},
+                       {Span{g.o_gZ, g.o_gZ + (int64_t)B * NT * NB}, Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F}});
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }

@@ -30,6 +30,8 @@ enum EpiFlags : uint32_t {
     EPI_COLSUM = 1u << 12,  // not a tile: c[n] = sum_{r < pad[1]} ws[pad[0] + r * pad[2] + n] for n in [n0, n_valid), rows added in order by
                             // one thread per column - exact fp32 reduction of per-workgroup partial sums (never through the MFMA,
                             // which would round the partials to bf16 in the bf16 configuration); honours EPI_SUMSQ
+    EPI_TWIN_ONLY = 1u << 13,      // with EPI_TWIN16: do not store the fp32 tile at all (nobody reads it: every consumer reads the twin)
+    EPI_TWIN_ONLY_FAN = 1u << 14,  // same for the fan-out copies
     EPI_SGD = 1u << 11,     // not a tile: the workgroup applies the optimiser update to params[4 pad[0] .. 4 pad[1]) (SgdSide)
     EPI_TWIN16_FAN = 1u << 10,   // same for the fan-out copies (fan_out_off)
     EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)

@@ -40,15 +40,10 @@ for i, ph in enumerate(phases):
     buf = np.zeros(n * 8, np.uint64)
     L.ta3n_debug_stamps(buf.ctypes.data, n * 8)
     st = buf.reshape(n, 8).astype(np.int64)
-    real = st[:, 5] > 0
+    real = st[:, 7] > 0
     t0 = st[real, 0].min()
-    end = st[real, 3].max() - t0
-    life = st[real, 3] - st[real, 0]
-    k = int(np.argmax(st[:, 3] * real))
-    print(f"launch {i} tile {ph['tile']} tasks {n} (real {real.sum()}): span {end} ticks; start spread {st[real,0].max()-t0}; wg life avg {life.mean():.0f} max {life.max()}; "
-          f"last finisher wg {k}: entry+{st[k,0]-t0} desc {st[k,1]-st[k,0]} kloop {st[k,2]-st[k,1]} epi {st[k,3]-st[k,2]} cost {st[k,4]} segs {st[k,5]}")
-    # by cost class
-    costs = np.unique(st[real, 4])
-    for cst in costs[-4:]:
-        m = real & (st[:, 4] == cst)
-        print(f"    cost {cst}: {m.sum()} wgs, kloop avg {np.mean(st[m,2]-st[m,1]):.0f} max {np.max(st[m,2]-st[m,1])}, epi avg {np.mean(st[m,3]-st[m,2]):.0f}, desc avg {np.mean(st[m,1]-st[m,0]):.0f}, finish avg {np.mean(st[m,3])-t0:.0f}")
+    print(f"launch {i} tile {ph['tile']} tasks {n} (real {real.sum()}): span {st[real, 5].max() - t0} ticks, entry spread {st[real, 0].max() - t0}")
+    for cst in np.unique(st[real, 6])[-4:]:
+        m = real & (st[:, 6] == cst)
+        d = lambda a, b: np.mean(st[m, a] - st[m, b])
+        print(f"    cost {cst:5d} x{m.sum():4d}: desc {d(1, 0):6.0f}  kloop {d(2, 1):6.0f}  wait-waves {d(3, 2):5.0f}  lds-transpose {d(4, 3):5.0f}  combine+store {d(5, 4):5.0f}  | finish {np.mean(st[m, 5]) - t0:7.0f}")
