@@ -57,7 +57,7 @@ class _HipForward(torch.autograd.Function):
         plan = model._plan(Bs, Bt)
         x = torch.cat((xs.reshape(Bs * model.train_segments, -1), xt.reshape(Bt * model.train_segments, -1)), 0)
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        ws = model._ws_template(plan).clone()
+        ws = model._ws_checkout(plan, ctx, any(ctx.needs_input_grad))
         h = _lib.Hyper()
         h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
         h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
@@ -100,11 +100,12 @@ class _HipForward(torch.autograd.Function):
 
         put("gY", g_y); put("gPr", g_pr); put("gPv", g_pv); put("gPf", g_pf)
         put("g_attn", g_attn if model._attn_on else None)
-        grads = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+        grads = torch.empty(plan.param_floats, dtype=torch.float32, device=dev)     # every live gradient is written in full
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
                                    stream), "ta3n_backward")
+        model._ws_release(ctx)
         # A discriminator whose logits feed no loss (place_adv 'N', use_target none, ...) keeps grad None in the reference,
         # so torch.optim.SGD skips it - no weight decay either (main.py:508-538).  Same here: None, not zeros.
         unused = []
@@ -137,7 +138,7 @@ class _HipForwardAvg(torch.autograd.Function):
         plan = model._plan(Bs, Bt)
         T = model.train_segments
         x = torch.cat((xs.reshape(Bs * T, -1), xt.reshape(Bt * T, -1)), 0).to(device=dev, dtype=torch.float32).contiguous()
-        ws = model._ws_template(plan).clone()
+        ws = model._ws_checkout(plan, ctx, any(ctx.needs_input_grad))
         h = _lib.Hyper()
         h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
         h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
@@ -171,10 +172,11 @@ class _HipForwardAvg(torch.autograd.Function):
                 ws[off:off + n].zero_()
             else:
                 ws[off:off + n].copy_(g.reshape(-1))
-        grads = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+        grads = torch.empty(plan.param_floats, dtype=torch.float32, device=dev)     # every live gradient is written in full
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(_lib.lib().ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
                                             stream), "ta3n_backward")
+        model._ws_release(ctx)
         unused = []                               # a discriminator that feeds no loss keeps grad None (see _HipForward.backward)
         if g_pf is None:
             unused += ["fc_feature_domain.", "fc_classifier_domain."]
@@ -280,6 +282,7 @@ class VideoModel(nn.Module):
         self._flat: Optional[torch.Tensor] = None
         self._plans: Dict[Tuple[int, int], _lib.Plan] = {}
         self._ws_init: Dict[int, torch.Tensor] = {}
+        self._ws_pool: Dict[int, list] = {}
         self._feat_dim_F = F_
 
     # ---- reference API ----
@@ -321,6 +324,30 @@ class VideoModel(nn.Module):
             self._ws_init[key] = t
         return t
 
+    def _ws_checkout(self, plan: _lib.Plan, ctx, keep: bool) -> torch.Tensor:
+        """A workspace for one forward (and its backward).  Workspaces are pooled per plan: a train loop alternates forward /
+        backward and therefore reuses ONE buffer (every region is rewritten in full by the launches, like the engine's), instead
+        of cloning ~40 MB per call; a second forward before the first one's backward takes another buffer.  keep=False
+        (nothing requires grad): the buffer goes straight back once the outputs have been copied out - the launches and the
+        output copies are stream-ordered before any later reuse."""
+        import weakref
+        pool = self._ws_pool.setdefault(id(plan), [])
+        tmpl = self._ws_template(plan)
+        entry = next((e for e in pool if not e[1] and e[0].device == tmpl.device), None)
+        if entry is None:
+            entry = [tmpl.clone(), False]
+            pool.append(entry)
+        if keep:
+            entry[1] = True
+            ctx._ws_entry = entry
+            weakref.finalize(ctx, lambda e=entry: e.__setitem__(1, False))      # a graph dropped without backward frees it too
+        return entry[0]
+
+    def _ws_release(self, ctx) -> None:
+        e = getattr(ctx, "_ws_entry", None)
+        if e is not None:
+            e[1] = False
+
     def _named_flat_params(self, plan: _lib.Plan):
         named = dict(self.named_parameters())
         return [(name, off, shape, named[name]) for name, off, shape, _ in plan.params]
@@ -350,6 +377,7 @@ class VideoModel(nn.Module):
                 mod._buffers[leaf] = b.to(device)
         self._flat = flat
         self._ws_init.clear()
+        self._ws_pool.clear()
 
     def forward(self, input_source, input_target, beta, mu, is_train, reverse):
         """models.py:545-722.  Returns (attn_s, out_s, out_s2, pred_domain_s, feat_s, attn_t, out_t,
