@@ -104,7 +104,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const int *__restrict__ labels = reinterpret_cast<const int *>(ptrs.ws + g.o_labels);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NR = g.n_rel, NT = g.n_tuples, C = g.C;
-    const int b0 = blockIdx.x * VPW;
+    const int b0 = ((int)blockIdx.x - g.n_frm_wg) * VPW;
     const int nv = min(VPW, g.B - b0);
     const int vloc = wv / WPV, sub = wv % WPV;     // per-video stages: this wave's video slot and its share of the relations
     const int b = b0 + vloc;
@@ -141,6 +141,14 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const float wct0 = Wcdv[tid], wct1 = Wcdv[NBH + tid];
     const float bcdv0 = P[g.p_bcdv], bcdv1 = P[g.p_bcdv + 1];
     const int label = (have && b < g.Bs) ? labels[b] : -1;
+    // small operands of the later stages, requested now as well (each used to cost its stage an exposed round trip):
+    // the class bias of this thread's class, the video-discriminator bias of its channel, and for the first relation this
+    // wave handles the tuple range and the output-layer bias
+    const float bcv_c = (tid >> 2) < C ? P[g.p_bcv + (tid >> 2)] : 0.f;
+    const float bdv_n = P[g.p_bdv + (tid >> 4) + 16 * (tid & 15)];
+    const int j_first = sub < NR ? sub : 0;
+    const int tf_lo0 = tf[j_first], tf_hi0 = tf[j_first + 1];
+    const float b2_00 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride], b2_01 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride + 1];
 
     STAMP(0);
     // ---- A: relation logits, attention, R, V, Vd (WPV waves per video, relations dealt round-robin) ----
@@ -160,12 +168,13 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                     d1 = fmaf(h, W2[NBH + c], d1);
                 }
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int t = tf[j]; t < tf[j + 1]; ++t) {
+                const int t_lo = j == j_first ? tf_lo0 : tf[j], t_hi = j == j_first ? tf_hi0 : tf[j + 1];
+                for (int t = t_lo; t < t_hi; ++t) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
                 }
-                d0 = wave_allreduce_sum(d0) + b2[0];
-                d1 = wave_allreduce_sum(d1) + b2[1];
+                d0 = wave_allreduce_sum(d0) + (j == j_first ? b2_00 : b2[0]);
+                d1 = wave_allreduce_sum(d1) + (j == j_first ? b2_01 : b2[1]);
                 float w = 0.f;
                 if (attn_on) w = 1.f - soft2(d0, d1).H;
 #pragma unroll
@@ -226,7 +235,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         acc += dpp_move<0xB1, 0xF>(0.f, acc);      // quad_perm [1,0,3,2]
         acc += dpp_move<0x4E, 0xF>(0.f, acc);      // quad_perm [2,3,0,1]: every lane of the quad holds the class logit
         if (c < C && part == 0) {
-            const float yc = acc + P[g.p_bcv + c];
+            const float yc = acc + bcv_c;
             smem[S_Y + c] = yc;
             if (have) ws[g.o_Y + (size_t)b * C + c] = yc;
         }
@@ -260,7 +269,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
             if (c16 == i) hv = p;
         }
         const int n = srow + 16 * c16;
-        const float h = fmaxf(hv + P[g.p_bdv + n], 0.f);
+        const float h = fmaxf(hv + bdv_n, 0.f);
         smem[S_HV + n] = h;
         if (have) ws[g.o_Hv + (size_t)b * NBH + n] = h;
     }
@@ -432,7 +441,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         }
     }
     STAMP(7);
-    write_loss_part(smem, ws, g.o_loss_part, blockIdx.x, hy->gamma);
+    write_loss_part(smem, ws, g.o_loss_part, (int)blockIdx.x - g.n_frm_wg, hy->gamma);
     STAMP(8);
 }
 
@@ -458,9 +467,18 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
         w0[q] = k < F ? W0[k] : 0.f;
         w1[q] = k < F ? W1[k] : 0.f;
     }
+    float a0[FQ], a1[FQ], sg0 = 0.f, sg1 = 0.f, l_frm = 0.f;
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+    // g.heads_rpw rows per workgroup, in groups of RPW = 16 (4 rows per wave held in registers); the plan picks heads_rpw so
+    // that video + frame workgroups all fit on the chip at once (a video workgroup owns a compute unit: the 11th..266th
+    // workgroup of a 266-workgroup grid would otherwise start when the first video workgroups END)
+#pragma unroll 1
+    for (int rg = 0; rg < g.heads_rpw / RPW; ++rg) {
+    const int row0 = wg * g.heads_rpw + rg * RPW;
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
-        const int r = wg * RPW + wv + 4 * i;
+        const int r = row0 + wv + 4 * i;
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {
             const int k = q * 64 + lane;
@@ -476,12 +494,9 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
     }
 #pragma unroll
     for (int i = 0; i < NROW; ++i) { d0[i] = wave_allreduce_sum(d0[i]) + bc0; d1[i] = wave_allreduce_sum(d1[i]) + bc1; }
-    float a0[FQ], a1[FQ], sg0 = 0.f, sg1 = 0.f, l_frm = 0.f;
-#pragma unroll
-    for (int q = 0; q < FQ; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
-        const int r = wg * RPW + wv + 4 * i;
+        const int r = row0 + wv + 4 * i;
         if (r < BT) {   // wave-uniform
             const int b = r / T;
             const bool valid = video_valid(g.Bs, hy, b);
@@ -513,6 +528,7 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
             }
         }
     }
+    }   // row groups
     // cross-wave sums through LDS: [4 waves][2][FQ*64] then [4][2] for the bias partials
     constexpr int FP = FQ * 64;
 #pragma unroll
@@ -536,8 +552,10 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
 template <int FQ>
 __global__ __launch_bounds__(256) void heads_kernel(Geom g, Ptrs ptrs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < g.n_vid_wg) video_wg(g, ptrs, smem);
-    else frame_wg<FQ>(g, ptrs, smem, (int)blockIdx.x - g.n_vid_wg);
+    // the (short) frame workgroups come first in the grid: if the grid does not fit on the chip at once, the workgroups that
+    // start late are video workgroups behind finished frame workgroups, not frame workgroups behind finished video ones
+    if ((int)blockIdx.x < g.n_frm_wg) frame_wg<FQ>(g, ptrs, smem, (int)blockIdx.x);
+    else video_wg(g, ptrs, smem);
 }
 
 template <int FQ>

@@ -877,7 +877,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     g.o_labels = (int32_t)b.add_region("labels", B);
     g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
     g.n_vid_wg = (B + HEADS_VPW - 1) / HEADS_VPW;
-    g.n_frm_wg = (BT + HEADS_RPW - 1) / HEADS_RPW;
+    g.heads_rpw = HEADS_RPW;      // all workgroups of the heads kernel resident at once if the chip (256 CUs) can hold them
+    while (g.n_vid_wg + (BT + g.heads_rpw - 1) / g.heads_rpw > 256 && g.heads_rpw < 8 * HEADS_RPW) g.heads_rpw *= 2;
+    g.n_frm_wg = (BT + g.heads_rpw - 1) / g.heads_rpw;
     g.o_fh_part = (int32_t)b.add_region("fh_part", (int64_t)g.n_frm_wg * 2 * F);
     g.o_fh_bpart = (int32_t)b.add_region("fh_bpart", (int64_t)g.n_frm_wg * 2);
     g.o_loss_part = (int32_t)b.add_region("loss_part", (int64_t)(g.n_vid_wg + g.n_frm_wg) * 8);

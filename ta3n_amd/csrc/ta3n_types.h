@@ -87,7 +87,7 @@ enum PhaseKind : int32_t {
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these
 constexpr int HEADS_VPW = 1;    // videos per video workgroup (one wave each for the per-video parts; 1, 2 or 4)
-constexpr int HEADS_RPW = 16;   // frame rows per frame workgroup
+constexpr int HEADS_RPW = 16;   // frame rows per row group of a frame workgroup (Geom.heads_rpw rows per workgroup, a multiple of this)
 
 struct Phase {
     int32_t kind;
@@ -129,6 +129,7 @@ struct Geom {
     int32_t o_fh_part, o_fh_bpart;       // per frame-workgroup partial sums of dWcd [n_frm_wg][2F] and dbcd [n_frm_wg][2]
     int32_t o_loss_part;                 // per heads-workgroup loss partials [n_vid_wg + n_frm_wg][8]
     int32_t n_vid_wg, n_frm_wg;
+    int32_t heads_rpw;                   // frame rows per frame workgroup of the fused heads kernel (multiple of HEADS_RPW)
     int32_t o_sumsq, n_sumsq;            // fused grad-norm partials (one slot per gradient tile of the fused step)
     int32_t o_metrics, o_confusion;      // validation: {sum CE, top-1 hits, top-5 hits, videos} and the int32 [C][C] confusion matrix
     // bf16 twins (TA3N_FLAG_BF16_STORE), all inside ws, offsets in floats: element e of ws / params / x lives, rounded

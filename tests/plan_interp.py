@@ -53,7 +53,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_gR", "o_gZ", "o_gZ1", "o_zeros", "o_ones", "o_losses", "o_norm_part", "o_grad_norm", "o_hyper", "o_labels",
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
-                "o_loss_part", "n_vid_wg", "n_frm_wg", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
+                "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
                 "o_ws16", "o_p16", "o_x16", "ws16_span"]
 
 
@@ -413,7 +413,7 @@ class Interp:
         self.ws[g.o_losses:g.o_losses + 8] = 0
         part = self.r(g.o_fh_part, (g.n_frm_wg, 2 * F)); bpart = self.r(g.o_fh_bpart, (g.n_frm_wg, 2))
         for w in range(g.n_frm_wg):
-            rows = slice(w * HEADS_RPW, min((w + 1) * HEADS_RPW, B * T))
+            rows = slice(w * g.heads_rpw, min((w + 1) * g.heads_rpw, B * T))
             part[w] = (gPf[rows].T @ Hf[rows]).reshape(-1)
             bpart[w] = gPf[rows].sum(0)
 
