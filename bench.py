@@ -54,11 +54,6 @@ CONFIGS = {
             name="two-stream RGB+Flow: two TA3N models on 1024-d I3D-shaped features, 12 segments, attentive entropy on, 128 src + 128 tgt "
                  "videos per stream and GPU-step, class logits summed (ta3n_amd/two_stream.py)"),
 }
-# per-GEMM-launch tile shapes measured best on MI355X for this workload (bench.py --autotune): launches 0-9 are the
-# forward/loss/backward sequence, 10-15 the fused sequence of ta3n_train_step
-DEFAULT_PHASE_TILES = [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222]
-# same, bf16-MFMA arithmetic: thousands digit = LDS stages (3 for the long-K launches)
-DEFAULT_PHASE_TILES_BF16 = [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2124]
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: v_mfma_f32_32x32x16_bf16, dense (16 x the fp32 rate)
 HBM_PEAK_GBS = 8000.0
@@ -204,6 +199,7 @@ def main():
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1]); default: the configuration's")
     ap.add_argument("--wgrads-late", action="store_true", help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
+    ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
     conf = CONFIGS[args.config]
@@ -235,9 +231,8 @@ def main():
         """Build the engine(s) for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
         bf16 = dtype == "bf16"
         twins = bf16 and not args.no_twins
-        phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v]
-        if not phase_tiles and headline:
-            phase_tiles = DEFAULT_PHASE_TILES_BF16 if bf16 else DEFAULT_PHASE_TILES
+        # None: the measured per-launch choices of ta3n_amd/tuning.py for this shape (what TrainEngine uses by default)
+        phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or None
         if args.autotune:
             from ta3n_amd.engine import ALL_FLAGS, autotune_phase_tiles
             from ta3n_amd import _lib
@@ -247,6 +242,8 @@ def main():
                                                   candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
         if args.tile:
             phase_tiles = []
+        if args.plan_heuristic:
+            phase_tiles = [0]
         engs = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                             clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
                             fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"])

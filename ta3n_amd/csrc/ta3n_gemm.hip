@@ -72,8 +72,12 @@ __device__ __forceinline__ void glds16_batch(const float *const (&src)[NP], unsi
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                      "s_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src[0]), "v"(src[1]), "s"(lds_byte_addr), "s"(stride) : "memory", "scc");
+    } else if constexpr (NP == 8) {
+        const float *const lo[4] = {src[0], src[1], src[2], src[3]}, *const hi[4] = {src[4], src[5], src[6], src[7]};
+        glds16_batch<4>(lo, lds_byte_addr, stride);
+        glds16_batch<4>(hi, lds_byte_addr + 4 * stride, stride);
     } else {
-        static_assert(NP == 4, "1, 2 or 4 pieces per wave");
+        static_assert(NP == 4, "1, 2, 4 or 8 pieces per wave");
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                      "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
                      "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
@@ -151,8 +155,9 @@ struct OperandStream {
                     constexpr int LPR = R / 8, KPP = 64 / LPR;
                     const int k = q * KPP + lane / LPR;
                     // R = 64: image rows k with (k >> 1) & 1 hold their 16-byte chunks swapped by four (the transpose reads of
-                    // compute_stage then touch every LDS bank once); R = 32 rows are 64 bytes and need no swizzle
-                    const int chunk = (lane % LPR) ^ (R == 64 ? ((k >> 1) & 1) << 2 : 0);
+                    // compute_stage then touch every LDS bank once); R = 128 (256-byte rows): chunks rotated by 4 (k & 3);
+                    // R = 32 rows are 64 bytes and need no swizzle
+                    const int chunk = (lane % LPR) ^ (R == 64 ? ((k >> 1) & 1) << 2 : R == 128 ? (k & 3) << 2 : 0);
                     const int r = r0_ + chunk * 8;
                     p[i] = origin_ + (size_t)k * ldf + (r >> 1);
                     kofs[i] = (r < rvalid_) ? k : K_NEVER;
@@ -217,11 +222,83 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 
 // BF == 2: the stage bytes are bf16 already (twins): a 16-byte slot is 8 consecutive k of one row, fed to the MFMA as is.
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF>
-__device__ __forceinline__ void compute_stage(f32x16 &acc, float &rs, const float *__restrict__ sa, const float *__restrict__ sb,
-                                              int ra, int rb, int wk, int lh, int krem) {
+// RM x RN: 32x32 blocks per wave (rows ra + 32 i, columns rb + 32 j): every fragment read feeds RN (RM) MFMAs, and the
+// workgroup's tile - what the LDS-DMA has to bring per flop - grows with it.  Twin path only.
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1>
+__device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rss)[RM], const float *__restrict__ sa,
+                                              const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
+    static_assert(BF == 2 || (RM == 1 && RN == 1), "register blocking exists on the bf16-twin path only");
+    f32x16 &acc = accs[0][0];
+    float &rs = rss[0];
+    if constexpr (BF == 2 && RM * RN > 1) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+        constexpr int QG = (RM + RN) * NQ <= 16 ? NQ : NQ / 2;   // k groups whose fragments are in registers together (<= 64 VGPRs)
+        const int lane = lh * 32 + (ra & 31);
+        const int trow = 8 * lh + ((lane >> 2) & 3);
+        const int tcol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+        const unsigned short *sa16 = reinterpret_cast<const unsigned short *>(sa);
+        const unsigned short *sb16 = reinterpret_cast<const unsigned short *>(sb);
+        const int swa = BM == 64 ? 32 * ((lane >> 3) & 1) : BM == 128 ? 32 * ((lane >> 2) & 3) : 0;
+        const int swb = BN == 64 ? 32 * ((lane >> 3) & 1) : BN == 128 ? 32 * ((lane >> 2) & 3) : 0;
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += QG) {
+            u32x4 ta[RM][QG], tb[RN][QG];
+#pragma unroll
+            for (int qq = 0; qq < QG; ++qq) {
+                const int q = q0 + qq;
+                const int G = wk * GPW + 2 * q + lh;
+                const int k0 = 8 * (wk * GPW + 2 * q) + trow;
+#pragma unroll
+                for (int i = 0; i < RM; ++i) {
+                    if (!AKM) {
+                        ta[i][qq] = *reinterpret_cast<const u32x4 *>(sa + (ra + 32 * i) * BKC + ((G ^ (ra & 15)) << 2));
+                    } else {
+                        const int acol = ((ra & ~31) + 32 * i + tcol) ^ swa;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + k0 * BM + acol));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + (k0 + 4) * BM + acol));
+                        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                        ta[i][qq] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    if (!BKM) {
+                        tb[j][qq] = *reinterpret_cast<const u32x4 *>(sb + (rb + 32 * j) * BKC + ((G ^ (rb & 15)) << 2));
+                    } else {
+                        const int bcol = ((rb & ~31) + 32 * j + tcol) ^ swb;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + k0 * BN + bcol));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + (k0 + 4) * BN + bcol));
+                        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                        tb[j][qq] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+                    }
+                }
+            }
+            if (RS) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int qq = 0; qq < QG; ++qq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            rss[i] += __builtin_bit_cast(float, ta[i][qq][j] << 16) + __builtin_bit_cast(float, ta[i][qq][j] & 0xFFFF0000u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qq = 0; qq < QG; ++qq)
+                if (FULL || 8 * (wk * GPW + 2 * (q0 + qq)) < krem) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j)
+                            accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[i][qq]),
+                                                                                 __builtin_bit_cast(bf16x8, tb[j][qq]), accs[i][j], 0, 0, 0);
+                }
+        }
+        return;
+    }
     if constexpr (BF == 2) {
         // stage of 128 k; slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): two transpose
         // reads (ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 rows] block, 8 contiguous bytes per lane, and lane i
@@ -355,15 +432,18 @@ namespace ta3n {
 
 // BF: bf16 MFMA on operands rounded in registers; NS: LDS stages in flight (2, or 3 with BF: once the MFMA is cheap the
 // loop is latency-bound and a third stage pays for long K; short-K tasks prefer the extra resident workgroup of NS = 2).
-template <int WM, int WN, int WK, int BF, int NS>
+// RM x RN: 32x32 output blocks per wave (bf16 twins only): the tile is (32 WM RM) x (32 WN RN).  What bounds these launches is
+// the rate at which a CU can fill its LDS (~41 B/clk measured, tools/proto_bf16.hip), i.e. the operand bytes brought per flop -
+// which only the tile size lowers.
+template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
                                                                  Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
-    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
     constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128)
     constexpr bool TW = BF == 2;
-    constexpr int EPI = NW * 32 * 36;                // epilogue staging (one padded 32x32 block per wave)
+    constexpr int EPI = NW * RM * RN * 32 * 36;      // epilogue staging (one padded 32x32 block per wave and register block)
     constexpr int LDS_FLOATS = NS * STAGE > EPI ? NS * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
 
@@ -471,9 +551,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             if (n + e < t.n_valid) ebias[e] = bias[n + e];
     }
 
-    f32x16 acc;
+    f32x16 acc[RM][RN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     GSTAMP(1);
 
     const int m0 = t.m0, n0 = t.n0, m_valid = t.m_valid, n_valid = t.n_valid;
@@ -483,8 +567,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     // task have the same operand kinds (the plan builder guarantees it), so the whole loop nest is instantiated per
     // kind combination and selected once per task: the register allocation is the maximum over the combinations,
     // not their union (loop-invariant LDS addresses of every combination used to be live together).
-    const int ra = wm * 32 + li, rb = wn * 32 + li;
-    float rs = 0.f;   // EPI_ROWSUM_A: K-sum of A(row ra, this half-wave's k) over this wave's K slices
+    const int ra = wm * (32 * RM) + li, rb = wn * (32 * RN) + li;   // first of this lane's RM (RN) rows, 32 apart
+    float rs[RM];     // EPI_ROWSUM_A: K-sum of A(row ra + 32 i, this half-wave's k) over this wave's K slices
+#pragma unroll
+    for (int i = 0; i < RM; ++i) rs[i] = 0.f;
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
         if constexpr (NS == 2) {
@@ -524,7 +610,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     stage_ready();
                     issue(buf ^ 1, (c + 1) * CH);
                     const float *sa = lds + buf * STAGE;
-                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
+                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                     buf ^= 1;
                 }
                 // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
@@ -536,11 +622,15 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     issue(buf ^ 1, 0);
                 }
                 const float *sa = lds + buf * STAGE;
-                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
+                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem);
                 if (c_scale != SK_ONE) {
                     const float sc = scale_of(c_scale);
     #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] *= sc;
+                    for (int i = 0; i < RM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < RN; ++j)
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
                 }
                 if (cseg >= seg_end) break;
                 buf ^= 1;
@@ -574,9 +664,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 }
             };
             auto wait_landed = [&](int younger) {     // the oldest chunk in flight has landed once only the younger ones' DMAs are out
+                static_assert((NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
                 if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (NS == 3 || younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+                else if (NS == 4 || younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+                else if (NS == 5 || younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPW) : "memory");
                 __builtin_amdgcn_s_barrier();          // ... everyone's pieces have; and everyone is done reading the stage refilled next
                 asm volatile("" ::: "memory");
             };
@@ -601,7 +694,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                         ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
                         i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                         const float *sa = lds + c_buf * STAGE;
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                         c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     }
                     // (issue cursor inside this Seg => NS - 1 of its chunks were in flight => the loop ran and sent its last chunk)
@@ -614,16 +707,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     if (i_seg < seg_end) issue_one();
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH);
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH);
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH);
                     c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     --ahead;
                 }
                 if (c_scale != SK_ONE) {
                     const float sc = scale_of(c_scale);
     #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] *= sc;
+                    for (int i = 0; i < RM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < RN; ++j)
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
                 }
                 if (++cseg >= seg_end) break;
             }
@@ -648,14 +745,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     GSTAMP(2);
     __syncthreads();
     GSTAMP(3);
-    {
-        float *cs = lds + wave * (32 * 36);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // 32x32 C/D fragment layout
-            cs[row * 36 + li] = acc[r];
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            float *cs = lds + ((wave * RM + i) * RN + j) * (32 * 36);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // 32x32 C/D fragment layout
+                cs[row * 36 + li] = acc[i][j][r];
+            }
         }
-    }
     __syncthreads();
     GSTAMP(4);
 
@@ -675,13 +775,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     // bias and the per-step scalars were fetched before the K loop, so the first dependent global access of a plain
     // tile is its store).
     constexpr int ITER = (BM * BN / 4 + NT - 1) / NT;
-#pragma unroll
+    constexpr int UNR = ITER <= 4 ? ITER : 2;
+#pragma unroll UNR
     for (int it = 0; it < ITER; ++it) {
         const int idx = tid + it * NT;
         if (idx >= BM * BN / 4) break;
         const int r = idx / (BN / 4);
         const int c4 = (idx % (BN / 4)) * 4;        // == ec4 for every iteration: NT is a multiple of BN / 4
-        const int tile = (r >> 5) * WN + (c4 >> 5);
+        // block (r >> 5, c4 >> 5) belongs to wave row (r >> 5) / RM, wave column (c4 >> 5) / RN; staging slot of K-split wave q:
+        // (((wm WN + wn) WK + q) RM + i) RN + j
+        const int br = r >> 5, bc = c4 >> 5;
+        const int slot0 = ((((br / RM) * WN + (bc / RN)) * WK) * RM + (br % RM)) * RN + (bc % RN);
         const int m = m0 + r, n = n0 + c4;
         const bool row_ok = m < m_valid;
         const int nrem = row_ok ? n_valid - n : 0;   // number of valid columns of this float4 (<= 0: none)
@@ -705,7 +809,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         float4 v4 = zero4();
 #pragma unroll
         for (int q = 0; q < WK; ++q) {
-            const float4 part = *reinterpret_cast<const float4 *>(&lds[(tile * WK + q) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
+            const float4 part = *reinterpret_cast<const float4 *>(&lds[(slot0 + q * RM * RN) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
             v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
         }
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -793,7 +897,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
     if (epi & EPI_ROWSUM_A) {   // wave-uniform: bias gradient = K-sums of the A rows, added over the two k halves and the K-split waves
         __syncthreads();
-        if (wn == 0) lds[(wk * 2 + lh) * BM + ra] = rs;
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i) lds[(wk * 2 + lh) * BM + ra + 32 * i] = rs[i];
+        }
         __syncthreads();
         if (tid < BM) {
             float b = 0.f;
@@ -824,13 +931,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
 
+// register-blocked tiles (bf16 twins only): (wm, wn, wk, rm, rn, stages...) - 128x128 with 8 or 4 waves, 64x128, 128x64
+#define TA3N_BLOCKED_CONFIGS(X) X(2, 2, 2, 2, 2, 2) X(2, 2, 1, 2, 2, 2) X(2, 2, 2, 1, 2, 2) X(2, 2, 2, 1, 2, 3) X(2, 2, 2, 2, 1, 2) X(2, 2, 2, 2, 1, 3)
+
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
-    template __global__ void gemm_tiles<wm, wn, wk, 0, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 3>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 2>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 3>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
+#define TA3N_INSTANTIATE_BLOCKED(wm, wn, wk, rm, rn, ns) \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
+TA3N_BLOCKED_CONFIGS(TA3N_INSTANTIATE_BLOCKED)
+
 
 #ifdef TA3N_GEMM_STAMPS
 extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
@@ -839,9 +953,20 @@ extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
 #endif
 
 bool tile_config_ok(int cfg) {
+    // optional ten-thousands digit: register blocking of the bf16-twin kernel (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2)
+    const int blk = cfg / 10000;
+    cfg %= 10000;
     const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice)
-    if (stages != 0 && stages != 2 && stages != 3) return false;
     cfg %= 1000;
+    if (stages != 0 && stages != 2 && stages != 3) return false;
+    if (blk != 0) {
+        if (blk < 0 || blk > 3) return false;
+        const int rm = 1 + (blk & 1), rn = 1 + (blk >> 1);
+#define TA3N_CHECK_BLOCKED(wm, wn, wk, rm_, rn_, ns) \
+        if (cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (stages == 0 || stages == ns)) return true;
+        TA3N_BLOCKED_CONFIGS(TA3N_CHECK_BLOCKED)
+        return false;
+    }
 #define TA3N_CHECK(wm, wn, wk) if (cfg == wm * 100 + wn * 10 + wk) return true;
     TA3N_TILE_CONFIGS(TA3N_CHECK)
     return false;
@@ -858,8 +983,21 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
+    const int rm = ph.rm > 0 ? ph.rm : 1, rn = ph.rn > 0 ? ph.rn : 1;
+    if (rm * rn > 1) {
+        if (ph.bf16 < 16) return -3;     // (the plan builder never emits this: blocked tiles read bf16 twins)
+#define TA3N_LAUNCH_BLOCKED(wm, wn, wk, rm_, rn_, ns)                                                                      \
+        if (!launched && cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (ph.bf16 & 15) == ns) {               \
+            hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, 2, ns, rm_, rn_>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
+                               ptrs, hyper_off, zeros_off, twin_off, sd);                                                  \
+            launched = true;                                                                                               \
+        }
+        TA3N_BLOCKED_CONFIGS(TA3N_LAUNCH_BLOCKED)
+        if (!launched) return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
-    hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
+    hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns, 1, 1>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
                        hyper_off, zeros_off, twin_off, sd)
 #define TA3N_LAUNCH(wm, wn, wk)                                   \
     if (cfg == wm * 100 + wn * 10 + wk) {                         \

@@ -125,7 +125,13 @@ struct Builder {
             if (gemm_phase_index < 16 && p.cfg.phase_tiles[gemm_phase_index] != 0) forced = p.cfg.phase_tiles[gemm_phase_index];
             ++gemm_phase_index;
         }
-        const int forced_stages = forced / 1000;
+        // ten-thousands digit: register blocking (bf16 twins only; dropped again for launches that turn out not to read twins,
+        // build_plan's retry loop - deny_blocking)
+        int blk = forced / 10000;
+        forced %= 10000;
+        const bool twins_flags = (p.cfg.flags & TA3N_FLAG_BF16_MFMA) && (p.cfg.flags & TA3N_FLAG_BF16_STORE);
+        if (!twins_flags || (p.deny_blocking >> (p.phases.size() & 63)) & 1) blk = 0;
+        int forced_stages = forced / 1000;
         forced %= 1000;
         if (forced != 0) {
             wm = forced / 100; wn = (forced / 10) % 10; wk = forced % 10;
@@ -138,14 +144,20 @@ struct Builder {
                 for (auto &g : specs) n += (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
                 return n;
             };
-            if (count(64, 64) >= 256) { wm = 2; wn = 2; wk = 2; }
+            // bf16 twins: 128x128 tiles (2 x 2 blocks per wave) once they still give every CU two workgroups - half the operand
+            // bytes per flop through the LDS-DMA (measured at the 512+512-video, 9-segment shape: 153 -> 132 us and 89 -> 73 us
+            // for the two long launches; with fewer tiles the 64x64 tile's better balance wins)
+            if (twins_flags && !((p.deny_blocking >> (p.phases.size() & 63)) & 1) && count(128, 128) >= 512) { wm = 2; wn = 2; wk = 2; blk = 3; }
+            else if (count(64, 64) >= 256) { wm = 2; wn = 2; wk = 2; }
             else if (count(32, 32) >= 512) { wm = 1; wn = 1; wk = 4; }
             else { wm = 1; wn = 1; wk = 8; }
         }
-        const int BM = 32 * wm, BN = 32 * wn;
+        const int rm = 1 + (blk & 1), rn = 1 + (blk >> 1);
+        if (forced_stages == 3 && rm * rn == 4) forced_stages = 2;   // three 64 KiB stages do not fit
+        const int BM = 32 * wm * rm, BN = 32 * wn * rn;
         Phase ph;
         std::memset(&ph, 0, sizeof(ph));
-        ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk;
+        ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk; ph.rm = rm; ph.rn = rn;
         if (p.cfg.flags & TA3N_FLAG_BF16_MFMA) {
             // a third stage pays once every tile streams a long K; short-K launches keep the extra resident workgroup
             int min_k = 1 << 30;
@@ -154,7 +166,7 @@ struct Builder {
                 for (auto &sg : g.segs) k += sg.klen;
                 min_k = std::min(min_k, k);
             }
-            ph.bf16 = forced_stages ? forced_stages : (min_k >= 1024 ? 3 : 2);
+            ph.bf16 = forced_stages ? forced_stages : (min_k >= 1024 && rm * rn < 4 ? 3 : 2);
         }
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all
@@ -740,7 +752,7 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
 
 }  // namespace
 
-int ta3n::build_plan(ta3n_plan &p, std::string &err) {
+static int build_plan_once(ta3n_plan &p, std::string &err) {
     const ta3n_config &c = p.cfg;
     const int Bs = c.batch_source, Bt = c.batch_target, T = c.num_segments, D = c.feature_dim;
     const int F = std::min(c.fc_dim, c.feature_dim);   // models.py:129
@@ -759,9 +771,9 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         return TA3N_ERR_INVALID;
     }
     auto tile_ok = [](int t) { return t == 0 || tile_config_ok(t); };
-    if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages)"; return TA3N_ERR_INVALID; }
+    if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages; + 10000 / 20000 / 30000: 2 row / 2 column / 2 x 2 blocks per wave with 222 or 221, bf16 twins)"; return TA3N_ERR_INVALID; }
     for (int i = 0; i < 16; ++i)
-        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages)"; return TA3N_ERR_INVALID; }
+        if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages; + 10000 / 20000 / 30000: 2 row / 2 column / 2 x 2 blocks per wave with 222 or 221, bf16 twins)"; return TA3N_ERR_INVALID; }
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
@@ -1175,7 +1187,8 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
             const Phase *f1 = nullptr;
             for (const Phase &ph : p.phases)
                 if (ph.group == 4 && ph.kind == PH_GEMM) { f1 = &ph; break; }
-            b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15);
+            b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15) +
+                           10000 * ((f1->rm > 1 ? 1 : 0) + (f1->rn > 1 ? 2 : 0));
             std::vector<GemmSpec> s{spec_F1()};
             b.add_gemm_phase(5, s);
             const int64_t i0 = p.first_floats / 4, i1 = p.live_floats / 4;
@@ -1214,4 +1227,27 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
     for (auto &t : p.tasks)      // (after the twin re-addressing: the copies must be the final Segs)
         if (t.seg_count > 0) t.seg0 = p.segs[t.seg_begin];
     return TA3N_OK;
+}
+
+// Register-blocked tiles exist for launches that read bf16 twins only, and whether a launch does is known once the whole
+// plan is laid out (add_bf16_twins): build, look, and rebuild without the blocking where it cannot be used.
+int ta3n::build_plan(ta3n_plan &p, std::string &err) {
+    const ta3n_config cfg = p.cfg;
+    uint64_t deny = 0;
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        p = ta3n_plan();
+        p.cfg = cfg;
+        p.deny_blocking = deny;
+        const int rc = build_plan_once(p, err);
+        if (rc != TA3N_OK) return rc;
+        uint64_t bad = 0;
+        for (size_t i = 0; i < p.phases.size(); ++i) {
+            const Phase &ph = p.phases[i];
+            if (ph.kind == PH_GEMM && ph.rm * ph.rn > 1 && ph.bf16 < 16) bad |= 1ull << (i & 63);
+        }
+        if (bad == 0) return TA3N_OK;
+        deny |= bad;
+    }
+    err = "internal: register-blocked tile selection did not settle";
+    return TA3N_ERR_INVALID;
 }

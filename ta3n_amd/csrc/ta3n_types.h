@@ -97,6 +97,7 @@ struct Phase {
     int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages;
                                  // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): the Segs' offsets address the
                                  // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
+    int32_t rm, rn;              // 32x32 blocks per wave (0 or 1: one): block tile = 32*wm*rm x 32*wn*rn; > 1 only when bf16 >= 16
 };
 
 // Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.

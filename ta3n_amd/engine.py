@@ -87,6 +87,10 @@ class TrainEngine:
         if aggregation == "avgpool":     # TemPooling: no relation features, no attention (use_attn none in the reference's script); with
             # use_target none (BASELINE configs[0]) the caller passes no adversarial flag either (flags_from_options)
             flags &= ~(_lib.FLAG_ATTN_ENTROPY | _lib.FLAG_TRANS_ATTN)
+        if phase_tiles is None and tile_config == 0 and aggregation == "trn-m":      # measured choices for the benchmarked shapes
+            from .tuning import tuned_phase_tiles
+            phase_tiles = tuned_phase_tiles(batch_source + batch_target, num_segments, feature_dim, min(fc_dim, feature_dim),
+                                            self.bf16, self.bf16_store)
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
@@ -479,6 +483,8 @@ def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int
     GPU (HIP events on the launch stream).  Returns (phase_tiles, table)."""
     if flags & _lib.FLAG_BF16_MFMA and all(c < 1000 for c in candidates):
         candidates = [s * 1000 + c for c in candidates for s in (2, 3)]      # bf16 kernels: 2 or 3 LDS stages
+        if flags & _lib.FLAG_BF16_STORE:      # register-blocked tiles of the twin kernel: 128x64, 64x128 (2 / 3 stages), 128x128
+            candidates = candidates + [12222, 13222, 22222, 23222, 32222, 32221]
     table = {}
     for cand in candidates:
         eng = TrainEngine(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags=flags,

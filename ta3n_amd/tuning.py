@@ -1,0 +1,34 @@
+"""Measured GEMM tile choices per launch for the shapes this repository benchmarks (MI355X, `bench.py --autotune`;
+engine.autotune_phase_tiles does the measurement: every candidate tile for every launch, HIP events on the launch stream).
+
+A tile code is WM*100 + WN*10 + WK (waves of the workgroup in M, N and the in-workgroup K split), + 1000 * LDS stages for the
+bf16 kernels, + 10000 / 20000 / 30000 for 2 row / 2 column / 2 x 2 32x32 blocks per wave (bf16-twin kernel: 128x64, 64x128,
+128x128 tiles).  Entries 0-9 are the forward / loss / backward launches of the unfused sequence, 10-15 the six GEMM launches of
+the fused step (ta3n_train_step); 0 = the plan builder's own choice (ta3n_plan.cpp: add_gemm_phase).
+
+What decides a launch ("tile choice"): a CU fills its LDS at ~41 B/clk whatever the tile, so a launch wants (a) at
+least one workgroup per CU and (b) beyond that the largest tile, which brings the fewest operand bytes per flop; launches with
+few, long tiles want a third LDS stage, launches with two workgroups per CU do not (they hide each other's latency)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+# (videos per step, segments, feature_dim, fc_dim, arithmetic) -> per-launch tile codes
+TUNED = {
+    # BASELINE configs[1] / [2]: UCF->HMDB_full, 128 + 74 videos, 5 segments, 2048-d
+    (202, 5, 2048, 512, "bf16"): [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2124],
+    (202, 5, 2048, 512, "f32"): [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222],
+    # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
+    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2222, 32222, 2222, 2214, 32222, 3222],
+}
+
+
+def tuned_phase_tiles(batch: int, num_segments: int, feature_dim: int, fc_dim: int, bf16: bool, twins: bool) -> Optional[List[int]]:
+    """The measured list for this shape, or None (the plan builder's heuristic then picks per launch)."""
+    key = (int(batch), int(num_segments), int(feature_dim), int(fc_dim), "bf16" if bf16 else "f32")
+    t = TUNED.get(key)
+    if t is None:
+        return None
+    if bf16 and not twins:      # register-blocked tiles exist for the twin kernel only (the plan would drop them anyway)
+        t = [c % 10000 for c in t]
+    return list(t)

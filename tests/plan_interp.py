@@ -36,7 +36,7 @@ class Task(C.Structure):
 
 
 class Phase(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16", "rm", "rn")]
 
 
 def round_bf16(a):
@@ -153,7 +153,7 @@ class Interp:
 
     # ---- phases ----
     def run_gemm(self, ph):
-        BM, BN = 32 * ph.wm, 32 * ph.wn
+        BM, BN = 32 * ph.wm * max(ph.rm, 1), 32 * ph.wn * max(ph.rn, 1)
         for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
             t = self.tasks[ti]
             if t.epi & EPI_COLSUM:       # exact column sums of a table of per-workgroup partials

@@ -258,7 +258,7 @@ GRAD_L2_MEDIAN_TOL = 1e-3   # median of the above over the step's tensors
 GRAD_MAX_TOL = 1e-1         # max |error| / max |want|
 
 
-def _oracle_gate(shape, wseed, wscale, xseed, lr, clip, n_src=None, n_tgt=None, store=True, steps=1):
+def _oracle_gate(shape, wseed, wscale, xseed, lr, clip, n_src=None, n_tgt=None, store=True, steps=1, tile_config=0):
     from ta3n_amd.engine import TrainEngine
     Bs, Bt, T, D, Fc, Cn = shape["Bs"], shape["Bt"], shape["T"], shape["D"], shape["F"], shape["C"]
     n_src = Bs if n_src is None else n_src
@@ -266,7 +266,8 @@ def _oracle_gate(shape, wseed, wscale, xseed, lr, clip, n_src=None, n_tgt=None, 
     cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, arithmetic="bf16",
                      bf16_twins=store)
     params = synth_state(orc.param_shapes(cfg), seed=wseed, scale=wscale)
-    eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=clip, bf16=True, bf16_store=store)
+    eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=clip, bf16=True, bf16_store=store,
+                      tile_config=tile_config)
     eng.load_state(params)
     state = orc.TrainState(params={k: v.clone() for k, v in params.items()}, lr=lr)
     report, bad = {}, []
@@ -349,4 +350,45 @@ def test_bf16_oracle_gate_at_the_other_baseline_config_shapes(shape, capsys):
     rep, bad = _oracle_gate(shape, wseed=11, wscale="trained", xseed=21, lr=1e-3, clip=20.0)
     with capsys.disabled():
         _print_report(str(shape), rep)
+    assert not bad, bad
+
+
+BLOCKED = [(32222, 2222), (22222, 2222), (23222, 3222), (12222, 2222), (13222, 3222), (32221, 2221)]
+
+
+@pytest.mark.parametrize("blocked,plain", BLOCKED, ids=[str(b) for b, _ in BLOCKED])
+@pytest.mark.parametrize("name", ["headline", "tiny_T9", "mid_T12"])
+def test_register_blocked_tiles_are_bit_identical_to_one_block_per_wave(name, blocked, plain):
+    """128x128 / 64x128 / 128x64 tiles (2 or 2x2 32x32 blocks per wave, bf16-twin kernel) change which workgroup computes an
+    output element, not how: the K chunking, the K split over the waves and the epilogue are those of the 64x64 tile with the
+    same wave grid, so logits and gradients must be bit-identical, with dropout on."""
+    from ta3n_amd.engine import TrainEngine
+    c = case_config(Golden(name))
+    st = step_schedule(c)[0]
+    out = []
+    for tile in (blocked, plain):
+        eng = TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.5, dropout_v=0.5, clip=c["clip"],
+                          bf16=True, bf16_store=True, tile_config=tile)
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, st["lr"], valid_source=st["n_src"], valid_target=st["n_tgt"])
+        torch.cuda.synchronize()
+        o = {k: v.detach().clone() for k, v in eng.outputs().items()}
+        o.update({"grad/" + k: v.detach().clone() for k, v in eng.param_views(eng.G).items()})
+        n_blocked = sum(1 for ph in eng.plan.description.get("phases", []) if ph.get("rm", 1) * ph.get("rn", 1) > 1)
+        out.append((o, n_blocked))
+    (a, nb), (b, _) = out
+    assert nb > 0, "the blocked plan has no blocked launch"
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())
+
+
+@pytest.mark.parametrize("tile", [32222, 22222, 12222])
+def test_bf16_oracle_gate_with_register_blocked_tiles(tile, capsys):
+    shape = dict(Bs=128, Bt=128, T=12, D=1024, F=512, C=12)
+    rep, bad = _oracle_gate(shape, wseed=11, wscale="trained", xseed=21, lr=1e-3, clip=20.0, tile_config=tile)
+    with capsys.disabled():
+        _print_report(f"{shape} tile {tile}", rep)
     assert not bad, bad

@@ -56,14 +56,39 @@ def test_bf16_oracle_is_near_but_not_equal_to_the_fp32_reference(name):
         assert 1e-5 < e < 5e-2, e          # bf16 operand noise: ~1e-3..1e-2 of rms, never fp32-exact
 
 
-@pytest.mark.parametrize("store", [False, True])
+@pytest.mark.parametrize("tile", [0, 32222, 22222, 12222, 32221])
+def test_register_blocked_tiles_only_where_the_launch_reads_twins(tile):
+    """Tile codes >= 10000 ask for 2 / 2x2 32x32 blocks per wave (bf16-twin kernel only).  The plan keeps them on launches that
+    read twins and silently falls back to one block per wave elsewhere (fp32 arithmetic, launches with odd-shaped operands)."""
+    from plan_interp import plan_arrays
+    c = case_config(Golden("tiny_T5"))
+    for flags in (ALL_FLAGS, ALL_FLAGS | _lib.FLAG_BF16_MFMA, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE):
+        plan = _lib.Plan(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], flags, tile_config=tile)
+        _, tasks, phases, _, _, _ = plan_arrays(plan)
+        blocked = 0
+        for ph in phases:
+            if ph.kind != 0:
+                continue
+            rm, rn = max(ph.rm, 1), max(ph.rn, 1)
+            if rm * rn > 1:
+                assert ph.bf16 >= 16, (tile, flags, ph.bf16)
+                blocked += 1
+            BM, BN = 32 * ph.wm * rm, 32 * ph.wn * rn
+            for t in tasks[ph.task_begin:ph.task_begin + ph.task_count]:
+                if t.seg_count > 0:
+                    assert t.m0 % BM == 0 and t.n0 % BN == 0
+        twins = bool(flags & _lib.FLAG_BF16_STORE)
+        assert (blocked > 0) == (twins and tile >= 10000), (tile, flags, blocked)
+
+
+@pytest.mark.parametrize("store,tile", [(False, 0), (True, 0), (True, 32222), (True, 22222), (True, 12222), (True, 32221)])
 @pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9", "tiny_T3", "tiny_T2"])
-def test_plan_in_bf16_matches_the_independent_bf16_oracle(name, store):
+def test_plan_in_bf16_matches_the_independent_bf16_oracle(name, store, tile):
     g = Golden(name)
     c = case_config(g)
     T = c["T"]
     flags = ALL_FLAGS | _lib.FLAG_BF16_MFMA | (_lib.FLAG_BF16_STORE if store else 0)
-    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags)
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, tile_config=tile)
     it = Interp(plan)
     shapes = {n: s for n, _, s, _ in plan.params}
     params = synth_state(shapes, seed=c["wseed"], scale=c["wscale"])

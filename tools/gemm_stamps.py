@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench
 CFG = bench.CFG
 bf16 = (sys.argv[1] if len(sys.argv) > 1 else "bf16") == "bf16"
-eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], phase_tiles=bench.DEFAULT_PHASE_TILES_BF16 if bf16 else bench.DEFAULT_PHASE_TILES,
+eng = TrainEngine(CFG["Bs"], CFG["Bt"], CFG["T"], CFG["D"], CFG["F"], CFG["C"], 
                   bf16=bf16, bf16_store=bf16)
 eng.load_state(synth_state({n: s for n, _, s, _ in eng.plan.params}, seed=7, scale="init"))
 xs, xt, ys, yt = synth_batch(CFG["C"], CFG["T"], CFG["D"], CFG["Bs"], CFG["Bt"], seed=1234)

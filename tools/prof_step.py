@@ -11,7 +11,7 @@ if tile == 0:                     # the bench's measured per-launch tile shapes
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
-    phase_tiles = bench.DEFAULT_PHASE_TILES_BF16 if bf16 else bench.DEFAULT_PHASE_TILES
+    phase_tiles = None      # engine default: ta3n_amd/tuning.py
 bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
 eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16, bf16_store=bf16)
 eng.X.uniform_(0, 1)
