@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1]); default: the configuration's")
-    ap.add_argument("--wgrads-late", action="store_true", help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
+    ap.add_argument("--wgrads-late", type=int, default=0, help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
     ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()

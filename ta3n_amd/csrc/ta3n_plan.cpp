@@ -1048,8 +1048,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j)));
         }
     };
-    auto push_trn_wgrads = [&](std::vector<GemmSpec> &s) {   // TRN weight (and bias) gradients
+    auto push_trn_wgrads = [&](std::vector<GemmSpec> &s, unsigned scale_mask = ~0u) {   // TRN weight (and bias) gradients of the scales in the mask
         for (int j = 0; j < NR; ++j) {
+            if (!((scale_mask >> (j & 31)) & 1)) continue;
             const int sl = T - j;
             for (int pos = 0; pos < sl; ++pos) {   // dW_j[:, pos*F:(pos+1)*F] = sum_t gZ_t^T F1[:, tau_t[pos]]
                 GemmSpec gw;
@@ -1165,21 +1166,23 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         // weight gradients and dWfd feed nothing but the optimiser, so they may ride with either of the last two launches
         // (ta3n_config.wgrads_late, default 0 = with the gradient at F1: measured faster at the headline shape, ta3n_hip.h).
         const bool twins_on = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
-        const bool late = c.wgrads_late != 0;
+        // wgrads_late: 0 = all with the gradient at F1, 1 = all with the shared-FC weight gradient, otherwise a mask:
+        // bit 1 = the frame discriminator's first layer, bit 2 + j = TRN scale j (j = 0: all T frames)
+        const unsigned late_mask = c.wgrads_late == 0 ? 0u : c.wgrads_late == 1 ? ~0u : (unsigned)c.wgrads_late;
+        const bool late_fd = (late_mask >> 1) & 1;
+        const unsigned late_trn = late_mask >> 2;
         {
             std::vector<GemmSpec> s;
-            if (twins_on && !late) push_frame_disc_wgrads(s);
-            if (!late) push_trn_wgrads(s);
+            if (twins_on && !late_fd) push_frame_disc_wgrads(s);
+            push_trn_wgrads(s, ~late_trn);
             push_f1_grad(s);
             b.add_gemm_phase(4, s);
         }
         {
             std::vector<GemmSpec> s;
             push_shared_fc_wgrad(s);
-            if (late) {
-                push_trn_wgrads(s);
-                if (twins_on) push_frame_disc_wgrads(s);
-            }
+            push_trn_wgrads(s, late_trn);
+            if (twins_on && late_fd) push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
         {   // group 5: the step's first launch once more, carrying the PREVIOUS step's optimiser update of every parameter

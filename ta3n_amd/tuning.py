@@ -16,7 +16,7 @@ from typing import List, Optional
 # (videos per step, segments, feature_dim, fc_dim, arithmetic) -> per-launch tile codes
 TUNED = {
     # BASELINE configs[1] / [2]: UCF->HMDB_full, 128 + 74 videos, 5 segments, 2048-d
-    (202, 5, 2048, 512, "bf16"): [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2124],
+    (202, 5, 2048, 512, "bf16"): [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2222],
     (202, 5, 2048, 512, "f32"): [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
     (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2222, 32222, 2222, 2214, 32222, 3222],
