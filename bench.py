@@ -329,7 +329,10 @@ def main():
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "bytes_per_launch": nbytes / max(len(gemm), 1),
                                "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
-        res["phase_tiles"] = [ph["tile"] for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] != 5]
+        # tile code per GEMM launch as the plan built it: WM WN WK + 1000 x (LDS stages, + 16: reads bf16 twins) + 100000 x blocking
+        # (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2 - 128x64 / 64x128 / 128x128 tiles)
+        res["phase_tiles"] = [ph["tile"] + 100000 * ((ph.get("rm", 1) > 1) + 2 * (ph.get("rn", 1) > 1))
+                              for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] != 5]
         return res
 
     main_res = run(args.dtype, args.steps, args.warmup)
