@@ -322,6 +322,14 @@ int ta3n_time_phases(ta3n_plan *plan, const float *x, float *params, float *grad
                      float *ws, void *stream, int reps, float *ms_out, int32_t *kind_out,
                      int32_t *group_out, int cap);
 
+/* Measurement aid for the pipelined step: ms_out2[0] = the optimiser launch that opens the step (update of the shared frame
+ * FC + the new scalars), ms_out2[1] = the first GEMM launch with the rest of the update riding as side workgroups - the
+ * two launches ta3n_train_step_after_update runs instead of the plain first launch that ta3n_time_phases times.  APPLIES
+ * the update `reps` times (use it at the end of a run).  Synchronises the stream. */
+int ta3n_time_update_launches(ta3n_plan *plan, const float *x, float *params, float *grads, float *momentum, float *ws,
+                              int fused_norm, float lr, float momentum_coef, float weight_decay, float clip, void *stream,
+                              int reps, float *ms_out2);
+
 /* Number of kernel launches the last ta3n_forward/ta3n_backward enqueued, and a
  * name for the dominant GEMM kernel symbol (for rocprof matching). */
 int ta3n_num_phases(const ta3n_plan *plan, int which /*0 fwd,1 loss,2 bwd,3 sgd,4 fused step*/);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "ta3n_workspace_floats", "ta3n_ws_offset", "ta3n_ws_size", "ta3n_plan_describe", "ta3n_set_hyper",
     "ta3n_init_workspace", "ta3n_forward", "ta3n_loss", "ta3n_backward", "ta3n_has_fused_step", "ta3n_train_step", "ta3n_eval_metrics",
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
-    "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_last_error", "ta3n_version",
+    "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_time_update_launches", "ta3n_last_error", "ta3n_version",
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
     "ta3n_gather_segments_bf16_into",
 ]
@@ -109,6 +109,8 @@ def lib() -> C.CDLL:
     L.ta3n_gather_segments_bf16_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_sgd_step_next.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_num_phases.argtypes = [vp, C.c_int]
+    L.ta3n_time_update_launches.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int,
+                                            C.POINTER(C.c_float)]
     L.ta3n_time_phases.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i32),
                                    C.c_int]
     L.ta3n_debug_arrays.argtypes = [vp] + [C.POINTER(vp), C.POINTER(i64)] * 3 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]

@@ -314,6 +314,47 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
     return n;
 }
 
+// The two launches that open a pipelined step (ta3n_train_step_after_update): the optimiser update of the shared frame FC,
+// and the first GEMM launch carrying the rest of the update as side workgroups.  Unlike ta3n_time_phases this APPLIES the
+// update `reps` times (a measurement aid for the end of a benchmark run).
+int ta3n_time_update_launches(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                              float lr, float momentum_coef, float weight_decay, float clip, void *stream, int reps, float *ms_out2) {
+    if (!p || !x || !params || !grads || !momentum || !ws || !ms_out2) return fail(TA3N_ERR_INVALID, "null argument");
+    if (ta3n_has_pipelined_step(p) != 1) return fail(TA3N_ERR_INVALID, "no pipelined step for this configuration");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (reps < 1) reps = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geom &g = p->geom;
+    hipEvent_t ev[3];
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    Hyper next;
+    HIP_TRY(hipMemcpyAsync(&next, ws + g.o_hyper, sizeof(Hyper), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
+                 fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
+    Ptrs ptrs{x, params, grads, ws};
+    HIP_TRY(hipEventRecord(ev[0], s));
+    for (int k = 0; k < reps; ++k)
+        if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                             &next, s) != 0)
+            return fail(TA3N_ERR_HIP, "sgd launch failed while timing");
+    HIP_TRY(hipEventRecord(ev[1], s));
+    for (int k = 0; k < reps; ++k) {
+        rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side);
+        if (rc != TA3N_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev[2], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < 2; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        ms_out2[i] = ms / (float)reps;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return TA3N_OK;
+}
+
 int ta3n_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                          const int32_t *video_ids, int n_videos, int num_segments, int feature_dim, float *out,
                          int32_t *labels_out, int32_t *segment_ids_out, void *stream) {

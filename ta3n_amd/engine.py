@@ -433,6 +433,18 @@ class TrainEngine:
                 for i, ph in enumerate(self.plan.description["phases"])
                 if all_groups or (int(groups[i]) in want and not (skip_norm and int(kinds[i]) == 4))]
 
+    def time_update_launches(self, reps: int = 20, lr: float = 1e-3):
+        """(ms of the optimiser launch that opens a pipelined step, ms of the step's first GEMM launch carrying the rest of the
+        update as side workgroups) - what train_step_pipelined runs instead of the plain first launch time_phases reports.
+        Applies the update `reps` times: a measurement aid for the END of a benchmark run."""
+        out = (C.c_float * 2)()
+        fused_norm = int(self.world == 1 and not self._ddp_selftest)
+        _lib.check(self._L.ta3n_time_update_launches(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                                     self.M.data_ptr(), self.ws.data_ptr(), fused_norm, float(lr), float(self.momentum),
+                                                     float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0,
+                                                     self._stream(), reps, out), "ta3n_time_update_launches")
+        return float(out[0]), float(out[1])
+
     def gemm_phase_times(self, reps: int = 20):
         """ms of every GEMM launch of the plan, in plan order (the index space of phase_tiles)."""
         return [ms for kind, _, _, ms in self.time_phases(reps, all_groups=True) if kind == 0]
