@@ -304,6 +304,10 @@ def main():
         if rank != 0:
             return res
         res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
+        res["gradient_exchange"] = (("RCCL ncclAllReduce from the C ABI on the step's stream, " +
+                                     ("bf16" if eng._g16 is not None else "fp32") + " transport") if eng.comm is not None else
+                                    "torch.distributed all_reduce (backend nccl = RCCL), fp32" +
+                                    (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
         res["deferred"] = deferred
         res["pipelined"] = pipelined
         res["fused"] = eng.fused
@@ -370,8 +374,7 @@ def main():
                        "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
                        ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "
                         "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
-                       "gradient_exchange": None if world == 1 else
-                       ("RCCL ncclAllReduce from the C ABI on the step's stream, " + ("bf16" if args.dtype == "bf16" else "fp32") + " transport"),
+                       "gradient_exchange": None if world == 1 else main_res.get("gradient_exchange"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],
         }

@@ -135,12 +135,20 @@ class TrainEngine:
         # torch.distributed instead).  Gradient transport: fp32, or bf16 (half the xGMI bytes) - default for the bf16
         # arithmetic, whose contractions see the gradients' operands in bf16 anyway; TA3N_DDP_BF16=0/1 overrides.
         self.comm = None
+        self.comm_fallback: Optional[str] = None
         self._g16 = None
         self._comm_stream: Optional[torch.cuda.Stream] = None
         rccl_group = self.world == 1 or torch.distributed.get_backend(self.pg) == "nccl"     # gloo (CPU / shared-GPU tests): torch path
         if (self.world > 1 or self._ddp_selftest) and rccl_group and os.environ.get("TA3N_DDP_NATIVE", "1") == "1":
-            self.comm = parallel.NativeComm(self.pg if self.world > 1 else None, self.device)
-            if os.environ.get("TA3N_DDP_BF16", "1" if self.bf16 else "0") == "1":
+            try:
+                self.comm = parallel.NativeComm(self.pg if self.world > 1 else None, self.device)
+            except Exception as ex:      # noqa: BLE001 - the same on every rank (parallel.NativeComm): still RCCL, through torch.distributed
+                self.comm = None
+                self.comm_fallback = f"{type(ex).__name__}: {ex}"
+                if self.rank == 0:
+                    print(f"[ta3n] RCCL communicator of the C ABI unavailable ({self.comm_fallback}); gradient all-reduce goes "
+                          f"through torch.distributed (backend nccl = RCCL)", flush=True)
+            if self.comm is not None and os.environ.get("TA3N_DDP_BF16", "1" if self.bf16 else "0") == "1":
                 self._g16 = torch.zeros(p.live_floats, dtype=torch.bfloat16, device=self.device)
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None

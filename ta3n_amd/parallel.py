@@ -104,11 +104,17 @@ class NativeComm:
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if world > 1 else 0
         buf = C.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(L.ta3n_comm_unique_id(buf), "ta3n_comm_unique_id")
-        ids = [bytes(buf.raw)]
+        ids = [None]
+        if rank == 0:        # a failure here (librccl.so not loadable) must not leave the other ranks waiting in the broadcast:
+            try:             # it travels as the payload and every rank raises the same error
+                _lib.check(L.ta3n_comm_unique_id(buf), "ta3n_comm_unique_id")
+                ids = [bytes(buf.raw)]
+            except Exception as ex:      # noqa: BLE001
+                ids = [RuntimeError(f"ta3n_comm_unique_id failed on rank 0: {ex}")]
         if world > 1:
             dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(ids[0], Exception):
+            raise ids[0]
         h = C.c_void_p()
         if device is not None:
             torch.cuda.set_device(device)
