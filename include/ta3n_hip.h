@@ -44,6 +44,14 @@ typedef enum {
 #define TA3N_FLAG_ADV_FRAME      (1u << 2)  /* place_adv[2]=='Y' */
 #define TA3N_FLAG_ATTN_ENTROPY   (1u << 3)  /* add_loss_DA=='attentive_entropy' (main.py:559-562) */
 #define TA3N_FLAG_TRANS_ATTN     (1u << 4)  /* use_attn=='TransAttn' (models.py:643-645) */
+/* ens_DA=='MCD' (opts.py:49; models.py:276-279, 716-720): a second video classifier "fc_classifier_video_source_2" on the
+ * same (dropped-out) video feature; its logits land in region "Y2", its logit gradient is read from "gY2".  The MCD loss
+ * itself (main.py:447, 548-556) is assembled by the caller from the two forwards; unfused entry points only. */
+#define TA3N_FLAG_MCD            (1u << 5)
+/* The backward pass accepts a caller-written gradient at the pooled video feature (region "gV_ext", [B][256], the feature
+ * the reference returns as feat[1], models.py:675) in addition to the logit gradients: entry point of the discrepancy losses
+ * (dis_DA DAN / JAN, main.py:452-505).  Unfused entry points only; the region is zero after ta3n_init_workspace. */
+#define TA3N_FLAG_FEATURE_GRADS  (1u << 6)
 /* Arithmetic of BASELINE.json configs[1]: every contraction rounds its two operands to bf16 (round to nearest
  * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and
  * everything outside the contractions (biases, softmax, losses, update) stay fp32.  Off = fp32 MFMA (configs[2]). */
@@ -107,7 +115,9 @@ typedef struct {
     int32_t valid_source;    /* rows [valid_source, Bs) are the reference's dummy rows (main.py:359-372, 421-422) */
     int32_t valid_target;
     int32_t train;           /* nn.Module.training: dropout active */
-    int32_t reserved[4];
+    int32_t reverse;         /* VideoModel.forward(..., reverse=True) (models.py:682-684): GradReverse(mu) on the video feature */
+    float mu;                /* ... its weight (the MCD step's second forward, main.py:550) */
+    int32_t reserved[2];
 } ta3n_hyper;
 
 typedef struct ta3n_plan ta3n_plan;

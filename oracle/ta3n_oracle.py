@@ -112,6 +112,10 @@ class Config:
     arithmetic: str = "fp32"                          # 'bf16': BASELINE configs[1] (bf16 MFMA operands, fp32 accumulation)
     compute_dead_branches: bool = False              # also evaluate what the reference computes and never uses (the frame classifier,
                                                       # models.py:617-618): for timing the CPU path fairly, no effect on any output
+    dis_DA: str = "none"                              # 'DAN' | 'JAN' (opts.py:44; main.py:452-505): MMD losses on the feature list
+    place_dis: Tuple[str, str, str] = ("N", "Y", "N")  # opts.py:65 (script_train_val.sh:148 passes N Y N); indexes feat = [Y, V, F1]
+    ens_DA: str = "none"                              # 'MCD' (opts.py:49): second video classifier + a gradient-reversed second forward
+    add_fc: int = 1
     bf16_twins: bool = True                           # bf16 only: operands are read from bf16 copies (TA3N_FLAG_BF16_STORE), so a bias
                                                       # gradient made by a weight-gradient launch sums ROUNDED values (BF16_POLICY bias16)
 
@@ -156,6 +160,8 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
     lin("fc_feature_video_source_2", NB, NB)        # :262 (unused)
     lin("fc_feature_domain_video", NB, NB)          # :267
     lin("fc_classifier_video_source", C, NB)        # :272
+    if cfg.ens_DA == "MCD":
+        lin("fc_classifier_video_source_2", C, NB)  # :276-279
     lin("fc_classifier_domain_video", 2, NB)        # :281
     for i in range(T - 1):                          # :286-294
         lin(f"relation_domain_classifier_all.{i}.0", NB, NB)
@@ -322,7 +328,7 @@ def trans_attn(pred_domain):
     return 1 - ent
 
 
-def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
+def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu=None):
     """One domain's pass through VideoModel.forward (models.py:545-722) for the
     trn-m / video / TransAttn configuration.  x [B,T,D].  drop_i / drop_v are
     optional multiplicative dropout masks already scaled by 1/(1-p)
@@ -369,10 +375,15 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None):
         rel_attn, attn = rel, rel[:, :, 0]
     v = torch.sum(rel_attn, 1)                                                       # :651
     vd = v * drop_v if drop_v is not None else v                                     # :679
+    if reverse_mu is not None:                                                       # :682-684 (the MCD step's second forward)
+        vd = _GradReverse.apply(vd, reverse_mu)
     y = _linear(p, "fc_classifier_video_source", vd, cfg)                            # :686
     hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg))  # :464-470
     pred_video = _linear(p, "fc_classifier_domain_video", hv, cfg)
-    return dict(attn=attn, out=y,
+    y2 = y
+    if cfg.ens_DA == "MCD":                                                          # :716-720
+        y2 = F.linear(vd, p["fc_classifier_video_source_2.weight"], p["fc_classifier_video_source_2.bias"])
+    return dict(attn=attn, out=y, out2=y2,
                 pred_domain=[pred_rel.view(B, T - 1, 2), pred_video, pred_frame],   # :697-707, :722 reversed
                 feat=[y, v, feat_frame])                                             # :578, :675, :690, :722
 
@@ -387,16 +398,81 @@ def attentive_entropy(pred, pred_domain):
     return torch.mean(w * torch.sum(-F.softmax(pred, 1) * F.log_softmax(pred, 1), 1))
 
 
+def gaussian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """loss.py:46-59: sum of kernel_num RBF kernels on the stacked [source; target] rows, bandwidths bw * mul^i around the mean
+    pairwise squared distance (taken from .data: no gradient through the bandwidth)."""
+    n = int(source.size(0)) + int(target.size(0))
+    total = torch.cat([source, target], dim=0)
+    l2 = ((total.unsqueeze(0) - total.unsqueeze(1)) ** 2).sum(2)
+    bw = fix_sigma if fix_sigma else torch.sum(l2.detach()) / (n * n - n)
+    bw = bw / kernel_mul ** (kernel_num // 2)
+    return sum(torch.exp(-l2 / (bw * kernel_mul ** i)) for i in range(kernel_num))
+
+
+def mmd_rbf(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """loss.py:61-85, ver=2 (the only one main.py uses)."""
+    b = int(source.size(0))
+    k = gaussian_kernel(source, target, kernel_mul, kernel_num, fix_sigma)
+    return torch.mean(k[:b, :b] + k[b:, b:] - k[:b, b:] - k[b:, :b])
+
+
+def jan(source_list, target_list, kernel_muls=(2.0, 2.0), kernel_nums=(2, 5), fix_sigma_list=(None, None)):
+    """loss.py:87-120, ver=2: the layers' kernels multiplied."""
+    b = int(source_list[0].size(0))
+    joint = None
+    for i in range(len(source_list)):
+        k = gaussian_kernel(source_list[i], target_list[i], kernel_muls[i], kernel_nums[i], fix_sigma_list[i])
+        joint = k if joint is None else joint * k
+    return torch.mean(joint[:b, :b] + joint[b:, b:] - joint[:b, b:] - joint[b:, :b])
+
+
+def dis_mcd(out1, out2):
+    """loss.py:27-29."""
+    return torch.mean(torch.abs(F.softmax(out1, dim=1) - F.softmax(out2, dim=1)))
+
+
+def discrepancy_loss(src, tgt, cfg: Config, n_src: int, n_tgt: int):
+    """main.py:452-505: JAN on [Y, V]; DAN = mmd_rbf per enabled feature level, in batches of <= 256 rows."""
+    fs = [f[:n_src] for f in src["feat"]]
+    ft = [f[:n_tgt] for f in tgt["feat"]]
+    kernel_muls, kernel_nums, fix_sigma = [2.0] * 2, [2, 5], [None] * 2
+    if cfg.dis_DA == "JAN":
+        fs, ft = fs[:-cfg.add_fc], ft[:-cfg.add_fc]
+        n = min(fs[0].size(0), ft[0].size(0))
+        return jan([f[:n] for f in fs], [f[:n] for f in ft], kernel_muls, kernel_nums, fix_sigma)
+    kernel_muls += [kernel_muls[-1]] * cfg.add_fc
+    kernel_nums += [kernel_nums[-1]] * cfg.add_fc
+    fix_sigma += [fix_sigma[-1]] * cfg.add_fc
+    loss = 0
+    for l in range(cfg.add_fc + 2):
+        if cfg.place_dis[l] != "Y":
+            continue
+        n = min(fs[l].size(0), ft[l].size(0))
+        a, b = fs[l][:n], ft[l][:n]
+        sb = min(256, n)
+        a = a.reshape((-1, sb) + tuple(a.shape[1:]))
+        b = b.reshape((-1, sb) + tuple(b.shape[1:]))
+        parts = [mmd_rbf(a[t], b[t], kernel_muls[l], kernel_nums[l], fix_sigma[l]) for t in range(a.size(0))]
+        loss = loss + sum(parts) / len(parts)
+    return loss
+
+
 def total_loss(src, tgt, label_source, gamma, cfg: Config,
-               n_src: Optional[int] = None, n_tgt: Optional[int] = None):
+               n_src: Optional[int] = None, n_tgt: Optional[int] = None, alpha: float = 0.0, tgt_rev=None):
     """main.py:421-422 (removeDummy), 439-451 (classification CE), 508-538
     (adversarial CE per enabled level), 559-562 (attentive entropy)."""
     n_src = src["out"].size(0) if n_src is None else n_src
     n_tgt = tgt["out"].size(0) if n_tgt is None else n_tgt
     out_s, out_t = src["out"][:n_src], tgt["out"][:n_tgt]
     loss_c = F.cross_entropy(out_s, label_source[:n_src])
+    if cfg.ens_DA == "MCD":                                                # main.py:447
+        loss_c = loss_c + F.cross_entropy(src["out2"][:n_src], label_source[:n_src])
     loss = loss_c
     parts = {"loss_c": loss_c}
+    if cfg.dis_DA != "none":                                               # main.py:452-505
+        loss_d = discrepancy_loss(src, tgt, cfg, n_src, n_tgt)
+        loss = loss + alpha * loss_d
+        parts["loss_d"] = loss_d
     pred_all = []
     loss_a = 0
     for l in range(3):
@@ -410,8 +486,15 @@ def total_loss(src, tgt, label_source, gamma, cfg: Config,
     if pred_all:
         loss = loss + loss_a
         parts["loss_a"] = loss_a
+    if cfg.ens_DA == "MCD":                                                # main.py:548-556: from the second, reversed forward
+        loss_s = -dis_mcd(tgt_rev["out"][:n_tgt], tgt_rev["out2"][:n_tgt])
+        loss = loss + loss_s
+        parts["loss_s"] = loss_s
     if cfg.add_loss_DA == "attentive_entropy" and cfg.use_attn != "none":
-        loss_e = attentive_entropy(torch.cat((out_s, out_t), 0), pred_all[1])
+        # with MCD the reference has re-bound out_target to the second, reversed forward's output by now (main.py:550-552),
+        # so the entropy term's gradient reaches the target features through GradReverse(mu)
+        out_t_e = tgt_rev["out"][:n_tgt] if cfg.ens_DA == "MCD" else out_t
+        loss_e = attentive_entropy(torch.cat((out_s, out_t_e), 0), pred_all[1])
         loss = loss + gamma * loss_e
         parts["loss_e"] = loss_e
     parts["loss"] = loss
@@ -440,7 +523,7 @@ class TrainState:
 
 def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config,
                momentum=0.9, weight_decay=1e-4, clip=20.0, drop_i=None, drop_v=None,
-               n_src=None, n_tgt=None, grad_hook=None):
+               n_src=None, n_tgt=None, grad_hook=None, alpha=0.0, mu=0.0):
     """One optimisation step: forward both domains, total loss, backward,
     clip_grad_norm_ (main.py:578-581), Nesterov SGD with weight decay
     (main.py:83, 583; torch.optim.SGD semantics: g += wd*p; buf = mu*buf + g
@@ -454,7 +537,10 @@ def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config
         dv_s, dv_t = drop_v
     src = forward_domain(p, xs, beta, cfg, di_s, dv_s)
     tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t)
-    loss, parts = total_loss(src, tgt, label_source, gamma, cfg, n_src, n_tgt)
+    tgt_rev = None
+    if cfg.ens_DA == "MCD":      # main.py:550: the whole model once more with reverse=True; only the target outputs are used
+        tgt_rev = forward_domain(p, xt, beta, cfg, di_t, dv_t, reverse_mu=mu)
+    loss, parts = total_loss(src, tgt, label_source, gamma, cfg, n_src, n_tgt, alpha=alpha, tgt_rev=tgt_rev)
     names = [k for k in p if is_live(k)]
     grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
     g = {k: gi for k, gi in zip(names, grads) if gi is not None}

@@ -22,6 +22,8 @@ FLAG_ADV_VIDEO = 1 << 1
 FLAG_ADV_FRAME = 1 << 2
 FLAG_ATTN_ENTROPY = 1 << 3
 FLAG_TRANS_ATTN = 1 << 4
+FLAG_MCD = 1 << 5              # ens_DA 'MCD': second video classifier (regions Y2 / gY2); unfused entry points
+FLAG_FEATURE_GRADS = 1 << 6    # backward also takes a gradient at the pooled video feature (region gV_ext): dis_DA DAN / JAN
 FLAG_BF16_MFMA = 1 << 8
 FLAG_BF16_STORE = 1 << 9
 AGG_TRN_M, AGG_AVGPOOL = 0, 1
@@ -53,7 +55,7 @@ class Hyper(C.Structure):
                 ("seed_i", C.c_uint32), ("seed_v", C.c_uint32), ("inv_n_cls", C.c_float), ("inv_n_rel", C.c_float),
                 ("inv_n_vid", C.c_float), ("inv_n_frm", C.c_float), ("inv_n_ent", C.c_float),
                 ("valid_source", C.c_int32), ("valid_target", C.c_int32), ("train", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("reverse", C.c_int32), ("mu", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 class Ta3nError(RuntimeError):

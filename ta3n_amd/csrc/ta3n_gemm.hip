@@ -539,6 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
             case SK_NEG_BETA_FRM: return -hh.beta[2];
             case SK_INV_KEEP_I: return (h_train && hh.p_drop_i > 0.f) ? (hh.p_drop_i < 1.f ? 1.f / (1.f - hh.p_drop_i) : 0.f) : 1.f;
             case SK_INV_KEEP_V: return (h_train && hh.p_drop_v > 0.f) ? (hh.p_drop_v < 1.f ? 1.f / (1.f - hh.p_drop_v) : 0.f) : 1.f;
+            case SK_REVERSE_MU: return hy->reverse ? -hy->mu : 1.f;      // (read here: only the one tile kind that needs it pays the load)
             default: return 1.f;
         }
     };

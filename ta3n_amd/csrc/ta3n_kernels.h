@@ -30,6 +30,7 @@ __device__ __forceinline__ float hyper_scale(const Hyper *__restrict__ hy, int k
         case SK_NEG_BETA_FRM: return -hy->beta[2];
         case SK_INV_KEEP_I: return (hy->train && hy->p_drop_i > 0.f) ? (hy->p_drop_i < 1.f ? 1.f / (1.f - hy->p_drop_i) : 0.f) : 1.f;
         case SK_INV_KEEP_V: return (hy->train && hy->p_drop_v > 0.f) ? (hy->p_drop_v < 1.f ? 1.f / (1.f - hy->p_drop_v) : 0.f) : 1.f;
+        case SK_REVERSE_MU: return hy->reverse ? -hy->mu : 1.f;
         default: return 1.f;
     }
 }

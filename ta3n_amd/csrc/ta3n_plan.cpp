@@ -820,6 +820,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     }
     lin("fc_feature_domain_video", NB, NB, live_vid);                  // :267
     b.add_linear("fc_classifier_video_source", C, NB, true);           // :272
+    const bool mcd = (c.flags & TA3N_FLAG_MCD) != 0;
+    const bool feat_grads = (c.flags & TA3N_FLAG_FEATURE_GRADS) != 0;
+    if (mcd) b.add_linear("fc_classifier_video_source_2", C, NB, true); // :276-279 (ens_DA MCD)
     lin("fc_classifier_domain_video", 2, NB, live_vid);                // :281
     p.live_floats = p.param_floats;
     for (auto &d : dead) b.add_linear(d.name, d.out, d.in, false);     // computed (zero or unused) gradients land past the live prefix
@@ -844,6 +847,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     const int64_t Wdv = P("fc_feature_domain_video.weight"), bdv = P("fc_feature_domain_video.bias");
     const int64_t Wcv = P("fc_classifier_video_source.weight"), bcv = P("fc_classifier_video_source.bias");
     const int64_t Wcdv = P("fc_classifier_domain_video.weight"), bcdv = P("fc_classifier_domain_video.bias");
+    const int64_t Wcv2 = mcd ? P("fc_classifier_video_source_2.weight") : 0, bcv2 = mcd ? P("fc_classifier_video_source_2.bias") : 0;
 
     // ---- workspace ----
     Geom &g = p.geom;
@@ -878,6 +882,11 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_gR = (int32_t)b.add_region("gR", (int64_t)B * NR * NB);
     g.o_gZ = (int32_t)b.add_region("gZ", (int64_t)B * NT * NB);
     g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
+    if (feat_grads) g.o_gV_ext = (int32_t)b.add_region("gV_ext", (int64_t)B * NB);
+    if (mcd) {
+        g.o_Y2 = (int32_t)b.add_region("Y2", (int64_t)B * C);
+        g.o_gY2 = (int32_t)b.add_region("gY2", (int64_t)B * C);
+    }
     g.o_zeros = (int32_t)b.add_region("zeros", 64);   // never written: source of out-of-range operand elements
     g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);   // [BT][4] block of ones (k-major A operand of the column sums)
     if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
@@ -964,6 +973,14 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         with_bias(s.proto, bcv);
         return s;
     };
+    auto spec_Y2 = [&]() {   // ens_DA MCD: the second video classifier on the same feature (models.py:717-718)
+        GemmSpec s;
+        s.M = B; s.N = C;
+        s.segs.push_back(mkseg(KC(BASE_WS, g.o_Vd, NB), KC(BASE_P, Wcv2, NB), NB));
+        s.proto = proto(BASE_WS, g.o_Y2, C);
+        with_bias(s.proto, bcv2);
+        return s;
+    };
     auto spec_Hv = [&]() {   // video-discriminator hidden layer (models.py:466-467)
         GemmSpec s;
         s.M = B; s.N = NB;
@@ -1011,7 +1028,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         gv.M = B; gv.N = NB;
         gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gHv, NB), KM(BASE_P, Wdv, NB), NB, SK_NEG_BETA_VID));
         gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY, C), KM(BASE_P, Wcv, NB), C));
+        if (mcd) gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY2, C), KM(BASE_P, Wcv2, NB), C));
         gv.proto = proto(BASE_WS, g.o_gVt, NB);
+        gv.proto.alpha_kind = SK_REVERSE_MU;      // forward(..., reverse=True): everything behind the video feature sees GradReverse(mu)
         gv.proto.epi |= EPI_DROP_V; gv.proto.gamma_kind = SK_INV_KEEP_V; gv.proto.drop_ld = NB;
         return gv;
     };
@@ -1034,6 +1053,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     auto push_video_head_wgrads = [&](std::vector<GemmSpec> &s) {   // dWcdv, dbcdv, dWcv, dbcv
         s.push_back(wgrad(2, NB, B, g.o_gPv, 2, g.o_Hv, NB, Wcdv, bcdv));
         s.push_back(wgrad(C, NB, B, g.o_gY, C, g.o_Vd, NB, Wcv, bcv));
+        if (mcd) s.push_back(wgrad(C, NB, B, g.o_gY2, C, g.o_Vd, NB, Wcv2, bcv2));
     };
     auto push_video_disc_wgrads = [&](std::vector<GemmSpec> &s) {   // dWdv, dbdv
         s.push_back(wgrad(NB, NB, B, g.o_gHv, NB, g.o_Vd, NB, Wdv, bdv));
@@ -1106,7 +1126,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         b.add_gemm_phase(0, s);
     }
     b.add_simple_phase(PH_POOL_FWD, 0);   // Pr, attention weights, R, V, Vd
-    { std::vector<GemmSpec> s{spec_Y(), spec_Hv()}; b.add_gemm_phase(0, s); }   // F6
+    { std::vector<GemmSpec> s{spec_Y(), spec_Hv()}; if (mcd) s.push_back(spec_Y2()); b.add_gemm_phase(0, s); }   // F6
     { std::vector<GemmSpec> s{spec_Pv()}; b.add_gemm_phase(0, s); }             // F7
     // ================= loss (group 1) =================
     b.add_simple_phase(PH_LOSS, 1);
@@ -1134,7 +1154,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // Same arithmetic in 7 launches instead of 15: everything between (Hr, Hf) and (gHr, gHf) - both
     // discriminator heads, the attention pooling, the classifier, the losses and their backward - is one
     // kernel (ta3n_heads.hip); its small weight gradients ride along with the relation level.
-    if (heads_supported(NB, C, F)) {
+    if (heads_supported(NB, C, F) && !mcd && !feat_grads) {   // (the fused heads kernel knows neither the second classifier nor an outside gradient)
         { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(4, s); }
         {
             std::vector<GemmSpec> s{spec_Hf()};

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(Geom g, Ptrs ptrs) {
     float gv[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) gv[q] = ws[g.o_gVt + (size_t)b * NB + q * 64 + lane];
+    if (g.o_gV_ext > 0) {   // TA3N_FLAG_FEATURE_GRADS: the caller's gradient at the pooled feature (discrepancy losses on feat[1])
+#pragma unroll
+        for (int q = 0; q < Q; ++q) gv[q] += ws[g.o_gV_ext + (size_t)b * NB + q * 64 + lane];
+    }
     for (int j = 0; j < NR; ++j) {
         const size_t bj = (size_t)b * NR + j;
         const float *__restrict__ W2 = ptrs.p + g.p_W2_0 + (size_t)j * g.p_W2_stride;

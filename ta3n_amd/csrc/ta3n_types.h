@@ -17,6 +17,7 @@ enum ScaleKind : int32_t {
     SK_NEG_BETA_FRM = 3,   // -beta[2]   (models.py:457)
     SK_INV_KEEP_I = 4,     // 1/(1-p_drop_i) when training else 1
     SK_INV_KEEP_V = 5,     // 1/(1-p_drop_v) when training else 1
+    SK_REVERSE_MU = 6,     // -mu when hyper.reverse else 1   (models.py:682-684)
 };
 
 enum EpiFlags : uint32_t {
@@ -108,7 +109,9 @@ struct Hyper {
     uint32_t seed_i, seed_v;
     float inv_n_cls, inv_n_rel, inv_n_vid, inv_n_frm, inv_n_ent;
     int32_t valid_source, valid_target, train;
-    int32_t reserved[4];
+    int32_t reverse;             // forward(..., reverse=True): GradReverse(mu) between dropout_v and the video heads (models.py:682-684)
+    float mu;
+    int32_t reserved[2];
 };
 
 // Device-side constant geometry handed to the pointwise kernels by value.
@@ -136,6 +139,8 @@ struct Geom {
     // bf16 twins (TA3N_FLAG_BF16_STORE), all inside ws, offsets in floats: element e of ws / params / x lives, rounded
     // to bf16, at byte (o_*16 * 4 + 2 e).  -1: no twins.
     int32_t o_ws16, o_p16, o_x16, ws16_span;   // ws16 mirrors ws[0 .. ws16_span)
+    int32_t o_gV_ext;                    // TA3N_FLAG_FEATURE_GRADS: caller-written gradient at V, added to gVt by the pooling backward (0: none)
+    int32_t o_Y2, o_gY2;                 // TA3N_FLAG_MCD: second classifier's logits / logit gradients (0: none)
 };
 
 }  // namespace ta3n

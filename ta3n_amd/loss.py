@@ -21,3 +21,40 @@ def attentive_entropy(pred, pred_domain):
 def dis_MCD(out1, out2):
     """loss.py:29-30."""
     return torch.mean(torch.abs(F.softmax(out1, dim=1) - F.softmax(out2, dim=1)))
+
+
+def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """loss.py:46-59 (name as in the reference): sum of kernel_num RBF kernels over the stacked [source; target] rows; the
+    bandwidth is the mean pairwise squared distance (no gradient through it), scaled by kernel_mul^(i - kernel_num // 2)."""
+    n = int(source.size(0)) + int(target.size(0))
+    total = torch.cat([source, target], dim=0)
+    sq = (total * total).sum(1)
+    l2 = (sq[:, None] + sq[None, :] - 2.0 * total @ total.t()).clamp_min(0.0)       # ||x_i - x_j||^2 as one product
+    bandwidth = fix_sigma if fix_sigma else torch.sum(l2.detach()) / (n * n - n)
+    bandwidth = bandwidth / kernel_mul ** (kernel_num // 2)
+    return sum(torch.exp(-l2 / (bandwidth * kernel_mul ** i)) for i in range(kernel_num))
+
+
+def _quadrants(kernels, batch_size):
+    XX, YY = kernels[:batch_size, :batch_size], kernels[batch_size:, batch_size:]
+    XY, YX = kernels[:batch_size, batch_size:], kernels[batch_size:, :batch_size]
+    return torch.mean(XX + YY - XY - YX)
+
+
+def mmd_rbf(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None, ver=2):
+    """loss.py:61-85 (ver 2, the one main.py uses)."""
+    if ver != 2:
+        raise ValueError('ver == 2 (main.py:470, 497 never ask for the linear-time estimate)')
+    return _quadrants(guassian_kernel(source, target, kernel_mul, kernel_num, fix_sigma), int(source.size(0)))
+
+
+def JAN(source_list, target_list, kernel_muls=[2.0, 2.0], kernel_nums=[2, 5], fix_sigma_list=[None, None], ver=2):
+    """loss.py:87-120 (ver 2): the layers' kernels multiplied, then the same four-quadrant mean."""
+    if ver != 2:
+        raise ValueError('ver == 2')
+    joint = None
+    for i in range(len(source_list)):
+        k = guassian_kernel(source_list[i], target_list[i], kernel_muls[i], kernel_nums[i], fix_sigma_list[i])
+        joint = k if joint is None else joint * k
+    return _quadrants(joint, int(source_list[0].size(0)))
+

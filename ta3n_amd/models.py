@@ -51,7 +51,7 @@ class _HipForward(torch.autograd.Function):
     """One autograd node for the whole forward; backward = ta3n_backward."""
 
     @staticmethod
-    def forward(ctx, model, xs, xt, beta, train, *params):
+    def forward(ctx, model, xs, xt, beta, train, reverse_mu, *params):
         dev = model._flat.device
         Bs, Bt = xs.shape[0], xt.shape[0]
         plan = model._plan(Bs, Bt)
@@ -60,6 +60,8 @@ class _HipForward(torch.autograd.Function):
         ws = model._ws_checkout(plan, ctx, any(ctx.needs_input_grad))
         h = _lib.Hyper()
         h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
+        if reverse_mu is not None:           # forward(..., reverse=True): GradReverse(mu) behind dropout_v (models.py:682-684); the
+            h.reverse, h.mu = 1, float(reverse_mu)      # workspace keeps the scalars, so this node's backward sees them again
         h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
         seeds = torch.randint(0, 2 ** 31 - 1, (2,))       # consumes the global torch RNG like nn.Dropout would
         h.seed_i, h.seed_v = int(seeds[0]), int(seeds[1])
@@ -80,14 +82,19 @@ class _HipForward(torch.autograd.Function):
         attn, y = reg("attn", (B, NR)), reg("Y", (B, Cn))
         pr, pv, pf = reg("Pr", (B, NR, 2)), reg("Pv", (B, 2)), reg("Pf", (B, T, 2))
         v, f1 = reg("V", (B, -1)), reg("F1", (B, T, -1))
-        ctx.mark_non_differentiable(v, f1)
+        y2 = reg("Y2", (B, Cn)) if model.ens_DA == 'MCD' else y.new_zeros(0)
+        # the pooled video feature takes a gradient from the caller (dis_DA DAN / JAN on feat[1], main.py:452-505); the frame
+        # features cannot be a loss operand in the reference either (loss.py:49 raises on 3-D features)
+        ctx.mark_non_differentiable(f1)
+        if model.ens_DA != 'MCD':
+            ctx.mark_non_differentiable(y2)
         if not model._attn_on:
             ctx.mark_non_differentiable(attn)
         ctx.set_materialize_grads(False)      # an output that feeds no loss arrives as None in backward (see there)
-        return attn, y, pr, pv, pf, v, f1
+        return attn, y, pr, pv, pf, v, f1, y2
 
     @staticmethod
-    def backward(ctx, g_attn, g_y, g_pr, g_pv, g_pf, g_v, g_f1):
+    def backward(ctx, g_attn, g_y, g_pr, g_pv, g_pf, g_v, g_f1, g_y2):
         model, plan, ws = ctx.model, ctx.plan, ctx.ws
         dev = ws.device
 
@@ -100,6 +107,9 @@ class _HipForward(torch.autograd.Function):
 
         put("gY", g_y); put("gPr", g_pr); put("gPv", g_pv); put("gPf", g_pf)
         put("g_attn", g_attn if model._attn_on else None)
+        put("gV_ext", g_v)
+        if model.ens_DA == 'MCD':
+            put("gY2", g_y2)
         grads = torch.empty(plan.param_floats, dtype=torch.float32, device=dev)     # every live gradient is written in full
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -113,8 +123,8 @@ class _HipForward(torch.autograd.Function):
             unused += ["fc_feature_domain.", "fc_classifier_domain."]
         if g_pv is None:
             unused += ["fc_feature_domain_video.", "fc_classifier_domain_video."]
-        if g_pr is None and (g_attn is None or not model._attn_on):
-            unused += ["relation_domain_classifier_all."]
+        if g_pr is None and not model._attn_on:      # with TransAttn the weights are not detached (models.py:351-357): the relation
+            unused += ["relation_domain_classifier_all."]      # discriminators receive a gradient through V whatever the loss uses
         out: List[Optional[torch.Tensor]] = []
         for name, off, shape, live in plan.params:
             if not live or name.startswith(tuple(unused)):
@@ -124,7 +134,7 @@ class _HipForward(torch.autograd.Function):
             for s_ in shape:
                 n *= s_
             out.append(grads[off:off + n].view(shape))
-        return (None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, *out)
 
 
 class _HipForwardAvg(torch.autograd.Function):
@@ -212,7 +222,8 @@ class VideoModel(nn.Module):
         if baseline_type != 'video': unsupported.append(f"baseline_type={baseline_type!r}")
         if share_params != 'Y': unsupported.append("share_params='N'")
         if use_bn != 'none': unsupported.append(f"use_bn={use_bn!r}")
-        if ens_DA != 'none': unsupported.append(f"ens_DA={ens_DA!r}")
+        if ens_DA not in ('none', 'MCD'): unsupported.append(f"ens_DA={ens_DA!r}")
+        if ens_DA == 'MCD' and frame_aggregation != 'trn-m': unsupported.append("ens_DA='MCD' with frame_aggregation other than 'trn-m'")
         if use_attn not in ('TransAttn', 'none'): unsupported.append(f"use_attn={use_attn!r}")
         if use_attn_frame != 'none': unsupported.append(f"use_attn_frame={use_attn_frame!r}")
         if not before_softmax: unsupported.append("before_softmax=False")
@@ -270,6 +281,8 @@ class VideoModel(nn.Module):
         self.fc_feature_video_source_2 = lin(A, A)                       # :262 (unused)
         self.fc_feature_domain_video = lin(A, A)                         # :267
         self.fc_classifier_video_source = lin(A, num_class)              # :272
+        if ens_DA == 'MCD':
+            self.fc_classifier_video_source_2 = lin(A, num_class)        # :276-279 second classifier for self-ensembling
         self.fc_classifier_domain_video = lin(A, 2)                      # :281
         if not self._avg:
             self.relation_domain_classifier_all = nn.ModuleList(         # :286-294 (default init)
@@ -305,7 +318,9 @@ class VideoModel(nn.Module):
         if self._avg:
             return _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME
         return (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME |
-                (_lib.FLAG_TRANS_ATTN if self._attn_on else 0))
+                (_lib.FLAG_TRANS_ATTN if self._attn_on else 0) |
+                _lib.FLAG_FEATURE_GRADS |                                   # feat[1] may carry a discrepancy loss (dis_DA)
+                (_lib.FLAG_MCD if self.ens_DA == 'MCD' else 0))
 
     def _plan(self, Bs: int, Bt: int) -> _lib.Plan:
         key = (Bs, Bt)
@@ -385,8 +400,8 @@ class VideoModel(nn.Module):
         frame [B,T,2]] and feat = [class logits, video feature V, frame features F1]."""
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("ta3n_amd.VideoModel.forward needs a HIP device; there is no CPU fallback")
-        if reverse:
-            raise NotImplementedError("reverse=True is only used by ens_DA='MCD' (main.py:549)")
+        if reverse and self._avg:
+            raise NotImplementedError("reverse=True (the MCD step's second forward, main.py:549) with frame_aggregation='avgpool'")
         num_segments = self.train_segments if is_train else self.val_segments
         if num_segments != self.train_segments:
             raise ValueError("val_segments must equal num_segments (static launch plans; TRN needs it anyway, models.py:222)")
@@ -408,8 +423,9 @@ class VideoModel(nn.Module):
             return (v[s][:, 0], y[s], y[s], [pv[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
                     v[t][:, 0], y[t], y[t], [pv[t], pv[t], pf[t]], [y[t], v[t], f1[t]])
         with torch.cuda.device(device):
-            attn, y, pr, pv, pf, v, f1 = _HipForward.apply(self, input_source, input_target, list(beta),
-                                                            self.training, *params)
+            attn, y, pr, pv, pf, v, f1, y2 = _HipForward.apply(self, input_source, input_target, list(beta), self.training,
+                                                                float(mu) if reverse else None, *params)
         out_s, out_t = y[s], y[t]
-        return (attn[s], out_s, out_s, [pr[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
-                attn[t], out_t, out_t, [pr[t], pv[t], pf[t]], [y[t], v[t], f1[t]])
+        out_s2, out_t2 = (y2[s], y2[t]) if self.ens_DA == 'MCD' else (out_s, out_t)      # models.py:713-720
+        return (attn[s], out_s, out_s2, [pr[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
+                attn[t], out_t, out_t2, [pr[t], pv[t], pf[t]], [y[t], v[t], f1[t]])

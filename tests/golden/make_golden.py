@@ -26,7 +26,13 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 
 ref_shim.install()
-import main as ref_main  # noqa: E402  (reference main.py; pulls models/loss/opts)
+import importlib.util  # noqa: E402
+
+# the reference's main.py BY PATH: this repository has a main.py of its own at its root, which `import main` would find first
+_spec = importlib.util.spec_from_file_location("ta3n_reference_main", os.path.join(ref_shim.REF, "main.py"))
+ref_main = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_main)  # (pulls the reference's models / loss / opts through sys.path, set up by ref_shim)
+assert "dis_DA != 'none'" in open(ref_main.__file__).read() and ref_main.__file__.startswith(ref_shim.REF)
 from models import VideoModel as RefVideoModel  # noqa: E402
 
 from ta3n_amd.synthetic import synth_batch, synth_state  # noqa: E402
@@ -74,7 +80,7 @@ def build_model(case):
     avg = case.get("agg", "trn-m") == "avgpool"       # BASELINE configs[0]: TemPooling, source-only (script_train_val.sh:103-119)
     m = RefVideoModel(case["C"], "video", "avgpool" if avg else "trn-m", "RGB", train_segments=case["T"], val_segments=case["T"],
                       base_model=case["arch"], add_fc=1, fc_dim=case["fc_dim"], dropout_i=0.0, dropout_v=0.0,
-                      partial_bn=False, use_bn="none", ens_DA="none", use_attn="none" if avg else "TransAttn", n_attn=1,
+                      partial_bn=False, use_bn="none", ens_DA=case.get("ens_DA", "none"), use_attn="none" if avg else "TransAttn", n_attn=1,
                       use_attn_frame="none", verbose=False, share_params="Y")
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = m.state_dict()
@@ -120,6 +126,10 @@ def make_args(case):
             a.use_target = "uSv"
             a.adv_DA = "RevGrad"
             a.place_adv = list(case["place_adv"])
+    # discrepancy-based DA (main.py:452-505) and MCD (main.py:402, 447, 548-556): SURVEY 8f rank 4
+    a.dis_DA = case.get("dis_DA", "none")
+    a.place_dis = list(case.get("place_dis", ("N", "Y", "N")))      # script_train_val.sh:148
+    a.ens_DA = case.get("ens_DA", "none")
     return a
 
 
@@ -147,6 +157,8 @@ def run_case(name, case):
             put(store, f"fwd/pd_s_{nm}", pd_s[i]); put(store, f"fwd/pd_t_{nm}", pd_t[i])
     for i, nm in enumerate(("y", "v", "f1")):
         put(store, f"fwd/feat_s_{nm}", feat_s[i]); put(store, f"fwd/feat_t_{nm}", feat_t[i])
+    if case.get("ens_DA", "none") == "MCD":
+        put(store, "fwd/out_s2", out_s2); put(store, "fwd/out_t2", out_t2)
 
     # ---- (2) the reference's own train loop for n_steps steps ----
     args = make_args(case)
@@ -179,7 +191,7 @@ def run_case(name, case):
         args.epochs = 30 * n_steps
         epoch_eff = n_steps + s
         ref_main.train(C, [src_batches[s]], [tgt_batches[s]], wrapped, crit, crit_d, opt, epoch_eff,
-                       log, log_short, 0, list(beta), gamma, 0)
+                       log, log_short, case.get("alpha", 0), list(beta), gamma, case.get("mu", 0))
         lrs.append(opt.param_groups[0]["lr"])
         p = float(epoch_eff) / args.epochs
         store[f"step{s}/p"] = np.array([p])
@@ -239,6 +251,18 @@ CASES = {
                              wscale="trained", xseed=59, steps=2, lr=2e-3),
     "tempooling_da": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet101", fc_dim=512, T=5, C=12, Bs=128, Bt=74, wseed=18,
                           wscale="trained", xseed=60, steps=2, lr=2e-3),
+    # discrepancy-based DA on top of TA3N's adversarial branches (dis_DA, main.py:452-505; loss.py:46-120) and MCD
+    # (ens_DA, second classifier + a second, gradient-reversed forward: models.py:276-279, 682-684, 716-720; main.py:548-556)
+    "tiny_dan": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=21, wscale="trained", xseed=201, steps=2, lr=2e-3,
+                     dis_DA="DAN", place_dis=("N", "Y", "N"), alpha=1.0),
+    "tiny_dan_all": dict(arch="resnet18", fc_dim=32, T=3, C=5, Bs=4, Bt=5, wseed=22, wscale="trained", xseed=202, steps=2, lr=2e-3,
+                         dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=0.5),   # (place_dis[2] = 'Y' raises in the reference: loss.py:49 on 3-D frame features)
+    "tiny_jan": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=23, wscale="trained", xseed=203, steps=2, lr=2e-3,
+                     dis_DA="JAN", alpha=1.0),
+    "tiny_mcd": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=24, wscale="trained", xseed=204, steps=2, lr=2e-3,
+                     ens_DA="MCD", mu=0.5),
+    "mid_dan_mcd": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=25, wscale="trained", xseed=205, steps=2,
+                        lr=2e-3, dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=1.0, ens_DA="MCD", mu=1.0),
 }
 
 if __name__ == "__main__":

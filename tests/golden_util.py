@@ -10,6 +10,7 @@ N_SAMP = 64
 CASES = ["tiny_T5", "tiny_T3", "tiny_T9", "tiny_T2", "tiny_clip", "headline", "headline_init", "mid_T12"]
 AVG_CASES = ["tiny_avgpool", "config1_avgpool"]      # BASELINE configs[0]: TemPooling (avgpool), source-only, every DA option off
 AVG_DA_CASES = ["tiny_avgpool_da", "tiny_avgpool_da3", "tiny_avgpool_dav", "tempooling_da"]   # TemPooling + RevGrad (place_adv in the fixture)
+DA_EXTRA_CASES = ["tiny_dan", "tiny_dan_all", "tiny_jan", "tiny_mcd", "mid_dan_mcd"]   # dis_DA DAN / JAN, ens_DA MCD on top of TA3N
 ARCH_DIM = dict(resnet18=512, resnet34=512, resnet50=2048, resnet101=2048, resnet152=2048)
 
 
@@ -77,7 +78,12 @@ def case_config(g):
                 clip=float(g.meta("clip")) if g.has_meta("clip") else 20.0,
                 short_last=tuple(int(v) for v in g.meta("short_last")) if g.has_meta("short_last") else None,
                 agg=str(g.meta("agg")) if g.has_meta("agg") else "trn-m",
-                place_adv=tuple(str(v) for v in g.meta("place_adv")) if g.has_meta("place_adv") else None)
+                place_adv=tuple(str(v) for v in g.meta("place_adv")) if g.has_meta("place_adv") else None,
+                dis_DA=str(g.meta("dis_DA")) if g.has_meta("dis_DA") else "none",
+                place_dis=tuple(str(v) for v in g.meta("place_dis")) if g.has_meta("place_dis") else ("N", "Y", "N"),
+                alpha=float(g.meta("alpha")) if g.has_meta("alpha") else 0.0,
+                ens_DA=str(g.meta("ens_DA")) if g.has_meta("ens_DA") else "none",
+                mu=float(g.meta("mu")) if g.has_meta("mu") else 0.0)
 
 
 def _has_meta(self, k):

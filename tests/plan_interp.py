@@ -54,7 +54,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
-                "o_ws16", "o_p16", "o_x16", "ws16_span"]
+                "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2"]
 
 
 class Geom(C.Structure):
@@ -136,6 +136,7 @@ class Interp:
         if kind == 3: return -h["beta"][2]
         if kind == 4: return 1.0 / (1.0 - h["p_drop_i"]) if (h["train"] and h["p_drop_i"] > 0) else 1.0
         if kind == 5: return 1.0 / (1.0 - h["p_drop_v"]) if (h["train"] and h["p_drop_v"] > 0) else 1.0
+        if kind == 6: return -h["mu"] if h.get("reverse", 0) else 1.0
         return 1.0
 
     def view2d(self, base, off, ld, rows, cols, r0=0, c0=0):
@@ -361,6 +362,8 @@ class Interp:
         g = self.g
         B, NR, NB = g.B, g.n_rel, g.NB
         gVt = self.r(g.o_gVt, (B, NB)); R = self.r(g.o_R, (B, NR, NB)); Pr = self.r(g.o_Pr, (B, NR, 2))
+        if g.o_gV_ext > 0:       # TA3N_FLAG_FEATURE_GRADS: the caller's gradient at the pooled feature joins here
+            gVt = gVt + self.r(g.o_gV_ext, (B, NB))
         gPr = self.r(g.o_gPr, (B, NR, 2)); gattn = self.r(g.o_gattn, (B, NR)); Hr = self.r(g.o_Hr, (B, NR, NB))
         gPrT = self.r(g.o_gPrT, (B, NR, 2)); gRa = self.r(g.o_gRa, (B, NR, NB)); gHr = self.r(g.o_gHr, (B, NR, NB))
         attn_on = bool(g.flags & _lib.FLAG_TRANS_ATTN)

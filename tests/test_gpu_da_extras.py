@@ -1,0 +1,127 @@
+"""dis_DA DAN / JAN and ens_DA MCD on the module path, end to end on the GPU: this repository's main.train
+(the reference's loss assembly, main.py:439-562) on ta3n_amd.models.VideoModel (HIP forward / backward through the C ABI) with
+ta3n_amd.loss, against fixtures written by the reference's own main.train with the same options
+(tests/golden/make_golden.py: tiny_dan, tiny_dan_all, tiny_jan, tiny_mcd, mid_dan_mcd): clipped gradients, parameters after
+each step, and the loss_d / loss_s the reference logged."""
+import argparse
+import importlib.util
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import DA_EXTRA_CASES, Golden, case_config, step_schedule
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_main():
+    spec = importlib.util.spec_from_file_location("ta3n_repo_main", os.path.join(ROOT, "main.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _args(c):
+    a = argparse.Namespace()
+    a.no_partialbn = True
+    a.batch_size = [c["Bs"], c["Bt"], c["Bs"]]
+    a.baseline_type, a.num_segments, a.pretrain_source, a.pred_normalize, a.tensorboard = "video", c["T"], False, "N", False
+    a.use_target, a.adv_DA, a.place_adv = "uSv", "RevGrad", ["Y", "Y", "Y"]
+    a.add_loss_DA, a.use_attn = "attentive_entropy", "TransAttn"
+    a.dis_DA, a.place_dis, a.ens_DA = c["dis_DA"], list(c["place_dis"]), c["ens_DA"]
+    a.clip_gradient, a.verbose, a.print_freq, a.show_freq = c["clip"], False, 1, 10 ** 9
+    a.lr_adaptive, a.lr, a.save_attention, a.epochs, a.add_fc = "dann", c["lr"], -1, 30, 1
+    a.momentum, a.weight_decay = 0.9, 1e-4
+    return a
+
+
+class _FakeDP:      # main.train uses model.module, model.train(), model(...), model.parameters()  (main.py:79)
+    def __init__(self, m):
+        self.module = m
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)
+
+    def train(self, mode=True):
+        return self.module.train(mode)
+
+    def parameters(self):
+        return self.module.parameters()
+
+
+@pytest.mark.parametrize("name", DA_EXTRA_CASES)
+def test_main_train_with_discrepancy_and_ensemble_losses_matches_the_reference(name):
+    from ta3n_amd.models import VideoModel
+    main = _load_main()
+    g = Golden(name)
+    c = case_config(g)
+    T, C = c["T"], c["C"]
+    arch = str(g.meta("arch"))
+    model = VideoModel(C, "video", "trn-m", "RGB", train_segments=T, val_segments=T, base_model=arch, add_fc=1, fc_dim=c["fc_dim"],
+                       dropout_i=0.0, dropout_v=0.0, partial_bn=False, use_bn="none", ens_DA=c["ens_DA"], use_attn="TransAttn",
+                       verbose=False).cuda()
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    sd.update({k: v.cuda() for k, v in synth_state(shapes, seed=c["wseed"], scale=c["wscale"]).items()})
+    model.load_state_dict(sd)
+    assert ("fc_classifier_video_source_2.weight" in shapes) == (c["ens_DA"] == "MCD")
+    args = _args(c)
+    main.args = args
+    opt = torch.optim.SGD(model.parameters(), args.lr, momentum=args.momentum, weight_decay=args.weight_decay, nesterov=True)
+    crit, crit_d = torch.nn.CrossEntropyLoss().cuda(), torch.nn.CrossEntropyLoss().cuda()
+    wrapped = _FakeDP(model)
+    n_steps = c["steps"]
+    log, log_short = io.StringIO(), io.StringIO()
+    live = set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        args.epochs = 30 * n_steps
+        main.train(C, [(xs, ys)], [(xt, yt)], wrapped, crit, crit_d, opt, n_steps + s, log, log_short, c["alpha"],
+                   [0.75, 0.75, 0.5], 0.003, c["mu"])
+        torch.cuda.synchronize()
+        got_live = {k for k, v in model.named_parameters() if v.grad is not None}
+        assert got_live == live, (got_live ^ live)
+        for k, v in model.named_parameters():
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", v.grad, 2e-4, 5e-6, rms_atol=2e-4)
+            g.check(f"step{s}/param/{k}", v, 2e-4, 5e-6)
+    # the loss components the reference logged (running averages over the steps of one "epoch" = one step each here)
+    want, got = str(g.meta("log")).strip().splitlines(), log.getvalue().strip().splitlines()
+    assert len(want) == len(got) == n_steps
+    for w, h in zip(want, got):
+        for key in ("Loss", "loss_c", "loss_d", "loss_a", "loss_e", "loss_s"):
+            mw = re.search(key + r" (-?[0-9.]+)", w)
+            mh = re.search(key + r" (-?[0-9.]+)", h)
+            assert (mw is None) == (mh is None), (key, w, h)
+            if mw:
+                assert abs(float(mw.group(1)) - float(mh.group(1))) <= 2e-3 * max(1.0, abs(float(mw.group(1)))), (key, w, h)
+
+
+def test_loss_functions_match_the_oracle_restatement_and_its_gradients():
+    """ta3n_amd.loss.mmd_rbf / JAN (one matrix product for the pairwise distances) against the oracle's broadcast form of
+    loss.py:46-120, values and gradients."""
+    from oracle import ta3n_oracle as orc
+    from ta3n_amd import loss as L
+    torch.manual_seed(3)
+    for n, d in ((4, 12), (37, 256), (128, 256)):
+        a = torch.randn(n, d, dtype=torch.float64).cuda().requires_grad_(True)
+        b = (0.5 * torch.randn(n, d, dtype=torch.float64) + 0.3).cuda().requires_grad_(True)
+        a2, b2 = a.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+        for num in (2, 5):
+            v = L.mmd_rbf(a, b, kernel_mul=2.0, kernel_num=num)
+            w = orc.mmd_rbf(a2, b2, 2.0, num)
+            assert abs(v.item() - w.item()) < 1e-9 * max(1.0, abs(w.item()))
+            ga, = torch.autograd.grad(v, a, retain_graph=True)
+            gw, = torch.autograd.grad(w, a2, retain_graph=True)
+            assert torch.allclose(ga.cpu(), gw, rtol=1e-7, atol=1e-12)
+        y1 = torch.randn(n, 7, dtype=torch.float64).cuda().requires_grad_(True)
+        y2 = torch.randn(n, 7, dtype=torch.float64).cuda().requires_grad_(True)
+        v = L.JAN([y1, a], [y2, b])
+        w = orc.jan([y1.detach().cpu(), a2], [y2.detach().cpu(), b2])
+        assert abs(v.item() - w.item()) < 1e-9 * max(1.0, abs(w.item()))

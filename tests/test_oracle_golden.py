@@ -4,7 +4,7 @@ the clipped gradients / updated parameters / DANN LR of main.train."""
 import pytest
 import torch
 
-from golden_util import AVG_CASES, CASES, Golden, case_config, step_schedule
+from golden_util import AVG_CASES, CASES, DA_EXTRA_CASES, Golden, case_config, step_schedule
 from oracle import ta3n_oracle as orc
 from ta3n_amd.synthetic import synth_batch, synth_state
 
@@ -15,12 +15,12 @@ def _setup(name):
     g = Golden(name)
     c = case_config(g)
     cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"],
-                     dropout_i=0.0, dropout_v=0.0)
+                     dropout_i=0.0, dropout_v=0.0, dis_DA=c["dis_DA"], place_dis=c["place_dis"], ens_DA=c["ens_DA"])
     params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
     return g, c, cfg, params
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES)
 def test_forward_matches_reference(name):
     g, c, cfg, params = _setup(name)
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
@@ -35,9 +35,11 @@ def test_forward_matches_reference(name):
             g.check(f"fwd/pd_{dom}_{nm}", o["pred_domain"][i], RTOL, ATOL)
         for i, nm in enumerate(("y", "v", "f1")):
             g.check(f"fwd/feat_{dom}_{nm}", o["feat"][i], RTOL, ATOL)
+        if c["ens_DA"] == "MCD":
+            g.check(f"fwd/out_{dom}2", o["out2"], RTOL, ATOL)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES)
 def test_train_steps_match_reference(name):
     g, c, cfg, params = _setup(name)
     state = orc.TrainState(params=params, lr=c["lr"])
@@ -51,7 +53,7 @@ def test_train_steps_match_reference(name):
         state.lr = st["lr"]
         assert abs(st["p"] - g.z[f"step{s}/p"][0]) < 1e-15
         res = orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, clip=c["clip"],
-                             n_src=st["n_src"], n_tgt=st["n_tgt"])
+                             n_src=st["n_src"], n_tgt=st["n_tgt"], alpha=c["alpha"], mu=c["mu"])
         lr_next = orc.lr_dann(c["lr"], st["p"])
         assert abs(lr_next - g.z[f"step{s}/lr_after"][0]) < 1e-12
         for k in params:

@@ -30,9 +30,11 @@ from ta3n_amd.models import ARCH_FEATURE_DIM  # noqa: E402
 from ta3n_amd.opts import parser  # noqa: E402
 
 
-def validate_options(args) -> None:
+def validate_options(args, module_path: bool = False) -> None:
     """The engine implements the TA3N hot path and BASELINE configs[0]; every behaviour-changing value
-    outside it stops the run here - a silently ignored flag would train a different model than the command line says."""
+    outside it stops the run here - a silently ignored flag would train a different model than the command line says.
+    module_path: the caller assembles the loss from VideoModel.forward's tensors (main.py) - there the discrepancy losses
+    (--dis_DA DAN / JAN) and --ens_DA MCD are built as well."""
     bad = []
 
     def need(cond, msg):
@@ -44,8 +46,18 @@ def validate_options(args) -> None:
         need(args.use_attn == "none" and (args.add_loss_DA == "none" or args.use_target == "none"),
              "avgpool is built without attention / attentive entropy (--use_attn none --add_loss_DA none, as the reference's script runs it)")
     need(args.optimizer == "SGD", f"--optimizer {args.optimizer} (built: SGD with Nesterov momentum, main.py:83)")
-    need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses are not built)")
-    need(args.ens_DA == "none", f"--ens_DA {args.ens_DA}")
+    if module_path:
+        need(args.dis_DA in ("none", "DAN", "JAN"), f"--dis_DA {args.dis_DA} (built: DAN, JAN)")
+        need(args.ens_DA in ("none", "MCD"), f"--ens_DA {args.ens_DA}")
+        if args.dis_DA != "none" or args.ens_DA != "none":
+            need(args.frame_aggregation == "trn-m", "--dis_DA / --ens_DA are built for --frame_aggregation trn-m")
+        if args.dis_DA == "DAN":
+            need(len(args.place_dis) == args.add_fc + 2 and args.place_dis[2] == "N",
+                 "--place_dis takes add_fc + 2 values [logits, video feature, frame features]; the reference itself fails on the "
+                 "frame features (loss.py:49 on a 3-D tensor)")
+    else:
+        need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses: use main.py, the module path)")
+        need(args.ens_DA == "none", f"--ens_DA {args.ens_DA} (use main.py, the module path)")
     need(args.use_bn == "none", f"--use_bn {args.use_bn}")
     need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
     need(args.use_target in ("none", "uSv"), f"--use_target {args.use_target} (target labels in the classification loss are not built)")
@@ -59,7 +71,7 @@ def validate_options(args) -> None:
     need(args.share_params == "Y", "--share_params N")
     need(args.add_fc == 1, f"--add_fc {args.add_fc}")
     need(args.modality == "RGB", f"modality {args.modality} (pre-extracted RGB features)")
-    need(args.mu == 0, f"--mu {args.mu} (only used by the discrepancy losses)")
+    need(args.mu == 0 or (module_path and args.ens_DA == "MCD"), f"--mu {args.mu} (only used by --ens_DA MCD)")
     need(len(args.beta) == 3 and len(args.place_adv) == 3, "--beta and --place_adv take three values [relation, video, frame]")
     need(len(args.batch_size) >= 2, "-b needs at least the source and target batch sizes")
     need(args.arch in ARCH_FEATURE_DIM, f"--arch {args.arch}")
