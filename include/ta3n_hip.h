@@ -52,6 +52,13 @@ typedef enum {
  * the reference returns as feat[1], models.py:675) in addition to the logit gradients: entry point of the discrepancy losses
  * (dis_DA DAN / JAN, main.py:452-505).  Unfused entry points only; the region is zero after ta3n_init_workspace. */
 #define TA3N_FLAG_FEATURE_GRADS  (1u << 6)
+/* use_bn 'AdaBN' / 'AutoDIAL' (models.py:195-198, 490-543, 569-570): a BatchNorm1d per domain ("bn_shared_S", "bn_shared_T":
+ * weight and bias are parameters of the plan) between the shared frame FC and its ReLU.  Train mode: batch statistics over
+ * the domain's rows (region "bn_batch" [2 domains][3][F] = mean, biased variance, 1/sqrt(var + eps) for the caller's running
+ * averages); eval mode (hyper.train == 0): the statistics the caller wrote to region "bn_run" [2][2][F] = mean, variance.
+ * alpha = 1 (no source/target batch mixing: what the reference's own program always runs).  Unfused entry points only,
+ * TA3N_AGG_TRN_M only. */
+#define TA3N_FLAG_BN_SHARED      (1u << 7)
 /* Arithmetic of BASELINE.json configs[1]: every contraction rounds its two operands to bf16 (round to nearest
  * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and
  * everything outside the contractions (biases, softmax, losses, update) stay fp32.  Off = fp32 MFMA (configs[2]). */

@@ -114,6 +114,8 @@ class Config:
                                                       # models.py:617-618): for timing the CPU path fairly, no effect on any output
     dis_DA: str = "none"                              # 'DAN' | 'JAN' (opts.py:44; main.py:452-505): MMD losses on the feature list
     place_dis: Tuple[str, str, str] = ("N", "Y", "N")  # opts.py:65 (script_train_val.sh:148 passes N Y N); indexes feat = [Y, V, F1]
+    use_bn: str = "none"                              # 'AdaBN' | 'AutoDIAL' (opts.py; models.py:195-198, 490-543, 569-570): domain-specific
+                                                      # BatchNorm1d between the shared FC and its ReLU (alpha = 1: no batch mixing)
     ens_DA: str = "none"                              # 'MCD' (opts.py:49): second video classifier + a gradient-reversed second forward
     add_fc: int = 1
     bf16_twins: bool = True                           # bf16 only: operands are read from bf16 copies (TA3N_FLAG_BF16_STORE), so a bias
@@ -147,6 +149,10 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
         lin("fc_classifier_domain_video", 2, Fd)
         return s
     lin("fc_feature_shared_source", Fd, D)          # models.py:141
+    if cfg.use_bn != "none":                        # :195-196 (the other BatchNorm layers the option creates are never used with trn-m)
+        for bn in ("bn_shared_S", "bn_shared_T"):
+            s[bn + ".weight"] = (Fd,)
+            s[bn + ".bias"] = (Fd,)
     lin("fc_feature_source", Fd, Fd)                # :156  (never used in fwd)
     lin("fc_feature_domain", Fd, Fd)                # :161
     lin("fc_classifier_source", C, Fd)              # :166  (dead for baseline 'video')
@@ -328,14 +334,26 @@ def trans_attn(pred_domain):
     return 1 - ent
 
 
-def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu=None):
+def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu=None, domain="S", bn_running=None, bn_batch=None):
     """One domain's pass through VideoModel.forward (models.py:545-722) for the
     trn-m / video / TransAttn configuration.  x [B,T,D].  drop_i / drop_v are
     optional multiplicative dropout masks already scaled by 1/(1-p)
     ([B*T,F] and [B,256]); None means dropout off (eval or p=0).
     Returns dict with the reference's per-domain outputs."""
     B, T = x.size(0), cfg.num_segments
-    f = F.relu(_linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1)), cfg))   # :557-572
+    z0 = _linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1)), cfg)          # :565-566
+    if cfg.use_bn != "none":
+        # domainAlign 'shared' (:490-543, 569-570) with alpha = 1 (self.alpha is ones(1); AutoDIAL's Parameter never receives a
+        # gradient, it is read with .item()): no source/target mixing, each domain through its own BatchNorm1d.  bn_running =
+        # (mean, var): eval mode; else batch statistics (and bn_batch, a dict, receives them for the running-average update)
+        w, b_ = p[f"bn_shared_{domain}.weight"], p[f"bn_shared_{domain}.bias"]
+        if bn_running is not None:
+            z0 = F.batch_norm(z0, bn_running[0], bn_running[1], w, b_, training=False, eps=1e-5)
+        else:
+            if bn_batch is not None:
+                bn_batch[domain] = (z0.detach().mean(0), z0.detach().var(0, unbiased=True), z0.size(0))
+            z0 = F.batch_norm(z0, None, None, w, b_, training=True, eps=1e-5)
+    f = F.relu(z0)                                                                   # :572
     if drop_i is not None:
         f = f * drop_i                                                               # :574-575
     feat_frame = f.view(B, T, -1)                                                    # :578
@@ -535,11 +553,11 @@ def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config
         di_s, di_t = drop_i
     if drop_v is not None:
         dv_s, dv_t = drop_v
-    src = forward_domain(p, xs, beta, cfg, di_s, dv_s)
-    tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t)
+    src = forward_domain(p, xs, beta, cfg, di_s, dv_s, domain="S")
+    tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t, domain="T")
     tgt_rev = None
     if cfg.ens_DA == "MCD":      # main.py:550: the whole model once more with reverse=True; only the target outputs are used
-        tgt_rev = forward_domain(p, xt, beta, cfg, di_t, dv_t, reverse_mu=mu)
+        tgt_rev = forward_domain(p, xt, beta, cfg, di_t, dv_t, reverse_mu=mu, domain="T")
     loss, parts = total_loss(src, tgt, label_source, gamma, cfg, n_src, n_tgt, alpha=alpha, tgt_rev=tgt_rev)
     names = [k for k in p if is_live(k)]
     grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)

@@ -24,6 +24,7 @@ FLAG_ATTN_ENTROPY = 1 << 3
 FLAG_TRANS_ATTN = 1 << 4
 FLAG_MCD = 1 << 5              # ens_DA 'MCD': second video classifier (regions Y2 / gY2); unfused entry points
 FLAG_FEATURE_GRADS = 1 << 6    # backward also takes a gradient at the pooled video feature (region gV_ext): dis_DA DAN / JAN
+FLAG_BN_SHARED = 1 << 7        # use_bn AdaBN / AutoDIAL: BatchNorm1d per domain behind the shared frame FC (regions Z0, bn_batch, bn_run)
 FLAG_BF16_MFMA = 1 << 8
 FLAG_BF16_STORE = 1 << 9
 AGG_TRN_M, AGG_AVGPOOL = 0, 1

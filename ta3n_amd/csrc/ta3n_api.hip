@@ -76,6 +76,8 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
             case PH_POOL_CLS: rc = launch_pool_cls(p->geom, ptrs, stream); break;
             case PH_POOL_AVG_FWD: rc = launch_pool_avg_fwd(p->geom, ptrs, stream); break;
             case PH_POOL_AVG_BWD: rc = launch_pool_avg_bwd(p->geom, ptrs, stream); break;
+            case PH_BN_FWD: rc = launch_bn_shared_fwd(p->geom, ptrs, stream); break;
+            case PH_BN_BWD: rc = launch_bn_shared_bwd(p->geom, ptrs, stream); break;
             case PH_GRAD_NORM: rc = launch_grad_norm(p->geom, ptrs.g, ptrs.ws, stream); break;
             case PH_SGD: rc = launch_sgd(p->geom, params_rw, ptrs.g, momentum, ptrs.ws, stream); break;
             default: rc = -1;
@@ -292,6 +294,8 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
                 case PH_POOL_CLS: lrc = launch_pool_cls(p->geom, ptrs, s); break;
                 case PH_POOL_AVG_FWD: lrc = launch_pool_avg_fwd(p->geom, ptrs, s); break;
                 case PH_POOL_AVG_BWD: lrc = launch_pool_avg_bwd(p->geom, ptrs, s); break;
+                case PH_BN_FWD: lrc = launch_bn_shared_fwd(p->geom, ptrs, s); break;
+                case PH_BN_BWD: lrc = launch_bn_shared_bwd(p->geom, ptrs, s); break;
                 case PH_GRAD_NORM: lrc = launch_grad_norm(p->geom, grads, ws, s); break;
                 case PH_SGD: lrc = launch_sgd(p->geom, params, grads, momentum, ws, s); break;
                 default: lrc = -1;

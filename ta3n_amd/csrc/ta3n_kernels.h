@@ -115,6 +115,8 @@ int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream);   // TA3N_AGG_AVGPOOL: between F1 and gZ1
 int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_bn_shared_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

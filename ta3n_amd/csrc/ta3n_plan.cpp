@@ -777,6 +777,10 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    if (c.aggregation == TA3N_AGG_AVGPOOL && (c.flags & (TA3N_FLAG_MCD | TA3N_FLAG_FEATURE_GRADS | TA3N_FLAG_BN_SHARED))) {
+        err = "TA3N_FLAG_MCD / _FEATURE_GRADS / _BN_SHARED are built for TA3N_AGG_TRN_M";
+        return TA3N_ERR_INVALID;
+    }
     if (c.aggregation == TA3N_AGG_AVGPOOL)      // source-only: the fused fast path (BASELINE configs[0]); with adversarial branches: the general one
         return (c.flags & (TA3N_FLAG_ADV_RELATION | TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_FRAME)) ? build_plan_avgpool_general(p, err)
                                                                                                  : build_plan_avgpool(p, err);
@@ -822,6 +826,11 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     b.add_linear("fc_classifier_video_source", C, NB, true);           // :272
     const bool mcd = (c.flags & TA3N_FLAG_MCD) != 0;
     const bool feat_grads = (c.flags & TA3N_FLAG_FEATURE_GRADS) != 0;
+    const bool bn_shared = (c.flags & TA3N_FLAG_BN_SHARED) != 0;
+    if (bn_shared) {   // models.py:195-196 (nn.BatchNorm1d(feat_shared_dim) x 2): weight and bias are trained
+        b.add_param("bn_shared_S.weight", F, 0, true); b.add_param("bn_shared_S.bias", F, 0, true);
+        b.add_param("bn_shared_T.weight", F, 0, true); b.add_param("bn_shared_T.bias", F, 0, true);
+    }
     if (mcd) b.add_linear("fc_classifier_video_source_2", C, NB, true); // :276-279 (ens_DA MCD)
     lin("fc_classifier_domain_video", 2, NB, live_vid);                // :281
     p.live_floats = p.param_floats;
@@ -883,6 +892,14 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_gZ = (int32_t)b.add_region("gZ", (int64_t)B * NT * NB);
     g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
     if (feat_grads) g.o_gV_ext = (int32_t)b.add_region("gV_ext", (int64_t)B * NB);
+    if (bn_shared) {
+        g.o_Z0 = (int32_t)b.add_region("Z0", (int64_t)BT * F);
+        g.o_gZ0 = (int32_t)b.add_region("gZ0", (int64_t)BT * F);
+        g.o_bn_batch = (int32_t)b.add_region("bn_batch", (int64_t)2 * 3 * F);
+        g.o_bn_run = (int32_t)b.add_region("bn_run", (int64_t)2 * 2 * F);
+        g.p_bn_w[0] = (int32_t)P("bn_shared_S.weight"); g.p_bn_b[0] = (int32_t)P("bn_shared_S.bias");
+        g.p_bn_w[1] = (int32_t)P("bn_shared_T.weight"); g.p_bn_b[1] = (int32_t)P("bn_shared_T.bias");
+    }
     if (mcd) {
         g.o_Y2 = (int32_t)b.add_region("Y2", (int64_t)B * C);
         g.o_gY2 = (int32_t)b.add_region("gY2", (int64_t)B * C);
@@ -922,6 +939,11 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         GemmSpec s;
         s.M = BT; s.N = F;
         s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        if (bn_shared) {   // the linear output only: BatchNorm, ReLU and dropout follow in the PH_BN_FWD launch (models.py:565-575)
+            s.proto = proto(BASE_WS, g.o_Z0, F);
+            with_bias(s.proto, bsh);
+            return s;
+        }
         s.proto = proto(BASE_WS, g.o_F1, F);
         with_bias(s.proto, bsh);
         s.proto.epi |= EPI_RELU | EPI_DROP_I;
@@ -1106,7 +1128,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     auto push_shared_fc_wgrad = [&](std::vector<GemmSpec> &s) {   // shared frame FC weight grad (no input gradient: the features are data)
         GemmSpec gw;
         gw.M = F; gw.N = D;
-        gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ1, F), KM(BASE_X, 0, D), BT));
+        gw.segs.push_back(mkseg(KM(BASE_WS, bn_shared ? g.o_gZ0 : g.o_gZ1, F), KM(BASE_X, 0, D), BT));   // (behind the BatchNorm with use_bn)
         gw.proto = proto(BASE_G, Wsh, D);
         gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bsh;   // dbsh
         s.push_back(gw);
@@ -1114,6 +1136,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
 
     // ================= forward (group 0) =================
     { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(0, s); }
+    if (bn_shared) b.add_simple_phase(PH_BN_FWD, 0);
     {   // F2
         std::vector<GemmSpec> s{spec_Hf()};
         for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
@@ -1146,6 +1169,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     b.add_simple_phase(PH_POOL_BWD, 2);   // gPrT (attention path), gRa = (1+w) gVt, gHr
     { std::vector<GemmSpec> s; push_relation_level(s); b.add_gemm_phase(2, s); }    // Q5
     { std::vector<GemmSpec> s; push_trn_level(s); b.add_gemm_phase(2, s); }         // Q6
+    if (bn_shared) b.add_simple_phase(PH_BN_BWD, 2);
     { std::vector<GemmSpec> s; push_shared_fc_wgrad(s); b.add_gemm_phase(2, s); }   // Q7
     // ================= optimiser (group 3) =================
     b.add_simple_phase(PH_GRAD_NORM, 3);
@@ -1154,7 +1178,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // Same arithmetic in 7 launches instead of 15: everything between (Hr, Hf) and (gHr, gHf) - both
     // discriminator heads, the attention pooling, the classifier, the losses and their backward - is one
     // kernel (ta3n_heads.hip); its small weight gradients ride along with the relation level.
-    if (heads_supported(NB, C, F) && !mcd && !feat_grads) {   // (the fused heads kernel knows neither the second classifier nor an outside gradient)
+    if (heads_supported(NB, C, F) && !mcd && !feat_grads && !bn_shared) {   // (the fused heads kernel knows neither the second classifier nor an outside gradient)
         { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(4, s); }
         {
             std::vector<GemmSpec> s{spec_Hf()};

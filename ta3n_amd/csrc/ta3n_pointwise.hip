@@ -608,6 +608,109 @@ int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---- use_bn AdaBN / AutoDIAL: BatchNorm1d per domain between the shared frame FC and its ReLU (models.py:490-543, 569-570) ----
+// One workgroup = 16 feature columns of one domain (blockIdx.y: 0 source rows [0, Bs T), 1 target rows [Bs T, B T)); thread
+// (r, c) = (threadIdx.x / 16, threadIdx.x % 16) walks rows r, r + 16, ...  Statistics as torch's CPU kernel takes them: the
+// mean first, then the sum of squared deviations (two passes); eps = 1e-5 (nn.BatchNorm1d default).
+constexpr float BN_EPS = 1e-5f;
+
+__device__ __forceinline__ float bn_colsum16(float v, float *red) {      // sum over the 16 row lanes of this thread's column
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    __syncthreads();
+    red[r * 16 + c] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i * 16 + c];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
+    __shared__ float red[256];
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
+    float *__restrict__ ws = ptrs.ws;
+    const int dom = blockIdx.y, r = threadIdx.x >> 4, c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
+    if (n == 0) return;
+    const bool col_ok = c < F;
+    const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
+    float mean, var, invstd;
+    if (hy->train) {
+        float sacc = 0.f;
+        if (col_ok) for (int i = r; i < n; i += 16) sacc += z[(size_t)i * F + c];
+        mean = bn_colsum16(sacc, red) / (float)n;
+        float q = 0.f;
+        if (col_ok) for (int i = r; i < n; i += 16) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
+        var = bn_colsum16(q, red) / (float)n;
+        invstd = 1.f / sqrtf(var + BN_EPS);
+        if (col_ok && r == 0) {
+            float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
+            st[c] = mean; st[F + c] = var; st[2 * F + c] = invstd;
+        }
+    } else {
+        const float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
+        mean = col_ok ? run[c] : 0.f;
+        var = col_ok ? run[F + c] : 1.f;
+        invstd = 1.f / sqrtf(var + BN_EPS);
+    }
+    if (!col_ok) return;
+    const float w = ptrs.p[g.p_bn_w[dom] + c], b = ptrs.p[g.p_bn_b[dom] + c];
+    const bool drop = hy->train && hy->p_drop_i > 0.f;
+    const float inv_keep = hyper_scale(hy, SK_INV_KEEP_I);
+    float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
+    for (int i = r; i < n; i += 16) {
+        float y = fmaf((z[(size_t)i * F + c] - mean) * invstd, w, b);
+        y = fmaxf(y, 0.f);
+        if (drop) y *= keep_mask(hy->seed_i, (uint32_t)((row0 + i) * F + c), hy->p_drop_i);
+        out[(size_t)i * F + c] = y * inv_keep;
+    }
+}
+
+// gZ1 = dL/d(BatchNorm output) (ReLU mask and dropout already applied by the launch that made it)  ->
+// d weight = sum g xhat, d bias = sum g, gZ0 = weight invstd (g - mean(g) - xhat mean(g xhat))   (train mode)
+__global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
+    __shared__ float red[256];
+    float *__restrict__ ws = ptrs.ws;
+    const int dom = blockIdx.y, r = threadIdx.x >> 4, c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
+    if (n == 0) return;
+    const bool col_ok = c < F;
+    const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
+    const float *__restrict__ gy = ws + g.o_gZ1 + (size_t)row0 * F;
+    const float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
+    const float mean = col_ok ? st[c] : 0.f, invstd = col_ok ? st[2 * F + c] : 0.f;
+    float sg = 0.f, sgx = 0.f;
+    if (col_ok)
+        for (int i = r; i < n; i += 16) {
+            const float gv = gy[(size_t)i * F + c];
+            sg += gv;
+            sgx = fmaf(gv, (z[(size_t)i * F + c] - mean) * invstd, sgx);
+        }
+    sg = bn_colsum16(sg, red);
+    sgx = bn_colsum16(sgx, red);
+    if (!col_ok) return;
+    if (r == 0) {
+        ptrs.g[g.p_bn_w[dom] + c] = sgx;
+        ptrs.g[g.p_bn_b[dom] + c] = sg;
+    }
+    const float w = ptrs.p[g.p_bn_w[dom] + c];
+    const float k = w * invstd, mg = sg / (float)n, mgx = sgx / (float)n;
+    float *__restrict__ out = ws + g.o_gZ0 + (size_t)row0 * F;
+    for (int i = r; i < n; i += 16) {
+        const float xh = (z[(size_t)i * F + c] - mean) * invstd;
+        out[(size_t)i * F + c] = k * (gy[(size_t)i * F + c] - mg - xh * mgx);
+    }
+}
+
+int launch_bn_shared_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_shared_fwd_kernel, dim3((g.F + 15) / 16, 2), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_shared_bwd_kernel, dim3((g.F + 15) / 16, 2), dim3(256), 0, stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     hipLaunchKernelGGL(pool_avg_bwd_kernel, dim3(g.B * g.T), dim3(256), 0, stream, g, ptrs, g.o_gHf < 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;

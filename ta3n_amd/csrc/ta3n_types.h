@@ -84,6 +84,8 @@ enum PhaseKind : int32_t {
     PH_POOL_CLS = 7,         // TA3N_AGG_AVGPOOL, source-only fused: mean over segments, dropout, classifier, CE and the way back to gZ1
     PH_POOL_AVG_FWD = 8,     // TA3N_AGG_AVGPOOL, general: V = mean over the segments of F1, Vd = dropout_v(V)
     PH_POOL_AVG_BWD = 9,     // TA3N_AGG_AVGPOOL, general: gradient at V spread back over the segments (-> gZ1 or its additive base)
+    PH_BN_FWD = 10,          // TA3N_FLAG_BN_SHARED: F1 = dropout_i(relu(BatchNorm_domain(Z0)))
+    PH_BN_BWD = 11,          // ... and back: gZ0, d(bn weight), d(bn bias) from gZ1
 };
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these
@@ -141,6 +143,9 @@ struct Geom {
     int32_t o_ws16, o_p16, o_x16, ws16_span;   // ws16 mirrors ws[0 .. ws16_span)
     int32_t o_gV_ext;                    // TA3N_FLAG_FEATURE_GRADS: caller-written gradient at V, added to gVt by the pooling backward (0: none)
     int32_t o_Y2, o_gY2;                 // TA3N_FLAG_MCD: second classifier's logits / logit gradients (0: none)
+    // TA3N_FLAG_BN_SHARED: linear output before / gradient behind the domain BatchNorm, batch and running statistics, parameters
+    int32_t o_Z0, o_gZ0, o_bn_batch, o_bn_run;
+    int32_t p_bn_w[2], p_bn_b[2];        // [source, target]
 };
 
 }  // namespace ta3n

@@ -70,7 +70,21 @@ class _HipForward(torch.autograd.Function):
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
+        bn = model.use_bn != 'none'
+        if bn and not train:                 # eval mode: the running statistics go to the kernel (region "bn_run" [S, T][mean, var][F])
+            off, n = plan.region("bn_run")
+            ws[off:off + n].copy_(torch.stack((model.bn_shared_S.running_mean, model.bn_shared_S.running_var,
+                                               model.bn_shared_T.running_mean, model.bn_shared_T.running_var)).reshape(-1))
         _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
+        if bn and train:                     # nn.BatchNorm1d's buffer update (momentum 0.1, unbiased batch variance), from the kernel's
+            off, n = plan.region("bn_batch")  # batch statistics [S, T][mean, biased var, 1/std][F]
+            st = ws[off:off + n].view(2, 3, -1)
+            for d, (mod, rows) in enumerate(((model.bn_shared_S, Bs * model.train_segments), (model.bn_shared_T, Bt * model.train_segments))):
+                if rows > 0:
+                    with torch.no_grad():
+                        mod.running_mean.mul_(0.9).add_(st[d, 0], alpha=0.1)
+                        mod.running_var.mul_(0.9).add_(st[d, 1] * (rows / max(rows - 1, 1)), alpha=0.1)
+                        mod.num_batches_tracked += 1
         ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
         ctx.n_params = len(params)
         B, T, NR, Cn = Bs + Bt, model.train_segments, model.train_segments - 1, model.num_class
@@ -221,7 +235,8 @@ class VideoModel(nn.Module):
             unsupported.append("frame_aggregation='avgpool' with use_attn (the reference's script runs TemPooling with use_attn none)")
         if baseline_type != 'video': unsupported.append(f"baseline_type={baseline_type!r}")
         if share_params != 'Y': unsupported.append("share_params='N'")
-        if use_bn != 'none': unsupported.append(f"use_bn={use_bn!r}")
+        if use_bn not in ('none', 'AdaBN', 'AutoDIAL'): unsupported.append(f"use_bn={use_bn!r}")
+        if use_bn != 'none' and frame_aggregation != 'trn-m': unsupported.append("use_bn with frame_aggregation other than 'trn-m'")
         if ens_DA not in ('none', 'MCD'): unsupported.append(f"ens_DA={ens_DA!r}")
         if ens_DA == 'MCD' and frame_aggregation != 'trn-m': unsupported.append("ens_DA='MCD' with frame_aggregation other than 'trn-m'")
         if use_attn not in ('TransAttn', 'none'): unsupported.append(f"use_attn={use_attn!r}")
@@ -266,6 +281,11 @@ class VideoModel(nn.Module):
 
         self.fc_feature_shared_source = lin(self.feature_dim, F_)        # :141
         self.fc_feature_source = lin(F_, F_)                             # :156 (unused in forward, kept for checkpoints)
+        if use_bn != 'none':                                             # :194-198 AdaBN (ICLRW 2017): BN for source / target
+            self.bn_shared_S = nn.BatchNorm1d(F_)                        # the two the trn-m forward uses (:515-516, 569-570)
+            self.bn_shared_T = nn.BatchNorm1d(F_)
+            self.bn_source_S = nn.BatchNorm1d(F_)                        # created by the reference, never used on this path
+            self.bn_source_T = nn.BatchNorm1d(F_)
         self.fc_feature_domain = lin(F_, F_)                             # :161
         self.fc_classifier_source = lin(F_, num_class)                   # :166 (dead for baseline_type='video')
         self.fc_classifier_domain = lin(F_, 2)                           # :170
@@ -287,7 +307,14 @@ class VideoModel(nn.Module):
         if not self._avg:
             self.relation_domain_classifier_all = nn.ModuleList(         # :286-294 (default init)
                 nn.Sequential(nn.Linear(NB, NB), nn.ReLU(), nn.Linear(NB, 2)) for _ in range(train_segments - 1))
+        if use_bn != 'none':                                             # :307-312 (unused with trn-m)
+            self.bn_source_video_S = nn.BatchNorm1d(A)
+            self.bn_source_video_T = nn.BatchNorm1d(A)
+            self.bn_source_video_2_S = nn.BatchNorm1d(A)
+            self.bn_source_video_2_T = nn.BatchNorm1d(A)
         self.alpha = torch.ones(1)                                       # :314 plain attribute
+        if use_bn == 'AutoDIAL':                                         # :315-316; read with .item() in forward: it never gets a gradient
+            self.alpha = nn.Parameter(self.alpha)
         self.relu = nn.ReLU(inplace=True)
         self.dropout_i = nn.Dropout(p=dropout_i)                         # kept as attributes; the HIP kernels apply them
         self.dropout_v = nn.Dropout(p=dropout_v)
@@ -320,6 +347,7 @@ class VideoModel(nn.Module):
         return (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME |
                 (_lib.FLAG_TRANS_ATTN if self._attn_on else 0) |
                 _lib.FLAG_FEATURE_GRADS |                                   # feat[1] may carry a discrepancy loss (dis_DA)
+                (_lib.FLAG_BN_SHARED if self.use_bn != 'none' else 0) |
                 (_lib.FLAG_MCD if self.ens_DA == 'MCD' else 0))
 
     def _plan(self, Bs: int, Bt: int) -> _lib.Plan:
@@ -402,6 +430,9 @@ class VideoModel(nn.Module):
             raise _lib.Ta3nError("ta3n_amd.VideoModel.forward needs a HIP device; there is no CPU fallback")
         if reverse and self._avg:
             raise NotImplementedError("reverse=True (the MCD step's second forward, main.py:549) with frame_aggregation='avgpool'")
+        if self.use_bn != 'none' and float(self.alpha) != 1.0:
+            raise NotImplementedError("use_bn with alpha != 1 (source/target batch mixing of domainAlign, models.py:497-508, 531-533): the "
+                                      "reference's own program never changes alpha from its initial 1")
         num_segments = self.train_segments if is_train else self.val_segments
         if num_segments != self.train_segments:
             raise ValueError("val_segments must equal num_segments (static launch plans; TRN needs it anyway, models.py:222)")

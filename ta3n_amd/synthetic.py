@@ -25,7 +25,9 @@ def synth_state(shapes: Dict[str, Tuple[int, ...]], seed: int = 7, scale: str = 
     for name, shp in sorted(shapes.items()):
         if len(shp) == 0 or "running_" in name or "num_batches" in name:
             continue
-        if name.startswith("bn_"):
+        if name == "alpha":           # use_bn='AutoDIAL' (models.py:314-316): initialised to one and never trained (it is read with
+            arr = np.ones(shp)        # .item(), so it has no gradient); no draw, so the other tensors do not depend on the option
+        elif name.startswith("bn_"):
             arr = np.ones(shp) if name.endswith("weight") else np.zeros(shp)
         elif name.endswith(".weight"):
             std = 1.0 / math.sqrt(shp[1]) if scale == "trained" else 0.001

@@ -80,7 +80,7 @@ def build_model(case):
     avg = case.get("agg", "trn-m") == "avgpool"       # BASELINE configs[0]: TemPooling, source-only (script_train_val.sh:103-119)
     m = RefVideoModel(case["C"], "video", "avgpool" if avg else "trn-m", "RGB", train_segments=case["T"], val_segments=case["T"],
                       base_model=case["arch"], add_fc=1, fc_dim=case["fc_dim"], dropout_i=0.0, dropout_v=0.0,
-                      partial_bn=False, use_bn="none", ens_DA=case.get("ens_DA", "none"), use_attn="none" if avg else "TransAttn", n_attn=1,
+                      partial_bn=False, use_bn=case.get("use_bn", "none"), ens_DA=case.get("ens_DA", "none"), use_attn="none" if avg else "TransAttn", n_attn=1,
                       use_attn_frame="none", verbose=False, share_params="Y")
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = m.state_dict()
@@ -200,6 +200,18 @@ def run_case(name, case):
             if v.grad is not None:
                 put(store, f"step{s}/clipped_grad/{k}", v.grad)
             put(store, f"step{s}/param/{k}", v)
+    if case.get("use_bn", "none") != "none":
+        # AdaBN / AutoDIAL (models.py:490-543, 569-570): the running statistics after the train-mode passes above (the plain
+        # forward of (1) counts as one: BatchNorm updates its buffers whenever it runs in train mode) and an eval-mode forward
+        # through them (main.validate's call, main.py:707)
+        for k, v in model.state_dict().items():
+            if "bn_shared" in k:
+                put(store, f"final/state/{k}", v.double() if v.dtype != torch.float32 else v)
+        model.eval()
+        with torch.no_grad():
+            ev = model(xs, xs, [0, 0, 0], 0, False, False)
+        put(store, "eval/out_t", ev[6]); put(store, "eval/feat_t_v", ev[9][1])
+        model.train()
     meta["live"] = [k for k, v in model.named_parameters() if v.grad is not None]
     meta["log"] = log.getvalue()
     store["meta/live"] = np.array(meta["live"])
@@ -261,6 +273,13 @@ CASES = {
                      dis_DA="JAN", alpha=1.0),
     "tiny_mcd": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=24, wscale="trained", xseed=204, steps=2, lr=2e-3,
                      ens_DA="MCD", mu=0.5),
+    # use_bn AdaBN / AutoDIAL (models.py:195-198, 490-543, 569-570): domain-specific BatchNorm between the shared FC and its ReLU
+    "tiny_adabn": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=26, wscale="trained", xseed=206, steps=3,
+                       short_last=(5, 3), lr=2e-3, use_bn="AdaBN"),
+    "tiny_autodial": dict(arch="resnet18", fc_dim=32, T=3, C=5, Bs=4, Bt=5, wseed=27, wscale="trained", xseed=207, steps=2, lr=2e-3,
+                          use_bn="AutoDIAL"),
+    "mid_adabn": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=28, wscale="trained", xseed=208, steps=2,
+                      lr=2e-3, use_bn="AdaBN"),
     "mid_dan_mcd": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=25, wscale="trained", xseed=205, steps=2,
                         lr=2e-3, dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=1.0, ens_DA="MCD", mu=1.0),
 }

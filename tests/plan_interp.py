@@ -16,7 +16,8 @@ from ta3n_amd import _lib
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_COLSUM = 1 << 12
-PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS, PH_POOL_AVG_FWD, PH_POOL_AVG_BWD = range(10)
+(PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS, PH_POOL_AVG_FWD, PH_POOL_AVG_BWD,
+ PH_BN_FWD, PH_BN_BWD) = range(12)
 HEADS_RPW = 16
 
 
@@ -54,7 +55,8 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "o_tuple_first", "n_norm_blocks", "live_floats", "p_W2_0", "p_b2_0", "p_W2_stride", "p_b2_stride",
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
-                "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2"]
+                "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2", "o_Z0", "o_gZ0", "o_bn_batch", "o_bn_run",
+                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1"]
 
 
 class Geom(C.Structure):
@@ -358,6 +360,47 @@ class Interp:
         self.r(g.o_gPr, (B * NR, 2))[:] = gPr; self.r(g.o_gPf, (B * T, 2))[:] = gPf
         self.ws[g.o_losses:g.o_losses + 6] = [l_cls + l_rel + l_vid + l_frm + h["gamma"] * l_ent, l_cls, l_rel, l_vid, l_frm, l_ent]
 
+    def _bn_rows(self, dom):
+        g = self.g
+        return (0, g.Bs * g.T) if dom == 0 else (g.Bs * g.T, g.Bt * g.T)
+
+    def run_bn_fwd(self):
+        """bn_shared_fwd_kernel: F1 = dropout_i(relu(BatchNorm_domain(Z0))), batch statistics to region bn_batch."""
+        g, h = self.g, self.hy
+        F, BT = g.F, g.B * g.T
+        Z0 = self.r(g.o_Z0, (BT, F)); F1 = self.r(g.o_F1, (BT, F))
+        for dom, (pw, pb) in enumerate(((g.p_bn_w0, g.p_bn_b0), (g.p_bn_w1, g.p_bn_b1))):
+            r0, n = self._bn_rows(dom)
+            if n == 0:
+                continue
+            z = Z0[r0:r0 + n]
+            if h["train"]:
+                mean = z.mean(0); var = ((z - mean) ** 2).mean(0); inv = 1.0 / np.sqrt(var + 1e-5)
+                st = self.r(g.o_bn_batch + dom * 3 * F, (3, F)); st[0] = mean; st[1] = var; st[2] = inv
+            else:
+                run = self.r(g.o_bn_run + dom * 2 * F, (2, F)); mean = run[0]; inv = 1.0 / np.sqrt(run[1] + 1e-5)
+            y = np.maximum((z - mean) * inv * self.P[pw:pw + F] + self.P[pb:pb + F], 0)
+            if h["train"] and h["p_drop_i"] > 0:
+                idx = (np.arange(r0, r0 + n)[:, None] * F + np.arange(F)[None, :])
+                y = y * keep_mask(h["seed_i"], idx, h["p_drop_i"])
+            F1[r0:r0 + n] = y * self.scale(4)
+
+    def run_bn_bwd(self):
+        """bn_shared_bwd_kernel: gZ0 and the BatchNorm weight / bias gradients from gZ1 (train mode)."""
+        g = self.g
+        F, BT = g.F, g.B * g.T
+        Z0 = self.r(g.o_Z0, (BT, F)); gy = self.r(g.o_gZ1, (BT, F)); gZ0 = self.r(g.o_gZ0, (BT, F))
+        for dom, (pw, pb) in enumerate(((g.p_bn_w0, g.p_bn_b0), (g.p_bn_w1, g.p_bn_b1))):
+            r0, n = self._bn_rows(dom)
+            if n == 0:
+                continue
+            st = self.r(g.o_bn_batch + dom * 3 * F, (3, F))
+            xh = (Z0[r0:r0 + n] - st[0]) * st[2]
+            gg = gy[r0:r0 + n]
+            sg, sgx = gg.sum(0), (gg * xh).sum(0)
+            self.G[pw:pw + F] = sgx; self.G[pb:pb + F] = sg
+            gZ0[r0:r0 + n] = self.P[pw:pw + F] * st[2] * (gg - sg / n - xh * sgx / n)
+
     def run_pool_bwd(self):
         g = self.g
         B, NR, NB = g.B, g.n_rel, g.NB
@@ -447,5 +490,7 @@ class Interp:
             elif ph.kind == PH_POOL_CLS: self.run_pool_cls()
             elif ph.kind == PH_POOL_AVG_FWD: self.run_pool_avg_fwd()
             elif ph.kind == PH_POOL_AVG_BWD: self.run_pool_avg_bwd()
+            elif ph.kind == PH_BN_FWD: self.run_bn_fwd()
+            elif ph.kind == PH_BN_BWD: self.run_bn_bwd()
             elif ph.kind == PH_GRAD_NORM: pass
             elif ph.kind == PH_SGD: self.run_sgd(fused_norm)

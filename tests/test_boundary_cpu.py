@@ -42,7 +42,14 @@ def test_constructor_rejects_what_is_not_the_hot_path():
     with pytest.raises(NotImplementedError):
         VideoModel(12, 'frame', 'trn-m', 'RGB', verbose=False)
     with pytest.raises(NotImplementedError):
-        VideoModel(12, 'video', 'trn-m', 'RGB', use_bn='AdaBN', verbose=False)
+        VideoModel(12, 'video', 'avgpool', 'RGB', use_attn='none', use_bn='AdaBN', verbose=False)      # use_bn / ens_DA: trn-m only
+    with pytest.raises(NotImplementedError):
+        VideoModel(12, 'video', 'rnn', 'RGB', verbose=False)
+    # built options of the DA tables construct and carry the reference's extra state_dict entries
+    m = VideoModel(12, 'video', 'trn-m', 'RGB', use_bn='AutoDIAL', ens_DA='MCD', fc_dim=64, base_model='resnet18', verbose=False)
+    keys = set(m.state_dict())
+    assert {"bn_shared_S.running_var", "bn_shared_T.weight", "bn_source_video_2_T.bias", "alpha",
+            "fc_classifier_video_source_2.weight"} <= keys
     with pytest.raises(ValueError):
         VideoModel(12, 'video', 'trn-m', 'RGB', add_fc=0, verbose=False)       # models.py:137-138
 

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import DA_EXTRA_CASES, Golden, case_config, step_schedule
+from golden_util import BN_CASES, DA_EXTRA_CASES, Golden, case_config, step_schedule
 from ta3n_amd.synthetic import synth_batch, synth_state
 
 pytestmark = pytest.mark.gpu
@@ -55,7 +55,7 @@ class _FakeDP:      # main.train uses model.module, model.train(), model(...), m
         return self.module.parameters()
 
 
-@pytest.mark.parametrize("name", DA_EXTRA_CASES)
+@pytest.mark.parametrize("name", DA_EXTRA_CASES + BN_CASES)
 def test_main_train_with_discrepancy_and_ensemble_losses_matches_the_reference(name):
     from ta3n_amd.models import VideoModel
     main = _load_main()
@@ -64,7 +64,7 @@ def test_main_train_with_discrepancy_and_ensemble_losses_matches_the_reference(n
     T, C = c["T"], c["C"]
     arch = str(g.meta("arch"))
     model = VideoModel(C, "video", "trn-m", "RGB", train_segments=T, val_segments=T, base_model=arch, add_fc=1, fc_dim=c["fc_dim"],
-                       dropout_i=0.0, dropout_v=0.0, partial_bn=False, use_bn="none", ens_DA=c["ens_DA"], use_attn="TransAttn",
+                       dropout_i=0.0, dropout_v=0.0, partial_bn=False, use_bn=c["use_bn"], ens_DA=c["ens_DA"], use_attn="TransAttn",
                        verbose=False).cuda()
     sd = model.state_dict()
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
@@ -79,8 +79,18 @@ def test_main_train_with_discrepancy_and_ensemble_losses_matches_the_reference(n
     n_steps = c["steps"]
     log, log_short = io.StringIO(), io.StringIO()
     live = set(str(k) for k in g.meta("live"))
+    bn = c["use_bn"] != "none"
+    xs0, xt0, _, _ = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    if bn:      # the fixture's plain train-mode forward comes first and moves the BatchNorm buffers like any train-mode pass
+        model.train()
+        with torch.no_grad():
+            o = model(xs0.cuda(), xt0.cuda(), [0.75, 0.75, 0.5], 0, True, False)
+        g.check("fwd/out_s", o[1], 2e-4, 2e-4)
+        g.check("fwd/feat_t_v", o[9][1], 2e-4, 2e-4)
     for s, st in enumerate(step_schedule(c)):
         xs, xt, ys, yt = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        if st["n_src"] < c["Bs"] or st["n_tgt"] < c["Bt"]:       # a short last batch: main.train pads it back with zero rows (main.py:359-364)
+            xs, ys, xt, yt = xs[:st["n_src"]], ys[:st["n_src"]], xt[:st["n_tgt"]], yt[:st["n_tgt"]]
         args.epochs = 30 * n_steps
         main.train(C, [(xs, ys)], [(xt, yt)], wrapped, crit, crit_d, opt, n_steps + s, log, log_short, c["alpha"],
                    [0.75, 0.75, 0.5], 0.003, c["mu"])
@@ -91,6 +101,18 @@ def test_main_train_with_discrepancy_and_ensemble_losses_matches_the_reference(n
             if k in live:
                 g.check(f"step{s}/clipped_grad/{k}", v.grad, 2e-4, 5e-6, rms_atol=2e-4)
             g.check(f"step{s}/param/{k}", v, 2e-4, 5e-6)
+    if bn:      # buffers after one plain + n_steps train-mode passes, then main.validate's eval-mode forward through them
+        sd = model.state_dict()
+        for d in "ST":
+            g.check(f"final/state/bn_shared_{d}.running_mean", sd[f"bn_shared_{d}.running_mean"], 2e-4, 2e-5)
+            g.check(f"final/state/bn_shared_{d}.running_var", sd[f"bn_shared_{d}.running_var"], 2e-4, 2e-5)
+            assert int(sd[f"bn_shared_{d}.num_batches_tracked"]) == int(g.z[f"final/state/bn_shared_{d}.num_batches_tracked#full"])
+        model.eval()
+        with torch.no_grad():
+            ev = model(xs0.cuda(), xs0.cuda(), [0, 0, 0], 0, False, False)
+        g.check("eval/out_t", ev[6], 3e-4, 3e-4)
+        g.check("eval/feat_t_v", ev[9][1], 3e-4, 3e-4)
+        model.train()
     # the loss components the reference logged (running averages over the steps of one "epoch" = one step each here)
     want, got = str(g.meta("log")).strip().splitlines(), log.getvalue().strip().splitlines()
     assert len(want) == len(got) == n_steps

@@ -4,7 +4,7 @@ the clipped gradients / updated parameters / DANN LR of main.train."""
 import pytest
 import torch
 
-from golden_util import AVG_CASES, CASES, DA_EXTRA_CASES, Golden, case_config, step_schedule
+from golden_util import AVG_CASES, BN_CASES, CASES, DA_EXTRA_CASES, Golden, case_config, step_schedule
 from oracle import ta3n_oracle as orc
 from ta3n_amd.synthetic import synth_batch, synth_state
 
@@ -15,19 +15,20 @@ def _setup(name):
     g = Golden(name)
     c = case_config(g)
     cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"],
-                     dropout_i=0.0, dropout_v=0.0, dis_DA=c["dis_DA"], place_dis=c["place_dis"], ens_DA=c["ens_DA"])
+                     dropout_i=0.0, dropout_v=0.0, dis_DA=c["dis_DA"], place_dis=c["place_dis"], ens_DA=c["ens_DA"],
+                     use_bn=c["use_bn"])
     params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
     return g, c, cfg, params
 
 
-@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES)
+@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES + BN_CASES)
 def test_forward_matches_reference(name):
     g, c, cfg, params = _setup(name)
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
     beta = [0.75, 0.75, 0.5]
     with torch.no_grad():
-        s = orc.forward_domain(params, xs, beta, cfg)
-        t = orc.forward_domain(params, xt, beta, cfg)
+        s = orc.forward_domain(params, xs, beta, cfg, domain="S")
+        t = orc.forward_domain(params, xt, beta, cfg, domain="T")
     for dom, o in (("s", s), ("t", t)):
         g.check(f"fwd/attn_{dom}", o["attn"], RTOL, ATOL)
         g.check(f"fwd/out_{dom}", o["out"], RTOL, ATOL)
@@ -39,7 +40,48 @@ def test_forward_matches_reference(name):
             g.check(f"fwd/out_{dom}2", o["out2"], RTOL, ATOL)
 
 
-@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES)
+@pytest.mark.parametrize("name", BN_CASES)
+def test_adabn_running_statistics_and_eval_forward_match_reference(name):
+    """The reference's BatchNorm buffers after its train-mode passes (one plain forward + the train steps: momentum 0.1,
+    unbiased batch variance, zero-padded dummy rows included - main.py:359-364 pads before the model) and an eval-mode forward
+    through them."""
+    g, c, cfg, params = _setup(name)
+    state = orc.TrainState(params=params, lr=c["lr"])
+    F_ = cfg.feat_dim
+    run = {d: [torch.zeros(F_), torch.ones(F_)] for d in "ST"}
+
+    def update(batch):
+        for d, (m, v, n) in batch.items():
+            run[d][0] = 0.9 * run[d][0] + 0.1 * m
+            run[d][1] = 0.9 * run[d][1] + 0.1 * v
+    xs0, xt0, _, _ = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    with torch.no_grad():                      # make_golden's plain forward (train mode)
+        b = {}
+        orc.forward_domain(state.params, xs0, [0.75, 0.75, 0.5], cfg, domain="S", bn_batch=b)
+        orc.forward_domain(state.params, xt0, [0.75, 0.75, 0.5], cfg, domain="T", bn_batch=b)
+        update(b)
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs = xs.clone(); xt = xt.clone()
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        with torch.no_grad():
+            b = {}
+            orc.forward_domain(state.params, xs, [0.75, 0.75, 0.5], cfg, domain="S", bn_batch=b)
+            orc.forward_domain(state.params, xt, [0.75, 0.75, 0.5], cfg, domain="T", bn_batch=b)
+            update(b)
+        state.lr = st["lr"]
+        orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, clip=c["clip"], n_src=st["n_src"], n_tgt=st["n_tgt"])
+    for d in "ST":
+        g.check(f"final/state/bn_shared_{d}.running_mean", run[d][0], 5e-5, 5e-6)
+        g.check(f"final/state/bn_shared_{d}.running_var", run[d][1], 5e-5, 5e-6)
+        g.check(f"final/state/bn_shared_{d}.weight", state.params[f"bn_shared_{d}.weight"], 5e-5, 5e-6)
+    with torch.no_grad():                      # main.validate: the data in both slots, eval mode -> the target slot uses bn_shared_T
+        ev = orc.forward_domain(state.params, xs0, [0.0, 0.0, 0.0], cfg, domain="T", bn_running=run["T"])
+    g.check("eval/out_t", ev["out"], 1e-4, 1e-5)
+    g.check("eval/feat_t_v", ev["feat"][1], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("name", CASES + DA_EXTRA_CASES + BN_CASES)
 def test_train_steps_match_reference(name):
     g, c, cfg, params = _setup(name)
     state = orc.TrainState(params=params, lr=c["lr"])

@@ -58,7 +58,11 @@ def validate_options(args, module_path: bool = False) -> None:
     else:
         need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses: use main.py, the module path)")
         need(args.ens_DA == "none", f"--ens_DA {args.ens_DA} (use main.py, the module path)")
-    need(args.use_bn == "none", f"--use_bn {args.use_bn}")
+    if module_path:
+        need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
+        need(args.use_bn == "none" or args.frame_aggregation == "trn-m", "--use_bn is built for --frame_aggregation trn-m")
+    else:
+        need(args.use_bn == "none", f"--use_bn {args.use_bn} (use main.py, the module path)")
     need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
     need(args.use_target in ("none", "uSv"), f"--use_target {args.use_target} (target labels in the classification loss are not built)")
     need(args.weighted_class_loss == "N", "--weighted_class_loss Y")
