@@ -100,7 +100,7 @@ except Exception as e:
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
-@pytest.mark.parametrize("flags", [TA3N, CONFIGS0])
+@pytest.mark.parametrize("flags", [TA3N, CONFIGS0, TA3N_ALL_DA], ids=["ta3n", "configs0", "ta3n_all_da"])
 def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path, flags):
     data = make_dataset(str(tmp_path / "data"), videos=(8, 6, 4))
     argv = [data[0], "RGB", data[1], data[2], data[3], "--exp_path", str(tmp_path / "exp") + "/", *flags, *COMMON]
