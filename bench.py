@@ -25,6 +25,7 @@ CPU path) on a bounded sample on this host.
 import argparse
 import gc
 import json
+import math
 import os
 import sys
 import time
@@ -313,6 +314,7 @@ def main():
         res["fused"] = eng.fused
         # live per-launch timing of the dominant kernel (the tile-list GEMM), HIP events on the launch stream
         phases = eng.time_phases(args.phase_reps)
+        gemm_plain_ms = sum(p[3] for p in phases if p[0] == 0)       # the six GEMM launches without the update riding in the first
         side_update = False
         if pipelined and eng._side_update and world == 1 and not selftest:
             # the timed loop ran ta3n_train_step_after_update: its first two launches are the shared-FC update and the first GEMM
@@ -330,7 +332,8 @@ def main():
         extra = {"kernel": f"ta3n::gemm_tiles ({len(gemm)} launches/step" + (" and stream)" if n_streams > 1 else ")"), "launches": len(gemm),
                  "flops_per_launch": flops / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
                  "all_kernels_us": 1e3 * sum(p[3] for p in phases), "traffic": traffic,
-                 "traffic_unit": "bytes per GEMM launch: rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (tools/measure_traffic.py)",
+                 "traffic_unit": "bytes per GEMM launch: rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE (tools/measure_traffic.py; the PMC passes "
+                                 "run the step with the update as its own kernel, so this compares with gemm_only.bytes_per_launch)",
                  "traffic_source": traffic_src,
                  "per_phase_us": [[p[0], p[1], p[2], round(1e3 * p[3], 2)] for p in phases],
                  "per_phase_note": "[kind (0 GEMM, 5 optimiser, 6 heads), tile, workgroups, us]; HIP events on the launch stream" +
@@ -340,10 +343,27 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": tflops / PEAK_FP32_MFMA_TFLOPS, **extra}
         else:              # bf16 MFMA makes the math 16x cheaper than fp32's: the binding roofline is HBM
-            nbytes = algorithmic_gemm_bytes_bf16(**SH, agg=conf["agg"])
+            gemm_bytes = algorithmic_gemm_bytes_bf16(**SH, agg=conf["agg"])
+            # In the pipelined step the kernel's first launch also applies the optimiser update of every parameter but the shared
+            # frame FC (256 side workgroups: read p, g, m, write p, m = 5 x 4 B per parameter) - the launch durations
+            # above contain that work, so the algorithmic bytes of the kernel's launches contain it too.  The contraction-only
+            # figure (bytes and launch times without the update) stays beside it as `gemm_only`.
+            upd_params = sum(math.prod(s_) for n_, _, s_, live in eng.plan.params
+                             if live and not n_.startswith("fc_feature_shared_source")) if side_update else 0
+            nbytes = gemm_bytes + 20 * upd_params
             gbs = nbytes / (gemm_ms * 1e-3) / 1e9
+            gbs_plain = gemm_bytes / (gemm_plain_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "bytes_per_launch": nbytes / max(len(gemm), 1),
+                               "bytes_note": "algorithmic bytes of the six launches of the kernel as the timed step runs them: contraction "
+                               "operands (input once as bf16, live weights 2+2 B read + 4 B gradient written) = %.2f MB, plus 20 B per "
+                               "parameter for the optimiser update that rides in the first launch (%d parameters) = %.2f MB" %
+                               (gemm_bytes / 1e6, upd_params, 20 * upd_params / 1e6),
+                               "gemm_only": {"bytes_per_launch": gemm_bytes / max(len(gemm), 1),
+                                             "avg_launch_us": 1e3 * gemm_plain_ms / max(len(gemm), 1), "achieved": gbs_plain,
+                                             "frac": gbs_plain / HBM_PEAK_GBS,
+                                             "what": "the same six launches without the update workgroups (ta3n_time_phases): the "
+                                                     "figure comparable with round 1's roofline.frac"},
                                "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
         # tile code per GEMM launch as the plan built it: WM WN WK + 1000 x (LDS stages, + 16: reads bf16 twins) + 100000 x blocking
         # (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2 - 128x64 / 64x128 / 128x128 tiles)
