@@ -124,6 +124,7 @@ def _worker(rank, world, port, out, buckets):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)        # (pytest-timeout: a rendezvous that never completes must not hold the whole GPU tier)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the round-end scaling run exercises this path on 8)")
 @pytest.mark.parametrize("buckets", [1, 2])
 def test_two_rccl_ranks_equal_single_process_global_batch(tmp_path, monkeypatch, buckets):
