@@ -56,8 +56,8 @@ typedef enum {
  * weight and bias are parameters of the plan) between the shared frame FC and its ReLU.  Train mode: batch statistics over
  * the domain's rows (region "bn_batch" [2 domains][3][F] = mean, biased variance, 1/sqrt(var + eps) for the caller's running
  * averages); eval mode (hyper.train == 0): the statistics the caller wrote to region "bn_run" [2][2][F] = mean, variance.
- * alpha = 1 (no source/target batch mixing: what the reference's own program always runs).  Unfused entry points only,
- * TA3N_AGG_TRN_M only. */
+ * alpha = 1 (no source/target batch mixing: what the reference's own program always runs).  Unfused entry points;
+ * TA3N_AGG_TRN_M and TA3N_AGG_AVGPOOL (there also ta3n_train_step's launch sequence, whose loss kernel ignores the options). */
 #define TA3N_FLAG_BN_SHARED      (1u << 7)
 /* Arithmetic of BASELINE.json configs[1]: every contraction rounds its two operands to bf16 (round to nearest
  * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and

@@ -138,6 +138,10 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
 
     if cfg.frame_aggregation == "avgpool":          # feat_aggregated_dim = feat_shared_dim (models.py:246-247), no TRN, no relation discriminators
         lin("fc_feature_shared_source", Fd, D)
+        if cfg.use_bn != "none":
+            for bn in ("bn_shared_S", "bn_shared_T"):
+                s[bn + ".weight"] = (Fd,)
+                s[bn + ".bias"] = (Fd,)
         lin("fc_feature_source", Fd, Fd)
         lin("fc_feature_domain", Fd, Fd)
         lin("fc_classifier_source", C, Fd)
@@ -146,6 +150,8 @@ def param_shapes(cfg: Config) -> Dict[str, Tuple[int, ...]]:
         lin("fc_feature_video_source_2", Fd, Fd)
         lin("fc_feature_domain_video", Fd, Fd)
         lin("fc_classifier_video_source", C, Fd)
+        if cfg.ens_DA == "MCD":
+            lin("fc_classifier_video_source_2", C, Fd)
         lin("fc_classifier_domain_video", 2, Fd)
         return s
     lin("fc_feature_shared_source", Fd, D)          # models.py:141
@@ -366,10 +372,15 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu
         # aggregate_frames, "1. averaging" (:421-433) without attention; attn is a placeholder column (:627-628)
         v = feat_frame.mean(1)
         vd = v * drop_v if drop_v is not None else v                                 # :679
+        if reverse_mu is not None:                                                   # :682-684
+            vd = _GradReverse.apply(vd, reverse_mu)
         y = _linear(p, "fc_classifier_video_source", vd, cfg)                        # :686
         hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg))
         pred_video = _linear(p, "fc_classifier_domain_video", hv, cfg)
-        return dict(attn=v[:, 0], out=y, pred_domain=[pred_video, pred_video, pred_frame], feat=[y, v, feat_frame])
+        y2 = y
+        if cfg.ens_DA == "MCD":                                                      # :716-720
+            y2 = F.linear(vd, p["fc_classifier_video_source_2.weight"], p["fc_classifier_video_source_2.bias"])
+        return dict(attn=v[:, 0], out=y, out2=y2, pred_domain=[pred_video, pred_video, pred_frame], feat=[y, v, feat_frame])
     # TRN (:632-636)
     rel, rel_parts = trn_multiscale(p, feat_frame, cfg, with_tuples=True)
     # relation discriminators (:472-488)

@@ -573,6 +573,14 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     lin("fc_classifier_domain", 2, F, live_frm);                       // :170
     lin("fc_feature_domain_video", F, F, live_vid);                    // :267 (feat_aggregated_dim = F)
     b.add_linear("fc_classifier_video_source", C, F, true);            // :272
+    const bool mcd = (c.flags & TA3N_FLAG_MCD) != 0;                   // the DA options of the TemPooling rows (module path)
+    const bool feat_grads = (c.flags & TA3N_FLAG_FEATURE_GRADS) != 0;
+    const bool bn_shared = (c.flags & TA3N_FLAG_BN_SHARED) != 0;
+    if (mcd) b.add_linear("fc_classifier_video_source_2", C, F, true); // :276-279
+    if (bn_shared) {                                                   // :195-196
+        b.add_param("bn_shared_S.weight", F, 0, true); b.add_param("bn_shared_S.bias", F, 0, true);
+        b.add_param("bn_shared_T.weight", F, 0, true); b.add_param("bn_shared_T.bias", F, 0, true);
+    }
     lin("fc_classifier_domain_video", 2, F, live_vid);                 // :281
     p.live_floats = p.param_floats;
     for (auto &d : dead) b.add_linear(d.name, d.out, d.in, false);
@@ -613,6 +621,20 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     g.o_gRa = (int32_t)b.add_region("gRa", live_frm ? (int64_t)BT * F : 4);   // gVt / T spread over the segments
     g.o_gZ1 = (int32_t)b.add_region("gZ1", (int64_t)BT * F);
     g.o_attn = (int32_t)b.add_region("attn", 4); g.o_gattn = (int32_t)b.add_region("g_attn", 4);
+    const int64_t Wcv2 = mcd ? P("fc_classifier_video_source_2.weight") : 0, bcv2 = mcd ? P("fc_classifier_video_source_2.bias") : 0;
+    if (feat_grads) g.o_gV_ext = (int32_t)b.add_region("gV_ext", (int64_t)B * F);
+    if (mcd) {
+        g.o_Y2 = (int32_t)b.add_region("Y2", (int64_t)B * C);
+        g.o_gY2 = (int32_t)b.add_region("gY2", (int64_t)B * C);
+    }
+    if (bn_shared) {
+        g.o_Z0 = (int32_t)b.add_region("Z0", (int64_t)BT * F);
+        g.o_gZ0 = (int32_t)b.add_region("gZ0", (int64_t)BT * F);
+        g.o_bn_batch = (int32_t)b.add_region("bn_batch", (int64_t)2 * 3 * F);
+        g.o_bn_run = (int32_t)b.add_region("bn_run", (int64_t)2 * 2 * F);
+        g.p_bn_w[0] = (int32_t)P("bn_shared_S.weight"); g.p_bn_b[0] = (int32_t)P("bn_shared_S.bias");
+        g.p_bn_w[1] = (int32_t)P("bn_shared_T.weight"); g.p_bn_b[1] = (int32_t)P("bn_shared_T.bias");
+    }
     g.o_zeros = (int32_t)b.add_region("zeros", 64);
     g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);
     if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
@@ -642,6 +664,11 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
         GemmSpec s;
         s.M = BT; s.N = F;
         s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
+        if (bn_shared) {   // the linear output only: BatchNorm, ReLU and dropout follow in the PH_BN_FWD launch
+            s.proto = proto(BASE_WS, g.o_Z0, F);
+            with_bias(s.proto, bsh);
+            return s;
+        }
         s.proto = proto(BASE_WS, g.o_F1, F);
         with_bias(s.proto, bsh);
         s.proto.epi |= EPI_RELU | EPI_DROP_I;
@@ -667,10 +694,12 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     };
     auto forward = [&](int group) {
         { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(group, s); }
+        if (bn_shared) b.add_simple_phase(PH_BN_FWD, group);
         if (live_frm) { std::vector<GemmSpec> s{fwd(BT, F, F, g.o_F1, Wfd, bfd, g.o_Hf, true)}; b.add_gemm_phase(group, s); }   // models.py:458-459
         b.add_simple_phase(PH_POOL_AVG_FWD, group);
         {
             std::vector<GemmSpec> s{fwd(B, C, F, g.o_Vd, Wcv, bcv, g.o_Y, false)};                                 // :686
+            if (mcd) s.push_back(fwd(B, C, F, g.o_Vd, Wcv2, bcv2, g.o_Y2, false));                                  // :717-718
             if (live_vid) s.push_back(fwd(B, F, F, g.o_Vd, Wdv, bdv, g.o_Hv, true));                                // :466-467
             b.add_gemm_phase(group, s);
         }
@@ -693,6 +722,7 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
                 s.push_back(wgrad(2, F, BT, g.o_gPf, 2, BASE_WS, g.o_Hf, F, Wcd, bcd));
             }
             s.push_back(wgrad(C, F, B, g.o_gY, C, BASE_WS, g.o_Vd, F, Wcv, bcv));
+            if (mcd) s.push_back(wgrad(C, F, B, g.o_gY2, C, BASE_WS, g.o_Vd, F, Wcv2, bcv2));
             b.add_gemm_phase(group, s);
         }
         {   // gVt = dropout_v'( -beta1 * gHv Wdv + gY Wcv ), first-layer weight gradients of the discriminators
@@ -701,7 +731,9 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
             gv.M = B; gv.N = F;
             if (live_vid) gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gHv, F), KM(BASE_P, Wdv, F), F, SK_NEG_BETA_VID));
             gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY, C), KM(BASE_P, Wcv, F), C));
+            if (mcd) gv.segs.push_back(mkseg(KC(BASE_WS, g.o_gY2, C), KM(BASE_P, Wcv2, F), C));
             gv.proto = proto(BASE_WS, g.o_gVt, F);
+            gv.proto.alpha_kind = SK_REVERSE_MU;      // forward(..., reverse=True): GradReverse(mu) behind dropout_v (models.py:682-684)
             gv.proto.epi |= EPI_DROP_V; gv.proto.gamma_kind = SK_INV_KEEP_V; gv.proto.drop_ld = F;
             s.push_back(gv);
             if (live_vid) s.push_back(wgrad(F, F, B, g.o_gHv, F, BASE_WS, g.o_Vd, F, Wdv, bdv));
@@ -720,7 +752,8 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
             std::vector<GemmSpec> s{gz};
             b.add_gemm_phase(group, s);
         }
-        { std::vector<GemmSpec> s{wgrad(F, D, BT, g.o_gZ1, F, BASE_X, 0, D, Wsh, bsh)}; b.add_gemm_phase(group, s); }
+        if (bn_shared) b.add_simple_phase(PH_BN_BWD, group);
+        { std::vector<GemmSpec> s{wgrad(F, D, BT, bn_shared ? g.o_gZ0 : g.o_gZ1, F, BASE_X, 0, D, Wsh, bsh)}; b.add_gemm_phase(group, s); }
     };
     forward(0);
     b.add_simple_phase(PH_LOSS, 1);
@@ -777,12 +810,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
-    if (c.aggregation == TA3N_AGG_AVGPOOL && (c.flags & (TA3N_FLAG_MCD | TA3N_FLAG_FEATURE_GRADS | TA3N_FLAG_BN_SHARED))) {
-        err = "TA3N_FLAG_MCD / _FEATURE_GRADS / _BN_SHARED are built for TA3N_AGG_TRN_M";
-        return TA3N_ERR_INVALID;
-    }
-    if (c.aggregation == TA3N_AGG_AVGPOOL)      // source-only: the fused fast path (BASELINE configs[0]); with adversarial branches: the general one
-        return (c.flags & (TA3N_FLAG_ADV_RELATION | TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_FRAME)) ? build_plan_avgpool_general(p, err)
+    if (c.aggregation == TA3N_AGG_AVGPOOL)      // source-only: the fused fast path (BASELINE configs[0]); with adversarial branches or a module-path option: the general one
+        return (c.flags & (TA3N_FLAG_ADV_RELATION | TA3N_FLAG_ADV_VIDEO | TA3N_FLAG_ADV_FRAME | TA3N_FLAG_MCD | TA3N_FLAG_FEATURE_GRADS |
+                           TA3N_FLAG_BN_SHARED)) ? build_plan_avgpool_general(p, err)
                                                                                                  : build_plan_avgpool(p, err);
 
     // ---- relation tuples ----

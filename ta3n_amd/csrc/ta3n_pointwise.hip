@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void pool_avg_bwd_kernel(Geom g, Ptrs ptrs, in
     const int row = blockIdx.x, b = row / g.T, F = g.F;
     const float inv_T = 1.f / (float)g.T, inv_keep_i = hyper_scale(hy, SK_INV_KEEP_I);
     for (int k = threadIdx.x; k < F; k += 256) {
-        const float base = ws[g.o_gVt + (size_t)b * F + k] * inv_T;
+        float gv = ws[g.o_gVt + (size_t)b * F + k];
+        if (g.o_gV_ext > 0) gv += ws[g.o_gV_ext + (size_t)b * F + k];      // TA3N_FLAG_FEATURE_GRADS: the caller's gradient at V (feat[1])
+        const float base = gv * inv_T;
         if (direct) ws[g.o_gZ1 + (size_t)row * F + k] = ws[g.o_F1 + (size_t)row * F + k] > 0.f ? base * inv_keep_i : 0.f;
         else ws[g.o_gRa + (size_t)row * F + k] = base;
     }

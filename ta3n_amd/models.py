@@ -47,6 +47,30 @@ class GradReverse(torch.autograd.Function):
         return grad_output.neg() * ctx.beta, None
 
 
+def _bn_before_forward(model, plan, ws, train):
+    """use_bn, eval mode: the running statistics go to the kernel (region "bn_run" [S, T][mean, var][F])."""
+    if model.use_bn != 'none' and not train:
+        off, n = plan.region("bn_run")
+        ws[off:off + n].copy_(torch.stack((model.bn_shared_S.running_mean, model.bn_shared_S.running_var,
+                                           model.bn_shared_T.running_mean, model.bn_shared_T.running_var)).reshape(-1))
+
+
+def _bn_after_forward(model, plan, ws, train, Bs, Bt):
+    """use_bn, train mode: nn.BatchNorm1d's buffer update (momentum 0.1, unbiased batch variance) from the kernel's batch
+    statistics (region "bn_batch" [S, T][mean, biased var, 1/std][F])."""
+    if model.use_bn == 'none' or not train:
+        return
+    off, n = plan.region("bn_batch")
+    st = ws[off:off + n].view(2, 3, -1)
+    T = model.train_segments
+    for d, (mod, rows) in enumerate(((model.bn_shared_S, Bs * T), (model.bn_shared_T, Bt * T))):
+        if rows > 0:
+            with torch.no_grad():
+                mod.running_mean.mul_(0.9).add_(st[d, 0], alpha=0.1)
+                mod.running_var.mul_(0.9).add_(st[d, 1] * (rows / max(rows - 1, 1)), alpha=0.1)
+                mod.num_batches_tracked += 1
+
+
 class _HipForward(torch.autograd.Function):
     """One autograd node for the whole forward; backward = ta3n_backward."""
 
@@ -70,21 +94,9 @@ class _HipForward(torch.autograd.Function):
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
-        bn = model.use_bn != 'none'
-        if bn and not train:                 # eval mode: the running statistics go to the kernel (region "bn_run" [S, T][mean, var][F])
-            off, n = plan.region("bn_run")
-            ws[off:off + n].copy_(torch.stack((model.bn_shared_S.running_mean, model.bn_shared_S.running_var,
-                                               model.bn_shared_T.running_mean, model.bn_shared_T.running_var)).reshape(-1))
+        _bn_before_forward(model, plan, ws, train)
         _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
-        if bn and train:                     # nn.BatchNorm1d's buffer update (momentum 0.1, unbiased batch variance), from the kernel's
-            off, n = plan.region("bn_batch")  # batch statistics [S, T][mean, biased var, 1/std][F]
-            st = ws[off:off + n].view(2, 3, -1)
-            for d, (mod, rows) in enumerate(((model.bn_shared_S, Bs * model.train_segments), (model.bn_shared_T, Bt * model.train_segments))):
-                if rows > 0:
-                    with torch.no_grad():
-                        mod.running_mean.mul_(0.9).add_(st[d, 0], alpha=0.1)
-                        mod.running_var.mul_(0.9).add_(st[d, 1] * (rows / max(rows - 1, 1)), alpha=0.1)
-                        mod.num_batches_tracked += 1
+        _bn_after_forward(model, plan, ws, train, Bs, Bt)
         ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
         ctx.n_params = len(params)
         B, T, NR, Cn = Bs + Bt, model.train_segments, model.train_segments - 1, model.num_class
@@ -156,7 +168,7 @@ class _HipForwardAvg(torch.autograd.Function):
     (F1 | Hf | mean | {Y, Hv} | {Pv, Pf}), backward = ta3n_backward from the caller's logit gradients."""
 
     @staticmethod
-    def forward(ctx, model, xs, xt, beta, train, *params):
+    def forward(ctx, model, xs, xt, beta, train, reverse_mu, *params):
         dev = model._flat.device
         Bs, Bt = xs.shape[0], xt.shape[0]
         plan = model._plan(Bs, Bt)
@@ -165,6 +177,8 @@ class _HipForwardAvg(torch.autograd.Function):
         ws = model._ws_checkout(plan, ctx, any(ctx.needs_input_grad))
         h = _lib.Hyper()
         h.beta[0], h.beta[1], h.beta[2] = float(beta[0]), float(beta[1]), float(beta[2])
+        if reverse_mu is not None:           # forward(..., reverse=True) (models.py:682-684)
+            h.reverse, h.mu = 1, float(reverse_mu)
         h.p_drop_i, h.p_drop_v = float(model.dropout_rate_i), float(model.dropout_rate_v)
         seeds = torch.randint(0, 2 ** 31 - 1, (2,))
         h.seed_i, h.seed_v = int(seeds[0]), int(seeds[1])
@@ -172,7 +186,9 @@ class _HipForwardAvg(torch.autograd.Function):
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_set_hyper(plan.handle, ws.data_ptr(), C.byref(h), stream), "ta3n_set_hyper")
+        _bn_before_forward(model, plan, ws, train)
         _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
+        _bn_after_forward(model, plan, ws, train, Bs, Bt)
         ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
         B, Cn = Bs + Bt, model.num_class
 
@@ -182,15 +198,18 @@ class _HipForwardAvg(torch.autograd.Function):
 
         y, pv, pf = reg("Y", (B, Cn)), reg("Pv", (B, 2)), reg("Pf", (B, T, 2))
         v, f1 = reg("V", (B, -1)), reg("F1", (B, T, -1))
-        ctx.mark_non_differentiable(v, f1)
+        y2 = reg("Y2", (B, Cn)) if model.ens_DA == 'MCD' else y.new_zeros(0)
+        ctx.mark_non_differentiable(f1)            # (V takes the caller's gradient: dis_DA on feat[1])
+        if model.ens_DA != 'MCD':
+            ctx.mark_non_differentiable(y2)
         ctx.set_materialize_grads(False)
-        return y, pv, pf, v, f1
+        return y, pv, pf, v, f1, y2
 
     @staticmethod
-    def backward(ctx, g_y, g_pv, g_pf, g_v, g_f1):
+    def backward(ctx, g_y, g_pv, g_pf, g_v, g_f1, g_y2):
         model, plan, ws = ctx.model, ctx.plan, ctx.ws
         dev = ws.device
-        for name, g in (("gY", g_y), ("gPv", g_pv), ("gPf", g_pf)):
+        for name, g in (("gY", g_y), ("gPv", g_pv), ("gPf", g_pf), ("gV_ext", g_v)) + ((("gY2", g_y2),) if model.ens_DA == 'MCD' else ()):
             off, n = plan.region(name)
             if g is None:
                 ws[off:off + n].zero_()
@@ -215,7 +234,7 @@ class _HipForwardAvg(torch.autograd.Function):
             for s_ in shape:
                 n *= s_
             out.append(grads[off:off + n].view(shape))
-        return (None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, *out)
 
 
 class VideoModel(nn.Module):
@@ -236,9 +255,9 @@ class VideoModel(nn.Module):
         if baseline_type != 'video': unsupported.append(f"baseline_type={baseline_type!r}")
         if share_params != 'Y': unsupported.append("share_params='N'")
         if use_bn not in ('none', 'AdaBN', 'AutoDIAL'): unsupported.append(f"use_bn={use_bn!r}")
-        if use_bn != 'none' and frame_aggregation != 'trn-m': unsupported.append("use_bn with frame_aggregation other than 'trn-m'")
+        if use_bn != 'none' and frame_aggregation not in ('trn-m', 'avgpool'): unsupported.append("use_bn with this frame_aggregation")
         if ens_DA not in ('none', 'MCD'): unsupported.append(f"ens_DA={ens_DA!r}")
-        if ens_DA == 'MCD' and frame_aggregation != 'trn-m': unsupported.append("ens_DA='MCD' with frame_aggregation other than 'trn-m'")
+        if ens_DA == 'MCD' and frame_aggregation not in ('trn-m', 'avgpool'): unsupported.append("ens_DA='MCD' with this frame_aggregation")
         if use_attn not in ('TransAttn', 'none'): unsupported.append(f"use_attn={use_attn!r}")
         if use_attn_frame != 'none': unsupported.append(f"use_attn_frame={use_attn_frame!r}")
         if not before_softmax: unsupported.append("before_softmax=False")
@@ -343,7 +362,8 @@ class VideoModel(nn.Module):
         # losses are assembled by the caller (main.py:439-562), so every discriminator has to be able to receive a gradient:
         # the adversarial flags only decide the plan's live parameter set here (the loss kernel is not used on this path)
         if self._avg:
-            return _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME
+            return (_lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME | _lib.FLAG_FEATURE_GRADS |
+                    (_lib.FLAG_BN_SHARED if self.use_bn != 'none' else 0) | (_lib.FLAG_MCD if self.ens_DA == 'MCD' else 0))
         return (_lib.FLAG_ADV_RELATION | _lib.FLAG_ADV_VIDEO | _lib.FLAG_ADV_FRAME |
                 (_lib.FLAG_TRANS_ATTN if self._attn_on else 0) |
                 _lib.FLAG_FEATURE_GRADS |                                   # feat[1] may carry a discrepancy loss (dis_DA)
@@ -428,9 +448,7 @@ class VideoModel(nn.Module):
         frame [B,T,2]] and feat = [class logits, video feature V, frame features F1]."""
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("ta3n_amd.VideoModel.forward needs a HIP device; there is no CPU fallback")
-        if reverse and self._avg:
-            raise NotImplementedError("reverse=True (the MCD step's second forward, main.py:549) with frame_aggregation='avgpool'")
-        if self.use_bn != 'none' and float(self.alpha) != 1.0:
+        if self.use_bn != 'none' and float(self.alpha.detach()) != 1.0:
             raise NotImplementedError("use_bn with alpha != 1 (source/target batch mixing of domainAlign, models.py:497-508, 531-533): the "
                                       "reference's own program never changes alpha from its initial 1")
         num_segments = self.train_segments if is_train else self.val_segments
@@ -449,10 +467,13 @@ class VideoModel(nn.Module):
         s, t = slice(0, Bs), slice(Bs, Bs + Bt)
         if self._avg:
             with torch.cuda.device(device):
-                y, pv, pf, v, f1 = _HipForwardAvg.apply(self, input_source, input_target, list(beta), self.training, *params)
+                y, pv, pf, v, f1, y2 = _HipForwardAvg.apply(self, input_source, input_target, list(beta), self.training,
+                                                            float(mu) if reverse else None, *params)
+            if self.ens_DA != 'MCD':
+                y2 = y
             # models.py:627-628 (attn placeholder = first feature column), :697-708 (the relation slot repeats the video logits)
-            return (v[s][:, 0], y[s], y[s], [pv[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
-                    v[t][:, 0], y[t], y[t], [pv[t], pv[t], pf[t]], [y[t], v[t], f1[t]])
+            return (v[s][:, 0], y[s], y2[s], [pv[s], pv[s], pf[s]], [y[s], v[s], f1[s]],
+                    v[t][:, 0], y[t], y2[t], [pv[t], pv[t], pf[t]], [y[t], v[t], f1[t]])
         with torch.cuda.device(device):
             attn, y, pr, pv, pf, v, f1, y2 = _HipForward.apply(self, input_source, input_target, list(beta), self.training,
                                                                 float(mu) if reverse else None, *params)

@@ -280,6 +280,15 @@ CASES = {
                           use_bn="AutoDIAL"),
     "mid_adabn": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=28, wscale="trained", xseed=208, steps=2,
                       lr=2e-3, use_bn="AdaBN"),
+    # the same options on TemPooling (the TemPooling + X rows of the paper's tables): avgpool aggregation, RevGrad on the video and
+    # frame level (place_adv N Y Y), no attention
+    "tiny_avgpool_dan_mcd": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=31,
+                                 wscale="trained", xseed=301, steps=2, lr=2e-3, dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=1.0,
+                                 ens_DA="MCD", mu=0.5),
+    "tiny_avgpool_jan": dict(agg="avgpool", place_adv=("N", "Y", "N"), arch="resnet18", fc_dim=32, T=4, C=5, Bs=5, Bt=3, wseed=32,
+                             wscale="trained", xseed=302, steps=2, lr=2e-3, dis_DA="JAN", alpha=0.5),
+    "tiny_avgpool_adabn": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=33,
+                               wscale="trained", xseed=303, steps=3, short_last=(5, 3), lr=2e-3, use_bn="AdaBN"),
     "mid_dan_mcd": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=25, wscale="trained", xseed=205, steps=2,
                         lr=2e-3, dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=1.0, ens_DA="MCD", mu=1.0),
 }

@@ -11,6 +11,7 @@ CASES = ["tiny_T5", "tiny_T3", "tiny_T9", "tiny_T2", "tiny_clip", "headline", "h
 AVG_CASES = ["tiny_avgpool", "config1_avgpool"]      # BASELINE configs[0]: TemPooling (avgpool), source-only, every DA option off
 AVG_DA_CASES = ["tiny_avgpool_da", "tiny_avgpool_da3", "tiny_avgpool_dav", "tempooling_da"]   # TemPooling + RevGrad (place_adv in the fixture)
 DA_EXTRA_CASES = ["tiny_dan", "tiny_dan_all", "tiny_jan", "tiny_mcd", "mid_dan_mcd"]   # dis_DA DAN / JAN, ens_DA MCD on top of TA3N
+AVG_DA_EXTRA_CASES = ["tiny_avgpool_dan_mcd", "tiny_avgpool_jan", "tiny_avgpool_adabn"]     # the same options on TemPooling
 BN_CASES = ["tiny_adabn", "tiny_autodial", "mid_adabn"]      # use_bn AdaBN / AutoDIAL: domain-specific BatchNorm after the shared FC
 ARCH_DIM = dict(resnet18=512, resnet34=512, resnet50=2048, resnet101=2048, resnet152=2048)
 

@@ -314,7 +314,10 @@ class Interp:
         """gVt / T spread over the segments: gZ1 directly (no frame discriminator) or the additive base of its launch."""
         g = self.g
         B, T, F = g.B, g.T, g.F
-        base = np.repeat(self.r(g.o_gVt, (B, F)) / T, T, axis=0)
+        gv = self.r(g.o_gVt, (B, F))
+        if g.o_gV_ext > 0:       # TA3N_FLAG_FEATURE_GRADS: the caller's gradient at V
+            gv = gv + self.r(g.o_gV_ext, (B, F))
+        base = np.repeat(gv / T, T, axis=0)
         if g.o_gHf < 0:
             self.r(g.o_gZ1, (B * T, F))[:] = np.where(self.r(g.o_F1, (B * T, F)) > 0, base * self.scale(4), 0.0)
         else:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import AVG_DA_CASES, Golden, case_config, step_schedule
+from golden_util import AVG_DA_CASES, AVG_DA_EXTRA_CASES, Golden, case_config, step_schedule
 from oracle import ta3n_oracle as orc
 from plan_interp import Interp
 from ta3n_amd import _lib
@@ -24,19 +24,20 @@ def _setup(name):
     c = case_config(g)
     assert c["agg"] == "avgpool" and c["place_adv"] is not None
     cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"], dropout_i=0.0, dropout_v=0.0,
-                     place_adv=c["place_adv"], add_loss_DA="none", use_attn="none", frame_aggregation="avgpool")
+                     place_adv=c["place_adv"], add_loss_DA="none", use_attn="none", frame_aggregation="avgpool",
+                     dis_DA=c["dis_DA"], place_dis=c["place_dis"], ens_DA=c["ens_DA"], use_bn=c["use_bn"])
     params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
     flags = flags_from_options(c["place_adv"], "none", "none", "RevGrad", "uSv")
     return g, c, cfg, params, flags
 
 
-@pytest.mark.parametrize("name", AVG_DA_CASES)
+@pytest.mark.parametrize("name", AVG_DA_CASES + AVG_DA_EXTRA_CASES)
 def test_oracle_matches_reference(name):
     g, c, cfg, params, _ = _setup(name)
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
     with torch.no_grad():
-        s = orc.forward_domain(params, xs, BETA, cfg)
-        t = orc.forward_domain(params, xt, BETA, cfg)
+        s = orc.forward_domain(params, xs, BETA, cfg, domain="S")
+        t = orc.forward_domain(params, xt, BETA, cfg, domain="T")
     for dom, o in (("s", s), ("t", t)):
         g.check(f"fwd/out_{dom}", o["out"], RTOL, ATOL)
         for i, nm in enumerate(("rel", "vid", "frm")):
@@ -49,7 +50,8 @@ def test_oracle_matches_reference(name):
         xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
         xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
         state.lr = st["lr"]
-        res = orc.train_step(state, xs, xt, ys, BETA, 0.0, cfg, clip=c["clip"], n_src=st["n_src"], n_tgt=st["n_tgt"])
+        res = orc.train_step(state, xs, xt, ys, BETA, 0.0, cfg, clip=c["clip"], n_src=st["n_src"], n_tgt=st["n_tgt"],
+                             alpha=c["alpha"], mu=c["mu"])
         assert set(res["clipped"]) == live
         for k in params:
             if k in live:

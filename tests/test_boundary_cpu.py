@@ -42,7 +42,9 @@ def test_constructor_rejects_what_is_not_the_hot_path():
     with pytest.raises(NotImplementedError):
         VideoModel(12, 'frame', 'trn-m', 'RGB', verbose=False)
     with pytest.raises(NotImplementedError):
-        VideoModel(12, 'video', 'avgpool', 'RGB', use_attn='none', use_bn='AdaBN', verbose=False)      # use_bn / ens_DA: trn-m only
+        VideoModel(12, 'video', 'trn-m', 'RGB', use_bn='BN', verbose=False)
+    assert "bn_shared_S.weight" in VideoModel(12, 'video', 'avgpool', 'RGB', use_attn='none', use_bn='AdaBN', ens_DA='MCD', fc_dim=64,
+                                              base_model='resnet18', verbose=False).state_dict()      # the TemPooling + X rows
     with pytest.raises(NotImplementedError):
         VideoModel(12, 'video', 'rnn', 'RGB', verbose=False)
     # built options of the DA tables construct and carry the reference's extra state_dict entries

@@ -49,8 +49,6 @@ def validate_options(args, module_path: bool = False) -> None:
     if module_path:
         need(args.dis_DA in ("none", "DAN", "JAN"), f"--dis_DA {args.dis_DA} (built: DAN, JAN)")
         need(args.ens_DA in ("none", "MCD"), f"--ens_DA {args.ens_DA}")
-        if args.dis_DA != "none" or args.ens_DA != "none":
-            need(args.frame_aggregation == "trn-m", "--dis_DA / --ens_DA are built for --frame_aggregation trn-m")
         if args.dis_DA == "DAN":
             need(len(args.place_dis) == args.add_fc + 2 and args.place_dis[2] == "N",
                  "--place_dis takes add_fc + 2 values [logits, video feature, frame features]; the reference itself fails on the "
@@ -60,7 +58,6 @@ def validate_options(args, module_path: bool = False) -> None:
         need(args.ens_DA == "none", f"--ens_DA {args.ens_DA} (use main.py, the module path)")
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
-        need(args.use_bn == "none" or args.frame_aggregation == "trn-m", "--use_bn is built for --frame_aggregation trn-m")
     else:
         need(args.use_bn == "none", f"--use_bn {args.use_bn} (use main.py, the module path)")
     need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
