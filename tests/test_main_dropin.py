@@ -67,6 +67,19 @@ def test_own_main_trains_logs_checkpoints_and_resumes(tmp_path, name, flags):
                      use_attn="TransAttn" if trn else "none", verbose=False,
                      **(dict(use_bn="AdaBN", ens_DA="MCD") if name == "ta3n_all_da" else {}))
     net.load_state_dict({'.'.join(k.split('.')[1:]): v for k, v in list(ck['state_dict'].items())})
+    # the tester (the reference's test_models.py command line) reads the checkpoint and reproduces main.validate's accuracy on
+    # the same list: Pred@1 == the prec1 stored with the checkpoint; confusion-matrix plot and per-class file are written
+    tm = [sys.executable, os.path.join(ROOT, "test_models.py"), data[0], "RGB", data[3], out + "checkpoint.pth.tar", "--arch", "resnet18",
+          "--test_segments", "5", "--fc_dim", "64", "--baseline_type", "video", "--frame_aggregation", "trn-m" if trn else "avgpool",
+          "--use_attn", "TransAttn" if trn else "none", "--bS", "8", "-j", "0", "--top", "1", "3",
+          "--save_confusion", str(tmp_path / "cm"), "--save_attention", str(tmp_path / "attn")]
+    if name == "ta3n_all_da":
+        tm += ["--use_bn", "AdaBN", "--ens_DA", "MCD"]
+    rt = subprocess.run(tm, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert rt.returncode == 0, rt.stdout[-2000:] + rt.stderr[-3000:]
+    last = [ln for ln in rt.stdout.splitlines() if ln.startswith("Pred@1 ") and "%" in ln][-1]
+    assert abs(float(last.split()[1].rstrip("%")) - float(ck["prec1"])) < 1e-2, (last, ck["prec1"])
+    assert os.path.getsize(str(tmp_path / "cm.png")) > 1000 and os.path.exists(str(tmp_path / "cm-top[1, 3].txt"))
     # --resume --resume_hp continues at epoch 3
     r2 = _run(os.path.join(ROOT, "main.py"), data, exp, flags, ["--resume", out + "checkpoint.pth.tar", "--resume_hp", "--epochs", "3",
                                                                    "--save_best_log", str(tmp_path / "best.log")])
