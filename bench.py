@@ -281,12 +281,12 @@ def main():
                 else:
                     e.train_step(beta, gamma, lr)
 
-        for i in range(warmup):
+        gc.collect()                                 # before the warmup, not between warmup and timing: a collection takes tens of
+        gc.disable()                                 # milliseconds during which the GPU would idle and drop its clocks; disabled while
+        for i in range(warmup):                      # timing - eager launches: a collector pause on the host would show up as GPU idle time
             step(i)
         for e in engs:
             e.flush()
-        gc.collect()
-        gc.disable()                                 # eager launches: a collector pause on the host would show up as GPU idle time
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
