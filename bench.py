@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--no-twins", action="store_true", help="bf16: round fp32 operands in registers everywhere instead of reading bf16 "
                     "twins")
     ap.add_argument("--single-dtype", action="store_true", help="do not also time the other arithmetic (N = 1 runs both by default)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f32x3"), default=None,
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1]); default: the configuration's")
     ap.add_argument("--wgrads-late", type=int, default=0, help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
@@ -231,6 +231,7 @@ def main():
     def run(dtype, steps, warmup):
         """Build the engine(s) for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
         bf16 = dtype == "bf16"
+        split = dtype == "f32x3"       # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers (TA3N_FLAG_F32_SPLIT)
         twins = bf16 and not args.no_twins
         # None: the measured per-launch choices of ta3n_amd/tuning.py for this shape (what TrainEngine uses by default)
         phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or None
@@ -239,7 +240,7 @@ def main():
             from ta3n_amd import _lib
             phase_tiles, _ = autotune_phase_tiles(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], device=dev,
                                                   flags=ALL_FLAGS | (_lib.FLAG_BF16_MFMA if bf16 else 0) |
-                                                  (_lib.FLAG_BF16_STORE if twins else 0),
+                                                  (_lib.FLAG_BF16_STORE if twins else 0) | (_lib.FLAG_F32_SPLIT if split else 0),
                                                   candidates=(114, 118, 212, 122, 214, 124, 221, 222), verbose=(rank == 0))
         if args.tile:
             phase_tiles = []
@@ -247,7 +248,8 @@ def main():
             phase_tiles = [0]
         engs = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                             clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                            fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"])
+                            fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],
+                            f32_split=split)
                 for _ in range(n_streams)]
         eng = engs[0]
         for k, e in enumerate(engs):
@@ -339,7 +341,11 @@ def main():
                  "per_phase_note": "[kind (0 GEMM, 5 optimiser, 6 heads), tile, workgroups, us]; HIP events on the launch stream" +
                  ("; the optimiser entry is the shared-FC update that opens the step, the first GEMM entry includes the 256 side "
                   "workgroups that apply the rest of the update" if side_update else "")}
-        if not bf16:       # fp32 MFMA: 95 FLOP/B against a machine balance of 25 -> MFMA-bound
+        if split:          # three bf16 MFMAs per product block: the matrix-core ceiling for these FLOPs is a third of the bf16 peak
+            peak = PEAK_BF16_MFMA_TFLOPS / 3
+            res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                               "peak_note": "bf16 MFMA peak / 3 (a_hi b_hi + a_hi b_lo + a_lo b_hi per product)", **extra}
+        elif not bf16:     # fp32 MFMA: 95 FLOP/B against a machine balance of 25 -> MFMA-bound
             res["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": tflops / PEAK_FP32_MFMA_TFLOPS, **extra}
         else:              # bf16 MFMA makes the math 16x cheaper than fp32's: the binding roofline is HBM
@@ -372,14 +378,20 @@ def main():
         return res
 
     main_res = run(args.dtype, args.steps, args.warmup)
-    other = None
+    other, third = None, None
     if headline and not args.single_dtype and not selftest:   # the other arithmetic, same process (all ranks): at N > 1 the fp32 line is BASELINE configs[2]
         other = run("f32" if args.dtype == "bf16" else "bf16", max(50, args.steps // 2), max(10, args.warmup // 2))
+        if args.dtype != "f32x3" and world == 1:               # and the fp32-grade split arithmetic (same fp32 parity tests as "f32")
+            third = run("f32x3", max(50, args.steps // 2), max(10, args.warmup // 2))
 
     if rank == 0:
         arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "
                          "(BASELINE configs[1]); parity gate: tests/test_gpu_bf16.py against the bf16-operand oracle",
-                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within 1e-3 of the reference's CPU path"}
+                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within 1e-3 of the reference's CPU path",
+                 "f32x3": "fp32-grade contractions on the bf16 MFMA: operands split hi + lo = bf16(x) + bf16(x - hi) in registers, "
+                          "a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 (~2^-16 per product; not IEEE fp32 multiplication); fp32 "
+                          "stage images, parameters, gradients, optimiser; passes the fp32 configuration's parity tests unchanged (logits "
+                          "within 1e-3 of the reference's CPU path, gradients rtol 2e-4: tests/test_gpu_parity.py [bf16x3])"}
         out = {
             "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N" if headline else
                       "src+tgt videos/sec per train step (BASELINE configs[%d])" % (args.config - 1),
@@ -407,6 +419,11 @@ def main():
             # the same numbers inside `roofline`, so that the parity-qualified fp32 figure travels with the headline line
             out["roofline"]["other_arithmetic"] = {"dtype": o_dtype, "value": other["value"], "ms_per_step": other["ms_per_step"],
                                                    **{k: other["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+        if third is not None:
+            out["roofline"]["split_arithmetic"] = {"dtype": "f32x3", "what": arith["f32x3"], "value": third["value"], "unit": "videos/s",
+                                                   "ms_per_step": third["ms_per_step"],
+                                                   **{k: third["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                                                        "avg_launch_us", "per_phase_us")}}
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)

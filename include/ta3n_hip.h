@@ -69,6 +69,13 @@ typedef enum {
  * ta3n_sgd_step*); whatever the CALLER writes - the input features, parameters loaded from a checkpoint - must be
  * followed by ta3n_refresh_bf16.  (A bf16 feature store can feed the input twin directly.) */
 #define TA3N_FLAG_BF16_STORE     (1u << 9)
+/* fp32-grade contractions on the bf16 matrix cores ("bf16x3"): every operand x is split in registers into hi = bf16(x) and
+ * lo = bf16(x - hi) (both round-to-nearest-even), and a product a b is accumulated in fp32 as a_hi b_hi + a_hi b_lo + a_lo b_hi -
+ * 16 mantissa bits per operand, a relative error of ~2^-16 per product instead of fp32's 2^-24 (the dropped a_lo b_lo term),
+ * at 3/16 of the fp32 MFMA's cycles.  Stage images, parameters, gradients and everything outside the MFMA stay fp32.  It is
+ * NOT IEEE fp32 multiplication; it is held to the same parity tests as the fp32 configuration (logits within 1e-3 of the
+ * reference's CPU path, gradients rtol 2e-4).  Exclusive with TA3N_FLAG_BF16_MFMA. */
+#define TA3N_FLAG_F32_SPLIT      (1u << 10)
 
 /* ta3n_config.aggregation */
 #define TA3N_AGG_TRN_M    0   /* 'trn-m': multi-scale TRN - the TA3N path (TRNmodule.py:27-86) */

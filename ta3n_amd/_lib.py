@@ -27,6 +27,7 @@ FLAG_FEATURE_GRADS = 1 << 6    # backward also takes a gradient at the pooled vi
 FLAG_BN_SHARED = 1 << 7        # use_bn AdaBN / AutoDIAL: BatchNorm1d per domain behind the shared frame FC (regions Z0, bn_batch, bn_run)
 FLAG_BF16_MFMA = 1 << 8
 FLAG_BF16_STORE = 1 << 9
+FLAG_F32_SPLIT = 1 << 10       # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers ("bf16x3")
 AGG_TRN_M, AGG_AVGPOOL = 0, 1
 
 # every symbol include/ta3n_hip.h declares (tests check the export list)

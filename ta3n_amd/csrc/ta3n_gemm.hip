@@ -375,6 +375,53 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         for (int q = 0; q < NQ; ++q) rs += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
+    if constexpr (BF == 3) {
+        // fp32-grade on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi
+        // (the a_lo b_lo term, ~2^-16 of the product, is dropped); fp32 accumulation in the MFMA
+        auto hi2 = [](float x0, float x1) { return pack_bf16(x0, x1); };
+        auto lo2 = [](float x0, float x1, unsigned hi) {
+            return pack_bf16(x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
+        };
+        if (NQ % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; q += 2) {
+                if (FULL || 4 * (wk * GPW + 2 * q) < krem) {
+                    unsigned ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            ah[2 * h + e] = hi2(av[q + h][2 * e], av[q + h][2 * e + 1]);
+                            al[2 * h + e] = lo2(av[q + h][2 * e], av[q + h][2 * e + 1], ah[2 * h + e]);
+                            bh[2 * h + e] = hi2(bv[q + h][2 * e], bv[q + h][2 * e + 1]);
+                            bl[2 * h + e] = lo2(bv[q + h][2 * e], bv[q + h][2 * e + 1], bh[2 * h + e]);
+                        }
+                    const u32x4 AH = {ah[0], ah[1], ah[2], ah[3]}, AL = {al[0], al[1], al[2], al[3]};
+                    const u32x4 BH = {bh[0], bh[1], bh[2], bh[3]}, BL = {bl[0], bl[1], bl[2], bl[3]};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AL), __builtin_bit_cast(bf16x8, BH), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BL), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BH), acc, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (FULL || 4 * (wk * GPW + 2 * q) < krem) {
+                    unsigned ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        ah[e] = hi2(av[q][2 * e], av[q][2 * e + 1]); al[e] = lo2(av[q][2 * e], av[q][2 * e + 1], ah[e]);
+                        bh[e] = hi2(bv[q][2 * e], bv[q][2 * e + 1]); bl[e] = lo2(bv[q][2 * e], bv[q][2 * e + 1], bh[e]);
+                    }
+                    const u32x2 AH = {ah[0], ah[1]}, AL = {al[0], al[1]}, BH = {bh[0], bh[1]}, BL = {bl[0], bl[1]};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, AL), __builtin_bit_cast(s16x4, BH), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, AH), __builtin_bit_cast(s16x4, BL), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, AH), __builtin_bit_cast(s16x4, BH), acc, 0, 0, 0);
+                }
+            }
+        }
+        return;
+    }
     if (BF) {
         if (NQ % 2 == 0) {
 #pragma unroll
@@ -940,7 +987,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
     template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
     template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 #define TA3N_INSTANTIATE_BLOCKED(wm, wn, wk, rm, rn, ns) \
     template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
@@ -986,7 +1035,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     bool launched = false;
     const int rm = ph.rm > 0 ? ph.rm : 1, rn = ph.rn > 0 ? ph.rn : 1;
     if (rm * rn > 1) {
-        if (ph.bf16 < 16) return -3;     // (the plan builder never emits this: blocked tiles read bf16 twins)
+        if (!(ph.bf16 & 16)) return -3;     // (the plan builder never emits this: blocked tiles read bf16 twins)
 #define TA3N_LAUNCH_BLOCKED(wm, wn, wk, rm_, rn_, ns)                                                                      \
         if (!launched && cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (ph.bf16 & 15) == ns) {               \
             hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, 2, ns, rm_, rn_>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
@@ -1007,6 +1056,8 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
             case 3: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 3); break;     \
             case 18: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 2); break;    \
             case 19: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 3); break;    \
+            case 34: TA3N_LAUNCH_ONE(wm, wn, wk, 3, 2); break;    \
+            case 35: TA3N_LAUNCH_ONE(wm, wn, wk, 3, 3); break;    \
             default: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 2); break;    \
         }                                                         \
         launched = true;                                          \

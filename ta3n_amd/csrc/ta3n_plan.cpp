@@ -158,7 +158,7 @@ struct Builder {
         Phase ph;
         std::memset(&ph, 0, sizeof(ph));
         ph.kind = PH_GEMM; ph.group = group; ph.wm = wm; ph.wn = wn; ph.wk = wk; ph.rm = rm; ph.rn = rn;
-        if (p.cfg.flags & TA3N_FLAG_BF16_MFMA) {
+        if (p.cfg.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_F32_SPLIT)) {
             // a third stage pays once every tile streams a long K; short-K launches keep the extra resident workgroup
             int min_k = 1 << 30;
             for (auto &g : specs) {
@@ -167,6 +167,7 @@ struct Builder {
                 min_k = std::min(min_k, k);
             }
             ph.bf16 = forced_stages ? forced_stages : (min_k >= 1024 && rm * rn < 4 ? 3 : 2);
+            if (p.cfg.flags & TA3N_FLAG_F32_SPLIT) ph.bf16 |= 32;      // split (hi + lo) operands, three MFMAs per product block
         }
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all
@@ -803,6 +804,10 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         err = "attentive_entropy requires place_adv[0]=='Y' and place_adv[1]=='Y'";
         return TA3N_ERR_INVALID;
     }
+    if ((c.flags & TA3N_FLAG_F32_SPLIT) && (c.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_BF16_STORE))) {
+        err = "TA3N_FLAG_F32_SPLIT and TA3N_FLAG_BF16_MFMA / _STORE are different arithmetics: set one";
+        return TA3N_ERR_INVALID;
+    }
     auto tile_ok = [](int t) { return t == 0 || tile_config_ok(t); };
     if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages; + 10000 / 20000 / 30000: 2 row / 2 column / 2 x 2 blocks per wave with 222 or 221, bf16 twins)"; return TA3N_ERR_INVALID; }
     for (int i = 0; i < 16; ++i)
@@ -1320,7 +1325,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         uint64_t bad = 0;
         for (size_t i = 0; i < p.phases.size(); ++i) {
             const Phase &ph = p.phases[i];
-            if (ph.kind == PH_GEMM && ph.rm * ph.rn > 1 && ph.bf16 < 16) bad |= 1ull << (i & 63);
+            if (ph.kind == PH_GEMM && ph.rm * ph.rn > 1 && !(ph.bf16 & 16)) bad |= 1ull << (i & 63);
         }
         if (bad == 0) return TA3N_OK;
         deny |= bad;

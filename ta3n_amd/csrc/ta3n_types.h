@@ -98,6 +98,7 @@ struct Phase {
     int32_t task_begin, task_count;
     int32_t wm, wn, wk;          // wave grid of the GEMM tile (block tile = 32*wm x 32*wn, wk-way K split)
     int32_t bf16;                // 0: fp32 MFMA; 2 / 3: operands rounded to bf16 for the MFMA (TA3N_FLAG_BF16_MFMA), LDS stages;
+                                 // + 32: TA3N_FLAG_F32_SPLIT - operands split hi + lo in registers, three bf16 MFMAs per product block;
                                  // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): the Segs' offsets address the
                                  // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
     int32_t rm, rn;              // 32x32 blocks per wave (0 or 1: one): block tile = 32*wm*rm x 32*wn*rn; > 1 only when bf16 >= 16

@@ -69,7 +69,8 @@ class TrainEngine:
                  dropout_v: float = 0.5, momentum: float = 0.9, weight_decay: float = 1e-4, clip: float = 20.0,
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
-                 bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False):
+                 bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
+                 f32_split: bool = False):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -78,6 +79,8 @@ class TrainEngine:
             flags |= _lib.FLAG_BF16_MFMA
         if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly
             flags |= _lib.FLAG_BF16_STORE
+        if f32_split:            # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers (ta3n_hip.h)
+            flags |= _lib.FLAG_F32_SPLIT
         self.bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
         self.bf16_store = bool(flags & _lib.FLAG_BF16_STORE)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -90,7 +93,7 @@ class TrainEngine:
         if phase_tiles is None and tile_config == 0 and aggregation == "trn-m":      # measured choices for the benchmarked shapes
             from .tuning import tuned_phase_tiles
             phase_tiles = tuned_phase_tiles(batch_source + batch_target, num_segments, feature_dim, min(fc_dim, feature_dim),
-                                            self.bf16, self.bf16_store)
+                                            self.bf16, self.bf16_store, split=bool(flags & _lib.FLAG_F32_SPLIT))
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
@@ -501,6 +504,8 @@ def autotune_phase_tiles(batch_source: int, batch_target: int, num_segments: int
                          candidates: Sequence[int] = (114, 118, 214, 124, 221, 222), verbose: bool = False):
     """Pick the fastest GEMM tile shape per launch by measuring each candidate on this
     GPU (HIP events on the launch stream).  Returns (phase_tiles, table)."""
+    if flags & _lib.FLAG_F32_SPLIT and all(c < 1000 for c in candidates):
+        candidates = [s * 1000 + c for c in candidates for s in (2, 3)]      # split arithmetic: 2 or 3 LDS stages of fp32 images
     if flags & _lib.FLAG_BF16_MFMA and all(c < 1000 for c in candidates):
         candidates = [s * 1000 + c for c in candidates for s in (2, 3)]      # bf16 kernels: 2 or 3 LDS stages
         if flags & _lib.FLAG_BF16_STORE:      # register-blocked tiles of the twin kernel: 128x64, 64x128 (2 / 3 stages), 128x128

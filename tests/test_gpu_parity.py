@@ -37,18 +37,23 @@ def test_library_loaded_and_device_is_mi355x():
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x3"])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tile", [0, 114, 118, 212, 122, 214, 124, 221, 222])
 @pytest.mark.parametrize("name", CASES)
-def test_train_steps_match_reference_golden(name, tile, fused):
-    """fused=False: ta3n_forward + ta3n_loss + ta3n_backward (15 launches); fused=True: ta3n_train_step (7 launches)."""
+def test_train_steps_match_reference_golden(name, tile, fused, split):
+    """fused=False: ta3n_forward + ta3n_loss + ta3n_backward (15 launches); fused=True: ta3n_train_step (7 launches).
+    split: TA3N_FLAG_F32_SPLIT - the contractions as three bf16 MFMAs on operands split hi + lo in registers - is held to the
+    fp32 configuration's bounds, all of them."""
     if tile not in (0, 114) and name not in ("tiny_T5", "tiny_T9", "headline"):
         pytest.skip("tile variants checked on three cases")
     if fused and tile not in (0, 114, 222):
         pytest.skip("fused step checked on three tile configs")
+    if split and tile not in (0, 3124, 222):
+        pytest.skip("split arithmetic checked on the default and two forced tiles")
     g = Golden(name)
     c = case_config(g)
-    eng = _engine(c, tile)
+    eng = _engine(c, tile, f32_split=split)
     _load(eng, c)
     live = set(eng.live_names())
     B, Bs, T = c["Bs"] + c["Bt"], c["Bs"], c["T"]
