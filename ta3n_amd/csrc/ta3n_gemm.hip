@@ -379,8 +379,11 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         // fp32-grade on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi
         // (the a_lo b_lo term, ~2^-16 of the product, is dropped); fp32 accumulation in the MFMA
         auto hi2 = [](float x0, float x1) { return pack_bf16(x0, x1); };
-        auto lo2 = [](float x0, float x1, unsigned hi) {
-            return pack_bf16(x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
+        auto lo2 = [](float x0, float x1, unsigned hi) {      // the two subtractions as one packed op (v_pk_add_f32)
+            const f32x2 x = {x0, x1};
+            const f32x2 h = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+            const f32x2 d = x - h;
+            return pack_bf16(d[0], d[1]);
         };
         if (NQ % 2 == 0) {
 #pragma unroll

@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o out --output-format csv -- python
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 python $R/tools/measure_traffic.py $O > $O/traffic_stdout.txt 2>&1
 cp $O/gemm_traffic.json $R/profiles/gemm_traffic.json      # so that the bench line below reports it as fresh
+# (also writes pmc_bf16.txt / pmc_f32.txt / pmc_f32x3.txt: per-dispatch counter tables of the last fused step per arithmetic)
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 for c in 1 4 5; do python bench.py --config $c --steps 50 --warmup 10 > $O/bench_config$c.json 2>> $O/bench.err; done

@@ -22,7 +22,7 @@ out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pr
 os.makedirs(out, exist_ok=True)
 PASSES = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"]
 result = {"source_hash": source_hash(), "shape": "128+74 videos, T=5, D=2048 (headline)"}
-for dtype in ("bf16", "f32"):
+for dtype in ("bf16", "f32", "f32x3"):
     per_pass = {}
     lines = []
     for p in PASSES:
