@@ -200,6 +200,8 @@ def main():
                     help="arithmetic of the contractions: f32 = fp32 MFMA (BASELINE configs[2]); bf16 = operands rounded to bf16, "
                          "bf16 MFMA, fp32 accumulation and fp32 parameters / optimiser state (configs[1]); default: the configuration's")
     ap.add_argument("--wgrads-late", type=int, default=0, help="A/B: TRN weight gradients in the last launch instead of the launch of the F1 gradient (measured slower)")
+    ap.add_argument("--serial-streams", action="store_true", help="two-stream configuration: step the two models one after the other on one "
+                    "HIP stream instead of concurrently on two")
     ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
@@ -270,10 +272,30 @@ def main():
         # host-to-device copy); the timed region ends with flush(), so it contains exactly `steps` updates
         pipelined = eng.fused and not args.graph and not deferred and not args.no_pipeline
 
+        # two-stream: the two models are independent - each steps on a HIP stream of its own, so one model's launches fill the CUs
+        # and the launch / prologue latencies the other leaves idle (--serial-streams: one after the other on one stream)
+        side = [torch.cuda.Stream(dev) for _ in engs] if (n_streams > 1 and not args.serial_streams) else None
+        if side:
+            for s_ in side:
+                s_.wait_stream(torch.cuda.current_stream(dev))
+
+        def flush_all():
+            for k, e in enumerate(engs):
+                if side:
+                    with torch.cuda.stream(side[k]):
+                        e.flush()
+                else:
+                    e.flush()
+
         def step(i):
             p = float(i % total_steps) / total_steps
             lr = lr0 if i == 0 else lr_dann(lr0, p)
-            for e in engs:                                                 # two-stream: both models step, one after the other
+            if side:
+                for e, s_ in zip(engs, side):
+                    with torch.cuda.stream(s_):
+                        (e.train_step_pipelined if pipelined else e.train_step)(beta, gamma, lr)
+                return
+            for e in engs:                                                 # (or: both models step, one after the other)
                 if args.static_hyper and e.graph is not None:
                     e.graph.replay()
                 elif deferred:
@@ -287,14 +309,12 @@ def main():
         gc.disable()                                 # milliseconds during which the GPU would idle and drop its clocks; disabled while
         for i in range(warmup):                      # timing - eager launches: a collector pause on the host would show up as GPU idle time
             step(i)
-        for e in engs:
-            e.flush()
+        flush_all()
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
-        for e in engs:
-            e.flush()                                # the K-th update is inside the timed region
+        flush_all()                                  # the K-th update is inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
         gc.enable()
