@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--serial-streams", action="store_true", help="two-stream configuration: step the two models one after the other on one "
                     "HIP stream instead of concurrently on two")
     ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
+    ap.add_argument("--per-step-calls", action="store_true", help="A/B: one host call per step instead of one ta3n_train_steps call for "
+                    "the whole timed region")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
     conf = CONFIGS[args.config]
@@ -305,15 +307,32 @@ def main():
                 else:
                     e.train_step(beta, gamma, lr)
 
+        # Default at N = 1: the K steps are enqueued by ONE call into the library (ta3n_train_steps; the schedule of beta / lr /
+        # dropout seeds is evaluated ahead of time and travels by value) - the host is then off the step's critical path, which
+        # under the 20-step protocol on a slow host core was 21 % of the step.  --per-step-calls: one call per step.
+        batched = pipelined and not side and len(engs) == 1 and world == 1 and not selftest and not args.per_step_calls
+
+        def sched(i0, n):
+            out = []
+            for i in range(i0, i0 + n):
+                p = float(i % total_steps) / total_steps
+                out.append((beta, gamma, lr0 if i == 0 else lr_dann(lr0, p)))
+            return out
+
+        def run_steps(i0, n):
+            if batched:
+                eng.train_steps(sched(i0, n))
+            else:
+                for i in range(i0, i0 + n):
+                    step(i)
+
         gc.collect()                                 # before the warmup, not between warmup and timing: a collection takes tens of
         gc.disable()                                 # milliseconds during which the GPU would idle and drop its clocks; disabled while
-        for i in range(warmup):                      # timing - eager launches: a collector pause on the host would show up as GPU idle time
-            step(i)
+        run_steps(0, warmup)                         # timing - eager launches: a collector pause on the host would show up as GPU idle time
         flush_all()
         fence()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
+        run_steps(warmup, steps)
         flush_all()                                  # the K-th update is inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
@@ -332,6 +351,7 @@ def main():
                                     "torch.distributed all_reduce (backend nccl = RCCL), fp32" +
                                     (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
         res["deferred"] = deferred
+        res["batched"] = batched
         res["pipelined"] = pipelined
         res["fused"] = eng.fused
         # live per-launch timing of the dominant kernel (the tile-list GEMM), HIP events on the launch stream
@@ -424,7 +444,9 @@ def main():
             "config": {"workload": conf["name"] + ", dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
                        "baseline_config": args.config - 1,
                        "global_batch": (SH["Bs"] + SH["Bt"]) * world, "parallelism": f"dp{world}",
-                       "launch": "hipGraph" if args.graph else "eager", "finite": main_res["finite"],
+                       "launch": "hipGraph" if args.graph else ("eager, all timed steps enqueued by one ta3n_train_steps call"
+                                                                if main_res.get("batched") else "eager, one host call per step"),
+                       "finite": main_res["finite"],
                        "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",
                        "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
                        ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "

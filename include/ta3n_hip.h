@@ -285,6 +285,29 @@ int ta3n_train_step_after_update(ta3n_plan *plan, const float *x, float *params,
                                  int fused_norm, float lr, float momentum_coef, float weight_decay, float clip,
                                  const ta3n_hyper *next, void *stream);
 
+/* Several pipelined steps from ONE call: for k in [0, n_steps): { optional batch assembly; ta3n_train_step_after_update with the
+ * update of the step before (its learning rate: lr_pending for k = 0, hypers[k-1].lr afterwards) and next = hypers[k] }.  The
+ * per-step scalars of main.train (beta, lr, dropout seeds, valid rows: main.py:350-352, 620-621, 800-802) are a function of the
+ * step index that the host evaluates ahead of time; the kernels receive them by value, so the call returns as soon as the
+ * launches are queued and the host is off the step's critical path (one ctypes call and 9 hipLaunchKernel per step measured
+ * ~100 us of host time on a slow core against ~100 us of GPU time).  Requires a pending update (a previous
+ * ta3n_train_step / ta3n_train_steps on the same buffers); the update of step n_steps - 1 stays pending with lr = hypers[n_steps-1].lr
+ * (apply it with ta3n_sgd_range or the next call).  Bit-identical to n_steps single calls.
+ * source / target (either may be NULL = the rows already in x): TSNDataSet.__getitem__ + DataLoader collation of step k on the
+ * device (dataset.py:118-144), i.e. ta3n_gather_segments[_bf16]_into with video_ids[k * ids_per_step ..] before step k. */
+typedef struct {
+    const void *store;          /* packed rows [total_frames, feature_dim]: fp32, or bf16 when bf16 != 0 */
+    int32_t bf16;
+    int32_t ids_per_step;       /* videos gathered per step: <= batch_source (source feed) / batch_target (target feed) */
+    const int64_t *first_row;   /* device [n_videos] */
+    const int32_t *num_frames;  /* device [n_videos] */
+    const int32_t *labels;      /* device [n_videos]; required for the source feed (written to ws["labels"]) */
+    const int32_t *video_ids;   /* device [n_steps][ids_per_step] */
+} ta3n_feed;
+int ta3n_train_steps(ta3n_plan *plan, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                     float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers,
+                     int n_steps, const ta3n_feed *source, const ta3n_feed *target, void *stream);
+
 /* TA3N_FLAG_BF16_STORE: (re)build the bf16 twins of x (B*T*feature_dim floats, may be NULL) and of params (may be
  * NULL) inside ws.  No-op without the flag. */
 int ta3n_refresh_bf16(ta3n_plan *plan, const float *x, const float *params, float *ws, void *stream);

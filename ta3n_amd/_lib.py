@@ -39,7 +39,7 @@ SYMBOLS = [
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_time_update_launches", "ta3n_last_error", "ta3n_version",
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
-    "ta3n_gather_segments_bf16_into",
+    "ta3n_gather_segments_bf16_into", "ta3n_train_steps",
 ]
 
 
@@ -58,6 +58,12 @@ class Hyper(C.Structure):
                 ("inv_n_vid", C.c_float), ("inv_n_frm", C.c_float), ("inv_n_ent", C.c_float),
                 ("valid_source", C.c_int32), ("valid_target", C.c_int32), ("train", C.c_int32),
                 ("reverse", C.c_int32), ("mu", C.c_float), ("reserved", C.c_int32 * 2)]
+
+
+class Feed(C.Structure):
+    """ta3n_feed (include/ta3n_hip.h): device-side batch assembly of a multi-step call."""
+    _fields_ = [("store", C.c_void_p), ("bf16", C.c_int32), ("ids_per_step", C.c_int32), ("first_row", C.c_void_p),
+                ("num_frames", C.c_void_p), ("labels", C.c_void_p), ("video_ids", C.c_void_p)]
 
 
 class Ta3nError(RuntimeError):
@@ -109,6 +115,8 @@ def lib() -> C.CDLL:
     L.ta3n_refresh_bf16.argtypes = [vp, vp, vp, vp, vp]
     L.ta3n_has_pipelined_step.argtypes = [vp]
     L.ta3n_train_step_after_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.ta3n_train_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
+                                   C.POINTER(Feed), C.POINTER(Feed), vp]
     L.ta3n_gather_segments_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_gather_segments_bf16_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_sgd_step_next.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]

@@ -41,23 +41,38 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    """Compile what is out of date (an object is rebuilt when its source or any header is newer), in parallel, and link."""
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    objs = []
     hipcc = _hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+    t_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    flags_file = os.path.join(LIBDIR, ".flags")
+    flags_now = " ".join([*common, *extra_flags])
+    try:
+        with open(flags_file) as f:
+            same_flags = f.read() == flags_now
+    except OSError:
+        same_flags = False
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *common, *extra_flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), t_hdr):
+            jobs.append([hipcc, *common, *extra_flags, "-x", "hip", "-c", path, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs, "-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    with open(flags_file, "w") as f:
+        f.write(flags_now)
+    run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

@@ -472,6 +472,61 @@ int ta3n_train_step_after_update(ta3n_plan *p, const float *x, float *params, fl
     return run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30);
 }
 
+// One batch assembly of a multi-step call: rows [first_video, first_video + ids_per_step) of the input from a packed store.
+static int feed_step(ta3n_plan *p, const ta3n_feed *f, int step, int first_video, int cap, float *x, float *ws, int32_t *labels_out,
+                     hipStream_t s) {
+    const Geom &g = p->geom;
+    if (!f->store || !f->first_row || !f->num_frames || !f->video_ids) return fail(TA3N_ERR_INVALID, "ta3n_feed: null table");
+    if (f->ids_per_step < 0 || f->ids_per_step > cap) return fail(TA3N_ERR_INVALID, "ta3n_feed: ids_per_step exceeds the batch half");
+    if (labels_out && !f->labels) return fail(TA3N_ERR_INVALID, "ta3n_feed: the source feed needs labels");
+    const int32_t *ids = f->video_ids + (size_t)step * f->ids_per_step;
+    const size_t row0 = (size_t)first_video * g.T;
+    float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
+    int rc;
+    if (f->bf16) {
+        if (!twin && !x) return fail(TA3N_ERR_INVALID, "ta3n_feed: a plan without bf16 twins needs the fp32 input rows");
+        rc = launch_gather_segments_bf16(f->store, f->first_row, f->num_frames, f->labels, ids, f->ids_per_step, g.T, g.D,
+                                         twin ? nullptr : x + row0 * g.D, labels_out, twin, s);
+    } else {
+        rc = launch_gather_segments(static_cast<const float *>(f->store), f->first_row, f->num_frames, f->labels, ids, f->ids_per_step,
+                                    g.T, g.D, x + row0 * g.D, labels_out, nullptr, twin, s);
+    }
+    return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
+}
+
+int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                     float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
+                     const ta3n_feed *source, const ta3n_feed *target, void *stream) {
+    if (!p || !x || !params || !grads || !momentum || !ws || !hypers) return fail(TA3N_ERR_INVALID, "null argument");
+    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(momentum) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_pipelined_step(p) != 1) return fail(TA3N_ERR_INVALID, "no pipelined step for this configuration");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geom &g = p->geom;
+    if ((source || target) && (g.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
+    Ptrs ptrs{x, params, grads, ws};
+    float lr = lr_pending;
+    for (int k = 0; k < n_steps; ++k) {
+        // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued)
+        if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(x), ws,
+                                      reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
+        if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(x), ws, nullptr, s)) != TA3N_OK) return rc;
+        if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+        if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                             reinterpret_cast<const Hyper *>(&hypers[k]), s) != 0)
+            return fail(TA3N_ERR_HIP, "sgd launch failed");
+        SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
+                     fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
+        if ((rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;
+        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30)) != TA3N_OK) return rc;
+        lr = hypers[k].lr;
+    }
+    return TA3N_OK;
+}
+
 int ta3n_refresh_bf16(ta3n_plan *p, const float *x, const float *params, float *ws, void *stream) {
     if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     if (p->geom.o_ws16 < 0) return TA3N_OK;

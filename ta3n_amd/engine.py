@@ -400,6 +400,72 @@ class TrainEngine:
         self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self.step_count += 1
 
+    def hyper_for(self, beta: Sequence[float], gamma: float, lr: float, step: Optional[int] = None, **hyper_kw) -> "_lib.Hyper":
+        """The per-step scalars of one step as a fresh ta3n_hyper (what set_hyper would upload)."""
+        keep = self._hyper
+        self._hyper = _lib.Hyper()
+        try:
+            self.set_hyper(beta, gamma, lr, train=True, upload=False, seed=step, **hyper_kw)
+            return self._hyper
+        finally:
+            self._hyper = keep
+
+    def train_steps(self, schedule: Sequence[Sequence], feeds=None) -> None:
+        """len(schedule) pipelined steps enqueued by ONE call into the library (ta3n_train_steps): schedule[k] = (beta, gamma, lr)
+        of step k (main.py:350-352, 620-621 evaluated ahead of time).  Same launches, same results as calling
+        train_step_pipelined once per entry; the host leaves the step's critical path (on a slow core the per-step ctypes call +
+        9 launches cost as much wall time as the GPU needs for the step).  feeds: optional (source, target) pairs of
+        (FeatureStore, int32 device tensor [len(schedule), n]) - the batch of step k is then assembled on the device before it.
+        Single rank; with a process group the steps go one by one (the all-reduce sits between backward and update)."""
+        n = len(schedule)
+        if n == 0:
+            return
+        if not self.fused or not self._side_update or self.world > 1 or self._ddp_selftest:
+            if feeds is not None:
+                raise _lib.Ta3nError("train_steps: device-side batch feeds need the single-rank pipelined step")
+            for beta, gamma, lr in schedule:
+                self.train_step_pipelined(beta, gamma, lr)
+            return
+        k0 = 0
+        if self._pending is None:            # the very first step has no update to open with
+            if feeds is not None:
+                for (store, ids), first in zip(feeds, (0, self.Bs)):
+                    if store is not None:
+                        store.gather_into(self, ids[0], first, labels_out=self._labels[: self.Bs] if first == 0 else None)
+            self.train_step_pipelined(*schedule[0])
+            k0 = 1
+            if n == 1:
+                return
+        hy = (_lib.Hyper * (n - k0))()
+        for k in range(k0, n):
+            beta, gamma, lr = schedule[k]
+            h = self.hyper_for(beta, gamma, lr, step=self.step_count + (k - k0))
+            C.memmove(C.byref(hy, (k - k0) * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
+        lr_p, mu, wd, clip = self._pending
+        fd = [None, None]
+        keep = []
+        if feeds is not None:
+            for i, (store, ids) in enumerate(feeds):
+                if store is None:
+                    continue
+                ids = ids[k0:].to(device=self.device, dtype=torch.int32).contiguous()
+                keep.append(ids)
+                f = _lib.Feed()
+                f.store = store.store.data_ptr(); f.bf16 = int(store.bf16); f.ids_per_step = ids.shape[1]
+                f.first_row = store.first_row.data_ptr(); f.num_frames = store.num_frames.data_ptr()
+                f.labels = store.labels.data_ptr(); f.video_ids = ids.data_ptr()
+                fd[i] = f
+        _lib.check(self._L.ta3n_train_steps(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
+                                            self.M.data_ptr(), self.ws.data_ptr(), 1, lr_p, mu, wd, clip, hy, n - k0,
+                                            C.byref(fd[0]) if fd[0] is not None else None,
+                                            C.byref(fd[1]) if fd[1] is not None else None, self._stream()), "ta3n_train_steps")
+        if keep:                              # the id tables must outlive the enqueued gathers
+            self._feed_keep = keep
+        last = schedule[-1]
+        self._pending = (float(last[2]), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
+        self._hyper = self.hyper_for(*last, step=self.step_count + (n - k0) - 1)
+        self.step_count += n - k0
+
     def capture(self) -> None:
         """Capture forward+loss+backward(+all-reduce)+update into one hipGraph (shapes
         are static).  set_hyper / set_batch stay outside: they only write device buffers."""
