@@ -105,7 +105,13 @@ typedef struct {
                               * weight gradient.  Measured slower at the headline shape (17.0 + 19.5 us against 22.1 + 9.3 us: a
                               * long-K tile alone on a compute unit is bound by the latency of its two LDS stages, not by the
                               * load path it no longer shares); kept for other shapes and A/B runs. */
-    int32_t reserved[4];
+    int32_t chain;           /* fused step, 1: consecutive GEMM dependency levels share ONE launch - forward: shared frame FC -> {frame
+                              * discriminator hidden layer, TRN tuple GEMMs} -> relation-discriminator hidden layer; backward: gradient at the
+                              * frame features + weight gradients -> shared-FC weight gradient - with tile-level hand-offs inside the launch
+                              * (a producer tile publishes its stores and bumps a counter, a consumer tile polls the counters of exactly
+                              * the tiles it reads; derived from the tiles' read / write spans).  5 launches per step instead of 8, the
+                              * same tiles and arithmetic: bit-identical results.  0: one launch per level. */
+    int32_t reserved[3];
 } ta3n_config;
 
 /* Per-step scalars; lives in device memory inside ws (region "hyper").  The host
@@ -388,6 +394,13 @@ int ta3n_debug_arrays(const ta3n_plan *plan, const void **segs, int64_t *n_segs,
                       int64_t *n_tasks, const void **phases, int64_t *n_phases, const void **geom,
                       const int32_t **tuples, const int32_t **tuple_first);
 int ta3n_debug_struct_sizes(int32_t *seg, int32_t *task, int32_t *phase, int32_t *geom, int32_t *hyper);
+/* ... and to the wait lists of the chained launches (ta3n_config.chain): {counter, target} int32 pairs. */
+int ta3n_debug_waits(const ta3n_plan *plan, const void **waits, int64_t *n_waits);
+
+/* ta3n_config.chain: 0 when every chained launch enqueued so far on `stream` ran to completion with all hand-offs served; 1
+ * (with a message in ta3n_last_error) when a workgroup gave up waiting or a launch left its counters dirty.  Synchronises
+ * the stream: a check for tests and for the end of a run, not for the step loop. */
+int ta3n_chain_status(ta3n_plan *plan, const float *ws, void *stream);
 
 const char *ta3n_last_error(void);
 const char *ta3n_version(void);

@@ -39,7 +39,7 @@ SYMBOLS = [
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_time_update_launches", "ta3n_last_error", "ta3n_version",
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
-    "ta3n_gather_segments_bf16_into", "ta3n_train_steps",
+    "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_chain_status", "ta3n_debug_waits",
 ]
 
 
@@ -48,7 +48,7 @@ class Config(C.Structure):
                 ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
                 ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
                 ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("aggregation", C.c_int32),
-                ("wgrads_late", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("wgrads_late", C.c_int32), ("chain", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Hyper(C.Structure):
@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
                                    C.c_int]
     L.ta3n_debug_arrays.argtypes = [vp] + [C.POINTER(vp), C.POINTER(i64)] * 3 + [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.ta3n_debug_struct_sizes.argtypes = [C.POINTER(i32)] * 5
+    L.ta3n_debug_waits.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.ta3n_chain_status.argtypes = [vp, vp, vp]
     L.ta3n_comm_unique_id.argtypes = [C.c_char_p]
     L.ta3n_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
     L.ta3n_comm_destroy.argtypes = [vp]
@@ -176,7 +178,8 @@ class Plan:
 
     def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
                  num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0,
-                 phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0, aggregation: int = 0, wgrads_late: int = 0):
+                 phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0, aggregation: int = 0, wgrads_late: int = 0,
+                 chain: int = 0):
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
@@ -185,6 +188,7 @@ class Plan:
         self.cfg.xcd_aware = int(xcd_aware)
         self.cfg.aggregation = int(aggregation)       # AGG_TRN_M / AGG_AVGPOOL
         self.cfg.wgrads_late = int(wgrads_late)
+        self.cfg.chain = int(chain)
         h = C.c_void_p()
         check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
         self.handle = h

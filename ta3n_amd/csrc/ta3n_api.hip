@@ -43,6 +43,8 @@ int ensure_uploaded(ta3n_plan *p) {
     HIP_TRY(hipMalloc(&p->d_tasks, p->tasks.size() * sizeof(Task)));
     HIP_TRY(hipMemcpy(p->d_segs, p->segs.data(), p->segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->d_tasks, p->tasks.data(), p->tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p->d_waits, (p->waits.size() + 1) * sizeof(Wait)));      // (+ 1: never a zero-byte allocation)
+    if (!p->waits.empty()) HIP_TRY(hipMemcpy(p->d_waits, p->waits.data(), p->waits.size() * sizeof(Wait), hipMemcpyHostToDevice));
     p->uploaded = true;
     return TA3N_OK;
 }
@@ -67,7 +69,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
         switch (ph.kind) {
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
-                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side);
+                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side, static_cast<const Wait *>(p->d_waits));
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -116,6 +118,7 @@ void ta3n_plan_destroy(ta3n_plan *p) {
     if (p->uploaded) {
         (void)hipFree(p->d_segs);
         (void)hipFree(p->d_tasks);
+        (void)hipFree(p->d_waits);
     }
     delete p;
 }
@@ -163,7 +166,8 @@ int64_t ta3n_plan_describe(const ta3n_plan *p, char *buf, int64_t cap) {
         const Phase &ph = p->phases[i];
         o << (i ? "," : "") << "{\"kind\":" << ph.kind << ",\"group\":" << ph.group << ",\"task_begin\":" << ph.task_begin
           << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * ph.bf16)
-          << ",\"rm\":" << (ph.rm > 0 ? ph.rm : 1) << ",\"rn\":" << (ph.rn > 0 ? ph.rn : 1) << "}";
+          << ",\"rm\":" << (ph.rm > 0 ? ph.rm : 1) << ",\"rn\":" << (ph.rn > 0 ? ph.rn : 1)
+          << ",\"chain_counters\":" << (ph.kind == PH_GEMM && ph.chain_off >= 0 ? ph.chain_n : -1) << "}";
     }
     o << "],\"n_tasks\":" << p->tasks.size() << ",\"n_segs\":" << p->segs.size() << "}";
     const std::string s = o.str();
@@ -189,6 +193,35 @@ int ta3n_debug_arrays(const ta3n_plan *p, const void **segs, int64_t *n_segs, co
     if (geom) *geom = &p->geom;
     if (tuples) *tuples = p->tuples.data();
     if (tuple_first) *tuple_first = p->tuple_first.data();
+    return TA3N_OK;
+}
+
+int ta3n_chain_status(ta3n_plan *p, const float *ws, void *stream) {
+    if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int bad = 0;
+    for (size_t i = 0; i < p->phases.size(); ++i) {
+        const Phase &ph = p->phases[i];
+        if (ph.kind != PH_GEMM || ph.chain_off < 0) continue;
+        int32_t head[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(head, ws + ph.chain_off, sizeof(head), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (head[1] != 0) {
+            bad = 1;
+            g_err = "chained launch (phase " + std::to_string(i) + "): workgroup " + std::to_string(head[1] - 1) + " gave up waiting for its producers";
+        }
+        if (head[0] != 0) {
+            bad = 1;
+            g_err = "chained launch (phase " + std::to_string(i) + "): " + std::to_string(head[0]) + " workgroups counted and the block was not reset";
+        }
+    }
+    return bad;
+}
+
+int ta3n_debug_waits(const ta3n_plan *p, const void **waits, int64_t *n_waits) {
+    if (!p) return fail(TA3N_ERR_INVALID, "null plan");
+    if (waits) *waits = p->waits.data();
+    if (n_waits) *n_waits = (int64_t)p->waits.size();
     return TA3N_OK;
 }
 
@@ -286,7 +319,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         for (int k = 0; k < r; ++k) {
             int lrc = 0;
             switch (ph.kind) {
-                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s); break;
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s, nullptr, static_cast<const Wait *>(p->d_waits)); break;
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;

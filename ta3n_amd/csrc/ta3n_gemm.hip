@@ -35,6 +35,7 @@
 // The epilogue goes through LDS once more so the K-split partials are reduced
 // and the stores / bias / mask operands are row-contiguous float4s.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 
 #include <type_traits>
@@ -460,6 +461,68 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
     }
 }
 
+// Write-through stores (sc0 sc1: the bytes leave the XCD's L2 at once) for tiles whose output another tile of the SAME launch
+// reads (chained launches): after s_waitcnt vmcnt(0) the data is visible to every CU, no L2 write-back (release fence) needed.
+__device__ __forceinline__ void st_pub(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_pub(void *p, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_pub(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_pub(unsigned short *p, unsigned v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// Chained launch, consumer side: wave 0 polls the task's (counter, target) pairs, one pair per lane (relaxed agent-scope loads:
+// served by the L2 / fabric, never by this CU's L1), then one agent-scope acquire (invalidates this CU's L1) and a workgroup
+// barrier.  A producer is always a lower-indexed task of the launch, i.e. already dispatched (workgroups are dispatched in
+// index order), so the wait ends; the spin is bounded anyway and a timeout is recorded in the launch's error word.
+constexpr int CHAIN_SPIN_LIMIT = 1 << 20;
+__device__ __forceinline__ void chain_wait(const Task &t, const Wait *__restrict__ waits, int *__restrict__ cnt, int tid, int knobs) {
+    const int nwait = (knobs & 1024) ? 0 : t.wait_count;       // (knob 1024: timing experiment without the waits - results void)
+    if (nwait > 0) {
+        if (tid < 64) {
+            for (int w0 = 0; w0 < nwait; w0 += 64) {
+                const bool mine = w0 + tid < nwait;
+                Wait w{0, 0};
+                if (mine) w = waits[t.wait_begin + w0 + tid];
+                bool ok = !mine;
+                int spins = 0;
+                for (;;) {
+                    if (!ok) ok = ((knobs & 2048) ? __hip_atomic_fetch_add(cnt + 2 + w.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : __hip_atomic_load(cnt + 2 + w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= w.target;
+                    if (__all(ok)) break;
+                    if (++spins > CHAIN_SPIN_LIMIT) {
+                        if (tid == 0) __hip_atomic_store(cnt + 1, 1 + (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    // somebody else already gave up: the launch's results are void, do not spin out the full limit as well
+                    if ((spins & 1023) == 0 && __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    for (int z = 0; z < (knobs & 255); ++z) __builtin_amdgcn_s_sleep(8);      // 8 x 64 cycles per unit
+                }
+            }
+            if (!(knobs & 256)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+}
+// ... producer side and launch bookkeeping: every thread's stores have been acknowledged (vmcnt(0)), then one thread bumps the
+// task's counter.  The last workgroup of the launch to get here zeroes the block for the next launch (nobody polls any more).
+__device__ __forceinline__ void chain_exit(int sig, int *__restrict__ cnt, int n_counters, int tid, int knobs) {
+    if ((knobs & 512) && sig < 0) return;       // A/B knob: the host resets the counters (memset before the launch), no launch accounting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (knobs & 512) { __hip_atomic_fetch_add(cnt + 2 + sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (sig >= 0) {     // ... and has been performed before this workgroup counts as done (the reset below must not overtake it)
+            const int before = __hip_atomic_fetch_add(cnt + 2 + sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(before) : "memory");
+        }
+        const int done = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            // (the bump above is ordered before this read-modify-write in program order on one address only; the counters of other
+            // addresses were bumped by workgroups whose `done` increments this one has observed through the same atomic unit)
+            for (int i = 0; i < n_counters; ++i) __hip_atomic_store(cnt + 2 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
     switch (base) {
         case BASE_X: return p.x;
@@ -486,8 +549,8 @@ namespace ta3n {
 // the rate at which a CU can fill its LDS (~41 B/clk measured, tools/proto_bf16.hip), i.e. the operand bytes brought per flop -
 // which only the tile size lowers.
 template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
-__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
-                                                                 Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side) {
+__device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__ segs, const Ptrs &ptrs, int hyper_off, int zeros_off,
+                                          int twin_off, const SgdSide &side) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
@@ -504,7 +567,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     GSTAMP(0);
-    const Task &t = tasks[blockIdx.x];
+    const bool pub = t.sig >= 0 && !(side.p16_off == -12345);    // chained launch: another task of this launch reads what this one writes -> write-through stores
     if (t.epi & EPI_SGD) {          // optimiser side job (uniform for the workgroup): arithmetic and summation order of sgd_range_kernel
         if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
         float part = 0.f;
@@ -529,10 +592,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                 d = fmaf(side.mu, mm[e], d);
                 pp[e] = fmaf(-side.lr, d, pp[e]);
             }
-            p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            if (pub) st_pub(reinterpret_cast<float *>(p4 + i), f32x4{pp[0], pp[1], pp[2], pp[3]});
+            else p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
             m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            if (side.p16_off >= 0)
-                reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+            if (side.p16_off >= 0) {
+                uint2 *tw = reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off) + i;
+                if (pub) st_pub(tw, u32x2{pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3])});
+                else *tw = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+            }
         }
         return;
     }
@@ -880,23 +947,25 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         if (epi & EPI_TWIN_ONLY) {
             // every consumer of this tile reads its bf16 twin: the fp32 copy is not written (a third of the store burst)
         } else if (nrem >= 4 && c_vec) {
-            *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            if (pub) st_pub(cp, f32x4{v[0], v[1], v[2], v[3]});
+            else *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (e < nrem) cp[e] = v[e];
+                if (e < nrem) { if (pub) st_pub(cp + e, v[e]); else cp[e] = v[e]; }
         }
         if (epi & EPI_TWIN16) {          // bf16 twin of the stored values (TA3N_FLAG_BF16_STORE)
             unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
             const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
             if (nrem >= 4 && c_vec) {
-                *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+                if (pub) st_pub(tp, u32x2{lo, hi});
+                else *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
             } else {
                 const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16), (unsigned short)(hi & 0xFFFF),
                                              (unsigned short)(hi >> 16)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < nrem) tp[e] = h[e];
+                    if (e < nrem) { if (pub) st_pub(tp + e, (unsigned)h[e]); else tp[e] = h[e]; }
             }
         }
         if (nfan > 0) {
@@ -922,24 +991,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                     for (int e = 0; e < 4; ++e) ov[e] = (e < nrem && fm[f][e] > 0.f) ? v[e] : 0.f;
                     if (epi & EPI_TWIN_ONLY_FAN) {
                     } else if (fan_vec && (t.fan_out_off[f] & 3) == 0) {
-                        *reinterpret_cast<float4 *>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                        if (pub) st_pub(op, f32x4{ov[0], ov[1], ov[2], ov[3]});
+                        else *reinterpret_cast<float4 *>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (e < nrem) op[e] = ov[e];
+                            if (e < nrem) { if (pub) st_pub(op + e, ov[e]); else op[e] = ov[e]; }
                     }
                     if (epi & EPI_TWIN16_FAN) {
                         unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) +
                                              ((size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n);
                         const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
                         if (nrem >= 4 && ((t.fan_out_off[f] | t.fan_ld) & 3) == 0) {
-                            *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
+                            if (pub) st_pub(tp, u32x2{lo, hi});
+                            else *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
                         } else {
                             const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16),
                                                          (unsigned short)(hi & 0xFFFF), (unsigned short)(hi >> 16)};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (e < nrem) tp[e] = h[e];
+                                if (e < nrem) { if (pub) st_pub(tp + e, (unsigned)h[e]); else tp[e] = h[e]; }
                         }
                     }
                 }
@@ -964,7 +1035,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
         }
     }
     GSTAMP(5);
-#ifdef TA3N_GEMM_STAMPS
+#if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 1
     if (threadIdx.x == 0 && blockIdx.x < 8192) { ta3n_dbg_stamps[blockIdx.x * 8 + 6] = (unsigned long long)t.cost; ta3n_dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)t.seg_count; }
 #endif
     if (epi & EPI_SUMSQ) {   // wave-uniform: fixed-order block sum -> this tile's slot (fused grad-norm partial)
@@ -980,22 +1051,40 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     }
 }
 
+// One workgroup = one Task of the launch's list.  chain_off >= 0: a chained launch (several dependency levels; ta3n_types.h).
+template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
+                                                                 Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side,
+                                                                 const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs) {
+    const Task &t = tasks[blockIdx.x];
+    int *cnt = reinterpret_cast<int *>(ptrs.ws + (chain_off >= 0 ? chain_off : 0));
+#if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2      // tools/chain_stamps.py: [6] = workgroup entry (before the wait), [7] = after the exit bookkeeping
+    GSTAMP(6);
+#endif
+    if (chain_off >= 0) chain_wait(t, waits, cnt, (int)threadIdx.x, knobs);
+    gemm_tile<WM, WN, WK, BF, NS, RM, RN>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side);
+    if (chain_off >= 0) chain_exit(t.sig, cnt, chain_n, (int)threadIdx.x, knobs);
+#if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2
+    GSTAMP(7);
+#endif
+}
+
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
 
 // register-blocked tiles (bf16 twins only): (wm, wn, wk, rm, rn, stages...) - 128x128 with 8 or 4 waves, 64x128, 128x64
 #define TA3N_BLOCKED_CONFIGS(X) X(2, 2, 2, 2, 2, 2) X(2, 2, 1, 2, 2, 2) X(2, 2, 2, 1, 2, 2) X(2, 2, 2, 1, 2, 3) X(2, 2, 2, 2, 1, 2) X(2, 2, 2, 2, 1, 3)
 
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
-    template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 3, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide); \
-    template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 #define TA3N_INSTANTIATE_BLOCKED(wm, wn, wk, rm, rn, ns) \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide);
+    template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int);
 TA3N_BLOCKED_CONFIGS(TA3N_INSTANTIATE_BLOCKED)
 
 
@@ -1026,7 +1115,21 @@ bool tile_config_ok(int cfg) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side) {
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits) {
+    const int chain_off = d_waits ? ph.chain_off : -1, chain_n = ph.chain_n;
+    if (ph.chain_off >= 0 && !d_waits) return -4;
+    // measurement knobs of the hand-off protocol (defaults = the shipped protocol): TA3N_CHAIN_SLEEP = poll back-off in units of 512
+    // cycles; TA3N_CHAIN_NOACQ = 1: no acquire fence after the poll; TA3N_CHAIN_MEMSET = 1: counters reset by a memset before the launch
+    static const int knobs_env = [] {
+        const char *a = getenv("TA3N_CHAIN_SLEEP"), *b = getenv("TA3N_CHAIN_NOACQ"), *c = getenv("TA3N_CHAIN_MEMSET");
+        const char *d = getenv("TA3N_CHAIN_NOWAIT"), *e = getenv("TA3N_CHAIN_RMWPOLL");
+        return ((a ? atoi(a) : 1) & 255) | ((b && atoi(b)) ? 256 : 0) | ((c && atoi(c)) ? 512 : 0) | ((d && atoi(d)) ? 1024 : 0) |
+               ((e && atoi(e)) ? 2048 : 0);
+    }();
+    const int knobs = knobs_env;
+    if (chain_off >= 0 && (knobs & 512)) {
+        if (hipMemsetAsync(ptrs.ws + chain_off, 0, sizeof(int) * (size_t)(2 + chain_n), stream) != hipSuccess) return -2;
+    }
     if (ph.task_count == 0) return 0;
     SgdSide sd;
     std::memset(&sd, 0, sizeof(sd));
@@ -1042,7 +1145,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
 #define TA3N_LAUNCH_BLOCKED(wm, wn, wk, rm_, rn_, ns)                                                                      \
         if (!launched && cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (ph.bf16 & 15) == ns) {               \
             hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, 2, ns, rm_, rn_>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
-                               ptrs, hyper_off, zeros_off, twin_off, sd);                                                  \
+                               ptrs, hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs);                                                  \
             launched = true;                                                                                               \
         }
         TA3N_BLOCKED_CONFIGS(TA3N_LAUNCH_BLOCKED)
@@ -1051,7 +1154,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     }
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
     hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns, 1, 1>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
-                       hyper_off, zeros_off, twin_off, sd)
+                       hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs)
 #define TA3N_LAUNCH(wm, wn, wk)                                   \
     if (cfg == wm * 100 + wn * 10 + wk) {                         \
         switch (ph.bf16) {                                        \

@@ -96,6 +96,17 @@ struct Builder {
 
     int gemm_phase_index = 0;
     int force_next = 0;         // tile code for the next add_gemm_phase only (a launch that mirrors an earlier one)
+    // chained launch under construction (begin_chain .. end_chain): the levels' task lists are concatenated into ONE phase whose
+    // tile shape is the first level's; chain_level[i] = level of chain_tasks[i]
+    bool chaining = false;
+    int chain_levels = 0;
+    Phase chain_ph;
+    std::vector<Task> chain_tasks;
+    void begin_chain() { chaining = true; chain_levels = 0; chain_tasks.clear(); }
+    void chain_append(std::vector<Task> extra) {
+        for (auto &t : extra) { t.sig = -1; t.wait_begin = t.wait_count = 0; chain_tasks.push_back(t); }
+    }
+    std::string end_chain();    // defined below (derive_chain); returns an error message or ""
     bool mixed_kinds = false;   // a GEMM spec whose Segs differ in operand kinds (not supported by the kernel)
     int sum8[3] = {-1, 0, 0};   // {dst, src, rows}: when dst >= 0 the first workgroup of the next GEMM phase also sums an [rows][8] table
     std::vector<Task> side_tasks;   // non-tile tasks (EPI_COLSUM) appended to the next GEMM phase
@@ -118,7 +129,11 @@ struct Builder {
     void add_gemm_phase(int group, std::vector<GemmSpec> &specs) {
         int wm = 1, wn = 1, wk = 4;
         int forced = p.cfg.tile_config;
-        if (force_next != 0) {
+        if (chaining && chain_levels > 0) {            // later level of a chained launch: the launch's tile shape is settled
+            ++gemm_phase_index;
+            forced = chain_ph.wm * 100 + chain_ph.wn * 10 + chain_ph.wk + 1000 * (chain_ph.bf16 & 15) +
+                     10000 * ((chain_ph.rm > 1 ? 1 : 0) + (chain_ph.rn > 1 ? 2 : 0));
+        } else if (force_next != 0) {
             forced = force_next;
             force_next = 0;
         } else {
@@ -248,7 +263,14 @@ struct Builder {
         // the short side tasks go right behind the first tile: they finish under the tiles instead of extending the launch's tail
         local.insert(local.begin() + (local.empty() ? 0 : 1), side_tasks.begin(), side_tasks.end());
         side_tasks.clear();
-        for (auto &t : local) p.tasks.push_back(t);
+        ph.chain_off = -1; ph.chain_n = 0;
+        if (chaining) {
+            if (chain_levels == 0) { chain_ph = ph; chain_ph.group = group; }
+            ++chain_levels;
+            for (auto &t : local) { t.sig = -1; chain_tasks.push_back(t); }
+            return;
+        }
+        for (auto &t : local) { t.sig = -1; p.tasks.push_back(t); }
         ph.task_count = (int32_t)local.size();
         p.phases.push_back(ph);
     }
@@ -261,6 +283,118 @@ struct Builder {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained launches: who waits for whom.  Every task's writes and reads are laid out as element intervals per buffer (the
+// twins mirror their originals element for element, so this runs on the original offsets, before add_bf16_twins); a task
+// depends on every EARLIER task of the launch whose writes overlap its reads.  Producers with the same set of consumers share
+// one counter (target = their number), a consumer's wait list names the counters of its producers.  A later task overwriting
+// what an earlier one reads or writes would be a race inside one launch: reported as an error (such levels must stay launches).
+struct Ival { int64_t lo, hi; int task; };
+
+static void tile_rows(std::vector<Ival> &out, int64_t off, int64_t ld, int r0, int nr, int c0, int nc, int task) {
+    for (int r = r0; r < r0 + nr; ++r) out.push_back(Ival{off + (int64_t)r * ld + c0, off + (int64_t)r * ld + c0 + nc, task});
+}
+
+std::string Builder::end_chain() {
+    chaining = false;
+    Phase ph = chain_ph;
+    const int BM = 32 * ph.wm * std::max(ph.rm, 1), BN = 32 * ph.wn * std::max(ph.rn, 1);
+    const int n = (int)chain_tasks.size();
+    std::vector<Ival> wr[BASE_COUNT], rd[BASE_COUNT];
+    auto operand = [&](std::vector<Ival> &out, int off, int ld, int kmajor, int r0, int rows_valid, int tile_rows_n, int klen, int task) {
+        const int nr = std::min(tile_rows_n, rows_valid - r0);
+        if (nr <= 0) return;
+        if (!kmajor) tile_rows(out, off, ld, r0, nr, 0, klen, task);
+        else for (int k = 0; k < klen; ++k) out.push_back(Ival{off + (int64_t)k * ld + r0, off + (int64_t)k * ld + r0 + nr, task});
+    };
+    for (int i = 0; i < n; ++i) {
+        const Task &t = chain_tasks[i];
+        if (t.epi & EPI_SGD) {            // optimiser side job: writes the parameters [4 pad0, 4 pad1) (reads gradients / norm partials of earlier launches)
+            wr[BASE_P].push_back(Ival{4ll * t.pad[0], 4ll * t.pad[1], i});
+            continue;
+        }
+        if (t.epi & EPI_COLSUM) {
+            tile_rows(rd[BASE_WS], t.pad[0], t.pad[2], 0, t.pad[1], t.n0, t.n_valid - t.n0, i);
+            wr[t.c_base].push_back(Ival{(int64_t)t.c_off + t.n0, (int64_t)t.c_off + t.n_valid, i});
+            if (t.epi & EPI_SUMSQ) wr[BASE_WS].push_back(Ival{t.pad[3], t.pad[3] + 1, i});
+            continue;
+        }
+        if (t.seg_count == 0) continue;
+        if (t.epi & EPI_SUMROWS8) {
+            rd[BASE_WS].push_back(Ival{t.pad[1], t.pad[1] + 8ll * t.pad[2], i});
+            wr[BASE_WS].push_back(Ival{t.pad[0], t.pad[0] + 8, i});
+        }
+        const int nr = std::min(BM, t.m_valid - t.m0), nc = std::min(BN, t.n_valid - t.n0);
+        for (int k = t.seg_begin; k < t.seg_begin + t.seg_count; ++k) {
+            const Seg &sg = p.segs[k];
+            operand(rd[sg.a_base], sg.a_off, sg.a_ld, sg.a_kmajor, t.m0, sg.pad[0] > 0 ? sg.pad[0] : t.m_valid, BM, sg.klen, i);
+            operand(rd[sg.b_base], sg.b_off, sg.b_ld, sg.b_kmajor, t.n0, t.n_valid, BN, sg.klen, i);
+        }
+        if (t.epi & EPI_BIAS) rd[t.bias_base].push_back(Ival{(int64_t)t.bias_off + t.n0, (int64_t)t.bias_off + t.n0 + nc, i});
+        if (t.epi & EPI_MASK) tile_rows(rd[t.aux_base], t.aux_off, t.aux_ld, t.m0, nr, t.n0, nc, i);
+        if (t.epi & EPI_ADD) tile_rows(rd[t.add_base], t.add_off, t.add_ld, t.m0, nr, t.n0, nc, i);
+        for (int f = 0; f < t.fan_count; ++f) {
+            tile_rows(rd[BASE_WS], t.fan_mask_off[f], t.fan_ld, t.m0, nr, t.n0, nc, i);
+            tile_rows(wr[BASE_WS], t.fan_out_off[f], t.fan_ld, t.m0, nr, t.n0, nc, i);
+        }
+        tile_rows(wr[t.c_base], t.c_off, t.c_ld, t.m0, nr, t.n0, nc, i);
+        if (t.epi & EPI_ROWSUM_A) wr[t.bias_base].push_back(Ival{(int64_t)t.bias_off + t.m0, (int64_t)t.bias_off + t.m0 + nr, i});
+        if (t.epi & EPI_SUMSQ) wr[BASE_WS].push_back(Ival{t.pad[3], t.pad[3] + 1, i});
+    }
+    std::vector<std::vector<int>> consumers(n), producers(n);
+    for (int b = 0; b < BASE_COUNT; ++b) {
+        auto &w = wr[b];
+        std::sort(w.begin(), w.end(), [](const Ival &a, const Ival &c) { return a.lo < c.lo; });
+        for (size_t k = 1; k < w.size(); ++k)
+            if (w[k].lo < w[k - 1].hi && w[k].task != w[k - 1].task)
+                return "chained launch: tasks " + std::to_string(w[k - 1].task) + " and " + std::to_string(w[k].task) + " write the same elements";
+        for (const Ival &r : rd[b]) {
+            // writers are sorted and disjoint: the first one that can overlap ends after r.lo
+            size_t k = std::lower_bound(w.begin(), w.end(), r.lo, [](const Ival &a, int64_t v) { return a.hi <= v; }) - w.begin();
+            for (; k < w.size() && w[k].lo < r.hi; ++k) {
+                if (w[k].task == r.task) continue;
+                if (w[k].task > r.task)
+                    return "chained launch: task " + std::to_string(w[k].task) + " overwrites what the earlier task " + std::to_string(r.task) + " reads";
+                producers[r.task].push_back(w[k].task);
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        auto &v = producers[i];
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        for (int j : v) consumers[j].push_back(i);      // (i ascending: the lists come out sorted)
+    }
+    std::vector<std::pair<std::vector<int>, int>> groups;   // (consumer set, counter)
+    std::vector<int> target;
+    for (int j = 0; j < n; ++j) {
+        if (consumers[j].empty()) continue;
+        int c = -1;
+        for (auto &gp : groups)
+            if (gp.first == consumers[j]) { c = gp.second; break; }
+        if (c < 0) { c = (int)target.size(); groups.push_back({consumers[j], c}); target.push_back(0); }
+        ++target[c];
+        chain_tasks[j].sig = c;
+    }
+    for (int i = 0; i < n; ++i) {
+        std::vector<int> cs;
+        for (int j : producers[i]) cs.push_back(chain_tasks[j].sig);
+        std::sort(cs.begin(), cs.end());
+        cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+        chain_tasks[i].wait_begin = (int32_t)p.waits.size();
+        chain_tasks[i].wait_count = (int32_t)cs.size();
+        for (int c : cs) p.waits.push_back(Wait{c, target[c]});
+    }
+    ph.chain_n = (int32_t)target.size();
+    ph.chain_off = (int32_t)add_region("chain" + std::to_string(p.phases.size()), 2 + ph.chain_n);
+    ph.task_begin = (int32_t)p.tasks.size();
+    ph.task_count = n;
+    for (auto &t : chain_tasks) p.tasks.push_back(t);
+    p.phases.push_back(ph);
+    chain_tasks.clear();
+    return "";
+}
 
 typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
 
@@ -1214,17 +1348,32 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // discriminator heads, the attention pooling, the classifier, the losses and their backward - is one
     // kernel (ta3n_heads.hip); its small weight gradients ride along with the relation level.
     if (heads_supported(NB, C, F) && !mcd && !feat_grads && !bn_shared) {   // (the fused heads kernel knows neither the second classifier nor an outside gradient)
-        { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(4, s); }
-        {
-            std::vector<GemmSpec> s{spec_Hf()};
-            for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
-            b.add_gemm_phase(4, s);
-        }
-        {
-            std::vector<GemmSpec> s;
-            for (int j = 0; j < NR; ++j) s.push_back(spec_Hr(j));
-            b.add_gemm_phase(4, s);
-        }
+        const bool chain = c.chain != 0;
+        std::string cerr;
+        // chain: the three forward GEMM levels are ONE launch (tile-level hand-offs inside it, Builder::end_chain), likewise the
+        // last two backward levels: 5 launches per step instead of 8 (north_star's "gather+concat and the
+        // relation MLP as one grouped GEMM launch")
+        auto forward_levels = [&](int group, const std::vector<Task> *side) {
+            if (chain) b.begin_chain();
+            { std::vector<GemmSpec> s{spec_F1()}; b.add_gemm_phase(group, s); }
+            if (side) {
+                if (chain) b.chain_append(*side);
+                else { for (auto &t : *side) p.tasks.push_back(t); p.phases.back().task_count += (int32_t)side->size(); }
+            }
+            if (!chain && group == 5) return;      // unchained: the pipelined variant only mirrors the first launch
+            {
+                std::vector<GemmSpec> s{spec_Hf()};
+                for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
+                b.add_gemm_phase(group, s);
+            }
+            {
+                std::vector<GemmSpec> s;
+                for (int j = 0; j < NR; ++j) s.push_back(spec_Hr(j));
+                b.add_gemm_phase(group, s);
+            }
+            if (chain) { const std::string e = b.end_chain(); if (!e.empty()) cerr = e; }
+        };
+        forward_levels(4, nullptr);
         b.add_simple_phase(PH_HEADS, 4);
         b.sum8[0] = g.o_losses; b.sum8[1] = g.o_loss_part; b.sum8[2] = g.n_vid_wg + g.n_frm_wg;   // logging scalars
         {
@@ -1250,11 +1399,18 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         const unsigned late_mask = c.wgrads_late == 0 ? 0u : c.wgrads_late == 1 ? ~0u : (unsigned)c.wgrads_late;
         const bool late_fd = (late_mask >> 1) & 1;
         const unsigned late_trn = late_mask >> 2;
+        if (chain) b.begin_chain();
         {
             std::vector<GemmSpec> s;
-            if (twins_on && !late_fd) push_frame_disc_wgrads(s);
-            push_trn_wgrads(s, ~late_trn);
-            push_f1_grad(s);
+            if (chain) {      // one launch: the tiles everything else waits for (the gradient at F1) are dispatched first
+                push_f1_grad(s);
+                if (twins_on && !late_fd) push_frame_disc_wgrads(s);
+                push_trn_wgrads(s, ~late_trn);
+            } else {
+                if (twins_on && !late_fd) push_frame_disc_wgrads(s);
+                push_trn_wgrads(s, ~late_trn);
+                push_f1_grad(s);
+            }
             b.add_gemm_phase(4, s);
         }
         {
@@ -1264,6 +1420,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             if (twins_on && late_fd) push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
+        if (chain) { const std::string e = b.end_chain(); if (!e.empty()) cerr = e; }
         {   // group 5: the step's first launch once more, carrying the PREVIOUS step's optimiser update of every parameter
             // it does not read itself (all but the shared frame FC) as EPI_SGD side tasks (ta3n_train_step_after_update)
             const Phase *f1 = nullptr;
@@ -1271,22 +1428,23 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
                 if (ph.group == 4 && ph.kind == PH_GEMM) { f1 = &ph; break; }
             b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15) +
                            10000 * ((f1->rm > 1 ? 1 : 0) + (f1->rn > 1 ? 2 : 0));
-            std::vector<GemmSpec> s{spec_F1()};
-            b.add_gemm_phase(5, s);
             const int64_t i0 = p.first_floats / 4, i1 = p.live_floats / 4;
             const int n_side = 256;
             const int64_t per = (i1 - i0 + n_side - 1) / n_side;
+            std::vector<Task> side;
             for (int k = 0; k < n_side; ++k) {
                 Task t;
                 std::memset(&t, 0, sizeof(t));
                 t.epi = EPI_SGD;
+                t.sig = -1;
                 t.c_base = BASE_NONE; t.bias_base = BASE_NONE; t.aux_base = BASE_NONE; t.add_base = BASE_NONE;
                 t.pad[0] = (int32_t)std::min(i0 + per * k, i1);
                 t.pad[1] = (int32_t)std::min(i0 + per * (k + 1), i1);
-                p.tasks.push_back(t);
+                side.push_back(t);
             }
-            p.phases.back().task_count += n_side;
+            forward_levels(5, &side);
         }
+        if (!cerr.empty()) { err = cerr; return TA3N_ERR_INVALID; }
         // every gradient tile of the fused step leaves the sum of its squares in its own slot: the optimiser
         // (ta3n_sgd_step_fused) adds the slots in a fixed order instead of re-reading the gradient buffer
         std::vector<size_t> grad_tasks;

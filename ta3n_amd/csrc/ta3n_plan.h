@@ -30,12 +30,14 @@ struct ta3n_plan {
     std::vector<ta3n::Seg> segs;
     std::vector<ta3n::Task> tasks;
     std::vector<ta3n::Phase> phases;
+    std::vector<ta3n::Wait> waits;      // wait lists of the chained launches (Task.wait_begin / wait_count)
     std::vector<int32_t> tuples, scale_len, scale_id, tuple_first;  // tuple_first[j..j+1) = tuples of scale j
     int n_tuples = 0;
     uint64_t deny_blocking = 0;   // bit i: phase i must not use register-blocked tiles (it does not read bf16 twins; build_plan's retry)
     // device copies (created lazily by the launcher)
     void *d_segs = nullptr;
     void *d_tasks = nullptr;
+    void *d_waits = nullptr;
     bool uploaded = false;
     int device = -1;
 

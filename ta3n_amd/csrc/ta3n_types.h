@@ -71,7 +71,16 @@ struct Task {
     int32_t cost;                        // sum of klen (for ordering / balance)
     int32_t pad[4];                      // EPI_SUMROWS8: [0..2] = {dst, src, rows} (ws offsets); EPI_SUMSQ: [3] = ws offset of the slot;
                                          // EPI_COLSUM: [0..2] = {src ws offset, rows, row stride}
+    // Chained launch (Phase.chain_off >= 0): several dependency levels in ONE launch.  A task whose output a later task of the
+    // same launch reads increments counter `sig` once its stores are visible at agent scope; a task that reads such output first
+    // waits until every (counter, target) pair of its wait list waits[wait_begin .. wait_begin + wait_count) is reached.  The plan
+    // builder derives both from the tasks' read / write spans (ta3n_plan.cpp: derive_chain); tasks only ever wait on tasks with
+    // a lower index in the launch.
+    int32_t sig;                         // -1: nobody in this launch reads what this task writes
+    int32_t wait_begin, wait_count;
+    int32_t pad2;
 };
+struct Wait { int32_t counter, target; };
 
 enum PhaseKind : int32_t {
     PH_GEMM = 0,
@@ -102,6 +111,8 @@ struct Phase {
                                  // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): the Segs' offsets address the
                                  // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
     int32_t rm, rn;              // 32x32 blocks per wave (0 or 1: one): block tile = 32*wm*rm x 32*wn*rn; > 1 only when bf16 >= 16
+    int32_t chain_off;           // chained launch: ws offset (floats) of its int32 block {done, error, counters[chain_n]}; -1: plain launch
+    int32_t chain_n;
 };
 
 // Mirror of ta3n_hyper (include/ta3n_hip.h); the device reads it from ws.

@@ -70,7 +70,7 @@ class TrainEngine:
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
-                 f32_split: bool = False):
+                 f32_split: bool = False, chain: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -94,10 +94,13 @@ class TrainEngine:
             from .tuning import tuned_phase_tiles
             phase_tiles = tuned_phase_tiles(batch_source + batch_target, num_segments, feature_dim, min(fc_dim, feature_dim),
                                             self.bf16, self.bf16_store, split=bool(flags & _lib.FLAG_F32_SPLIT))
+        if chain is None:        # chained launches (ta3n_config.chain): the fused trn-m step in 5 launches instead of 8
+            chain = os.environ.get("TA3N_CHAIN", "0") == "1" and aggregation == "trn-m" and fused
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
-                              wgrads_late=int(wgrads_late))
+                              wgrads_late=int(wgrads_late), chain=int(chain))
+        self.chain = bool(chain)
         self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
         self.B = batch_source + batch_target
         self.F = min(fc_dim, feature_dim)
@@ -465,6 +468,11 @@ class TrainEngine:
         self._pending = (float(last[2]), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self._hyper = self.hyper_for(*last, step=self.step_count + (n - k0) - 1)
         self.step_count += n - k0
+
+    def chain_status(self) -> None:
+        """Raises if a chained launch enqueued so far left a hand-off unserved (synchronises; tests / end of a run)."""
+        if self._L.ta3n_chain_status(self.plan.handle, self.ws.data_ptr(), self._stream()) != 0:
+            raise _lib.Ta3nError(self._L.ta3n_last_error().decode())
 
     def capture(self) -> None:
         """Capture forward+loss+backward(+all-reduce)+update into one hipGraph (shapes

@@ -16,6 +16,7 @@ from ta3n_amd import _lib
 BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_COLSUM = 1 << 12
+EPI_SGD = 1 << 11
 (PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS, PH_POOL_AVG_FWD, PH_POOL_AVG_BWD,
  PH_BN_FWD, PH_BN_BWD) = range(12)
 HEADS_RPW = 16
@@ -33,11 +34,11 @@ class Task(C.Structure):
                                           "aux_base", "aux_off", "aux_ld", "add_base", "add_off", "add_ld", "drop_ld",
                                           "fan_count", "fan_ld")] +
                 [("fan_mask_off", C.c_int32 * 3), ("fan_out_off", C.c_int32 * 3), ("seg0", Seg), ("cost", C.c_int32),
-                 ("pad", C.c_int32 * 4)])
+                 ("pad", C.c_int32 * 4), ("sig", C.c_int32), ("wait_begin", C.c_int32), ("wait_count", C.c_int32), ("pad2", C.c_int32)])
 
 
 class Phase(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16", "rm", "rn")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16", "rm", "rn", "chain_off", "chain_n")]
 
 
 def round_bf16(a):
@@ -86,6 +87,15 @@ def plan_arrays(plan):
     return segs, tasks, phases, geom, tup, tf
 
 
+def plan_waits(plan):
+    """[n, 2] int array of the (counter, target) pairs of the plan's chained launches."""
+    w = C.c_void_p(); n = C.c_int64()
+    _lib.lib().ta3n_debug_waits(plan.handle, C.byref(w), C.byref(n))
+    if n.value == 0:
+        return np.zeros((0, 2), np.int32)
+    return np.ctypeslib.as_array(C.cast(w, C.POINTER(C.c_int32)), shape=(n.value, 2)).copy()
+
+
 def mix32(x):
     x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
     x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
@@ -117,6 +127,7 @@ class Interp:
         self.X = None
         self.labels = np.zeros(g.B, np.int64)
         self.hy = None
+        self.side = None          # scalars of the update that rides in a pipelined step's first launch: dict(lr, momentum, weight_decay, clip)
 
     # ---- helpers ----
     def set_params(self, state):
@@ -155,10 +166,47 @@ class Interp:
         return b[idx]
 
     # ---- phases ----
-    def run_gemm(self, ph):
+    def chain_order(self, ph, adversarial=True, seed=0):
+        """An execution order of a chained launch's tasks that respects ONLY the declared hand-offs (Task.sig / wait lists):
+        among the tasks whose counters are reached, the highest index runs first (adversarial: consumers as early as their
+        wait lists allow) or a random one.  If a wait list misses a producer, the consumer runs before it and reads stale data."""
+        waits = plan_waits(self.plan)
+        rng = np.random.default_rng(seed)
+        ids = list(range(ph.task_begin, ph.task_begin + ph.task_count))
+        cnt = np.zeros(max(ph.chain_n, 1), np.int64)
+        pending = set(ids)
+        order = []
+        while pending:
+            ready = [i for i in pending
+                     if all(cnt[waits[w, 0]] >= waits[w, 1] for w in range(self.tasks[i].wait_begin, self.tasks[i].wait_begin + self.tasks[i].wait_count))]
+            assert ready, "chained launch deadlocks: no task is ready"
+            i = max(ready) if adversarial else int(rng.choice(ready))
+            order.append(i)
+            pending.discard(i)
+            if self.tasks[i].sig >= 0:
+                cnt[self.tasks[i].sig] += 1
+        return order
+
+    def run_gemm(self, ph, order=None):
+        for ti in (order if order is not None else range(ph.task_begin, ph.task_begin + ph.task_count)):
+            self.run_task(ph, ti)
+
+    def run_task(self, ph, ti):
         BM, BN = 32 * ph.wm * max(ph.rm, 1), 32 * ph.wn * max(ph.rn, 1)
-        for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
+        if True:
             t = self.tasks[ti]
+            if t.epi & EPI_SGD:          # optimiser side job of a pipelined step's first launch: update of params [4 pad0, 4 pad1)
+                if self.side is None:
+                    return
+                g, sd = self.g, self.side
+                total = np.sqrt(self.ws[g.o_sumsq:g.o_sumsq + g.n_sumsq].sum())
+                coef = min(sd["clip"] / (total + 1e-6), 1.0) if sd["clip"] > 0 else 1.0
+                lo, hi = 4 * t.pad[0], 4 * t.pad[1]
+                d = self.G[lo:hi] * coef + sd["weight_decay"] * self.P[lo:hi]
+                self.M[lo:hi] = sd["momentum"] * self.M[lo:hi] + d
+                d = d + sd["momentum"] * self.M[lo:hi]
+                self.P[lo:hi] -= sd["lr"] * d
+                return
             if t.epi & EPI_COLSUM:       # exact column sums of a table of per-workgroup partials
                 src, rows, ld = t.pad[0], t.pad[1], t.pad[2]
                 n = np.arange(t.n0, t.n_valid)
@@ -166,9 +214,9 @@ class Interp:
                 self.buf(t.c_base)[t.c_off + n] = v
                 if t.epi & EPI_SUMSQ:
                     self.ws[t.pad[3]] = float((v * v).sum())
-                continue
+                return
             if t.seg_count == 0:
-                continue
+                return
             if t.epi & EPI_SUMROWS8:
                 dst, src, rows = t.pad[0], t.pad[1], t.pad[2]
                 self.ws[dst:dst + 8] = self.ws[src:src + 8 * rows].reshape(rows, 8).sum(0)
