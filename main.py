@@ -167,7 +167,9 @@ def train(num_class, source_loader, target_loader, model, criterion, criterion_d
     for i, ((source_data, source_label), (target_data, target_label)) in enumerate(zip(source_loader, target_loader)):   # :348
         p = float(i + start_steps) / total_steps                                        # :350-352
         beta_dann = 2. / (1. + np.exp(-10 * p)) - 1
-        beta_new = [beta_dann if beta[k] < 0 else beta[k] for k in range(len(beta))]
+        # (:352 rebinds `beta` itself: a negative entry takes the DANN value of the epoch's FIRST step and keeps it for the rest of the
+        # train() call - after the first iteration no entry is negative any more.  Reproduced, not "fixed".)
+        beta = beta_new = [beta_dann if beta[k] < 0 else beta[k] for k in range(len(beta))]
         source_size_ori, target_size_ori = source_data.size(), target_data.size()       # :354-372
         batch_source_ori, batch_target_ori = source_size_ori[0], target_size_ori[0]
         source_data, target_data = _pad(source_data, args.batch_size[0]), _pad(target_data, args.batch_size[1])

@@ -70,7 +70,7 @@ class TrainEngine:
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
-                 f32_split: bool = False, chain: Optional[bool] = None):
+                 f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -138,23 +138,28 @@ class TrainEngine:
         self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1"))
         self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
         # N > 1 (or the 1-rank self-test): RCCL straight from the C ABI on the step's streams (TA3N_DDP_NATIVE=0: through
-        # torch.distributed instead).  Gradient transport: fp32, or bf16 (half the xGMI bytes) - default for the bf16
-        # arithmetic, whose contractions see the gradients' operands in bf16 anyway; TA3N_DDP_BF16=0/1 overrides.
+        # torch.distributed instead).
         self.comm = None
         self.comm_fallback: Optional[str] = None
         self._g16 = None
         self._comm_stream: Optional[torch.cuda.Stream] = None
         rccl_group = self.world == 1 or torch.distributed.get_backend(self.pg) == "nccl"     # gloo (CPU / shared-GPU tests): torch path
         if (self.world > 1 or self._ddp_selftest) and rccl_group and os.environ.get("TA3N_DDP_NATIVE", "1") == "1":
+            # Either EVERY rank uses the library's communicator or none does (parallel.NativeComm agrees on that over the torch group
+            # before and after ncclCommInitRank): ranks that disagreed would enqueue different collectives and hang.
             try:
                 self.comm = parallel.NativeComm(self.pg if self.world > 1 else None, self.device)
-            except Exception as ex:      # noqa: BLE001 - the same on every rank (parallel.NativeComm): still RCCL, through torch.distributed
+            except Exception as ex:      # noqa: BLE001 - raised on every rank together: still RCCL, through torch.distributed
                 self.comm = None
                 self.comm_fallback = f"{type(ex).__name__}: {ex}"
                 if self.rank == 0:
                     print(f"[ta3n] RCCL communicator of the C ABI unavailable ({self.comm_fallback}); gradient all-reduce goes "
                           f"through torch.distributed (backend nccl = RCCL)", flush=True)
-            if self.comm is not None and os.environ.get("TA3N_DDP_BF16", "1" if self.bf16 else "0") == "1":
+            # Gradient transport: fp32 unless asked otherwise (grad_transport="bf16" / TA3N_DDP_BF16=1: every rank's gradients are
+            # rounded to bf16 and SUMMED in bf16 - half the xGMI bytes, but the N-rank result then differs from the 1-rank /
+            # fp32-transport one by up to ~N * 2^-9 relative per element, and the clip norm is taken on the rounded sum)
+            want16 = (grad_transport == "bf16") if grad_transport is not None else os.environ.get("TA3N_DDP_BF16", "0") == "1"
+            if self.comm is not None and want16:
                 self._g16 = torch.zeros(p.live_floats, dtype=torch.bfloat16, device=self.device)
         self.step_count = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None

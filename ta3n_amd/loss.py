@@ -28,8 +28,11 @@ def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None
     bandwidth is the mean pairwise squared distance (no gradient through it), scaled by kernel_mul^(i - kernel_num // 2)."""
     n = int(source.size(0)) + int(target.size(0))
     total = torch.cat([source, target], dim=0)
-    sq = (total * total).sum(1)
-    l2 = (sq[:, None] + sq[None, :] - 2.0 * total @ total.t()).clamp_min(0.0)       # ||x_i - x_j||^2 as one product
+    # ||x_i - x_j||^2 in the reference's explicit difference form (loss.py:50-52), a block of rows at a time so the [rows, n, d]
+    # intermediate stays small.  (Not |x|^2 + |y|^2 - 2 x.y: in fp32 that cancels catastrophically for near-duplicate rows -
+    # zero-padded dummy rows, logits - and moves the data-dependent bandwidth; ADVICE r02.)
+    rows = max(1, min(n, (1 << 24) // max(n * int(total.size(1)), 1)))
+    l2 = torch.cat([((total[r0:r0 + rows, None, :] - total[None, :, :]) ** 2).sum(2) for r0 in range(0, n, rows)], dim=0)
     bandwidth = fix_sigma if fix_sigma else torch.sum(l2.detach()) / (n * n - n)
     bandwidth = bandwidth / kernel_mul ** (kernel_num // 2)
     return sum(torch.exp(-l2 / (bandwidth * kernel_mul ** i)) for i in range(kernel_num))

@@ -401,15 +401,25 @@ class VideoModel(nn.Module):
             entry = [tmpl.clone(), False]
             pool.append(entry)
         if keep:
-            entry[1] = True
-            ctx._ws_entry = entry
-            weakref.finalize(ctx, lambda e=entry: e.__setitem__(1, False))      # a graph dropped without backward frees it too
+            # Ownership token: the entry is free again only when THIS checkout gives it back.  The finalizer of an autograd node
+            # runs when the node dies - which can be long after its backward released the entry and another forward checked the
+            # same buffer out (the previous iteration's graph lives until `loss` is rebound) - so neither path may clear an
+            # entry that carries somebody else's token.
+            tok = object()
+            entry[1] = tok
+            ctx._ws_entry = (entry, tok)
+            weakref.finalize(ctx, self._ws_give_back, entry, tok)      # a graph dropped without backward frees it too
         return entry[0]
+
+    @staticmethod
+    def _ws_give_back(entry, tok) -> None:
+        if entry[1] is tok:
+            entry[1] = False
 
     def _ws_release(self, ctx) -> None:
         e = getattr(ctx, "_ws_entry", None)
         if e is not None:
-            e[1] = False
+            self._ws_give_back(*e)
 
     def _named_flat_params(self, plan: _lib.Plan):
         named = dict(self.named_parameters())

@@ -103,22 +103,44 @@ class NativeComm:
         L = _lib.lib()
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if world > 1 else 0
-        buf = C.create_string_buffer(128)
-        ids = [None]
-        if rank == 0:        # a failure here (librccl.so not loadable) must not leave the other ranks waiting in the broadcast:
-            try:             # it travels as the payload and every rank raises the same error
-                _lib.check(L.ta3n_comm_unique_id(buf), "ta3n_comm_unique_id")
-                ids = [bytes(buf.raw)]
-            except Exception as ex:      # noqa: BLE001
-                ids = [RuntimeError(f"ta3n_comm_unique_id failed on rank 0: {ex}")]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        if isinstance(ids[0], Exception):
-            raise ids[0]
-        h = C.c_void_p()
         if device is not None:
             torch.cuda.set_device(device)
-        _lib.check(L.ta3n_comm_create(C.c_char_p(ids[0]), rank, world, C.byref(h)), "ta3n_comm_create")
+
+        def agree(ok: bool, what: str, detail: str = "") -> None:
+            """Every rank learns whether EVERY rank succeeded; if not, all of them raise (the caller falls back together)."""
+            if world > 1:
+                flags = [None] * world
+                dist.all_gather_object(flags, (bool(ok), detail), group=group)
+            else:
+                flags = [(bool(ok), detail)]
+            bad = [(r, d) for r, (o, d) in enumerate(flags) if not o]
+            if bad:
+                raise RuntimeError(f"{what} failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
+
+        # (1) can every rank load RCCL at all?  A rank that cannot must not leave the others waiting inside ncclCommInitRank.
+        buf = C.create_string_buffer(128)
+        ok, detail = True, ""
+        try:
+            _lib.check(L.ta3n_comm_unique_id(buf), "ta3n_comm_unique_id")
+        except Exception as ex:      # noqa: BLE001
+            ok, detail = False, str(ex)
+        agree(ok, "loading RCCL (ta3n_comm_unique_id)", detail)
+        # (2) rank 0's id to everybody, (3) the collective init, (4) did it succeed everywhere?
+        ids = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = C.c_void_p()
+        ok, detail = True, ""
+        try:
+            _lib.check(L.ta3n_comm_create(C.c_char_p(ids[0]), rank, world, C.byref(h)), "ta3n_comm_create")
+        except Exception as ex:      # noqa: BLE001
+            ok, detail = False, str(ex)
+        try:
+            agree(ok, "ta3n_comm_create (ncclCommInitRank)", detail)
+        except Exception:
+            if ok and h:
+                L.ta3n_comm_destroy(h)
+            raise
         self.handle, self.world, self.rank, self._L = h, world, rank, L
 
     def close(self):

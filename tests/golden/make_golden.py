@@ -130,6 +130,8 @@ def make_args(case):
     a.dis_DA = case.get("dis_DA", "none")
     a.place_dis = list(case.get("place_dis", ("N", "Y", "N")))      # script_train_val.sh:148
     a.ens_DA = case.get("ens_DA", "none")
+    if "add_loss_DA" in case:                      # (e.g. MCD without the attentive-entropy term: main.py:559-562 off)
+        a.add_loss_DA = case["add_loss_DA"]
     return a
 
 
@@ -289,6 +291,12 @@ CASES = {
                              wscale="trained", xseed=302, steps=2, lr=2e-3, dis_DA="JAN", alpha=0.5),
     "tiny_avgpool_adabn": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=33,
                                wscale="trained", xseed=303, steps=3, short_last=(5, 3), lr=2e-3, use_bn="AdaBN"),
+    # MCD WITHOUT attentive entropy, four steps: nothing but `loss` keeps an iteration's graph alive, so the previous iteration's
+    # autograd node dies in the middle of the next one (workspace pool handed out a buffer that was in use from step 2 on)
+    "tiny_mcd_noent": dict(arch="resnet18", fc_dim=64, T=5, C=12, Bs=6, Bt=4, wseed=29, wscale="trained", xseed=209, steps=4, lr=2e-3,
+                           ens_DA="MCD", mu=0.5, add_loss_DA="none"),
+    "tiny_avgpool_mcd_noent": dict(agg="avgpool", place_adv=("N", "Y", "Y"), arch="resnet18", fc_dim=64, T=5, C=5, Bs=6, Bt=4, wseed=34,
+                                   wscale="trained", xseed=304, steps=4, lr=2e-3, ens_DA="MCD", mu=0.5),
     "mid_dan_mcd": dict(arch="resnet101", fc_dim=128, T=5, C=12, Bs=16, Bt=12, wseed=25, wscale="trained", xseed=205, steps=2,
                         lr=2e-3, dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=1.0, ens_DA="MCD", mu=1.0),
 }

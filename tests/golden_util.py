@@ -10,8 +10,8 @@ N_SAMP = 64
 CASES = ["tiny_T5", "tiny_T3", "tiny_T9", "tiny_T2", "tiny_clip", "headline", "headline_init", "mid_T12"]
 AVG_CASES = ["tiny_avgpool", "config1_avgpool"]      # BASELINE configs[0]: TemPooling (avgpool), source-only, every DA option off
 AVG_DA_CASES = ["tiny_avgpool_da", "tiny_avgpool_da3", "tiny_avgpool_dav", "tempooling_da"]   # TemPooling + RevGrad (place_adv in the fixture)
-DA_EXTRA_CASES = ["tiny_dan", "tiny_dan_all", "tiny_jan", "tiny_mcd", "mid_dan_mcd"]   # dis_DA DAN / JAN, ens_DA MCD on top of TA3N
-AVG_DA_EXTRA_CASES = ["tiny_avgpool_dan_mcd", "tiny_avgpool_jan", "tiny_avgpool_adabn"]     # the same options on TemPooling
+DA_EXTRA_CASES = ["tiny_dan", "tiny_dan_all", "tiny_jan", "tiny_mcd", "tiny_mcd_noent", "mid_dan_mcd"]   # dis_DA DAN / JAN, ens_DA MCD on top of TA3N
+AVG_DA_EXTRA_CASES = ["tiny_avgpool_dan_mcd", "tiny_avgpool_jan", "tiny_avgpool_adabn", "tiny_avgpool_mcd_noent"]     # the same options on TemPooling
 BN_CASES = ["tiny_adabn", "tiny_autodial", "mid_adabn"]      # use_bn AdaBN / AutoDIAL: domain-specific BatchNorm after the shared FC
 ARCH_DIM = dict(resnet18=512, resnet34=512, resnet50=2048, resnet101=2048, resnet152=2048)
 
@@ -86,7 +86,8 @@ def case_config(g):
                 alpha=float(g.meta("alpha")) if g.has_meta("alpha") else 0.0,
                 ens_DA=str(g.meta("ens_DA")) if g.has_meta("ens_DA") else "none",
                 mu=float(g.meta("mu")) if g.has_meta("mu") else 0.0,
-                use_bn=str(g.meta("use_bn")) if g.has_meta("use_bn") else "none")
+                use_bn=str(g.meta("use_bn")) if g.has_meta("use_bn") else "none",
+                add_loss_DA=str(g.meta("add_loss_DA")) if g.has_meta("add_loss_DA") else None)
 
 
 def _has_meta(self, k):

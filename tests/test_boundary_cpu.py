@@ -142,3 +142,42 @@ def test_dataset_items_match_reference_format(tmp_path):
     x, y = ds[1]                                                  # short video: last frame repeated (dataset.py:110-114)
     assert [int(v) - 100 for v in x[:, 0]] == [1, 2, 3, 4, 4] and y == 7
     assert ds[3][1] == 3                                          # wrapped around
+
+
+def test_workspace_pool_release_is_tied_to_the_checkout():
+    """the finalizer of an OLD autograd node fires after its entry was released and checked out again by the
+    next iteration's first forward; it must not mark that in-use buffer free (the MCD step's second forward would then take it
+    and overwrite the first forward's activations before backward)."""
+    import gc
+    import torch
+    from ta3n_amd.models import VideoModel
+
+    m = VideoModel(12, 'video', 'trn-m', 'RGB', train_segments=5, val_segments=5, base_model='resnet101', fc_dim=64,
+                   verbose=False, ens_DA='MCD')
+    plan = object()
+    m._ws_template = lambda p: torch.zeros(8)
+
+    class Ctx:        # stands in for the autograd context (weakref-able)
+        pass
+
+    it1 = Ctx()
+    a = m._ws_checkout(plan, it1, True)
+    m._ws_release(it1)                     # backward of iteration 1 ran
+    it2_first = Ctx()
+    b = m._ws_checkout(plan, it2_first, True)
+    assert b.data_ptr() == a.data_ptr()    # one loop, one buffer
+    del it1                                # `loss` rebound: iteration 1's graph dies only now
+    gc.collect()
+    it2_second = Ctx()                     # ens_DA MCD: forward(..., reverse=True) before iteration 2's backward
+    c = m._ws_checkout(plan, it2_second, True)
+    assert c.data_ptr() != b.data_ptr(), "the stale finalizer freed a workspace that is in use"
+    m._ws_release(it2_second)
+    m._ws_release(it2_first)
+    d = m._ws_checkout(plan, Ctx(), False)
+    assert d.data_ptr() in (b.data_ptr(), c.data_ptr())
+    dropped = Ctx()
+    e = m._ws_checkout(plan, dropped, True)
+    del dropped                            # a graph dropped without backward gives its buffer back
+    gc.collect()
+    f = m._ws_checkout(plan, Ctx(), True)
+    assert f.data_ptr() == e.data_ptr()

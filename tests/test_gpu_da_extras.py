@@ -36,6 +36,8 @@ def _args(c):
     a.add_loss_DA, a.use_attn = "attentive_entropy", "TransAttn"
     if c["agg"] == "avgpool":        # TemPooling + RevGrad on the fixture's levels, no attention (make_golden.make_args)
         a.place_adv, a.add_loss_DA, a.use_attn = list(c["place_adv"]), "none", "none"
+    if c.get("add_loss_DA"):
+        a.add_loss_DA = c["add_loss_DA"]
     a.dis_DA, a.place_dis, a.ens_DA = c["dis_DA"], list(c["place_dis"]), c["ens_DA"]
     a.clip_gradient, a.verbose, a.print_freq, a.show_freq = c["clip"], False, 1, 10 ** 9
     a.lr_adaptive, a.lr, a.save_attention, a.epochs, a.add_fc = "dann", c["lr"], -1, 30, 1

@@ -56,7 +56,8 @@ def test_one_rank_rccl_step_equals_the_plain_step(monkeypatch, buckets):
 
 
 def test_bf16_transport_rounds_each_ranks_gradient_to_bf16(monkeypatch):
-    eng = _engine(monkeypatch, bf16=True, transport=None)          # default for the bf16 arithmetic: bf16 transport
+    assert _engine(monkeypatch, bf16=True, transport=None)._g16 is None      # default: fp32 transport in every arithmetic
+    eng = _engine(monkeypatch, bf16=True, transport="1")           # opt-in (TA3N_DDP_BF16=1 / TrainEngine(grad_transport="bf16"))
     assert eng._g16 is not None
     c = CFG
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)

@@ -16,7 +16,7 @@ def _setup(name):
     c = case_config(g)
     cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc_dim"],
                      dropout_i=0.0, dropout_v=0.0, dis_DA=c["dis_DA"], place_dis=c["place_dis"], ens_DA=c["ens_DA"],
-                     use_bn=c["use_bn"])
+                     use_bn=c["use_bn"], **(dict(add_loss_DA=c["add_loss_DA"]) if c.get("add_loss_DA") else {}))
     params = synth_state(orc.param_shapes(cfg), seed=c["wseed"], scale=c["wscale"])
     return g, c, cfg, params
 

@@ -117,3 +117,60 @@ def test_shard_ranges_cover_batch_without_overlap():
     assert parallel.padded_shard_size(74, 8) == 10
     n = parallel.loss_normalisers(128, 74, 5)
     assert n["inv_n_cls"] == 1 / 128 and n["inv_n_rel"] == 1 / (202 * 4) and n["inv_n_frm"] == 1 / (202 * 5)
+
+
+def _comm_agreement_worker(rank, world, port, fail_rank, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = _lib.lib()
+
+    class Fake:      # the two C entry points NativeComm uses, with a failure injected on ONE rank
+        def __init__(self, real):
+            self._real = real
+
+        def __getattr__(self, k):
+            return getattr(self._real, k)
+
+        def ta3n_comm_unique_id(self, buf):
+            return -2 if (fail_rank == ("id", rank)) else 0
+
+        def ta3n_comm_create(self, *a):
+            return -2 if (fail_rank == ("create", rank)) else 0
+
+        def ta3n_comm_destroy(self, h):
+            out.put(("destroyed", rank))
+
+        def ta3n_last_error(self):
+            return b"injected failure"
+    fake = Fake(L)
+    _lib._LIB = fake
+    try:
+        try:
+            parallel.NativeComm(None, None)
+            out.put(("ok", rank))
+        except RuntimeError as ex:
+            out.put(("raised", rank, str(ex)))
+    finally:
+        _lib._LIB = L
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["id", "create"])
+def test_native_comm_failure_on_one_rank_is_raised_on_every_rank(where):
+    """if the library's RCCL communicator cannot be created on SOME rank, every rank must learn it and fall
+    back together - otherwise the ranks enqueue different collectives and hang."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_agreement_worker, args=(r, 2, port, (where, 1), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = []
+    while not q.empty():
+        got.append(q.get())
+    raised = sorted(g[1] for g in got if g[0] == "raised")
+    assert raised == [0, 1], got
+    assert all("rank(s) [1]" in g[2] for g in got if g[0] == "raised"), got

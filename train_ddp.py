@@ -209,8 +209,8 @@ def main():
             tgt = list_loader(args.train_target_list, n_tgt_train, Bt_g, T, 2000 + epoch)
         for i, ((xs, ys), (xt, _)) in enumerate(zip(src, tgt)):
             p = float(i + epoch * len_source_loader) / (args.epochs * len_source_loader)   # main.py:334-335, 350
-            bd = beta_dann(p)
-            beta = [bd if b < 0 else b for b in args.beta]                            # main.py:352
+            if i == 0:      # main.py:352 rebinds `beta` inside the loop: a negative entry is replaced by the DANN value of the
+                beta = [beta_dann(p) if b < 0 else b for b in args.beta]              # epoch's first step and stays there for the epoch
             lo, hi = parallel.shard_range(xs.size(0), world, rank)                    # this rank's videos
             lo_t, hi_t = parallel.shard_range(xt.size(0), world, rank)
             if stores:                                                                # batch assembled on the device
