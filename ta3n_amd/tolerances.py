@@ -1,0 +1,36 @@
+"""Parity bounds of the HIP train step, in ONE place: the GPU tests assert them (tests/test_gpu_parity.py, test_gpu_gradients.py,
+test_gpu_bf16.py) and bench.py quotes them in its `config.workload` strings, so what the benchmark line says is what the tests
+check.  Floors measured on MI355X are recorded in profiles/r03_parity_floors.txt (tests/test_gpu_gradients.py prints them).
+
+Metrics: "max" = max |got - want|; "rel. L2" = ||got - want||_2 / ||want||_2 per tensor, every element of every tensor;
+"max/scale" = max |got - want| / max |want| per tensor."""
+
+# ---- fp32 MFMA: against the reference's fp32 CPU path (oracle pinned to it; re-synchronised to the engine's parameters each step) ----
+LOGIT_ATOL = 1e-3            # north_star: class and domain logits within 1e-3 absolute at trained-scale (O(1..10)) logits
+F32_RTOL, F32_ATOL = 2e-4, 5e-5     # parameters after a step, features, attention weights (elementwise)
+# Gradients, every element of every tensor of every step.  Typical tensors agree to 1e-6 .. 2e-5 (fp32 summation order); a tensor
+# behind a ReLU mask moves by ~1/rows of its norm for every hidden unit whose pre-activation sits within round-off of zero and
+# lands on the other side (measured worst: 2.2e-3, the video discriminator's hidden layer at 1024 videos) - hence a tight bound
+# on the MEDIAN over the step's tensors and a looser one on each tensor.
+F32_GRAD_REL_L2_MEDIAN = 2e-5      # measured <= 3.1e-6
+F32_GRAD_REL_L2 = 5e-3             # measured worst 2.2e-3
+F32_GRAD_MAX_SCALE = 3e-2          # measured worst 7.7e-3
+# Against the reference's RECORDED multi-step trajectories (golden vectors): from the second step on the two sides stand on
+# parameters that differ by round-off, more ReLU units switch sides; the per-tensor bound is scaled by this factor there.
+GOLDEN_DRIFT_FACTOR = 2.0         # measured worst later-step tensor: 1.1e-3 (fp32), 1.6e-3 (f32x3)
+# ---- fp32-grade split arithmetic (f32x3: 16 mantissa bits per operand, ~2^-16 per product): same reference, its own bounds ----
+# logits stay within LOGIT_ATOL (measured <= 1.5e-4); gradients are 30-100x further from the reference than the fp32 MFMA's
+F32X3_GRAD_REL_L2_MEDIAN = 2e-4    # measured <= 2.0e-5
+F32X3_GRAD_REL_L2 = 1.5e-2   # measured worst 5.3e-3
+F32X3_GRAD_MAX_SCALE = 6e-2  # measured worst 2.2e-2
+
+# ---- bf16 arithmetic: against the independent bf16-operand oracle (same arithmetic contract, fp64 accumulation) ----
+BF16_LOGIT_REL_RMS = 5e-3    # max |error| / rms(reference tensor)
+BF16_GRAD_REL_L2 = 2e-2      # per gradient / update tensor
+BF16_GRAD_REL_L2_MEDIAN = 1e-3
+BF16_GRAD_MAX_SCALE = 1e-1
+# ---- bf16 arithmetic: distance from the fp32 REFERENCE (what rounding the contraction operands to bf16 costs) ----
+BF16_REF_LOGIT_REL_RMS = 2.5e-2          # measured 1.1e-2 .. 1.7e-2 of rms at the three benchmarked shapes
+BF16_REF_GRAD_REL_L2_MEDIAN = 2e-2       # measured 3.4e-3 .. 6.4e-3
+BF16_REF_GRAD_REL_L2 = 0.25              # per weight-gradient tensor; measured 0.8 - 1.3 % at the headline shape, up to 15 % for single
+                                         # relation-discriminator hidden layers at 1024 videos / 12 segments (ReLU-masked, few active rows)

@@ -71,6 +71,22 @@ class Golden:
         return float(np.abs(mine - st).max())
 
 
+def _rel_l2(self, key, t):
+    """||t - ref||_2 / ||ref||_2 over the stored entries of record `key` (the whole tensor, or head + sampled entries of a big one)."""
+    a = t.detach().to(torch.float64).cpu().numpy() if torch.is_tensor(t) else np.asarray(t, np.float64)
+    if key + "#full" in self.z:
+        ref = self.z[key + "#full"].astype(np.float64)
+        d = a.reshape(ref.shape) - ref
+    else:
+        flat = a.reshape(-1)
+        ref = np.concatenate([self.z[key + "#head"], self.z[key + "#samp"]]).astype(np.float64)
+        d = np.concatenate([flat[:N_SAMP], flat[sample_index(flat.size)]]) - ref
+    return float(np.sqrt((d * d).sum()) / (np.sqrt((ref * ref).sum()) + 1e-300))
+
+
+Golden.rel_l2 = _rel_l2
+
+
 def case_config(g):
     """(num_class, T, feature_dim, fc_dim, Bs, Bt) of a fixture."""
     return dict(C=int(g.meta("C")), T=int(g.meta("T")), D=int(g.meta("feature_dim")), fc_dim=int(g.meta("fc_dim")),

@@ -251,11 +251,12 @@ def test_bf16_twins_fall_back_per_launch_on_odd_shapes(shape):
 # discriminators' hidden layers (downstream of the un-detached attention and of a ReLU mask) up to 1.3e-2 at the
 # largest shape.  The gate bounds the max logit error against rms, every gradient / update tensor in relative L2, their
 # MEDIAN tightly, plus a max bound that still catches a wrong tile, a stale twin or a missing term (those are O(1)).
-LOGIT_TOL = 5e-3            # max |error| / rms(reference tensor)
-GRAD_L2_TOL = 2e-2          # ||got - want||_2 / ||want||_2 per gradient / update tensor
-GRAD_L2_TOL_BIAS = 2e-2
-GRAD_L2_MEDIAN_TOL = 1e-3   # median of the above over the step's tensors
-GRAD_MAX_TOL = 1e-1         # max |error| / max |want|
+from ta3n_amd import tolerances as tol
+LOGIT_TOL = tol.BF16_LOGIT_REL_RMS              # max |error| / rms(reference tensor)
+GRAD_L2_TOL = tol.BF16_GRAD_REL_L2              # ||got - want||_2 / ||want||_2 per gradient / update tensor
+GRAD_L2_TOL_BIAS = tol.BF16_GRAD_REL_L2
+GRAD_L2_MEDIAN_TOL = tol.BF16_GRAD_REL_L2_MEDIAN   # median of the above over the step's tensors
+GRAD_MAX_TOL = tol.BF16_GRAD_MAX_SCALE          # max |error| / max |want|
 
 
 def _oracle_gate(shape, wseed, wscale, xseed, lr, clip, n_src=None, n_tgt=None, store=True, steps=1, tile_config=0):

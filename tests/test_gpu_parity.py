@@ -15,8 +15,10 @@ from ta3n_amd.synthetic import synth_batch, synth_state
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_ATOL = 1e-3          # north_star: logits within 1e-3 (fp32)
-RTOL, ATOL = 2e-4, 5e-5    # everything else (fp32 MFMA K-order differs from MKL's)
+from ta3n_amd import tolerances as tol
+
+LOGIT_ATOL = tol.LOGIT_ATOL                  # north_star: logits within 1e-3 (fp32)
+RTOL, ATOL = tol.F32_RTOL, tol.F32_ATOL      # everything else (fp32 MFMA K-order differs from MKL's)
 
 
 def _engine(c, tile=0, **kw):
@@ -57,6 +59,7 @@ def test_train_steps_match_reference_golden(name, tile, fused, split):
     _load(eng, c)
     live = set(eng.live_names())
     B, Bs, T = c["Bs"] + c["Bt"], c["Bs"], c["T"]
+    report = []
     for s, st in enumerate(step_schedule(c)):
         xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
         xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0            # the reference's dummy rows (main.py:359-364)
@@ -88,10 +91,21 @@ def test_train_steps_match_reference_golden(name, tile, fused, split):
         torch.cuda.synchronize()
         coef = eng.region("grad_norm")[1].item()
         new = eng.param_views()
+        l2s = {}
         for k in new:
             if k in live:
-                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-2 if s == 0 else 0.15)
+                if s == 0:      # same parameters on both sides: elementwise
+                    g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 1e-3, 2e-5, rms_atol=1e-2)
+                # every step: relative L2 per tensor against the reference's recorded gradient.  From the second step on the two
+                # sides stand on parameters that differ by the first step's round-off, so hidden units within that distance of zero
+                # switch sides; the single-step bound on identical parameters is tests/test_gpu_gradients.py (every element).
+                l2s[k] = g.rel_l2(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef)
             g.check(f"step{s}/param/{k}", new[k].cpu(), RTOL, ATOL)
+        bound = (tol.F32X3_GRAD_REL_L2 if split else tol.F32_GRAD_REL_L2) * (1 if s == 0 else tol.GOLDEN_DRIFT_FACTOR)
+        worst = max(l2s, key=l2s.get)
+        assert l2s[worst] <= bound, f"step {s} {worst}: relative L2 {l2s[worst]:.3e} > {bound:.1e}"
+        report.append((s, worst, l2s[worst], float(np.median(list(l2s.values())))))
+    print(f"\n[golden grads] {name} tile {tile} fused={fused} split={split}: " + "; ".join(f"step {a} worst {b} {c:.1e} median {d:.1e}" for a, b, c, d in report))
 
 
 @pytest.mark.parametrize("fused", [False, True])
