@@ -112,6 +112,24 @@ def algorithmic_flops(cfg):
     return algorithmic_gemm_flops(**sh)
 
 
+HBM_ACHIEVABLE_GBS = 6300.0       # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy); SURVEY.md 8(d)'s single-GPU bounds use it
+
+
+def whole_step_bound(conf, dtype, eng):
+    """t >= max(algorithmic FLOPs / MFMA peak of the arithmetic, algorithmic bytes / achievable HBM bandwidth) for ONE
+    train step of a CONFIGS entry (all its streams).  Bytes: the input once (fp32 features, the survey's convention) + 8 x 4 B per
+    live parameter (weights read in forward and backward, gradient written, optimiser: read p, g, m, write p, m)."""
+    sh = conf["shape"]
+    live = sum(math.prod(s_) for _, _, s_, lv in eng.plan.params if lv)
+    nbytes = (sh["Bs"] + sh["Bt"]) * sh["T"] * sh["D"] * 4 + live * 4 * 8
+    flops = algorithmic_flops(conf)
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_BF16_MFMA_TFLOPS / 3 if dtype == "f32x3" else PEAK_FP32_MFMA_TFLOPS
+    t_flop, t_bytes = flops / (peak * 1e12) * 1e6, nbytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6
+    n = conf["streams"]
+    return {"bound": "mfma" if t_flop >= t_bytes else "hbm", "t_flop_us": n * t_flop, "t_bytes_us": n * t_bytes,
+            "bound_us": n * max(t_flop, t_bytes), "flops": n * flops, "bytes": n * nbytes}
+
+
 def cpu_baseline(conf=None, seconds=12.0, max_steps=40):
     """The CPU path on this host: oracle train step (same ATen CPU kernels the
     reference dispatches, including the frame classifier it computes and never uses), dropout on, a bounded sample."""
@@ -205,6 +223,7 @@ def main():
     ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
     ap.add_argument("--per-step-calls", action="store_true", help="A/B: one host call per step instead of one ta3n_train_steps call for "
                     "the whole timed region")
+    ap.add_argument("--no-other-configs", action="store_true", help="do not add the 20-step timings of configs[0] / [3] / [4] to the line")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
     conf = CONFIGS[args.config]
@@ -232,8 +251,12 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
-    def run(dtype, steps, warmup):
-        """Build the engine(s) for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line."""
+    def run(dtype, steps, warmup, conf=conf, brief=False):
+        """Build the engine(s) for one arithmetic, time `steps` train steps after `warmup`; returns the numbers of the JSON line.
+        brief: only the step time and the whole-step bound (the other BASELINE configurations inside the default line)."""
+        SH = conf["shape"]
+        n_streams = conf["streams"]
+        headline = conf is CONFIGS[2] or conf is CONFIGS[3]
         bf16 = dtype == "bf16"
         split = dtype == "f32x3"       # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers (TA3N_FLAG_F32_SPLIT)
         twins = bf16 and not args.no_twins
@@ -345,6 +368,11 @@ def main():
         res = {"ms_per_step": 1e3 * elapsed / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / elapsed}
         if rank != 0:
             return res
+        wsb = whole_step_bound(conf, dtype, eng)
+        res["whole_step"] = {**wsb, "frac": wsb["bound_us"] / (1e3 * res["ms_per_step"]),
+                             "what": "SURVEY.md 8(d): max(algorithmic FLOPs / MFMA peak, algorithmic bytes / 6.3 TB/s) per step, divided by the measured step time"}
+        if brief:
+            return res
         res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
         res["gradient_exchange"] = (("RCCL ncclAllReduce from the C ABI on the step's stream, " +
                                      ("bf16" if eng._g16 is not None else "fp32") + " transport") if eng.comm is not None else
@@ -390,27 +418,29 @@ def main():
                                "frac": tflops / PEAK_FP32_MFMA_TFLOPS, **extra}
         else:              # bf16 MFMA makes the math 16x cheaper than fp32's: the binding roofline is HBM
             gemm_bytes = algorithmic_gemm_bytes_bf16(**SH, agg=conf["agg"])
-            # In the pipelined step the kernel's first launch also applies the optimiser update of every parameter but the shared
-            # frame FC (256 side workgroups: read p, g, m, write p, m = 5 x 4 B per parameter) - the launch durations
-            # above contain that work, so the algorithmic bytes of the kernel's launches contain it too.  The contraction-only
-            # figure (bytes and launch times without the update) stays beside it as `gemm_only`.
+            # ONE definition across rounds: `frac` = algorithmic bytes of the CONTRACTIONS per launch / the average duration of
+            # the kernel's launches without any rider (ta3n_time_phases) - round 1's figure.  In the pipelined step the first launch also
+            # carries the optimiser update of every parameter but the shared frame FC (256 side workgroups, 20 B per parameter); that
+            # inclusive figure (round 2's `frac`) is published beside it as `with_update`.
             upd_params = sum(math.prod(s_) for n_, _, s_, live in eng.plan.params
                              if live and not n_.startswith("fc_feature_shared_source")) if side_update else 0
             nbytes = gemm_bytes + 20 * upd_params
             gbs = nbytes / (gemm_ms * 1e-3) / 1e9
             gbs_plain = gemm_bytes / (gemm_plain_ms * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "bytes_per_launch": nbytes / max(len(gemm), 1),
-                               "bytes_note": "algorithmic bytes of the six launches of the kernel as the timed step runs them: contraction "
-                               "operands (input once as bf16, live weights 2+2 B read + 4 B gradient written) = %.2f MB, plus 20 B per "
-                               "parameter for the optimiser update that rides in the first launch (%d parameters) = %.2f MB" %
-                               (gemm_bytes / 1e6, upd_params, 20 * upd_params / 1e6),
-                               "gemm_only": {"bytes_per_launch": gemm_bytes / max(len(gemm), 1),
-                                             "avg_launch_us": 1e3 * gemm_plain_ms / max(len(gemm), 1), "achieved": gbs_plain,
-                                             "frac": gbs_plain / HBM_PEAK_GBS,
-                                             "what": "the same six launches without the update workgroups (ta3n_time_phases): the "
-                                                     "figure comparable with round 1's roofline.frac"},
+            extra["avg_launch_us"] = 1e3 * gemm_plain_ms / max(len(gemm), 1)
+            res["roofline"] = {"bound": "hbm", "achieved": gbs_plain, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_plain / HBM_PEAK_GBS,
+                               "bytes_per_launch": gemm_bytes / max(len(gemm), 1),
+                               "bytes_note": "algorithmic bytes of the contraction launches: input once as bf16, live weights 2 + 2 B read "
+                               "(forward + backward) + 4 B gradient written = %.2f MB per step, over %d launches" % (gemm_bytes / 1e6, len(gemm)),
+                               "with_update": {"bytes_per_launch": nbytes / max(len(gemm), 1), "avg_launch_us": 1e3 * gemm_ms / max(len(gemm), 1),
+                                               "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                               "what": "the same launches as the timed step runs them: the first one also applies the optimiser "
+                                                       "update of %d parameters (20 B each = %.2f MB) - round 2's `frac`" % (upd_params, 20 * upd_params / 1e6)},
                                "mfma_tflops": tflops, "mfma_frac_of_bf16_peak": tflops / PEAK_BF16_MFMA_TFLOPS, **extra}
+            if wsb["bound"] == "mfma":      # (configs[3]: 59.6 us of bf16 MFMA against 51 us of bytes - the matrix cores are the binding roofline there)
+                res["roofline"].update({"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": tflops / PEAK_BF16_MFMA_TFLOPS, "hbm_gbs": gbs_plain, "hbm_frac": gbs_plain / HBM_PEAK_GBS})
+        res["roofline"]["whole_step"] = res["whole_step"]
         # tile code per GEMM launch as the plan built it: WM WN WK + 1000 x (LDS stages, + 16: reads bf16 twins) + 100000 x blocking
         # (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2 - 128x64 / 64x128 / 128x128 tiles)
         res["phase_tiles"] = [ph["tile"] + 100000 * ((ph.get("rm", 1) > 1) + 2 * (ph.get("rn", 1) > 1))
@@ -427,14 +457,35 @@ def main():
             except Exception as ex:      # noqa: BLE001 - an extra line must not cost the headline line
                 print(f"[bench] split-arithmetic run failed: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
 
+    # the other BASELINE configurations, bounded (20 steps after 5: well under 2 s each), so that the default line carries
+    # driver-visible timings of configs[0] / [3] / [4] with their SURVEY 8(d) bounds
+    configs_line = None
+    if headline and world == 1 and not args.single_dtype and not selftest and not args.no_other_configs:
+        configs_line = {}
+        for cnum in (1, 4, 5):
+            cf = CONFIGS[cnum]
+            try:
+                r = run(cf["dtype"], 20, 5, conf=cf, brief=True)
+                ws = r["whole_step"]
+                configs_line[f"configs[{cnum - 1}]"] = {"workload": cf["name"], "dtype": cf["dtype"], "ms_per_step": r["ms_per_step"],
+                                                        "value": r["value"], "unit": "videos/s", "steps": 20, "warmup": 5,
+                                                        "bound": ws["bound"], "bound_us": ws["bound_us"], "frac_of_bound": ws["frac"]}
+            except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
+                configs_line[f"configs[{cnum - 1}]"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if rank == 0:
+        from ta3n_amd import tolerances as tol
         arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "
-                         "(BASELINE configs[1]); parity gate: tests/test_gpu_bf16.py against the bf16-operand oracle",
-                 "f32": "fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within 1e-3 of the reference's CPU path",
+                         f"(BASELINE configs[1]); parity gate tests/test_gpu_bf16.py against the bf16-operand oracle: logits <= {tol.BF16_LOGIT_REL_RMS:g} of "
+                         f"rms, every gradient tensor rel. L2 <= {tol.BF16_GRAD_REL_L2:g} (median <= {tol.BF16_GRAD_REL_L2_MEDIAN:g}); distance from the fp32 "
+                         f"reference (tests/test_gpu_gradients.py): logits <= {tol.BF16_REF_LOGIT_REL_RMS:g} of rms, gradient tensors median rel. L2 <= "
+                         f"{tol.BF16_REF_GRAD_REL_L2_MEDIAN:g}",
+                 "f32": f"fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, "
+                        f"every gradient tensor rel. L2 <= {tol.F32_GRAD_REL_L2:g} (median over tensors <= {tol.F32_GRAD_REL_L2_MEDIAN:g}) "
+                        "(tests/test_gpu_parity.py, tests/test_gpu_gradients.py)",
                  "f32x3": "fp32-grade contractions on the bf16 MFMA: operands split hi + lo = bf16(x) + bf16(x - hi) in registers, "
                           "a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 (~2^-16 per product; not IEEE fp32 multiplication); fp32 "
-                          "stage images, parameters, gradients, optimiser; passes the fp32 configuration's parity tests unchanged (logits "
-                          "within 1e-3 of the reference's CPU path, gradients rtol 2e-4: tests/test_gpu_parity.py [bf16x3])"}
+                          f"stage images, parameters, gradients, optimiser; logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, every gradient "
+                          f"tensor rel. L2 <= {tol.F32X3_GRAD_REL_L2:g} (median <= {tol.F32X3_GRAD_REL_L2_MEDIAN:g}) (same tests, [f32x3] / [bf16x3] ids)"}
         out = {
             "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N" if headline else
                       "src+tgt videos/sec per train step (BASELINE configs[%d])" % (args.config - 1),
@@ -462,13 +513,16 @@ def main():
                                                                 "per_phase_us")}}
             out["other_arithmetic"] = o
             # the same numbers inside `roofline`, so that the parity-qualified fp32 figure travels with the headline line
-            out["roofline"]["other_arithmetic"] = {"dtype": o_dtype, "value": other["value"], "ms_per_step": other["ms_per_step"],
+            out["roofline"]["other_arithmetic"] = {"dtype": o_dtype, "value": other["value"], "value_unit": "videos/s", "ms_per_step": other["ms_per_step"],
+                                                   "whole_step": other["whole_step"],
                                                    **{k: other["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
         if third is not None:
-            out["roofline"]["split_arithmetic"] = {"dtype": "f32x3", "what": arith["f32x3"], "value": third["value"], "unit": "videos/s",
-                                                   "ms_per_step": third["ms_per_step"],
+            out["roofline"]["split_arithmetic"] = {"dtype": "f32x3", "what": arith["f32x3"], "value": third["value"], "value_unit": "videos/s",
+                                                   "ms_per_step": third["ms_per_step"], "whole_step": third["whole_step"],
                                                    **{k: third["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac",
                                                                                         "avg_launch_us", "per_phase_us")}}
+        if configs_line:
+            out["configs"] = configs_line
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)
