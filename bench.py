@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--plan-heuristic", action="store_true", help="A/B: the plan builder's own tile choice instead of ta3n_amd/tuning.py")
     ap.add_argument("--per-step-calls", action="store_true", help="A/B: one host call per step instead of one ta3n_train_steps call for "
                     "the whole timed region")
+    ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32", help="N > 1: what the gradient all-reduce moves - fp32 (default: "
+                    "the exact sum up to the reduction order), or bf16 (every rank's gradients rounded to bf16 and summed in bf16: half the xGMI bytes; "
+                    "stated in the line)")
     ap.add_argument("--no-other-configs", action="store_true", help="do not add the 20-step timings of configs[0] / [3] / [4] to the line")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
@@ -276,7 +279,7 @@ def main():
         engs = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                             clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
                             fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],
-                            f32_split=split)
+                            f32_split=split, grad_transport=args.grad_transport)
                 for _ in range(n_streams)]
         eng = engs[0]
         for k, e in enumerate(engs):
@@ -333,7 +336,8 @@ def main():
         # Default at N = 1: the K steps are enqueued by ONE call into the library (ta3n_train_steps; the schedule of beta / lr /
         # dropout seeds is evaluated ahead of time and travels by value) - the host is then off the step's critical path, which
         # under the 20-step protocol on a slow host core was 21 % of the step.  --per-step-calls: one call per step.
-        batched = pipelined and not side and len(engs) == 1 and world == 1 and not selftest and not args.per_step_calls
+        batched = (pipelined and not side and len(engs) == 1 and not args.per_step_calls and
+                   ((world == 1 and not selftest) or (eng.comm is not None and eng._ddp_buckets == 1)))
 
         def sched(i0, n):
             out = []
@@ -366,6 +370,26 @@ def main():
             elapsed = t.item()
         # a two-stream step processes each video through both models: videos/s counts videos, not model passes
         res = {"ms_per_step": 1e3 * elapsed / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / elapsed}
+        if (world > 1 or selftest) and not brief:
+            # what the gradient exchange costs per step: the same loop once more WITHOUT the collective (every rank skips it; the
+            # numbers it trains on are then wrong, the timing is what is wanted) - the difference is the exposed collective time
+            eng.skip_collective = True
+            run_steps(warmup + steps, min(warmup, 5))
+            flush_all()
+            fence()
+            t1 = time.perf_counter()
+            run_steps(warmup + steps + 5, steps)
+            flush_all()
+            fence()
+            e2 = time.perf_counter() - t1
+            eng.skip_collective = False
+            if world > 1:
+                t = torch.tensor([e2], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                e2 = t.item()
+            res["collective"] = {"exposed_us_per_step": 1e6 * (elapsed - e2) / steps, "step_without_collective_ms": 1e3 * e2 / steps,
+                                 "bytes": eng.plan.live_floats * (2 if eng._g16 is not None else 4),
+                                 "what": "the timed loop repeated with the all-reduce skipped on every rank; exposed = difference per step"}
         if rank != 0:
             return res
         wsb = whole_step_bound(conf, dtype, eng)
@@ -502,7 +526,8 @@ def main():
                        "update": "deferred: overlaps the next step's first launch" if main_res["deferred"] else
                        ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "
                         "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
-                       "gradient_exchange": None if world == 1 else main_res.get("gradient_exchange"),
+                       "gradient_exchange": None if (world == 1 and not selftest) else main_res.get("gradient_exchange"),
+                       "collective": main_res.get("collective"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],
         }

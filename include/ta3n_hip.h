@@ -111,7 +111,10 @@ typedef struct {
                               * (a producer tile publishes its stores and bumps a counter, a consumer tile polls the counters of exactly
                               * the tiles it reads; derived from the tiles' read / write spans).  5 launches per step instead of 8, the
                               * same tiles and arithmetic: bit-identical results.  0: one launch per level. */
-    int32_t reserved[3];
+    int32_t cost_model;      /* how the plan orders a launch's tiles over the 8 XCD queues: 0 = by the length of their K loops; 1 = by an
+                              * estimate of their TIME (fixed per-tile overhead + K, weight-gradient tiles weighted up).  Ordering only:
+                              * results are bit-identical. */
+    int32_t reserved[2];
 } ta3n_config;
 
 /* Per-step scalars; lives in device memory inside ws (region "hyper").  The host
@@ -298,7 +301,8 @@ int ta3n_train_step_after_update(ta3n_plan *plan, const float *x, float *params,
  * launches are queued and the host is off the step's critical path (one ctypes call and 9 hipLaunchKernel per step measured
  * ~100 us of host time on a slow core against ~100 us of GPU time).  Requires a pending update (a previous
  * ta3n_train_step / ta3n_train_steps on the same buffers); the update of step n_steps - 1 stays pending with lr = hypers[n_steps-1].lr
- * (apply it with ta3n_sgd_range or the next call).  Bit-identical to n_steps single calls.
+ * (apply it with ta3n_sgd_range or the next call).  Bit-identical to n_steps single calls.  The hypers' inv_n_* must be the
+ * GLOBAL counts when a communicator is given.
  * source / target (either may be NULL = the rows already in x): TSNDataSet.__getitem__ + DataLoader collation of step k on the
  * device (dataset.py:118-144), i.e. ta3n_gather_segments[_bf16]_into with video_ids[k * ids_per_step ..] before step k. */
 typedef struct {
@@ -310,9 +314,12 @@ typedef struct {
     const int32_t *labels;      /* device [n_videos]; required for the source feed (written to ws["labels"]) */
     const int32_t *video_ids;   /* device [n_steps][ids_per_step] */
 } ta3n_feed;
+typedef struct ta3n_comm ta3n_comm;
 int ta3n_train_steps(ta3n_plan *plan, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
                      float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers,
-                     int n_steps, const ta3n_feed *source, const ta3n_feed *target, void *stream);
+                     int n_steps, const ta3n_feed *source, const ta3n_feed *target,
+                     ta3n_comm *comm /* NULL, or: ta3n_all_reduce_sum of the live gradients after every step (fused_norm must be 0) */,
+                     void *scratch_bf16 /* as in ta3n_all_reduce_sum */, void *stream);
 
 /* TA3N_FLAG_BF16_STORE: (re)build the bf16 twins of x (B*T*feature_dim floats, may be NULL) and of params (may be
  * NULL) inside ws.  No-op without the flag. */
@@ -343,7 +350,6 @@ int ta3n_sgd_step_fused(ta3n_plan *plan, float *params, float *grads, float *mom
  * channel: torch.distributed store, MPI, a file), every rank calls ta3n_comm_create on its device - a collective over
  * `world` ranks (ncclCommInitRank).  RCCL is dlopen'ed at the first of these calls; a process that never calls them
  * never loads it. */
-typedef struct ta3n_comm ta3n_comm;
 int ta3n_comm_unique_id(char *id128);
 int ta3n_comm_create(const char *id128, int rank, int world, ta3n_comm **out);
 void ta3n_comm_destroy(ta3n_comm *comm);

@@ -48,7 +48,7 @@ class Config(C.Structure):
                 ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
                 ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
                 ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("aggregation", C.c_int32),
-                ("wgrads_late", C.c_int32), ("chain", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("wgrads_late", C.c_int32), ("chain", C.c_int32), ("cost_model", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Hyper(C.Structure):
@@ -116,7 +116,7 @@ def lib() -> C.CDLL:
     L.ta3n_has_pipelined_step.argtypes = [vp]
     L.ta3n_train_step_after_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_train_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
-                                   C.POINTER(Feed), C.POINTER(Feed), vp]
+                                   C.POINTER(Feed), C.POINTER(Feed), vp, vp, vp]
     L.ta3n_gather_segments_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_gather_segments_bf16_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_sgd_step_next.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
@@ -179,7 +179,7 @@ class Plan:
     def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
                  num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0,
                  phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0, aggregation: int = 0, wgrads_late: int = 0,
-                 chain: int = 0):
+                 chain: int = 0, cost_model: int = 0):
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
@@ -189,6 +189,7 @@ class Plan:
         self.cfg.aggregation = int(aggregation)       # AGG_TRN_M / AGG_AVGPOOL
         self.cfg.wgrads_late = int(wgrads_late)
         self.cfg.chain = int(chain)
+        self.cfg.cost_model = int(cost_model)
         h = C.c_void_p()
         check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
         self.handle = h

@@ -529,7 +529,7 @@ static int feed_step(ta3n_plan *p, const ta3n_feed *f, int step, int first_video
 
 int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
                      float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
-                     const ta3n_feed *source, const ta3n_feed *target, void *stream) {
+                     const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm, void *scratch_bf16, void *stream) {
     if (!p || !x || !params || !grads || !momentum || !ws || !hypers) return fail(TA3N_ERR_INVALID, "null argument");
     if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
     if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(momentum) || !aligned16(ws))
@@ -540,6 +540,7 @@ int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geom &g = p->geom;
     if ((source || target) && (g.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
+    if (comm && fused_norm) return fail(TA3N_ERR_INVALID, "with a communicator the norm is taken from the REDUCED gradients: fused_norm must be 0");
     Ptrs ptrs{x, params, grads, ws};
     float lr = lr_pending;
     for (int k = 0; k < n_steps; ++k) {
@@ -555,6 +556,8 @@ int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, 
                      fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
         if ((rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;
         if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30)) != TA3N_OK) return rc;
+        // data parallel: the step's single exchange, on the step's stream, between the last gradient launch and the update
+        if (comm && (rc = ta3n_all_reduce_sum(comm, grads, p->live_floats, scratch_bf16, stream)) != TA3N_OK) return rc;
         lr = hypers[k].lr;
     }
     return TA3N_OK;

@@ -207,8 +207,14 @@ struct Builder {
                 const int a_rows = s.pad[0] > 0 ? s.pad[0] : g.M;
                 const bool a_vec = s.a_kmajor ? ((s.a_off | s.a_ld | a_rows) & 3) == 0 : ((s.a_off | s.a_ld | s.klen) & 3) == 0;
                 const bool b_vec = s.b_kmajor ? ((s.b_off | s.b_ld | g.N) & 3) == 0 : ((s.b_off | s.b_ld | s.klen) & 3) == 0;
-                cost += (s.klen + 63) / 64 * 64 * ((a_vec ? 1 : 3) + (b_vec ? 1 : 3)) / 2;
+                int seg_cost = (s.klen + 63) / 64 * 64 * ((a_vec ? 1 : 3) + (b_vec ? 1 : 3)) / 2;
+                // cost_model 1 (measured, profiles/r03_chain_handoff_ab.txt: a weight-gradient tile - both operands k-major - streams
+                // a k in ~9 ns, the other kinds in ~5.5 ns; every tile pays ~3 us of descriptor fetch + epilogue whatever its K):
+                // the XCD queues are balanced on time, not on K
+                if (p.cfg.cost_model == 1 && s.a_kmajor && s.b_kmajor) seg_cost = seg_cost * 17 / 10;
+                cost += seg_cost;
             }
+            if (p.cfg.cost_model == 1) cost += 576;
             const bool split_m = g.M >= g.N;
             const int outer = split_m ? g.M : g.N, inner = split_m ? g.N : g.M;
             const int bo = split_m ? BM : BN, bi = split_m ? BN : BM;

@@ -99,7 +99,8 @@ class TrainEngine:
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
-                              wgrads_late=int(wgrads_late), chain=int(chain))
+                              wgrads_late=int(wgrads_late), chain=int(chain),
+                              cost_model=int(os.environ.get("TA3N_COST_MODEL", "0")))
         self.chain = bool(chain)
         self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
         self.B = batch_source + batch_target
@@ -162,6 +163,7 @@ class TrainEngine:
             if self.comm is not None and want16:
                 self._g16 = torch.zeros(p.live_floats, dtype=torch.bfloat16, device=self.device)
         self.step_count = 0
+        self.skip_collective = False
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._hyper = _lib.Hyper()
 
@@ -264,6 +266,8 @@ class TrainEngine:
                                          self.ws.data_ptr(), self._stream()), "ta3n_backward")
 
     def all_reduce_grads(self) -> None:
+        if self.skip_collective:      # measurement only (bench.py: the step without its exchange -> exposed collective time)
+            return
         if self.comm is not None:      # RCCL on the step's stream, enqueued by the library
             _lib.check(self._L.ta3n_all_reduce_sum(self.comm.handle, self.G.data_ptr(), self.plan.live_floats,
                                                    self._g16.data_ptr() if self._g16 is not None else None, self._stream()),
@@ -424,13 +428,14 @@ class TrainEngine:
         train_step_pipelined once per entry; the host leaves the step's critical path (on a slow core the per-step ctypes call +
         9 launches cost as much wall time as the GPU needs for the step).  feeds: optional (source, target) pairs of
         (FeatureStore, int32 device tensor [len(schedule), n]) - the batch of step k is then assembled on the device before it.
-        Single rank; with a process group the steps go one by one (the all-reduce sits between backward and update)."""
+        With a process group and the library's RCCL communicator the step's all-reduce is part of the same call."""
         n = len(schedule)
         if n == 0:
             return
-        if not self.fused or not self._side_update or self.world > 1 or self._ddp_selftest:
+        ddp = self.world > 1 or self._ddp_selftest
+        if not self.fused or not self._side_update or (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)):
             if feeds is not None:
-                raise _lib.Ta3nError("train_steps: device-side batch feeds need the single-rank pipelined step")
+                raise _lib.Ta3nError("train_steps: device-side batch feeds need the pipelined step")
             for beta, gamma, lr in schedule:
                 self.train_step_pipelined(beta, gamma, lr)
             return
@@ -464,9 +469,12 @@ class TrainEngine:
                 f.labels = store.labels.data_ptr(); f.video_ids = ids.data_ptr()
                 fd[i] = f
         _lib.check(self._L.ta3n_train_steps(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
-                                            self.M.data_ptr(), self.ws.data_ptr(), 1, lr_p, mu, wd, clip, hy, n - k0,
+                                            self.M.data_ptr(), self.ws.data_ptr(), 0 if ddp else 1, lr_p, mu, wd, clip, hy, n - k0,
                                             C.byref(fd[0]) if fd[0] is not None else None,
-                                            C.byref(fd[1]) if fd[1] is not None else None, self._stream()), "ta3n_train_steps")
+                                            C.byref(fd[1]) if fd[1] is not None else None,
+                                            self.comm.handle if ddp else None,
+                                            self._g16.data_ptr() if (ddp and self._g16 is not None) else None,
+                                            self._stream()), "ta3n_train_steps")
         if keep:                              # the id tables must outlive the enqueued gathers
             self._feed_keep = keep
         last = schedule[-1]
