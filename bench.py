@@ -398,10 +398,15 @@ def main():
         if brief:
             return res
         res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
-        res["gradient_exchange"] = (("RCCL ncclAllReduce from the C ABI on the step's stream, " +
-                                     ("bf16" if eng._g16 is not None else "fp32") + " transport") if eng.comm is not None else
-                                    "torch.distributed all_reduce (backend nccl = RCCL), fp32" +
-                                    (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
+        if eng.peer is not None:
+            res["gradient_exchange"] = ("two-shot all-reduce over peer-mapped buffers (csrc/ta3n_peer.hip), " +
+                                        ("bf16" if eng.peer.bf16 else "fp32") + " transport")
+        elif eng.comm is not None:
+            res["gradient_exchange"] = ("RCCL ncclAllReduce from the C ABI on the step's stream, " +
+                                        ("bf16" if eng._g16 is not None else "fp32") + " transport")
+        else:
+            res["gradient_exchange"] = ("torch.distributed all_reduce (backend nccl = RCCL), fp32" +
+                                        (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
         res["deferred"] = deferred
         res["batched"] = batched
         res["pipelined"] = pipelined

@@ -361,6 +361,24 @@ int ta3n_comm_world(const ta3n_comm *comm);
  * (nearest even), summed in bf16 and widened back: half the bytes over xGMI, bf16 precision of the summed gradient. */
 int ta3n_all_reduce_sum(ta3n_comm *comm, float *buf, int64_t count, void *scratch_bf16, void *stream);
 
+/* The same exchange WITHOUT RCCL: a two-shot all-reduce over peer-mapped buffers (one process per GPU; every rank reduces one
+ * 1/world chunk reading all its peers over xGMI at once, then every rank reads the reduced chunks back; csrc/ta3n_peer.hip).
+ * Two crossings of 7/8 of the buffer on all 7 links in parallel instead of a ring's 14 sequential hops - what the 13.9 MB
+ * exchange of this step needs to stay under the step time.  ta3n_peer_create allocates the staging buffers (fine-grained
+ * device memory, for up to max_count elements, transport fp32 or bf16) on the current device; ta3n_peer_handle fills 128 bytes
+ * (two HIP IPC handles) that the launcher gathers from every rank, in rank order, and hands to ta3n_peer_connect as world x 128
+ * bytes.  ta3n_peer_all_reduce_sum: in-place SUM over the ranks, enqueued on `stream` (three kernels); every rank receives
+ * bit-identical results; every cross-rank wait is bounded (3 s) and failures are reported by ta3n_peer_status (synchronises).
+ * ta3n_comm_attach_peer routes ta3n_all_reduce_sum / ta3n_train_step_ddp / ta3n_train_steps of a communicator through it. */
+typedef struct ta3n_peer ta3n_peer;
+int ta3n_peer_create(int rank, int world, int64_t max_count, int bf16_transport, ta3n_peer **out);
+int ta3n_peer_handle(ta3n_peer *peer, char *handle128);
+int ta3n_peer_connect(ta3n_peer *peer, const char *all_handles);
+int ta3n_peer_all_reduce_sum(ta3n_peer *peer, float *buf, int64_t count, void *stream);
+int ta3n_peer_status(ta3n_peer *peer, void *stream);
+void ta3n_peer_destroy(ta3n_peer *peer);
+int ta3n_comm_attach_peer(ta3n_comm *comm, ta3n_peer *peer);
+
 /* ta3n_train_step followed by the all-reduce of the live gradient prefix - the data-parallel step up to the optimiser
  * (continue with ta3n_sgd_step, whose norm pass reads the reduced gradients).  Losses must be normalised by GLOBAL row
  * counts (ta3n_hyper.inv_n_*), so the summed gradients are the global-batch gradients.

@@ -40,6 +40,8 @@ SYMBOLS = [
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_time_update_launches", "ta3n_last_error", "ta3n_version",
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
     "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_chain_status", "ta3n_debug_waits",
+    "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
+    "ta3n_comm_attach_peer",
 ]
 
 
@@ -136,6 +138,14 @@ def lib() -> C.CDLL:
     L.ta3n_comm_world.argtypes = [vp]
     L.ta3n_all_reduce_sum.argtypes = [vp, vp, i64, vp, vp]
     L.ta3n_train_step_ddp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ta3n_peer_create.argtypes = [C.c_int, C.c_int, i64, C.c_int, C.POINTER(vp)]
+    L.ta3n_peer_handle.argtypes = [vp, C.c_char_p]
+    L.ta3n_peer_connect.argtypes = [vp, C.c_char_p]
+    L.ta3n_peer_all_reduce_sum.argtypes = [vp, vp, i64, vp]
+    L.ta3n_peer_status.argtypes = [vp, vp]
+    L.ta3n_peer_destroy.argtypes = [vp]
+    L.ta3n_peer_destroy.restype = None
+    L.ta3n_comm_attach_peer.argtypes = [vp, vp]
     L.ta3n_last_error.restype = C.c_char_p
     L.ta3n_version.restype = C.c_char_p
     _LIB = L

@@ -75,6 +75,7 @@ __global__ void from_bf16_kernel(const uint2 *__restrict__ src, float4 *__restri
 }  // namespace
 
 struct ta3n_comm {
+    ta3n_peer *peer = nullptr;       // ta3n_comm_attach_peer: the exchange goes over peer-mapped buffers instead of ncclAllReduce
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -125,9 +126,16 @@ void ta3n_comm_destroy(ta3n_comm *c) {
 
 int ta3n_comm_world(const ta3n_comm *c) { return c ? c->world : TA3N_ERR_INVALID; }
 
+int ta3n_comm_attach_peer(ta3n_comm *c, ta3n_peer *peer) {
+    if (!c) return fail(TA3N_ERR_INVALID, "null communicator");
+    c->peer = peer;      // NULL detaches; the communicator does not own the peer object
+    return TA3N_OK;
+}
+
 int ta3n_all_reduce_sum(ta3n_comm *c, float *buf, int64_t count, void *scratch_bf16, void *stream) {
     if (!c || !buf || count < 0) return fail(TA3N_ERR_INVALID, "bad all-reduce arguments");
     if (count == 0) return TA3N_OK;
+    if (c->peer) return ta3n_peer_all_reduce_sum(c->peer, buf, count, stream);      // (transport type chosen at ta3n_peer_create)
     Rccl &r = rccl();
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;

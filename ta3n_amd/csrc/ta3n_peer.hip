@@ -1,0 +1,266 @@
+// Two-shot SUM all-reduce over peer-mapped buffers (xGMI load/store, no RCCL): the data-parallel gradient exchange of the TA3N
+// train step (replaces nn.DataParallel's reduce + broadcast, reference main.py:79) when 13.9 MB have to cross 8 GPUs between the
+// last gradient launch and the update and a ring's 2 x 7 hops of per-link latency are what the step waits for.
+//
+//   every rank owns   stage_in  [count]   its gradients in the transport type (fp32, or bf16 = half the xGMI bytes)
+//                     stage_red [count]   the chunk it reduced (only its own 1/world of the range is used)
+//                     flags     [3][world] epochs written BY the peers: READY_IN, READY_RED, DONE
+//   all three in fine-grained device memory (hipDeviceMallocFinegrained: coherent across devices for system-scope accesses),
+//   exported with hipIpcGetMemHandle and mapped by every peer (one process per GPU).
+//
+//   sync DONE      tell the peers "I am done with the previous exchange", wait until they all are (nobody still reads the
+//                  buffers this call overwrites) - a one-workgroup kernel, like the other two synchronisation points
+//   pack           stage_in = gradients (in the transport type)
+//   sync READY_IN  publish, wait for everybody's
+//   reduce         rank r reads chunk r of EVERY rank's stage_in (7 remote streams over 7 links at once + 1 local), adds them in
+//                  rank order, writes its stage_red chunk
+//   sync READY_RED publish, wait
+//   gather         every rank reads every chunk from the rank that reduced it -> gradients
+//   Each chunk is reduced by exactly one rank, in a fixed order: every rank ends up with bit-identical sums.
+//
+// Per rank and phase 7/8 of the buffer cross the links, all 7 links in parallel: 2 x 12.2 MB at 7 x ~45 GB/s ~ 80 us in fp32,
+// ~40 us in bf16, against 14 sequential ring steps each way inside ncclAllReduce.  Kernel boundaries order a rank's own phases
+// (and write its results back), the flags order the ranks; every spin is bounded (a peer that never arrives sets an error word
+// instead of hanging the GPU).
+//
+// NOT the default: with one GPU per box in this build environment only the protocol could be exercised (two processes sharing one
+// device, tests/test_gpu_peer.py); TA3N_DDP_PEER=1 selects it, ncclAllReduce stays the default exchange.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/ta3n_hip.h"
+#include "ta3n_kernels.h"
+#include "ta3n_plan.h"
+
+using namespace ta3n;
+
+namespace {
+
+constexpr int MAXR = 16;
+enum { F_READY_IN = 0, F_READY_RED = 1, F_DONE = 2 };
+constexpr unsigned long long SPIN_TICKS = 3ull * 100000000ull;     // wall_clock64 runs at 100 MHz: 3 s
+
+struct PeerView {
+    const void *in[MAXR];       // every rank's stage_in (own entry = own buffer)
+    const void *red[MAXR];      // every rank's stage_red
+    unsigned *flags[MAXR];      // every rank's flag block
+    int rank, world, bf16;
+};
+
+int fail(int code, const std::string &msg) {
+    ta3n::set_error(msg);
+    return code;
+}
+
+__device__ __forceinline__ float ld_elem(const void *base, int64_t i, int bf16) {
+    if (bf16) return __builtin_bit_cast(float, (unsigned)static_cast<const unsigned short *>(base)[i] << 16);
+    return static_cast<const float *>(base)[i];
+}
+
+// One cross-rank synchronisation point = ONE 64-thread workgroup (lane p talks to rank p): publish `epoch` in slot [which][me] of
+// every peer's flag block, then wait until every rank's epoch in MY block has reached it.  Stream order puts it behind this rank's
+// previous phase (whose stores the kernel boundary has written back) and in front of the next; the data kernels themselves never
+// spin, so a waiting rank occupies one wave, not the device (two processes may share a GPU in tests).  The wait is bounded.
+__global__ __launch_bounds__(64) void peer_sync_kernel(PeerView v, int which, unsigned epoch, unsigned *err) {
+    const int p = threadIdx.x;
+    if (p < v.world) {
+        __threadfence_system();
+        __hip_atomic_store(v.flags[p] + which * MAXR + v.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned *f = v.flags[v.rank] + which * MAXR + p;
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            if (wall_clock64() - t0 > SPIN_TICKS) {
+                __hip_atomic_store(err, 1u + which + 4u * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __threadfence_system();
+    }
+}
+
+__global__ __launch_bounds__(256) void peer_pack_kernel(PeerView v, const float *__restrict__ buf, void *__restrict__ stage_in, int64_t count,
+                                                        unsigned epoch, unsigned *err) {
+    const int64_t n4 = count / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(buf)[i];
+        if (v.bf16) static_cast<uint2 *>(stage_in)[i] = make_uint2(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w));
+        else static_cast<float4 *>(stage_in)[i] = x;
+    }
+    for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += stride) {
+        if (v.bf16) static_cast<unsigned short *>(stage_in)[i] = (unsigned short)(pack_bf16(buf[i], 0.f) & 0xFFFF);
+        else static_cast<float *>(stage_in)[i] = buf[i];
+    }
+}
+
+// four consecutive elements starting at i (i % 4 == 0, base 16-byte aligned): one 16-byte (fp32) or 8-byte (bf16) load
+__device__ __forceinline__ float4 ld4(const void *base, int64_t i, int bf16) {
+    if (bf16) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const unsigned short *>(base) + i);
+        return make_float4(__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xFFFF0000u),
+                           __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xFFFF0000u));
+    }
+    return *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + i);
+}
+
+__global__ __launch_bounds__(256) void peer_reduce_kernel(PeerView v, void *__restrict__ stage_red, int64_t c0, int64_t c1, unsigned epoch,
+                                                          unsigned *err) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = (c1 - c0) / 4;                   // c0 is a multiple of 4
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const int64_t i = c0 + 4 * q;
+        float4 part[MAXR];
+#pragma unroll
+        for (int p = 0; p < MAXR; ++p)
+            if (p < v.world) part[p] = ld4(v.in[p], i, v.bf16);        // all the remote streams in flight together
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < MAXR; ++p)                               // rank order: the same sum whoever computes it
+            if (p < v.world) { s.x += part[p].x; s.y += part[p].y; s.z += part[p].z; s.w += part[p].w; }
+        if (v.bf16) *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(stage_red) + i) = make_uint2(pack_bf16(s.x, s.y), pack_bf16(s.z, s.w));
+        else *reinterpret_cast<float4 *>(static_cast<float *>(stage_red) + i) = s;
+    }
+    for (int64_t i = c0 + 4 * n4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < c1; i += stride) {
+        float s = 0.f;
+        for (int p = 0; p < v.world; ++p) s += ld_elem(v.in[p], i, v.bf16);
+        if (v.bf16) static_cast<unsigned short *>(stage_red)[i] = (unsigned short)(pack_bf16(s, 0.f) & 0xFFFF);
+        else static_cast<float *>(stage_red)[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void peer_gather_kernel(PeerView v, float *__restrict__ buf, int64_t count, int64_t chunk, unsigned epoch,
+                                                          unsigned *err) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = count / 4;                        // chunk is a multiple of 4: a group of four never straddles two owners
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const int64_t i = 4 * q;
+        reinterpret_cast<float4 *>(buf)[q] = ld4(v.red[(int)(i / chunk)], i, v.bf16);
+    }
+    for (int64_t i = 4 * n4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += stride)
+        buf[i] = ld_elem(v.red[(int)(i / chunk)], i, v.bf16);
+}
+
+}  // namespace
+
+struct ta3n_peer {
+    int rank = 0, world = 1, bf16 = 0;
+    int64_t cap = 0;                 // elements
+    char *stage = nullptr;           // [2][cap] transport elements (sized for fp32)
+    unsigned *flags = nullptr;       // [4][MAXR]: three flag rows + the error word at [3][0]
+    void *peer_stage[MAXR] = {};
+    unsigned *peer_flags[MAXR] = {};
+    bool connected = false;
+    unsigned epoch = 0;
+};
+
+extern "C" {
+
+int ta3n_peer_create(int rank, int world, int64_t max_count, int bf16_transport, ta3n_peer **out) {
+    if (!out || world < 1 || world > MAXR || rank < 0 || rank >= world || max_count <= 0) return fail(TA3N_ERR_INVALID, "bad peer arguments");
+    ta3n_peer *p = new ta3n_peer();
+    p->rank = rank; p->world = world; p->cap = max_count; p->bf16 = bf16_transport ? 1 : 0;
+    const size_t bytes = 2 * (size_t)max_count * sizeof(float);
+    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&p->stage), bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipExtMallocWithFlags(reinterpret_cast<void **>(&p->flags), 4 * MAXR * sizeof(unsigned), hipDeviceMallocFinegrained) != hipSuccess) {
+        const std::string e = hipGetErrorString(hipGetLastError());
+        if (p->stage) (void)hipFree(p->stage);
+        delete p;
+        return fail(TA3N_ERR_HIP, "fine-grained device allocation failed: " + e);
+    }
+    if (hipMemset(p->flags, 0, 4 * MAXR * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        ta3n_peer_destroy(p);
+        return fail(TA3N_ERR_HIP, "flag initialisation failed");
+    }
+    p->peer_stage[rank] = p->stage;
+    p->peer_flags[rank] = p->flags;
+    *out = p;
+    return TA3N_OK;
+}
+
+int ta3n_peer_handle(ta3n_peer *p, char *handle128) {
+    if (!p || !handle128) return fail(TA3N_ERR_INVALID, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "two IPC handles travel in 128 bytes");
+    hipIpcMemHandle_t h[2];
+    if (hipIpcGetMemHandle(&h[0], p->stage) != hipSuccess || hipIpcGetMemHandle(&h[1], p->flags) != hipSuccess)
+        return fail(TA3N_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(hipGetLastError()));
+    std::memcpy(handle128, h, 128);
+    return TA3N_OK;
+}
+
+int ta3n_peer_connect(ta3n_peer *p, const char *all_handles) {
+    if (!p || !all_handles) return fail(TA3N_ERR_INVALID, "null argument");
+    for (int r = 0; r < p->world; ++r) {
+        if (r == p->rank) continue;
+        hipIpcMemHandle_t h[2];
+        std::memcpy(h, all_handles + 128 * (size_t)r, 128);
+        if (hipIpcOpenMemHandle(&p->peer_stage[r], h[0], hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+            hipIpcOpenMemHandle(reinterpret_cast<void **>(&p->peer_flags[r]), h[1], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+            return fail(TA3N_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(r) + "): " + hipGetErrorString(hipGetLastError()));
+    }
+    p->connected = true;
+    return TA3N_OK;
+}
+
+void ta3n_peer_destroy(ta3n_peer *p) {
+    if (!p) return;
+    for (int r = 0; r < p->world; ++r) {
+        if (r == p->rank) continue;
+        if (p->peer_stage[r]) (void)hipIpcCloseMemHandle(p->peer_stage[r]);
+        if (p->peer_flags[r]) (void)hipIpcCloseMemHandle(p->peer_flags[r]);
+    }
+    if (p->stage) (void)hipFree(p->stage);
+    if (p->flags) (void)hipFree(p->flags);
+    delete p;
+}
+
+int ta3n_peer_all_reduce_sum(ta3n_peer *p, float *buf, int64_t count, void *stream) {
+    if (!p || !buf || count < 0) return fail(TA3N_ERR_INVALID, "bad all-reduce arguments");
+    if (!p->connected && p->world > 1) return fail(TA3N_ERR_INVALID, "ta3n_peer_connect has not been called");
+    if (count > p->cap) return fail(TA3N_ERR_INVALID, "count exceeds the peer buffers");
+    if (count == 0) return TA3N_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned epoch = ++p->epoch;
+    const size_t esz = p->bf16 ? 2 : 4;
+    PeerView v;
+    std::memset(&v, 0, sizeof(v));
+    v.rank = p->rank; v.world = p->world; v.bf16 = p->bf16;
+    for (int r = 0; r < p->world; ++r) {
+        v.in[r] = static_cast<char *>(p->peer_stage[r]);
+        v.red[r] = static_cast<char *>(p->peer_stage[r]) + (size_t)p->cap * sizeof(float);
+        v.flags[r] = p->peer_flags[r];
+    }
+    (void)esz;
+    // chunk = multiple of 4 elements so that every rank's range starts 16-byte aligned
+    const int64_t chunk = ((count + p->world - 1) / p->world + 3) / 4 * 4;
+    const int64_t c0 = std::min<int64_t>(chunk * p->rank, count), c1 = std::min<int64_t>(c0 + chunk, count);
+    unsigned *err = p->flags + 3 * MAXR;
+    const int blocks = (int)std::min<int64_t>((count / 4 + 255) / 256 + 1, 1024);
+    // "I am done reading everybody's buffers of the previous exchange" / wait until everybody is: the staging buffers may be overwritten
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_DONE, epoch - 1, err);
+    hipLaunchKernelGGL(peer_pack_kernel, dim3(blocks), dim3(256), 0, s, v, buf, static_cast<void *>(p->stage), count, epoch, err);
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_IN, epoch, err);
+    const int rblocks = (int)std::max<int64_t>(1, std::min<int64_t>((c1 - c0 + 255) / 256, 1024));
+    hipLaunchKernelGGL(peer_reduce_kernel, dim3(rblocks), dim3(256), 0, s, v, static_cast<void *>(p->stage + (size_t)p->cap * sizeof(float)), c0, c1,
+                       epoch, err);
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_RED, epoch, err);
+    hipLaunchKernelGGL(peer_gather_kernel, dim3(blocks), dim3(256), 0, s, v, buf, count, chunk, epoch, err);
+    if (hipGetLastError() != hipSuccess) return fail(TA3N_ERR_HIP, "peer all-reduce launch failed");
+    return TA3N_OK;
+}
+
+int ta3n_peer_status(ta3n_peer *p, void *stream) {
+    if (!p) return fail(TA3N_ERR_INVALID, "null argument");
+    unsigned e = 0;
+    if (hipMemcpyAsync(&e, p->flags + 3 * MAXR, sizeof(e), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)) != hipSuccess ||
+        hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(TA3N_ERR_HIP, "reading the peer status failed");
+    if (e != 0)
+        return fail(1, "peer all-reduce: rank " + std::to_string(p->rank) + " gave up waiting for rank " + std::to_string((e - 1) / 4) +
+                           " in phase " + std::to_string((e - 1) % 4));
+    return 0;
+}
+
+}  // extern "C"

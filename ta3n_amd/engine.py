@@ -162,6 +162,19 @@ class TrainEngine:
             want16 = (grad_transport == "bf16") if grad_transport is not None else os.environ.get("TA3N_DDP_BF16", "0") == "1"
             if self.comm is not None and want16:
                 self._g16 = torch.zeros(p.live_floats, dtype=torch.bfloat16, device=self.device)
+        # TA3N_DDP_PEER=1: the exchange as a two-shot all-reduce over peer-mapped buffers (csrc/ta3n_peer.hip) instead of ncclAllReduce;
+        # opt-in (only its protocol could be exercised on the one-GPU boxes this was built on); any backend of the process group
+        self.peer = None
+        if (self.world > 1 or self._ddp_selftest) and os.environ.get("TA3N_DDP_PEER", "0") == "1":
+            want16 = (grad_transport == "bf16") if grad_transport is not None else os.environ.get("TA3N_DDP_BF16", "0") == "1"
+            try:
+                self.peer = parallel.PeerComm(self.pg if self.world > 1 else None, self.device, p.live_floats, bf16=want16)
+                if self.comm is not None:      # ta3n_all_reduce_sum / ta3n_train_steps of the communicator go through the peer path
+                    _lib.check(self._L.ta3n_comm_attach_peer(self.comm.handle, self.peer.handle), "ta3n_comm_attach_peer")
+            except Exception as ex:      # noqa: BLE001 - raised on every rank together (PeerComm): keep the default exchange
+                self.peer = None
+                if self.rank == 0:
+                    print(f"[ta3n] peer all-reduce unavailable ({type(ex).__name__}: {ex}); using the default exchange", flush=True)
         self.step_count = 0
         self.skip_collective = False
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -267,6 +280,9 @@ class TrainEngine:
 
     def all_reduce_grads(self) -> None:
         if self.skip_collective:      # measurement only (bench.py: the step without its exchange -> exposed collective time)
+            return
+        if self.peer is not None and self.comm is None:      # (with a communicator the library routes through the attached peer itself)
+            self.peer.all_reduce_sum_(self.G[: self.plan.live_floats])
             return
         if self.comm is not None:      # RCCL on the step's stream, enqueued by the library
             _lib.check(self._L.ta3n_all_reduce_sum(self.comm.handle, self.G.data_ptr(), self.plan.live_floats,

@@ -153,3 +153,79 @@ class NativeComm:
             self.close()
         except Exception:
             pass
+
+
+class PeerComm:
+    """Two-shot all-reduce over peer-mapped buffers (include/ta3n_hip.h: ta3n_peer_*; csrc/ta3n_peer.hip): staging buffers in
+    fine-grained device memory, their HIP IPC handles exchanged over the existing torch.distributed group (any backend), every
+    rank maps every peer.  Creation is agreed on by all ranks: if any step fails anywhere, every rank raises and the caller keeps
+    the default exchange."""
+
+    def __init__(self, group, device, max_count: int, bf16: bool = False):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        if device is not None:
+            torch.cuda.set_device(device)
+        self._L, self.handle, self.world, self.rank, self.bf16 = L, None, world, rank, bool(bf16)
+
+        def agree(ok, what, detail=""):
+            flags = [None] * world
+            if world > 1:
+                dist.all_gather_object(flags, (bool(ok), detail), group=group)
+            else:
+                flags = [(bool(ok), detail)]
+            bad = [(r, d) for r, (o, d) in enumerate(flags) if not o]
+            if bad:
+                self.close()
+                raise RuntimeError(f"{what} failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
+
+        h = C.c_void_p()
+        buf = C.create_string_buffer(128)
+        ok, detail = True, ""
+        try:
+            _lib.check(L.ta3n_peer_create(rank, world, int(max_count), int(bool(bf16)), C.byref(h)), "ta3n_peer_create")
+            self.handle = h
+            _lib.check(L.ta3n_peer_handle(h, buf), "ta3n_peer_handle")
+        except Exception as ex:      # noqa: BLE001
+            ok, detail = False, str(ex)
+        agree(ok, "peer buffer allocation / export", detail)
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, bytes(buf.raw), group=group)
+        else:
+            handles = [bytes(buf.raw)]
+        ok, detail = True, ""
+        try:
+            _lib.check(L.ta3n_peer_connect(h, C.c_char_p(b"".join(handles))), "ta3n_peer_connect")
+        except Exception as ex:      # noqa: BLE001
+            ok, detail = False, str(ex)
+        agree(ok, "mapping the peers' buffers (hipIpcOpenMemHandle)", detail)
+
+    def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        import ctypes as C
+        from . import _lib
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+        _lib.check(self._L.ta3n_peer_all_reduce_sum(self.handle, flat.data_ptr(), flat.numel(), stream), "ta3n_peer_all_reduce_sum")
+        return flat
+
+    def status(self, device=None) -> None:
+        import ctypes as C
+        from . import _lib
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        if self._L.ta3n_peer_status(self.handle, stream) != 0:
+            raise _lib.Ta3nError(self._L.ta3n_last_error().decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.ta3n_peer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
