@@ -171,8 +171,8 @@ class _HipForwardAvg(torch.autograd.Function):
     def forward(ctx, model, xs, xt, beta, train, reverse_mu, *params):
         dev = model._flat.device
         Bs, Bt = xs.shape[0], xt.shape[0]
-        plan = model._plan(Bs, Bt)
-        T = model.train_segments
+        T = int(xs.shape[1])                  # TemPooling averages whatever number of segments it is given (models.py:421-433):
+        plan = model._plan(Bs, Bt, T)         # validation may use val_segments != train_segments (models.py:60, 555): a plan per count
         x = torch.cat((xs.reshape(Bs * T, -1), xt.reshape(Bt * T, -1)), 0).to(device=dev, dtype=torch.float32).contiguous()
         ws = model._ws_checkout(plan, ctx, any(ctx.needs_input_grad))
         h = _lib.Hyper()
@@ -370,10 +370,11 @@ class VideoModel(nn.Module):
                 (_lib.FLAG_BN_SHARED if self.use_bn != 'none' else 0) |
                 (_lib.FLAG_MCD if self.ens_DA == 'MCD' else 0))
 
-    def _plan(self, Bs: int, Bt: int) -> _lib.Plan:
-        key = (Bs, Bt)
+    def _plan(self, Bs: int, Bt: int, T: Optional[int] = None) -> _lib.Plan:
+        T = self.train_segments if T is None else int(T)
+        key = (Bs, Bt, T)
         if key not in self._plans:
-            self._plans[key] = _lib.Plan(Bs, Bt, self.train_segments, self.feature_dim, self._feat_dim_F, self.num_class,
+            self._plans[key] = _lib.Plan(Bs, Bt, T, self.feature_dim, self._feat_dim_F, self.num_class,
                                          self._flags(), aggregation=_lib.AGG_AVGPOOL if self._avg else _lib.AGG_TRN_M)
         return self._plans[key]
 
@@ -462,8 +463,10 @@ class VideoModel(nn.Module):
             raise NotImplementedError("use_bn with alpha != 1 (source/target batch mixing of domainAlign, models.py:497-508, 531-533): the "
                                       "reference's own program never changes alpha from its initial 1")
         num_segments = self.train_segments if is_train else self.val_segments
-        if num_segments != self.train_segments:
-            raise ValueError("val_segments must equal num_segments (static launch plans; TRN needs it anyway, models.py:222)")
+        if num_segments != self.train_segments and not self._avg:
+            # (the reference's TRN is built for train_segments frames, models.py:222-224: another count fails there too; TemPooling
+            # averages any number of segments and gets a plan per count)
+            raise ValueError("val_segments must equal num_segments for frame_aggregation 'trn-m' (the relation module is built for train_segments)")
         if input_source.dim() != 3 or input_target.dim() != 3 or input_source.size(1) != num_segments or \
                 input_source.size(2) != self.feature_dim or input_target.size(2) != self.feature_dim:
             raise ValueError("inputs must be [B, num_segments, feature_dim]")
@@ -471,7 +474,7 @@ class VideoModel(nn.Module):
         if device.type != "cuda":
             device = torch.device("cuda", torch.cuda.current_device())
         Bs, Bt = input_source.size(0), input_target.size(0)
-        plan = self._plan(Bs, Bt)
+        plan = self._plan(Bs, Bt, num_segments if self._avg else None)
         self._ensure_flat(plan, device)
         params = [p for _, _, _, p in self._named_flat_params(plan)]
         s, t = slice(0, Bs), slice(Bs, Bs + Bt)

@@ -191,3 +191,36 @@ def test_module_path_avgpool_matches_oracle(place_adv):
     for k, w in res["grads"].items():
         got = named[k].grad.cpu()
         assert torch.allclose(got, w, rtol=2e-3, atol=2e-4 * w.abs().max().item() + 1e-7), (k, (got - w).abs().max().item(), w.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_module_path_avgpool_validates_with_another_segment_count():
+    """models.py:60, 555: val_segments (default 25) need not equal train_segments; TemPooling averages whatever it is given
+    (models.py:421-433).  The module path builds a plan per segment count: a train-mode pass on 4 segments, then an eval-mode pass
+    on 9 (main.validate feeds the validation clip in BOTH slots, main.py:707), both against the oracle."""
+    from ta3n_amd.models import VideoModel
+    C_, Tt, Tv, D, Fc, Bs, Bt = 7, 4, 9, 512, 64, 6, 5
+    mk = lambda T: orc.Config(num_class=C_, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, place_adv=("N", "Y", "Y"),
+                              add_loss_DA="none", use_attn="none", frame_aggregation="avgpool")
+    params = synth_state(orc.param_shapes(mk(Tt)), seed=21)
+    assert orc.param_shapes(mk(Tv)) == orc.param_shapes(mk(Tt))
+    m = VideoModel(C_, "video", "avgpool", "RGB", train_segments=Tt, val_segments=Tv, base_model="resnet18", fc_dim=Fc, dropout_i=0.0,
+                   dropout_v=0.0, use_attn="none", verbose=False)
+    sd = m.state_dict(); sd.update(params); m.load_state_dict(sd)
+    m = m.cuda()
+    m.train()
+    xs, xt, ys, yt = synth_batch(C_, Tt, D, Bs, Bt, seed=22)
+    out = m(xs, xt, BETA, 0, True, False)
+    with torch.no_grad():
+        want = orc.forward_domain(params, xs, BETA, mk(Tt), domain="S")
+    assert torch.allclose(out[1].cpu(), want["out"], atol=1e-3)
+    m.eval()
+    xv, _, _, _ = synth_batch(C_, Tv, D, Bs, Bt, seed=23)
+    with torch.no_grad():
+        ev = m(xv, xv, [0, 0, 0], 0, False, False)
+        want = orc.forward_domain(params, xv, [0, 0, 0], mk(Tv), domain="T")
+    assert ev[6].shape == (Bs, C_) and ev[9][2].shape == (Bs, Tv, Fc)
+    assert torch.allclose(ev[6].cpu(), want["out"], atol=1e-3) and torch.allclose(ev[9][1].cpu(), want["feat"][1], atol=1e-4)
+    with pytest.raises(ValueError):      # trn-m: the relation module is built for train_segments frames, in the reference too
+        VideoModel(C_, "video", "trn-m", "RGB", train_segments=Tt, val_segments=Tv, base_model="resnet18", fc_dim=Fc, verbose=False).cuda()(
+            xv, xv, [0, 0, 0], 0, False, False)

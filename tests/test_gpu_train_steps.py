@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(c, **kw):
-    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["F"], c["C"], dropout_i=0.5, dropout_v=0.5, **kw)
+    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.5, dropout_v=0.5, **kw)
 
 
 def _load(eng, seed=7):
