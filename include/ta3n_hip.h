@@ -321,6 +321,22 @@ int ta3n_train_steps(ta3n_plan *plan, const float *x, float *params, float *grad
                      ta3n_comm *comm /* NULL, or: ta3n_all_reduce_sum of the live gradients after every step (fused_norm must be 0) */,
                      void *scratch_bf16 /* as in ta3n_all_reduce_sum */, void *stream);
 
+/* The same steps with the optimiser INSIDE the gradient launches: every gradient tile of ta3n_train_step applies the Nesterov /
+ * weight-decay update (main.py:83, 583) to its own block of parameters in its epilogue - the gradient is in registers, the old
+ * parameter and momentum entries are read once, the new ones written once - instead of a separate pass over 5 x 4 B per parameter
+ * after the step.  New parameters go to the OTHER of two buffers (params / params_alt alternate; launches of the same step that
+ * still read the old values are not disturbed), the bf16 twins likewise ("p16" / "p16b").  clip_grad_norm_ (main.py:578-581)
+ * needs the norm of the whole gradient, known only after the last launch: the tiles update with the clip coefficient taken as
+ * 1 and one short launch per step (which also delivers the next step's scalars) checks the norm and, if it exceeded `clip`,
+ * corrects parameters and momentum exactly (the update is linear in the gradient).  Bit-identical to ta3n_train_steps whenever
+ * no step clips; within fp32 rounding of the correction otherwise.  Single rank (a gradient all-reduce would have to sit
+ * between the tiles and the update).  Returns with the result in `params` (copied back after an odd number of steps) and nothing
+ * pending; requires that no update is pending on entry.  ta3n_has_fused_update: 1 when the plan supports it (trn-m fused step). */
+int ta3n_has_fused_update(const ta3n_plan *plan);
+int ta3n_train_steps_fused_update(ta3n_plan *plan, const float *x, float *params, float *params_alt, float *grads, float *momentum,
+                                  float *ws, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers,
+                                  int n_steps, const ta3n_feed *source, const ta3n_feed *target, void *stream);
+
 /* TA3N_FLAG_BF16_STORE: (re)build the bf16 twins of x (B*T*feature_dim floats, may be NULL) and of params (may be
  * NULL) inside ws.  No-op without the flag. */
 int ta3n_refresh_bf16(ta3n_plan *plan, const float *x, const float *params, float *ws, void *stream);

@@ -41,7 +41,7 @@ SYMBOLS = [
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
     "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_chain_status", "ta3n_debug_waits",
     "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
-    "ta3n_comm_attach_peer",
+    "ta3n_comm_attach_peer", "ta3n_has_fused_update", "ta3n_train_steps_fused_update",
 ]
 
 
@@ -119,6 +119,9 @@ def lib() -> C.CDLL:
     L.ta3n_train_step_after_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_train_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
                                    C.POINTER(Feed), C.POINTER(Feed), vp, vp, vp]
+    L.ta3n_has_fused_update.argtypes = [vp]
+    L.ta3n_train_steps_fused_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
+                                                C.POINTER(Feed), C.POINTER(Feed), vp]
     L.ta3n_gather_segments_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_gather_segments_bf16_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ta3n_sgd_step_next.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]

@@ -51,6 +51,12 @@ int ensure_uploaded(ta3n_plan *p) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// buffers of one launch sequence; the parameter twins it reads are those of region `twin_region` (0: "p16", 1: "p16b")
+Ptrs make_ptrs(const ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, int twin_region = 0) {
+    const int32_t o = twin_region ? p->geom.o_p16b : p->geom.o_p16;
+    return Ptrs{x, params, grads, ws, (ws && o >= 0) ? ws + o : nullptr};
+}
+
 int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float *momentum, hipStream_t stream,
               hipEvent_t join_after_first = nullptr, int first_launch = 0, int n_launches = 1 << 30,
               const SgdSide *side = nullptr) {
@@ -275,7 +281,7 @@ int ta3n_forward(ta3n_plan *p, const float *x, const float *params, float *ws, v
     if (!aligned16(x) || !aligned16(params) || !aligned16(ws)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{x, params, nullptr, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, nullptr, ws);
     return run_group(p, 0, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -283,7 +289,7 @@ int ta3n_loss(ta3n_plan *p, float *ws, void *stream) {
     if (!p || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{nullptr, nullptr, nullptr, ws};
+    Ptrs ptrs = make_ptrs(p, nullptr, nullptr, nullptr, ws);
     return run_group(p, 1, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -293,7 +299,7 @@ int ta3n_backward(ta3n_plan *p, const float *x, const float *params, float *grad
         return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     return run_group(p, 2, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -311,7 +317,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
     if (cap < n) return fail(TA3N_ERR_INVALID, "output too small");
     std::vector<hipEvent_t> ev(2 * n);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     for (int i = 0; i < n; ++i) {
         const Phase &ph = p->phases[i];
         const int r = (ph.kind == PH_SGD || ph.kind == PH_GRAD_NORM) ? 1 : reps;
@@ -370,7 +376,7 @@ int ta3n_time_update_launches(ta3n_plan *p, const float *x, float *params, float
     HIP_TRY(hipStreamSynchronize(s));
     SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
                  fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     HIP_TRY(hipEventRecord(ev[0], s));
     for (int k = 0; k < reps; ++k)
         if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
@@ -469,7 +475,7 @@ int ta3n_train_step_range(ta3n_plan *p, const float *x, const float *params, flo
         return fail(TA3N_ERR_INVALID, "launch range outside the fused sequence");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, first_launch, n_launches);
 }
 
@@ -499,7 +505,7 @@ int ta3n_train_step_after_update(ta3n_plan *p, const float *x, float *params, fl
     // (2) the new step's first launch, with the rest of the update as side tasks; (3) the other launches of the step
     SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
                  fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side);
     if (rc != TA3N_OK) return rc;
     return run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30);
@@ -541,7 +547,7 @@ int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, 
     const Geom &g = p->geom;
     if ((source || target) && (g.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
     if (comm && fused_norm) return fail(TA3N_ERR_INVALID, "with a communicator the norm is taken from the REDUCED gradients: fused_norm must be 0");
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     float lr = lr_pending;
     for (int k = 0; k < n_steps; ++k) {
         // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued)
@@ -559,6 +565,60 @@ int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, 
         // data parallel: the step's single exchange, on the step's stream, between the last gradient launch and the update
         if (comm && (rc = ta3n_all_reduce_sum(comm, grads, p->live_floats, scratch_bf16, stream)) != TA3N_OK) return rc;
         lr = hypers[k].lr;
+    }
+    return TA3N_OK;
+}
+
+int ta3n_has_fused_update(const ta3n_plan *p) {
+    if (!p) return TA3N_ERR_INVALID;
+    // every live parameter's gradient is produced by a tile / column-sum task of the fused step (those carry the update)
+    return ta3n_has_fused_step(p) == 1 && p->cfg.aggregation == TA3N_AGG_TRN_M ? 1 : 0;
+}
+
+int ta3n_train_steps_fused_update(ta3n_plan *p, const float *x, float *params, float *params_alt, float *grads, float *momentum, float *ws,
+                                  float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
+                                  const ta3n_feed *source, const ta3n_feed *target, void *stream) {
+    if (!p || !x || !params || !params_alt || !grads || !momentum || !ws || !hypers) return fail(TA3N_ERR_INVALID, "null argument");
+    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
+    if (!aligned16(x) || !aligned16(params) || !aligned16(params_alt) || !aligned16(grads) || !aligned16(momentum) || !aligned16(ws))
+        return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
+    if (ta3n_has_fused_update(p) != 1) return fail(TA3N_ERR_INVALID, "no fused-update step for this configuration");
+    int rc = ensure_uploaded(p);
+    if (rc != TA3N_OK) return rc;
+    if (n_steps == 0) return TA3N_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geom &g = p->geom;
+    if ((source || target) && (g.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
+    const bool twins = g.o_p16 >= 0;
+    float *P[2] = {params, params_alt};
+    float *T16[2] = {twins ? ws + g.o_p16 : nullptr, twins ? ws + g.o_p16b : nullptr};
+    // whatever no tile rewrites (parameters without a gradient in this configuration) must be the same in both buffers
+    HIP_TRY(hipMemcpyAsync(params_alt, params, (size_t)p->param_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (twins) HIP_TRY(hipMemcpyAsync(T16[1], T16[0], (size_t)((p->param_floats + 1) / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the first step's scalars; every later step receives its own from the launch that closes the step before it
+    Hyper h0;
+    std::memcpy(&h0, &hypers[0], sizeof(h0));
+    if (launch_set_hyper(ws + g.o_hyper, h0, s) != 0) return fail(TA3N_ERR_HIP, "set_hyper launch failed");
+    int cur = 0;
+    for (int k = 0; k < n_steps; ++k) {
+        if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(x), ws, reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
+        if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(x), ws, nullptr, s)) != TA3N_OK) return rc;
+        // forward, heads, backward on P[cur]; every gradient tile writes its block of P[1 - cur] (and its twins)
+        Ptrs ptrs = make_ptrs(p, x, P[cur], grads, ws, cur);
+        SgdSide side;
+        std::memset(&side, 0, sizeof(side));
+        side.momentum = momentum; side.lr = hypers[k].lr; side.mu = momentum_coef; side.wd = weight_decay; side.clip = clip;
+        side.p16_off = -1; side.p_new = P[1 - cur]; side.p16_new = T16[1 - cur];
+        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;
+        cur ^= 1;
+        // norm / clip check of step k on the buffer it wrote, carrying step k + 1's scalars
+        if (launch_sgd_fixup(g, P[cur], grads, momentum, ws, T16[cur], hypers[k].lr, momentum_coef, clip,
+                             k + 1 < n_steps ? reinterpret_cast<const Hyper *>(&hypers[k + 1]) : nullptr, s) != 0)
+            return fail(TA3N_ERR_HIP, "sgd fixup launch failed");
+    }
+    if (cur == 1) {      // an odd number of steps: the result goes back to the caller's buffer (and its twin region)
+        HIP_TRY(hipMemcpyAsync(params, params_alt, (size_t)p->live_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (twins) HIP_TRY(hipMemcpyAsync(T16[0], T16[1], (size_t)((p->param_floats + 1) / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return TA3N_OK;
 }
@@ -617,7 +677,7 @@ int ta3n_train_step_join(ta3n_plan *p, const float *x, const float *params, floa
                                       "use ta3n_forward + ta3n_loss + ta3n_backward");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{x, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     return run_group(p, 4, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(join_event));
 }
 
@@ -637,7 +697,7 @@ int ta3n_sgd_step(ta3n_plan *p, float *params, float *grads, float *momentum, fl
     if (!aligned16(params) || !aligned16(grads) || !aligned16(momentum)) return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
     int rc = ensure_uploaded(p);
     if (rc != TA3N_OK) return rc;
-    Ptrs ptrs{nullptr, params, grads, ws};
+    Ptrs ptrs = make_ptrs(p, nullptr, params, grads, ws);
     return run_group(p, 3, ptrs, params, momentum, static_cast<hipStream_t>(stream));
 }
 

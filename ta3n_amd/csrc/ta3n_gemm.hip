@@ -528,6 +528,7 @@ __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
         case BASE_X: return p.x;
         case BASE_P: return p.p;
         case BASE_G: return p.g;
+        case BASE_P16: return p.p16;
         default: return p.ws;
     }
 }
@@ -612,6 +613,15 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             for (int r = 0; r < t.pad[1]; ++r) v += src[(size_t)r * t.pad[2] + n];
             dst[n] = v;
             sq = fmaf(v, v, sq);
+            if (side.p_new != nullptr && t.c_base == BASE_G) {     // fused update of these parameters (see the tile epilogue)
+                const size_t pi = (size_t)t.c_off + n;
+                const float p0 = ptrs.p[pi];
+                float d = fmaf(side.wd, p0, v), mm = fmaf(side.mu, side.momentum[pi], d);
+                d = fmaf(side.mu, mm, d);
+                const float p1 = fmaf(-side.lr, d, p0);
+                side.p_new[pi] = p1; side.momentum[pi] = mm;
+                if (side.p16_new != nullptr) reinterpret_cast<unsigned short *>(side.p16_new)[pi] = (unsigned short)(pack_bf16(p1, 0.f) & 0xFFFF);
+            }
         }
         if (t.epi & EPI_SUMSQ) {
             sq = wave_allreduce_sum(sq);
@@ -667,6 +677,35 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (n + e < t.n_valid) ebias[e] = bias[n + e];
+    }
+
+    // Fused update (SgdSide::p_new, gradient tiles only): the old parameter and momentum entries this thread will update are
+    // requested NOW, like the bias, and consumed in the epilogue - in the epilogue itself the two dependent loads were ~1.5 us on
+    // the critical path of every weight-gradient tile.  Tiles with more than two epilogue passes per thread (register-blocked
+    // 128-wide tiles) load them in the epilogue instead: 8 registers per pass are too many to carry through the K loop.
+    constexpr int ITER_E = (BM * BN / 4 + NT - 1) / NT;
+    constexpr bool UPD_PREFETCH = ITER_E <= 2;
+    const bool upd_early = UPD_PREFETCH && side.p_new != nullptr && t.c_base == BASE_G;
+    float up_e[UPD_PREFETCH ? ITER_E : 1][4], um_e[UPD_PREFETCH ? ITER_E : 1][4];
+    if (upd_early) {
+        const bool cv = ((t.c_off | t.c_ld) & 3) == 0;
+#pragma unroll
+        for (int it = 0; it < (UPD_PREFETCH ? ITER_E : 1); ++it) {
+            const int idx = tid + it * NT;
+            const int mm_ = t.m0 + idx / (BN / 4), nn_ = t.n0 + (idx % (BN / 4)) * 4;
+            const int nr_ = (idx < BM * BN / 4 && mm_ < t.m_valid) ? t.n_valid - nn_ : 0;
+            const size_t pi = (size_t)t.c_off + (size_t)mm_ * t.c_ld + nn_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { up_e[it][e] = 0.f; um_e[it][e] = 0.f; }
+            if (nr_ >= 4 && cv) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(ptrs.p + pi), r4 = *reinterpret_cast<const float4 *>(side.momentum + pi);
+                up_e[it][0] = q4.x; up_e[it][1] = q4.y; up_e[it][2] = q4.z; up_e[it][3] = q4.w;
+                um_e[it][0] = r4.x; um_e[it][1] = r4.y; um_e[it][2] = r4.z; um_e[it][3] = r4.w;
+            } else if (nr_ > 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nr_) { up_e[it][e] = ptrs.p[pi + e]; um_e[it][e] = side.momentum[pi + e]; }
+            }
+        }
     }
 
     f32x16 acc[RM][RN];
@@ -888,6 +927,11 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     const bool c_vec = ((t.c_off | t.c_ld) & 3) == 0;
     const bool aux_vec = ((t.aux_off | t.aux_ld) & 3) == 0, add_vec = ((t.add_off | t.add_ld) & 3) == 0;
     const int nfan = t.fan_count;
+    // Fused update (SgdSide::p_new): a gradient tile is also the optimiser step of its block of parameters.  torch.optim.SGD with
+    // nesterov and weight decay (main.py:83, 583) in the arithmetic of sgd_kernel with the clip coefficient taken as 1:
+    //   d = wd p + g;  m = mu m + d;  p_new = p - lr (d + mu m)
+    // (a step whose gradient norm exceeds clip_gradient is corrected afterwards by sgd_fixup_kernel: the update is linear in g).
+    const bool upd = side.p_new != nullptr && t.c_base == BASE_G;      // workgroup-uniform
     float sumsq = 0.f;   // EPI_SUMSQ: this thread's share of the tile's sum of squares
     // Every flag test below is workgroup-uniform: a tile without bias / mask / residual issues no load for it (the
     // bias and the per-step scalars were fetched before the K loop, so the first dependent global access of a plain
@@ -924,6 +968,20 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 for (int e = 0; e < 4; ++e) if (e < nrem) mv[e] = xp[e];
             }
         }
+        float up[4] = {0.f, 0.f, 0.f, 0.f}, um[4] = {0.f, 0.f, 0.f, 0.f};      // fused update: old parameters and momentum of these entries
+        if (upd_early) {                          // requested before the K loop
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { up[e] = up_e[UPD_PREFETCH ? it : 0][e]; um[e] = um_e[UPD_PREFETCH ? it : 0][e]; }
+        } else if (upd && nrem > 0) {             // requested here: the latency overlaps the LDS reads below
+            const size_t pi = (size_t)t.c_off + (size_t)m * t.c_ld + n;
+            if (nrem >= 4 && c_vec) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(ptrs.p + pi), r4 = *reinterpret_cast<const float4 *>(side.momentum + pi);
+                up[0] = q4.x; up[1] = q4.y; up[2] = q4.z; up[3] = q4.w; um[0] = r4.x; um[1] = r4.y; um[2] = r4.z; um[3] = r4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nrem) { up[e] = ptrs.p[pi + e]; um[e] = side.momentum[pi + e]; }
+            }
+        }
         float4 v4 = zero4();
 #pragma unroll
         for (int q = 0; q < WK; ++q) {
@@ -953,6 +1011,30 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (e < nrem) { if (pub) st_pub(cp + e, v[e]); else cp[e] = v[e]; }
+        }
+        if (upd) {
+            const size_t pi = (size_t)t.c_off + (size_t)m * t.c_ld + n;
+            float pn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = fmaf(side.wd, up[e], v[e]);
+                um[e] = fmaf(side.mu, um[e], d);
+                d = fmaf(side.mu, um[e], d);
+                pn[e] = fmaf(-side.lr, d, up[e]);
+            }
+            if (nrem >= 4 && c_vec) {
+                *reinterpret_cast<float4 *>(side.p_new + pi) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                *reinterpret_cast<float4 *>(side.momentum + pi) = make_float4(um[0], um[1], um[2], um[3]);
+                if (side.p16_new != nullptr)
+                    *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(side.p16_new) + pi) = u32x2{pack_bf16(pn[0], pn[1]), pack_bf16(pn[2], pn[3])};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nrem) {
+                        side.p_new[pi + e] = pn[e]; side.momentum[pi + e] = um[e];
+                        if (side.p16_new != nullptr) reinterpret_cast<unsigned short *>(side.p16_new)[pi + e] = (unsigned short)(pack_bf16(pn[e], 0.f) & 0xFFFF);
+                    }
+            }
         }
         if (epi & EPI_TWIN16) {          // bf16 twin of the stored values (TA3N_FLAG_BF16_STORE)
             unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
@@ -1031,6 +1113,15 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             if (m0 + tid < m_valid) {
                 const_cast<float *>(base_ptr(ptrs, t.bias_base))[(size_t)t.bias_off + m0 + tid] = b;
                 sumsq = fmaf(b, b, sumsq);
+                if (upd && t.bias_base == BASE_G) {      // the bias gradient's own parameter entries
+                    const size_t pi = (size_t)t.bias_off + m0 + tid;
+                    const float p0 = ptrs.p[pi];
+                    float d = fmaf(side.wd, p0, b), mm = fmaf(side.mu, side.momentum[pi], d);
+                    d = fmaf(side.mu, mm, d);
+                    const float p1 = fmaf(-side.lr, d, p0);
+                    side.p_new[pi] = p1; side.momentum[pi] = mm;
+                    if (side.p16_new != nullptr) reinterpret_cast<unsigned short *>(side.p16_new)[pi] = (unsigned short)(pack_bf16(p1, 0.f) & 0xFFFF);
+                }
             }
         }
     }

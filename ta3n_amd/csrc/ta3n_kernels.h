@@ -11,6 +11,7 @@ struct Ptrs {
     const float *p;   // BASE_P  flat parameters
     float *g;         // BASE_G  flat gradients
     float *ws;        // BASE_WS workspace
+    const float *p16; // BASE_P16 bf16 twins of the parameters this launch reads (inside ws; nullptr: no twins)
 };
 
 // Side job of a GEMM launch (EPI_SGD tasks): the optimiser update of a parameter range, with its scalars by value.
@@ -21,6 +22,12 @@ struct SgdSide {
     float lr, mu, wd, clip;
     int32_t norm_off, norm_n;    // ws offsets of the squared-norm partials (fused per-tile slots or the grad_norm kernel's)
     int32_t p16_off;             // ws offset of the parameter twins, -1: none
+    // Fused update (ta3n_train_steps_fused_update): every gradient tile applies the Nesterov step to its own block of parameters in
+    // its epilogue - reads the parameters the step computes with (Ptrs.p) and the momentum, writes the NEW parameters (and their
+    // twins) into the other buffer, so launches of the same step that still read the old values are not disturbed.  The clip
+    // coefficient is taken as 1; sgd_fixup_kernel corrects the rare step whose gradient norm exceeds the clip value.
+    float *p_new;                // nullptr: no fused update
+    float *p16_new;              // twin region of p_new (floats), nullptr: no twins
 };
 
 __device__ __forceinline__ float hyper_scale(const Hyper *__restrict__ hy, int kind) {
@@ -125,6 +132,8 @@ int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum
                bool fused_norm = false);
 int launch_fill(float *dst, float value, int64_t n, hipStream_t stream);
 int launch_set_hyper(float *ws_hyper, const Hyper &h, hipStream_t stream);   // scalars by kernel argument (no staging copy)
+int launch_sgd_fixup(const Geom &g, float *params, const float *grads, float *momentum, float *ws, float *p16, float lr, float mu,
+                     float clip, const Hyper *next, hipStream_t stream);
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
                      bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);

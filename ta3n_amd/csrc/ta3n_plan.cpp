@@ -417,8 +417,10 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
     g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
     g.o_x16 = (int32_t)b.add_region("x16", ((int64_t)BT * D + 1) / 2);
+    g.o_p16b = (int32_t)b.add_region("p16b", (p.param_floats + 1) / 2);      // (fused-update step: twins of the second parameter buffer)
     auto twin = [&](int32_t &base, int32_t &off) {
-        const int32_t origin = base == BASE_WS ? g.o_ws16 : base == BASE_P ? g.o_p16 : g.o_x16;
+        if (base == BASE_P) { base = BASE_P16; off = off / 2; return; }      // relative to the twin region the launch is handed
+        const int32_t origin = base == BASE_WS ? g.o_ws16 : g.o_x16;
         off = origin + off / 2;
         base = BASE_WS;
     };
@@ -594,7 +596,7 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
     g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = -1;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_V = (int32_t)b.add_region("V", (int64_t)B * F);
     g.o_Vd = (int32_t)b.add_region("Vd", (int64_t)B * F);
@@ -741,7 +743,7 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
     g.n_tuples = 0; g.n_rel = 0; g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = -1;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_Hf = (int32_t)b.add_region("Hf", live_frm ? (int64_t)BT * F : 4);
     g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
@@ -1038,7 +1040,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = NB; g.C = C;
     g.n_tuples = NT; g.n_rel = NR; g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = -1; g.ws16_span = 0;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1; g.ws16_span = 0;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_Hf = (int32_t)b.add_region("Hf", (int64_t)BT * F);
     g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);

@@ -557,6 +557,42 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
     }
 }
 
+// Closes a fused-update step (gemm_tiles with SgdSide::p_new: every gradient tile already applied the Nesterov step to its own
+// parameters with the clip coefficient taken as 1).  Adds up the step's norm partials in the fixed order of sgd_kernel; leaves the
+// norm / coefficient and - like sgd_range_kernel - the NEXT step's scalars in the workspace; and if the gradient norm did exceed
+// clip_gradient (coef < 1), corrects parameters and momentum: the update is linear in the gradient,
+//   p(coef) = p(1) + lr (1 + mu) (1 - coef) g,   m(coef) = m(1) - (1 - coef) g
+// (clip_grad_norm_ + SGD, main.py:578-583; equal to the direct computation up to fp32 rounding of these two operations).
+__global__ __launch_bounds__(256) void sgd_fixup_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
+                                                        float *__restrict__ mom, float *__restrict__ ws, float *__restrict__ p16, int n4,
+                                                        float lr, float mu, float clip, Hyper next, int has_next) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < g.n_sumsq; k += blockDim.x) acc += ws[g.o_sumsq + k];
+    const float total = sqrtf(block_sum(acc, red));
+    float coef = 1.f;
+    if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ws[g.o_grad_norm] = total;
+        ws[g.o_grad_norm + 1] = coef;
+    }
+    if (has_next && blockIdx.x == 0 && threadIdx.x < (int)(sizeof(Hyper) / 4))
+        reinterpret_cast<uint32_t *>(ws + g.o_hyper)[threadIdx.x] = reinterpret_cast<const uint32_t *>(&next)[threadIdx.x];
+    if (coef >= 1.f) return;                       // (uniform over the grid) the speculation held: nothing to correct
+    const float c = 1.f - coef, a = lr * (1.f + mu) * c;
+    float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
+    float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const float4 gr = g4[i];
+        float4 p = p4[i], m = m4[i];
+        p.x = fmaf(a, gr.x, p.x); p.y = fmaf(a, gr.y, p.y); p.z = fmaf(a, gr.z, p.z); p.w = fmaf(a, gr.w, p.w);
+        m.x = fmaf(-c, gr.x, m.x); m.y = fmaf(-c, gr.y, m.y); m.z = fmaf(-c, gr.z, m.z); m.w = fmaf(-c, gr.w, m.w);
+        p4[i] = p; m4[i] = m;
+        if (p16 != nullptr) reinterpret_cast<uint2 *>(p16)[i] = make_uint2(pack_bf16(p.x, p.y), pack_bf16(p.z, p.w));
+    }
+}
+
 __global__ void to_bf16_kernel(const float4 *__restrict__ src, uint2 *__restrict__ dst, int64_t n4) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = src[i];
@@ -774,6 +810,16 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
     hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip, nh,
                        next ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sgd_fixup(const Geom &g, float *params, const float *grads, float *momentum, float *ws, float *p16, float lr, float mu,
+                     float clip, const Hyper *next, hipStream_t stream) {
+    Hyper nx;
+    std::memset(&nx, 0, sizeof(nx));
+    if (next) nx = *next;
+    hipLaunchKernelGGL(sgd_fixup_kernel, dim3(128), dim3(256), 0, stream, g, params, grads, momentum, ws, p16, g.live_floats / 4, lr, mu, clip,
+                       nx, next ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

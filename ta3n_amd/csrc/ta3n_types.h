@@ -7,7 +7,9 @@
 
 namespace ta3n {
 
-enum Base : int32_t { BASE_NONE = -1, BASE_X = 0, BASE_P = 1, BASE_G = 2, BASE_WS = 3, BASE_COUNT = 4 };
+// BASE_P16: the bf16 twins of the parameters (TA3N_FLAG_BF16_STORE), addressed in floats from the start of the twin region the
+// launch is given (Ptrs.p16): the fused-update step alternates between two parameter buffers and their twin regions
+enum Base : int32_t { BASE_NONE = -1, BASE_X = 0, BASE_P = 1, BASE_G = 2, BASE_WS = 3, BASE_P16 = 4, BASE_COUNT = 5 };
 
 // segment / epilogue scale kinds: value is taken from the device Hyper struct
 enum ScaleKind : int32_t {
@@ -158,6 +160,7 @@ struct Geom {
     // TA3N_FLAG_BN_SHARED: linear output before / gradient behind the domain BatchNorm, batch and running statistics, parameters
     int32_t o_Z0, o_gZ0, o_bn_batch, o_bn_run;
     int32_t p_bn_w[2], p_bn_b[2];        // [source, target]
+    int32_t o_p16b;                      // second parameter-twin region (fused-update step: ping-pong with the second parameter buffer); -1: none
 };
 
 }  // namespace ta3n

@@ -175,6 +175,7 @@ class TrainEngine:
                 self.peer = None
                 if self.rank == 0:
                     print(f"[ta3n] peer all-reduce unavailable ({type(ex).__name__}: {ex}); using the default exchange", flush=True)
+        self._P2: Optional[torch.Tensor] = None      # second parameter buffer of the fused-update steps (train_steps)
         self.step_count = 0
         self.skip_collective = False
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -438,17 +439,59 @@ class TrainEngine:
         finally:
             self._hyper = keep
 
-    def train_steps(self, schedule: Sequence[Sequence], feeds=None) -> None:
+    def _feeds(self, feeds, k0: int):
+        """ta3n_feed structs (and the id tables that must outlive the enqueued gathers) of a multi-step call."""
+        fd, keep = [None, None], []
+        if feeds is not None:
+            for i, (store, ids) in enumerate(feeds):
+                if store is None:
+                    continue
+                ids = ids[k0:].to(device=self.device, dtype=torch.int32).contiguous()
+                keep.append(ids)
+                f = _lib.Feed()
+                f.store = store.store.data_ptr(); f.bf16 = int(store.bf16); f.ids_per_step = ids.shape[1]
+                f.first_row = store.first_row.data_ptr(); f.num_frames = store.num_frames.data_ptr()
+                f.labels = store.labels.data_ptr(); f.video_ids = ids.data_ptr()
+                fd[i] = f
+        return fd, keep
+
+    def train_steps(self, schedule: Sequence[Sequence], feeds=None, fused_update: Optional[bool] = None) -> None:
         """len(schedule) pipelined steps enqueued by ONE call into the library (ta3n_train_steps): schedule[k] = (beta, gamma, lr)
         of step k (main.py:350-352, 620-621 evaluated ahead of time).  Same launches, same results as calling
         train_step_pipelined once per entry; the host leaves the step's critical path (on a slow core the per-step ctypes call +
         9 launches cost as much wall time as the GPU needs for the step).  feeds: optional (source, target) pairs of
         (FeatureStore, int32 device tensor [len(schedule), n]) - the batch of step k is then assembled on the device before it.
-        With a process group and the library's RCCL communicator the step's all-reduce is part of the same call."""
+        With a process group and the library's RCCL communicator the step's all-reduce is part of the same call.
+        fused_update (TA3N_FUSED_UPDATE=1; single rank): the optimiser runs INSIDE the gradient launches
+        (ta3n_train_steps_fused_update) - bit-identical whenever no step clips, within fp32 rounding of the clip correction otherwise.
+        Measured time-neutral (profiles/r03_fused_update_ab.txt: the 63 MB of optimiser traffic cost ~8 us wherever they run), so the
+        default stays the update as launches of its own (ta3n_train_steps), which is also what the data-parallel path needs."""
         n = len(schedule)
         if n == 0:
             return
         ddp = self.world > 1 or self._ddp_selftest
+        if fused_update is None:
+            fused_update = os.environ.get("TA3N_FUSED_UPDATE", "0") == "1"
+        if fused_update and not ddp and self.fused and self._L.ta3n_has_fused_update(self.plan.handle) == 1:
+            # the optimiser inside the gradient launches (ta3n_train_steps_fused_update): no separate update launches at all
+            self.flush()
+            if self._P2 is None:
+                self._P2 = torch.empty_like(self.P)
+            hy = (_lib.Hyper * n)()
+            for k, (beta, gamma, lr) in enumerate(schedule):
+                h = self.hyper_for(beta, gamma, lr, step=self.step_count + k)
+                C.memmove(C.byref(hy, k * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
+            fd, keep = self._feeds(feeds, 0)
+            _lib.check(self._L.ta3n_train_steps_fused_update(
+                self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self._P2.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
+                self.ws.data_ptr(), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0,
+                hy, n, C.byref(fd[0]) if fd[0] is not None else None, C.byref(fd[1]) if fd[1] is not None else None, self._stream()),
+                "ta3n_train_steps_fused_update")
+            if keep:
+                self._feed_keep = keep
+            self._hyper = self.hyper_for(*schedule[-1], step=self.step_count + n - 1)
+            self.step_count += n
+            return
         if not self.fused or not self._side_update or (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)):
             if feeds is not None:
                 raise _lib.Ta3nError("train_steps: device-side batch feeds need the pipelined step")
@@ -471,19 +514,7 @@ class TrainEngine:
             h = self.hyper_for(beta, gamma, lr, step=self.step_count + (k - k0))
             C.memmove(C.byref(hy, (k - k0) * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
         lr_p, mu, wd, clip = self._pending
-        fd = [None, None]
-        keep = []
-        if feeds is not None:
-            for i, (store, ids) in enumerate(feeds):
-                if store is None:
-                    continue
-                ids = ids[k0:].to(device=self.device, dtype=torch.int32).contiguous()
-                keep.append(ids)
-                f = _lib.Feed()
-                f.store = store.store.data_ptr(); f.bf16 = int(store.bf16); f.ids_per_step = ids.shape[1]
-                f.first_row = store.first_row.data_ptr(); f.num_frames = store.num_frames.data_ptr()
-                f.labels = store.labels.data_ptr(); f.video_ids = ids.data_ptr()
-                fd[i] = f
+        fd, keep = self._feeds(feeds, k0)
         _lib.check(self._L.ta3n_train_steps(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                             self.M.data_ptr(), self.ws.data_ptr(), 0 if ddp else 1, lr_p, mu, wd, clip, hy, n - k0,
                                             C.byref(fd[0]) if fd[0] is not None else None,

@@ -13,7 +13,7 @@ import numpy as np
 
 from ta3n_amd import _lib
 
-BASE_X, BASE_P, BASE_G, BASE_WS = 0, 1, 2, 3
+BASE_X, BASE_P, BASE_G, BASE_WS, BASE_P16 = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_COLSUM = 1 << 12
 EPI_SGD = 1 << 11
@@ -57,7 +57,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
                 "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2", "o_Z0", "o_gZ0", "o_bn_batch", "o_bn_run",
-                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1"]
+                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b"]
 
 
 class Geom(C.Structure):
@@ -234,12 +234,13 @@ class Interp:
                         g = self.g
                         if off >= g.o_x16:
                             return BASE_X, (off - g.o_x16) * 2
-                        if off >= g.o_p16:
-                            return BASE_P, (off - g.o_p16) * 2
+                        assert not (g.o_p16 <= off < g.o_x16)      # parameter twins use BASE_P16
                         assert off >= g.o_ws16
                         return BASE_WS, (off - g.o_ws16) * 2
-                    assert s.a_base == BASE_WS and s.b_base == BASE_WS
-                    ab, ao = untwin(s.a_off); bb, bo = untwin(s.b_off)
+                    # (parameter twins are addressed relative to their own region: base BASE_P16, offset in pairs of elements)
+                    ab, ao = (BASE_P, s.a_off * 2) if s.a_base == BASE_P16 else untwin(s.a_off)
+                    bb, bo = (BASE_P, s.b_off * 2) if s.b_base == BASE_P16 else untwin(s.b_off)
+                    assert s.a_base in (BASE_WS, BASE_P16) and s.b_base in (BASE_WS, BASE_P16)
                     A = round_bf16(self.operand(ab, ao, s.a_ld, s.a_kmajor, t.m0, nr, s.klen))
                     Bm = round_bf16(self.operand(bb, bo, s.b_ld, s.b_kmajor, t.n0, nc, s.klen))
                     rowsum += A.sum(1)          # the bias gradient of a twin-reading tile sums the rounded values

@@ -122,13 +122,17 @@ def test_bf16_plan_on_cpu(store):
     if store:
         geo = it.g
         lo, hi = geo.o_ws16, geo.o_x16 + (c["Bs"] + c["Bt"]) * T * c["D"] // 2
-        assert 0 <= geo.o_ws16 < geo.o_p16 < geo.o_x16
+        assert 0 <= geo.o_ws16 < geo.o_p16 < geo.o_x16 < geo.o_p16b
         for ph in twin_phases:
             for ti in range(ph.task_begin, ph.task_begin + ph.task_count):
                 t = it.tasks[ti]
                 for si in range(t.seg_begin, t.seg_begin + t.seg_count):
                     s = it.segs[si]
-                    assert lo <= s.a_off < hi and lo <= s.b_off < hi and s.a_base == 3 and s.b_base == 3
+                    for base, off in ((s.a_base, s.a_off), (s.b_base, s.b_off)):
+                        if base == 4:      # BASE_P16: parameter twins, relative to the twin region the launch is handed
+                            assert 0 <= off < (plan.param_floats + 1) // 2
+                        else:
+                            assert base == 3 and lo <= off < hi and not (geo.o_p16 <= off < geo.o_x16)
     shapes = {n: s for n, _, s, _ in plan.params}
     it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
     st = step_schedule(c)[0]
