@@ -361,6 +361,19 @@ int ta3n_train_step_join(ta3n_plan *plan, const float *x, const float *params, f
 int ta3n_sgd_step_fused(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws,
                         void *stream);
 
+/* ---- discrepancy losses (dis_DA DAN / JAN): loss.py:46-120, called from main.py:452-505 ----------------------------------------
+ * ta3n_gaussian_kernel = loss.py:46-59 `guassian_kernel` on the stacked rows total = [source; target] ([n, d] fp32 device
+ * memory): k_out [n, n] = sum_i exp(-||t_p - t_q||^2 / bw_i) with the reference's data-dependent bandwidth (fix_sigma <= 0) or the
+ * fixed one, bw_i = bw / mul^(num / 2) * mul^i; kp_out [n, n] (may be NULL) = d k / d ||.||^2 with the bandwidth held constant
+ * (loss.py:55 reads `.data`).  Distances in the explicit-difference form, fp32.  scratch: ta3n_gaussian_kernel_scratch_floats(n).
+ * ta3n_mmd_rowdiff: out[p][:] = scale * sum_q c[p][q] (t[p][:] - t[q][:]) - with c = 2 kp o (gK + gK^T) the gradient of any loss at
+ * the features, given its gradient gK at the kernel matrix (mmd_rbf's four-quadrant mean, JAN's product of the layers' kernels).
+ * Both enqueue only; cross-workgroup sums are added in a fixed order. */
+int64_t ta3n_gaussian_kernel_scratch_floats(int n);
+int ta3n_gaussian_kernel(const float *total, int n, int d, float kernel_mul, int kernel_num, float fix_sigma, float *k_out, float *kp_out,
+                         float *scratch, void *stream);
+int ta3n_mmd_rowdiff(const float *c, const float *total, int n, int d, float scale, float *out, void *stream);
+
 /* ---- data parallelism: RCCL from the C ABI (replaces nn.DataParallel's per-step broadcast / gather / reduce, main.py:79) ----
  * One process per GPU.  Rank 0 makes a 128-byte id (ta3n_comm_unique_id), the launcher hands it to every rank (any
  * channel: torch.distributed store, MPI, a file), every rank calls ta3n_comm_create on its device - a collective over

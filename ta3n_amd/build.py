@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libta3n_hip.so")
-SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
+SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_mmd.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
 HEADERS = ["ta3n_types.h", "ta3n_kernels.h", "ta3n_plan.h", os.path.join("..", "..", "include", "ta3n_hip.h")]
 
 

@@ -23,11 +23,46 @@ def dis_MCD(out1, out2):
     return torch.mean(torch.abs(F.softmax(out1, dim=1) - F.softmax(out2, dim=1)))
 
 
+class _GaussianKernelHip(torch.autograd.Function):
+    """loss.py:46-59 on the GPU through the C ABI (ta3n_gaussian_kernel / ta3n_mmd_rowdiff, csrc/ta3n_mmd.hip): the [n, n] kernel
+    matrix of the stacked rows in forward, the O(n^2 d) contraction back to the features in backward."""
+
+    @staticmethod
+    def forward(ctx, total, kernel_mul, kernel_num, fix_sigma):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        total = total.contiguous()
+        n, d = int(total.size(0)), int(total.size(1))
+        k = torch.empty(n, n, dtype=torch.float32, device=total.device)
+        kp = torch.empty_like(k)
+        scratch = torch.empty(int(L.ta3n_gaussian_kernel_scratch_floats(n)), dtype=torch.float32, device=total.device)
+        stream = C.c_void_p(torch.cuda.current_stream(total.device).cuda_stream)
+        _lib.check(L.ta3n_gaussian_kernel(total.data_ptr(), n, d, float(kernel_mul), int(kernel_num), float(fix_sigma) if fix_sigma else 0.0,
+                                          k.data_ptr(), kp.data_ptr(), scratch.data_ptr(), stream), "ta3n_gaussian_kernel")
+        ctx.save_for_backward(total, kp)
+        return k
+
+    @staticmethod
+    def backward(ctx, gk):
+        import ctypes as C
+        from . import _lib
+        total, kp = ctx.saved_tensors
+        n, d = int(total.size(0)), int(total.size(1))
+        c = (2.0 * kp * (gk + gk.t())).contiguous()             # d ||t_p - t_q||^2 / d t_p = 2 (t_p - t_q), from both (p, q) and (q, p)
+        out = torch.empty_like(total)
+        stream = C.c_void_p(torch.cuda.current_stream(total.device).cuda_stream)
+        _lib.check(_lib.lib().ta3n_mmd_rowdiff(c.data_ptr(), total.data_ptr(), n, d, 1.0, out.data_ptr(), stream), "ta3n_mmd_rowdiff")
+        return out, None, None, None
+
+
 def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
     """loss.py:46-59 (name as in the reference): sum of kernel_num RBF kernels over the stacked [source; target] rows; the
     bandwidth is the mean pairwise squared distance (no gradient through it), scaled by kernel_mul^(i - kernel_num // 2)."""
     n = int(source.size(0)) + int(target.size(0))
     total = torch.cat([source, target], dim=0)
+    if total.is_cuda and total.dtype == torch.float32 and n >= 2:      # the product path: HIP kernels (fp64 / CPU tensors: the torch form below)
+        return _GaussianKernelHip.apply(total, kernel_mul, kernel_num, fix_sigma)
     # ||x_i - x_j||^2 in the reference's explicit difference form (loss.py:50-52), a block of rows at a time so the [rows, n, d]
     # intermediate stays small.  (Not |x|^2 + |y|^2 - 2 x.y: in fp32 that cancels catastrophically for near-duplicate rows -
     # zero-padded dummy rows, logits - and moves the data-dependent bandwidth; ADVICE r02.)

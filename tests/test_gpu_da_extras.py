@@ -152,3 +152,44 @@ def test_loss_functions_match_the_oracle_restatement_and_its_gradients():
         v = L.JAN([y1, a], [y2, b])
         w = orc.jan([y1.detach().cpu(), a2], [y2.detach().cpu(), b2])
         assert abs(v.item() - w.item()) < 1e-9 * max(1.0, abs(w.item()))
+
+
+@pytest.mark.parametrize("n,d", [(4, 12), (37, 256), (74, 256), (128, 12), (200, 512)])
+def test_hip_kernel_matrix_and_its_gradient_match_the_oracle(n, d):
+    """fp32 CUDA tensors take the HIP path of ta3n_amd.loss (ta3n_gaussian_kernel / ta3n_mmd_rowdiff, csrc/ta3n_mmd.hip): mmd_rbf and
+    JAN values and feature gradients against the oracle's fp64 restatement of loss.py:46-120 - ragged sizes, fixed and
+    data-dependent bandwidths, duplicated rows (exact zeros on the diagonal: the explicit-difference form)."""
+    from oracle import ta3n_oracle as orc
+    from ta3n_amd import loss as L
+    g = torch.Generator().manual_seed(n + d)
+    a64 = torch.randn(n, d, generator=g, dtype=torch.float64)
+    b64 = 0.5 * torch.randn(n, d, generator=g, dtype=torch.float64) + 0.3
+    b64[: n // 4] = a64[: n // 4]                                    # duplicated rows across the domains
+    a = a64.float().cuda().requires_grad_(True)
+    b = b64.float().cuda().requires_grad_(True)
+    a2, b2 = a64.float().double().requires_grad_(True), b64.float().double().requires_grad_(True)
+    for num, sigma in ((5, None), (2, None), (5, 1.68)):
+        v = L.mmd_rbf(a, b, kernel_mul=2.0, kernel_num=num, fix_sigma=sigma)
+        w = orc.mmd_rbf(a2, b2, 2.0, num) if sigma is None else None
+        if w is None:      # the oracle's signature has no fixed bandwidth: the torch form of the same module in fp64
+            w = L.mmd_rbf(a2, b2, kernel_mul=2.0, kernel_num=num, fix_sigma=sigma)
+        assert abs(v.item() - w.item()) <= 2e-5 * max(1.0, abs(w.item())), (num, sigma, v.item(), w.item())
+        ga, gb = torch.autograd.grad(v, (a, b))
+        wa, wb = torch.autograd.grad(w, (a2, b2))
+        for got, want in ((ga, wa), (gb, wb)):      # fp32 kernels vs fp64: relative L2 per tensor (single entries are differences of nearly equal terms)
+            err = (got.cpu().double() - want).norm().item()      # (a fixed bandwidth far below the distances underflows both sides to ~0)
+            assert err <= 5e-4 * want.norm().item() + 1e-9, (num, sigma, err, want.norm().item())
+    y1 = torch.randn(n, 7, generator=g).cuda().requires_grad_(True)
+    y2 = torch.randn(n, 7, generator=g).cuda().requires_grad_(True)
+    v = L.JAN([y1, a], [y2, b])
+    y1d, y2d = y1.detach().cpu().double().requires_grad_(True), y2.detach().cpu().double().requires_grad_(True)
+    w = orc.jan([y1d, a2], [y2d, b2])
+    assert abs(v.item() - w.item()) <= 2e-5 * max(1.0, abs(w.item()))
+    got = torch.autograd.grad(v, (y1, a, b))
+    want = torch.autograd.grad(w, (y1d, a2, b2))
+    for x, y in zip(got, want):
+        err = (x.cpu().double() - y).norm().item()
+        assert err <= 5e-4 * y.norm().item() + 1e-9, (err, y.norm().item())
+    # bitwise reproducible (fixed-order partial sums)
+    v2 = L.mmd_rbf(a, b)
+    assert torch.equal(v2, L.mmd_rbf(a, b))
