@@ -70,11 +70,28 @@ class TrainEngine:
                  device: Optional[torch.device] = None, tile_config: int = 0, process_group=None,
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
-                 f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None):
+                 f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
+                 dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
             flags = ALL_FLAGS if aggregation == "trn-m" else 0
+        # dis_DA DAN / JAN (main.py:452-505, loss.py:46-120): a discrepancy loss on the class logits (feat[0]) and / or the pooled
+        # video feature (feat[1]), weighted by alpha.  It enters the step as one more gradient at those two tensors: the unfused
+        # launch lists (ta3n_forward / ta3n_loss / ta3n_backward) with the gradient entry at the video feature
+        # (TA3N_FLAG_FEATURE_GRADS), the loss itself by the HIP kernels of csrc/ta3n_mmd.hip.  Single rank: the loss couples every
+        # pair of videos of the batch (the reference computes it on the gathered batch of its DataParallel replicas).
+        if dis_DA not in ("none", "DAN", "JAN"):
+            raise NotImplementedError(f"dis_DA {dis_DA!r} (built: DAN, JAN)")
+        self.dis_DA, self.place_dis, self.alpha = dis_DA, tuple(place_dis), float(alpha)
+        self.loss_d = None                       # device scalar: the discrepancy loss of the last step (main.py's loss_d)
+        if dis_DA != "none":
+            if aggregation != "trn-m":
+                raise NotImplementedError("dis_DA on the engine path is built for trn-m (TemPooling + DAN / JAN: the module path)")
+            if dis_DA == "DAN" and len(self.place_dis) > 2 and self.place_dis[2] == "Y":
+                raise ValueError("place_dis[2]: the reference itself fails on the 3-D frame features (loss.py:49)")
+            flags |= _lib.FLAG_FEATURE_GRADS
+            fused = False
         if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
             flags |= _lib.FLAG_BF16_MFMA
         if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly
@@ -112,6 +129,8 @@ class TrainEngine:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
             self.rank = torch.distributed.get_rank(process_group)
+        if self.dis_DA != "none" and self.world > 1:
+            raise NotImplementedError("dis_DA with more than one rank (the discrepancy loss couples all videos of the global batch)")
         p = self.plan
         with torch.cuda.device(self.device):
             self.P = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
@@ -275,6 +294,39 @@ class TrainEngine:
     def loss(self) -> None:
         _lib.check(self._L.ta3n_loss(self.plan.handle, self.ws.data_ptr(), self._stream()), "ta3n_loss")
 
+    def discrepancy(self) -> None:
+        """main.py:452-505 between ta3n_loss and ta3n_backward: alpha * (DAN: mmd_rbf per selected feature, in chunks of <= 256
+        videos; JAN: the joint kernel of logits and video feature) on the first min(Bs, Bt) valid rows of each domain; its gradient
+        is added to the logit gradient (region gY) and written to the feature-gradient entry (gV_ext).  HIP kernels through
+        ta3n_amd.loss (ta3n_gaussian_kernel / ta3n_mmd_rowdiff); torch only differentiates the O(n^2) glue."""
+        from . import loss as L
+        if self.dis_DA == "none":
+            return
+        ns, nt = int(self._hyper.valid_source), int(self._hyper.valid_target)
+        size = min(ns, nt)
+        y = self.region("Y", (self.B, self.C)).detach().clone().requires_grad_(True)
+        v = self.region("V", (self.B, -1)).detach().clone().requires_grad_(True)
+        feat_s, feat_t = [y[:size], v[:size]], [y[self.Bs:self.Bs + size], v[self.Bs:self.Bs + size]]
+        muls, nums = [2.0, 2.0], [2, 5]
+        loss = y.new_zeros(())
+        if self.dis_DA == "JAN":
+            loss = L.JAN(feat_s, feat_t, kernel_muls=muls, kernel_nums=nums, fix_sigma_list=[None, None], ver=2)
+        else:
+            for l in range(2):
+                if self.place_dis[l] != "Y":
+                    continue
+                sb = min(256, size)
+                fs = feat_s[l].view((-1, sb) + feat_s[l].shape[1:])
+                ft = feat_t[l].view((-1, sb) + feat_t[l].shape[1:])
+                parts = [L.mmd_rbf(fs[t], ft[t], kernel_mul=muls[l], kernel_num=nums[l], fix_sigma=None, ver=2) for t in range(fs.size(0))]
+                loss = loss + sum(parts) / len(parts)
+        self.loss_d = loss.detach()
+        gy, gv = torch.autograd.grad(self.alpha * loss, (y, v), allow_unused=True)
+        if gy is not None:
+            self.region("gY", (self.B, self.C)).add_(gy)
+        gve = self.region("gV_ext", (self.B, -1))
+        gve.zero_() if gv is None else gve.copy_(gv)
+
     def backward(self) -> None:
         _lib.check(self._L.ta3n_backward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                          self.ws.data_ptr(), self._stream()), "ta3n_backward")
@@ -342,6 +394,7 @@ class TrainEngine:
         else:
             self.forward()
             self.loss()
+            self.discrepancy()
             self.backward()
         self.all_reduce_grads()
         if self.fused and self.world == 1 and not self._ddp_selftest:

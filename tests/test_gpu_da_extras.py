@@ -193,3 +193,34 @@ def test_hip_kernel_matrix_and_its_gradient_match_the_oracle(n, d):
     # bitwise reproducible (fixed-order partial sums)
     v2 = L.mmd_rbf(a, b)
     assert torch.equal(v2, L.mmd_rbf(a, b))
+
+
+@pytest.mark.parametrize("name", ["tiny_dan", "tiny_dan_all", "tiny_jan"])
+def test_engine_path_with_discrepancy_losses_matches_the_reference(name):
+    """TrainEngine(dis_DA=...): the same fixtures as above (written by the reference's main.train with --dis_DA DAN / JAN) through the
+    ENGINE - ta3n_forward, ta3n_loss, the HIP discrepancy kernels, ta3n_backward, ta3n_sgd_step - instead of the module path:
+    clipped gradients, parameters after each step, the logged loss_d."""
+    from ta3n_amd.engine import TrainEngine
+    g = Golden(name)
+    c = case_config(g)
+    T, C = c["T"], c["C"]
+    eng = TrainEngine(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], C, dropout_i=0.0, dropout_v=0.0, clip=c["clip"], dis_DA=c["dis_DA"],
+                      place_dis=c["place_dis"], alpha=c["alpha"])
+    assert not eng.fused
+    eng.load_state(synth_state({n: s for n, _, s, _ in eng.plan.params}, seed=c["wseed"], scale=c["wscale"]))
+    live = set(str(k) for k in g.meta("live"))
+    assert set(eng.live_names()) == live
+    want_log = str(g.meta("log")).strip().splitlines()
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, st["lr"], valid_source=st["n_src"], valid_target=st["n_tgt"])
+        torch.cuda.synchronize()
+        coef = eng.region("grad_norm")[1].item()
+        raw = eng.param_views(eng.G)
+        for k, v in eng.param_views().items():
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k].cpu() * coef, 2e-4, 5e-6, rms_atol=2e-4)
+            g.check(f"step{s}/param/{k}", v.cpu(), 2e-4, 5e-6)
+        m = re.search(r"loss_d (-?[0-9.]+)", want_log[s])
+        assert m is not None and abs(float(m.group(1)) - eng.loss_d.item()) <= 2e-3 * max(1.0, abs(float(m.group(1))))

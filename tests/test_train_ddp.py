@@ -20,10 +20,14 @@ BASE = ["classInd.txt", "RGB", "s.txt", "t.txt", "v.txt", "--baseline_type", "vi
 
 def test_headline_command_line_is_accepted():
     train_ddp.validate_options(parser.parse_args(BASE))
+    train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "DAN"]))      # round 3: discrepancy losses on the engine path (one rank)
+    train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "JAN"]))
     train_ddp.validate_options(parser.parse_args(["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool"]))
 
 
-@pytest.mark.parametrize("extra", [["--optimizer", "Adam"], ["--dis_DA", "JAN"], ["--dis_DA", "DAN"], ["--add_loss_DA", "target_entropy"],
+@pytest.mark.parametrize("extra", [["--optimizer", "Adam"], ["--dis_DA", "CORAL"], ["--dis_DA", "DAN", "--frame_aggregation", "avgpool", "--use_attn", "none",
+                                                                                     "--add_loss_DA", "none"],
+                                   ["--add_loss_DA", "target_entropy"],
                                    ["--use_target", "Sv"], ["--weighted_class_loss", "Y"], ["--weighted_class_loss_DA", "Y"],
                                    ["--pred_normalize", "Y"], ["--pretrain_source"], ["--lr_adaptive", "loss"], ["--ens_DA", "MCD"],
                                    ["--use_bn", "AdaBN"], ["--share_params", "N"], ["--frame_aggregation", "rnn"],

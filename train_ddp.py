@@ -13,6 +13,7 @@ counts and gradients are summed by one RCCL all-reduce per step (ta3n_amd/parall
 Schedules follow main.py: beta (main.py:350-352), learning rate (DANN main.py:620-621, step decay :236-237), the
 list-repeat rule of --copy_list (main.py:145-153), checkpoints in the reference's format (ta3n_amd/checkpoint.py).
 Every option value the engine does not implement is REJECTED at start-up (validate_options) instead of being ignored."""
+import math
 import os
 import sys
 import time
@@ -54,7 +55,11 @@ def validate_options(args, module_path: bool = False) -> None:
                  "--place_dis takes add_fc + 2 values [logits, video feature, frame features]; the reference itself fails on the "
                  "frame features (loss.py:49 on a 3-D tensor)")
     else:
-        need(args.dis_DA == "none", f"--dis_DA {args.dis_DA} (discrepancy losses: use main.py, the module path)")
+        need(args.dis_DA in ("none", "DAN", "JAN"), f"--dis_DA {args.dis_DA} (built: DAN, JAN)")
+        if args.dis_DA != "none":
+            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--dis_DA {args.dis_DA} on more than one rank (the discrepancy loss couples all "
+                 "videos of the global batch: one GPU, or main.py)")
+            need(args.frame_aggregation == "trn-m", f"--dis_DA {args.dis_DA} with avgpool (use main.py, the module path)")
         need(args.ens_DA == "none", f"--ens_DA {args.ens_DA} (use main.py, the module path)")
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
@@ -140,7 +145,8 @@ def main():
     eng = TrainEngine(Bs, Bt, T, D, args.fc_dim, num_class, flags=flags, dropout_i=args.dropout_i,
                       dropout_v=args.dropout_v, momentum=args.momentum, weight_decay=args.weight_decay,
                       clip=args.clip_gradient, device=dev, bf16=(args.arithmetic == "bf16"), bf16_store=(args.arithmetic == "bf16"),
-                      f32_split=(args.arithmetic == "f32x3"), aggregation=args.frame_aggregation)
+                      f32_split=(args.arithmetic == "f32x3"), aggregation=args.frame_aggregation,
+                      dis_DA=args.dis_DA, place_dis=args.place_dis, alpha=max(args.alpha, 0.0))
     from ta3n_amd.models import VideoModel
     torch.manual_seed(1)
     model = VideoModel(num_class, args.baseline_type, args.frame_aggregation, args.modality, train_segments=T,
@@ -198,6 +204,8 @@ def main():
     for epoch in range(start_epoch, args.epochs + 1):
         if args.lr_adaptive == "none" and epoch in args.lr_steps:                     # main.py:236-237, 790-793
             lr /= args.lr_decay
+        # main.py:233: the discrepancy-loss weight follows the epoch when --alpha is negative
+        eng.alpha = 2 / (1 + math.exp(-1 * epoch / args.epochs)) - 1 if args.alpha < 0 else args.alpha
         if stores:
             src = ((ids, None) for ids in store_loader(n_src, n_src_train, Bs_g, 1000 + epoch))
             tgt = ((ids, None) for ids in store_loader(max(n_tgt, 1), n_tgt_train, Bt_g, 2000 + epoch))
