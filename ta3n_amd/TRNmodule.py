@@ -39,25 +39,8 @@ class RelationModuleMultiScale(nn.Module):
         import itertools
         return list(itertools.combinations(range(num_frames), num_frames_relation))
 
-    def forward(self, input):
-        """TRNmodule.py:58-82 on its own: input [B, T, D] -> [B, T-1, bottleneck].  Runs the SAME grouped tile-list launch the
-        train step uses for the tuple GEMMs (gather + concat folded into the operand addressing, bias + ReLU in the
-        epilogue; csrc/ta3n_plan.cpp: spec_Z) on a plan of B source videos; the per-scale sum of the (at most 3) tuple
-        activations is the only thing done here.  Inference only: inside VideoModel the module trains through the fused
-        step, a standalone autograd backward is not provided (raises if a gradient is required)."""
+    def _hip_state(self, B, T, D, NB, dev):
         import ctypes as C
-        if not torch.cuda.is_available():
-            raise _lib.Ta3nError("RelationModuleMultiScale.forward needs a HIP device; there is no CPU fallback")
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("standalone RelationModuleMultiScale.forward is forward-only: call it under torch.no_grad() "
-                                      "(it trains inside ta3n_amd.models.VideoModel)")
-        if input.dim() != 3 or input.size(1) != self.num_frames or input.size(2) != self.img_feature_dim:
-            raise ValueError("input must be [B, num_frames, img_feature_dim]")
-        B, T, D = input.shape
-        NB = self.fc_fusion_scales[0][1].out_features
-        if NB != 256:
-            raise NotImplementedError("the fused launch sequence exists for num_bottleneck = 256 (TA3N's value, models.py:223)")
-        dev = input.device if input.is_cuda else torch.device("cuda", torch.cuda.current_device())
         key = (B, str(dev))
         cache = self.__dict__.setdefault("_hip_cache", {})
         if key not in cache:
@@ -68,10 +51,36 @@ class RelationModuleMultiScale(nn.Module):
                            "ta3n_init_workspace")
             cache[key] = (plan, ws, torch.zeros(plan.param_floats, dtype=torch.float32, device=dev),
                           torch.zeros(plan.param_floats, dtype=torch.float32, device=dev), torch.zeros(B * T, D, dtype=torch.float32, device=dev))
-        plan, ws, flat, grads, x = cache[key]
+        return cache[key]
+
+    def forward(self, input):
+        """TRNmodule.py:58-82 on its own: input [B, T, D] -> [B, T-1, bottleneck].  Runs the SAME grouped tile-list launches the
+        train step uses: forward = the tuple GEMMs (gather + concat folded into the operand addressing, bias + ReLU in the
+        epilogue; csrc/ta3n_plan.cpp: spec_Z), backward = the launch of the TRN weight gradients and the scatter-free input
+        gradient (push_trn_wgrads / push_f1_grad) - on a plan of B source videos; the per-scale sum of the (at most 3) tuple
+        activations and its fan-out back through their ReLU masks are the only things done here."""
+        if not torch.cuda.is_available():
+            raise _lib.Ta3nError("RelationModuleMultiScale.forward needs a HIP device; there is no CPU fallback")
+        if input.dim() != 3 or input.size(1) != self.num_frames or input.size(2) != self.img_feature_dim:
+            raise ValueError("input must be [B, num_frames, img_feature_dim]")
+        NB = self.fc_fusion_scales[0][1].out_features
+        if NB != 256:
+            raise NotImplementedError("the fused launch sequence exists for num_bottleneck = 256 (TA3N's value, models.py:223)")
+        params = [t for seq in self.fc_fusion_scales for t in (seq[1].weight, seq[1].bias)]
+        return _TrnStandalone.apply(self, input, *params)
+
+
+class _TrnStandalone(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, input, *params):
+        import ctypes as C
+        B, T, D = input.shape
+        NB = mod.fc_fusion_scales[0][1].out_features
+        dev = input.device if input.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        plan, ws, flat, grads, x = mod._hip_state(B, T, D, NB, dev)
         offs = {n: (o, sh) for n, o, sh, _ in plan.params}
-        for j, seq in enumerate(self.fc_fusion_scales):
-            for nm, t in (("weight", seq[1].weight), ("bias", seq[1].bias)):
+        for j in range(len(mod.fc_fusion_scales)):
+            for nm, t in (("weight", params[2 * j]), ("bias", params[2 * j + 1])):
                 o, sh = offs[f"TRN.fc_fusion_scales.{j}.1.{nm}"]
                 flat[o:o + t.numel()].copy_(t.detach().reshape(-1))
         o_f1, n_f1 = plan.region("F1")
@@ -87,10 +96,48 @@ class RelationModuleMultiScale(nn.Module):
         o_z, n_z = plan.region("Zr")
         z = ws[o_z:o_z + n_z].view(B, -1, NB)
         out, t0 = [], 0
-        for tuples in self.relations_selected:            # sum of the scale's tuple activations (TRNmodule.py:73-79)
+        for tuples in mod.relations_selected:             # sum of the scale's tuple activations (TRNmodule.py:73-79)
             out.append(z[:, t0:t0 + len(tuples)].sum(1, keepdim=True))
             t0 += len(tuples)
+        ctx.mod, ctx.dev, ctx.dims = mod, dev, (B, T, D, NB)
+        ctx.in_device, ctx.in_dtype = input.device, input.dtype
         return torch.cat(out, 1)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes as C
+        mod, dev, (B, T, D, NB) = ctx.mod, ctx.dev, ctx.dims
+        plan, ws, flat, grads, x = mod._hip_state(B, T, D, NB, dev)      # (the forward's activations are still in this workspace)
+        o_z, n_z = plan.region("Zr")
+        z = ws[o_z:o_z + n_z].view(B, -1, NB)
+        o_gz, n_gz = plan.region("gZ")
+        gz = ws[o_gz:o_gz + n_gz].view(B, -1, NB)
+        g = g_out.to(dev, torch.float32)
+        t0 = 0
+        for j, tuples in enumerate(mod.relations_selected):     # d(sum of the scale's tuples) through each tuple's ReLU
+            for k in range(len(tuples)):
+                gz[:, t0 + k] = g[:, j] * (z[:, t0 + k] > 0)
+            t0 += len(tuples)
+        o, n = plan.region("gHf")
+        ws[o:o + n].zero_()                                        # (no frame discriminator behind the standalone module)
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        n_launch = L.ta3n_num_phases(plan.handle, 4)
+        with torch.cuda.device(dev):                              # second-to-last launch: TRN weight gradients + gradient at the frame features
+            _lib.check(L.ta3n_train_step_range(plan.handle, x.data_ptr(), flat.data_ptr(), grads.data_ptr(), ws.data_ptr(), n_launch - 2, 1, stream),
+                       "ta3n_train_step_range")
+        o, n = plan.region("gZ1")
+        g_in = ws[o:o + n].view(B, T, D).clone().to(ctx.in_device, ctx.in_dtype) if ctx.needs_input_grad[1] else None
+        offs = {nm: (o_, sh) for nm, o_, sh, _ in plan.params}
+        out = []
+        for j in range(len(mod.fc_fusion_scales)):
+            for nm in ("weight", "bias"):
+                o_, sh = offs[f"TRN.fc_fusion_scales.{j}.1.{nm}"]
+                cnt = 1
+                for v in sh:
+                    cnt *= v
+                out.append(grads[o_:o_ + cnt].view(sh).clone())
+        return (None, g_in, *out)
 
 
 class RelationModule(nn.Module):

@@ -134,5 +134,35 @@ def test_standalone_relation_module_forward_matches_reference_math():
             got = m(x.cuda()).cpu()
         assert got.shape == (B, T - 1, 256)
         assert torch.allclose(got, want, rtol=2e-4, atol=2e-5), (got - want).abs().max()
-    with pytest.raises(NotImplementedError):
-        m(x.cuda())          # gradients required: forward-only
+
+
+def test_standalone_relation_module_backward_matches_autograd_of_the_reference_math():
+    """... and its backward (TRNmodule.py:58-82 is differentiable): gradients at the input and at every fusion layer's weight / bias
+    through the plan's TRN weight-gradient / input-gradient launch, against torch autograd of the same formula on the CPU."""
+    import torch.nn.functional as Fn
+    from ta3n_amd.TRNmodule import RelationModuleMultiScale
+    torch.manual_seed(5)
+    for T, D, B in ((5, 128, 7), (9, 64, 4), (3, 512, 33)):
+        m = RelationModuleMultiScale(D, 256, T, verbose=False)
+        x = torch.randn(B, T, D)
+        xr = x.clone().requires_grad_(True)
+        ref_params = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+        want = []
+        for j, tuples in enumerate(m.relations_selected):
+            w, b = ref_params[2 * j], ref_params[2 * j + 1]
+            acc = 0
+            for tup in tuples:
+                a = torch.relu(xr[:, list(tup), :]).reshape(B, -1)
+                acc = acc + torch.relu(Fn.linear(a, w, b))
+            want.append(acc.unsqueeze(1))
+        want = torch.cat(want, 1)
+        gout = torch.randn_like(want)
+        want.backward(gout)
+        m = m.cuda()
+        xg = x.cuda().requires_grad_(True)
+        got = m(xg)
+        got.backward(gout.cuda())
+        assert torch.allclose(got.detach().cpu(), want.detach(), rtol=2e-4, atol=2e-5)
+        assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=2e-4, atol=2e-5 * xr.grad.abs().max().item()), (xg.grad.cpu() - xr.grad).abs().max()
+        for p, r in zip(m.parameters(), ref_params):
+            assert torch.allclose(p.grad.cpu(), r.grad, rtol=2e-4, atol=2e-5 * r.grad.abs().max().item()), (p.grad.cpu() - r.grad).abs().max()
