@@ -549,7 +549,7 @@ class TrainEngine:
             if feeds is not None:
                 raise _lib.Ta3nError("train_steps: device-side batch feeds need the pipelined step")
             for beta, gamma, lr in schedule:
-                self.train_step_pipelined(beta, gamma, lr)
+                (self.train_step_pipelined if self.fused else self.train_step)(beta, gamma, lr)
             return
         k0 = 0
         if self._pending is None:            # the very first step has no update to open with

@@ -182,3 +182,29 @@ def test_bf16_store_feeds_the_input_twin_directly(tmp_path):
     s16.gather_into(eng, ids[:Bs].cuda(), 0)
     torch.cuda.synchronize()
     assert torch.equal(eng.X[: Bs * T].view(Bs, T, D), s16.gather(ids[:Bs].cuda(), T)[0])
+
+
+@pytest.mark.gpu
+def test_train_script_chunked_steps_log_the_same_numbers(tmp_path):
+    """train_ddp.py sends the steps between two log lines to the GPU in one call (TrainEngine.train_steps with device-side batch
+    feeds); with TA3N_TRAIN_CHUNKS=0 it makes one call per step.  Same arithmetic: the logged losses and the validation results
+    must be identical, line by line."""
+    import os
+    import subprocess
+    import sys
+    lst, D, lengths = _make_dataset(tmp_path, D=512, lengths=(3, 5, 8, 13, 21, 34, 55, 9, 6, 40, 17, 25, 11, 4, 30, 7, 19, 23))
+    prefix = str(tmp_path / "packed")
+    feature_store.pack(lst, prefix)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_ddp.py"), "no_class_file", "RGB", "a", "b", "c",
+           "--frame_aggregation", "trn-m", "--baseline_type", "video", "--arch", "resnet18", "--num_segments", "5",
+           "--add_fc", "1", "--fc_dim", "64", "-b", "6", "3", "6", "--epochs", "2", "--lr", "0.01", "--lr_adaptive", "dann",
+           "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "TransAttn", "--add_loss_DA", "attentive_entropy",
+           "--place_adv", "Y", "Y", "Y", "--beta", "0.75", "0.75", "0.5", "--gamma", "0.003", "--print_freq", "2",
+           "--dropout_i", "0", "--dropout_v", "0", "--feature_store", prefix, prefix, prefix, "--arithmetic", "f32"]
+    outs = []
+    for chunks in ("1", "0"):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, TA3N_TRAIN_CHUNKS=chunks))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("Train: [", "Test: ["))])
+    assert len(outs[0]) >= 4 and outs[0] == outs[1], "\n".join(outs[0] + ["---"] + outs[1])

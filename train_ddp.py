@@ -215,12 +215,50 @@ def main():
         else:
             src = list_loader(args.train_source_list, n_src_train, Bs_g, T, 1000 + epoch)
             tgt = list_loader(args.train_target_list, n_tgt_train, Bt_g, T, 2000 + epoch)
+        # With packed stores and full, evenly sharded batches the steps between two log lines go to the GPU in ONE call
+        # (TrainEngine.train_steps: the library gathers each step's batch on the device, runs the step, exchanges the gradients and
+        # opens the next step with the update) - same arithmetic as one call per step, bit for bit.
+        chunked = (bool(stores) and eng.fused and not args.graph and Bs_g % world == 0 and Bt_g % world == 0 and
+                   os.environ.get("TA3N_TRAIN_CHUNKS", "1") == "1")
+        chunk = []
+
+        def log_line(i, lr_used, beta):
+            # one host sync every print_freq steps (the reference syncs 5-6x per step).  A rank's loss scalars are its
+            # shard's sums divided by the GLOBAL counts: the job's losses are their sum over ranks.
+            scal = eng.region("losses")[:6].clone()
+            if world > 1:
+                torch.distributed.all_reduce(scal)
+            if rank == 0:
+                v = scal.tolist()
+                print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
+                      f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
+
+        def flush_chunk():
+            if not chunk:
+                return
+            ids_s = torch.stack([c[3] for c in chunk]).to(dev)
+            ids_t = torch.stack([c[4] for c in chunk]).to(dev)
+            eng.train_steps([(c[2], args.gamma, c[1]) for c in chunk], feeds=((stores[0], ids_s), (stores[1], ids_t)))
+            i_last, lr_last, beta_last = chunk[-1][0], chunk[-1][1], chunk[-1][2]
+            chunk.clear()
+            if i_last % max(args.print_freq, 1) == 0:
+                log_line(i_last, lr_last, beta_last)
+
         for i, ((xs, ys), (xt, _)) in enumerate(zip(src, tgt)):
             p = float(i + epoch * len_source_loader) / (args.epochs * len_source_loader)   # main.py:334-335, 350
             if i == 0:      # main.py:352 rebinds `beta` inside the loop: a negative entry is replaced by the DANN value of the
                 beta = [beta_dann(p) if b < 0 else b for b in args.beta]              # epoch's first step and stays there for the epoch
             lo, hi = parallel.shard_range(xs.size(0), world, rank)                    # this rank's videos
             lo_t, hi_t = parallel.shard_range(xt.size(0), world, rank)
+            if chunked and xs.size(0) == Bs_g and xt.size(0) == Bt_g:
+                chunk.append((i, lr, list(beta), xs[lo:hi].to(torch.int32), xt[lo_t:hi_t].to(torch.int32)))
+                if args.lr_adaptive == "dann":
+                    lr = lr_dann(args.lr, p)                                          # main.py:620-621 (takes effect at the next step)
+                if i % max(args.print_freq, 1) == 0:
+                    flush_chunk()
+                continue
+            flush_chunk()                                                             # a ragged (last) batch: one step the plain way
+            eng.flush()
             if stores:                                                                # batch assembled on the device
                 eng.X.zero_()
                 if eng.bf16_store:
@@ -242,15 +280,9 @@ def main():
             if args.lr_adaptive == "dann":
                 lr = lr_dann(args.lr, p)                                              # main.py:620-621 (takes effect at the next step)
             if i % max(args.print_freq, 1) == 0:
-                # one host sync every print_freq steps (the reference syncs 5-6x per step).  A rank's loss scalars are its
-                # shard's sums divided by the GLOBAL counts: the job's losses are their sum over ranks.
-                scal = eng.region("losses")[:6].clone()
-                if world > 1:
-                    torch.distributed.all_reduce(scal)
-                if rank == 0:
-                    v = scal.tolist()
-                    print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
-                          f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
+                log_line(i, lr_used, beta)
+        flush_chunk()
+        eng.flush()                                                                   # the epoch's last update, before validation / checkpoint
         if epoch % max(args.eval_freq, 1) == 0 or epoch == args.epochs:                   # main.py:252-274
             prec1 = validate(epoch) if (stores and len(stores) > 2) else 0.0
             is_best = prec1 > best_prec1
