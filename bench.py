@@ -262,7 +262,7 @@ def main():
         headline = conf is CONFIGS[2] or conf is CONFIGS[3]
         bf16 = dtype == "bf16"
         split = dtype == "f32x3"       # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers (TA3N_FLAG_F32_SPLIT)
-        twins = bf16 and not args.no_twins
+        twins = (bf16 or split) and not args.no_twins      # (f32x3: "pair twins" - hi and lo planes stored by the producers)
         # None: the measured per-launch choices of ta3n_amd/tuning.py for this shape (what TrainEngine uses by default)
         phase_tiles = [int(v) for v in args.phase_tiles.split(",") if v] or None
         if args.autotune:
@@ -511,7 +511,8 @@ def main():
                  "f32": f"fp32 MFMA throughout (BASELINE configs[2] arithmetic); parity: logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, "
                         f"every gradient tensor rel. L2 <= {tol.F32_GRAD_REL_L2:g} (median over tensors <= {tol.F32_GRAD_REL_L2_MEDIAN:g}) "
                         "(tests/test_gpu_parity.py, tests/test_gpu_gradients.py)",
-                 "f32x3": "fp32-grade contractions on the bf16 MFMA: operands split hi + lo = bf16(x) + bf16(x - hi) in registers, "
+                 "f32x3": "fp32-grade contractions on the bf16 MFMA: operands split hi + lo = bf16(x) + bf16(x - hi) " +
+                          ("in registers, " if args.no_twins else "by the producing kernels (hi / lo planes in HBM, nothing converted in the K loops), ") +
                           "a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 (~2^-16 per product; not IEEE fp32 multiplication); fp32 "
                           f"stage images, parameters, gradients, optimiser; logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, every gradient "
                           f"tensor rel. L2 <= {tol.F32X3_GRAD_REL_L2:g} (median <= {tol.F32X3_GRAD_REL_L2_MEDIAN:g}) (same tests, [f32x3] / [bf16x3] ids)"}

@@ -74,7 +74,13 @@ typedef enum {
  * 16 mantissa bits per operand, a relative error of ~2^-16 per product instead of fp32's 2^-24 (the dropped a_lo b_lo term),
  * at 3/16 of the fp32 MFMA's cycles.  Stage images, parameters, gradients and everything outside the MFMA stay fp32.  It is
  * NOT IEEE fp32 multiplication; it is held to the same parity tests as the fp32 configuration (logits within 1e-3 of the
- * reference's CPU path, gradients rtol 2e-4).  Exclusive with TA3N_FLAG_BF16_MFMA. */
+ * reference's CPU path, gradients rtol 2e-4).  Exclusive with TA3N_FLAG_BF16_MFMA.
+ * With TA3N_FLAG_BF16_STORE ("pair twins"): the split is made ONCE by whoever produces the data - every twin region of ws gets a
+ * second plane holding lo beside hi (regions "ws16_lo", "p16_lo", "x16_lo"; GEMM epilogues, the heads kernel, the optimiser,
+ * ta3n_refresh_bf16 and the feature-store gathers write both planes; rows of a bf16 feature store are their own hi plane, lo = 0) -
+ * and the launches of ta3n_train_step whose operands qualify stream both planes (the same bytes as the fp32 images) and multiply
+ * without converting anything in the K loop; the others keep splitting fp32 operands in registers.  Same products, other
+ * summation order inside the MFMAs.  ta3n_train_steps_fused_update is not built for it (ta3n_has_fused_update returns 0). */
 #define TA3N_FLAG_F32_SPLIT      (1u << 10)
 
 /* ta3n_config.aggregation */

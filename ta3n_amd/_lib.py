@@ -228,6 +228,7 @@ class Plan:
         self.description = json.loads(buf.value.decode())
         self.regions: Dict[str, Tuple[int, int]] = {k: tuple(v) for k, v in self.description["regions"].items()}
         self.has_fused_step = L.ta3n_has_fused_step(h) == 1
+        self.has_fused_update = L.ta3n_has_fused_update(h) == 1
 
     def region(self, name: str) -> Tuple[int, int]:
         return self.regions[name]

@@ -75,7 +75,8 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
         switch (ph.kind) {
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
-                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side, static_cast<const Wait *>(p->d_waits));
+                                 p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side, static_cast<const Wait *>(p->d_waits),
+                                 p->geom.pair_delta);
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -325,7 +326,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         for (int k = 0; k < r; ++k) {
             int lrc = 0;
             switch (ph.kind) {
-                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s, nullptr, static_cast<const Wait *>(p->d_waits)); break;
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s, nullptr, static_cast<const Wait *>(p->d_waits), p->geom.pair_delta); break;
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;
@@ -422,7 +423,7 @@ int ta3n_gather_segments_into(ta3n_plan *p, const float *store, const int64_t *f
     const size_t row0 = (size_t)first_video * g.T;
     float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
     if (launch_gather_segments(store, first_row, num_frames, labels, video_ids, n_videos, g.T, g.D, x + row0 * g.D, labels_out, nullptr,
-                               twin, static_cast<hipStream_t>(stream)) != 0)
+                               twin, static_cast<hipStream_t>(stream), g.pair_delta) != 0)
         return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
     return TA3N_OK;
 }
@@ -439,7 +440,7 @@ int ta3n_gather_segments_bf16_into(ta3n_plan *p, const void *store16, const int6
     const size_t row0 = (size_t)first_video * g.T;
     float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
     if (launch_gather_segments_bf16(store16, first_row, num_frames, labels, video_ids, n_videos, g.T, g.D, x ? x + row0 * g.D : nullptr, labels_out,
-                                    twin, static_cast<hipStream_t>(stream)) != 0)
+                                    twin, static_cast<hipStream_t>(stream), g.pair_delta) != 0)
         return fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
     return TA3N_OK;
 }
@@ -525,10 +526,10 @@ static int feed_step(ta3n_plan *p, const ta3n_feed *f, int step, int first_video
     if (f->bf16) {
         if (!twin && !x) return fail(TA3N_ERR_INVALID, "ta3n_feed: a plan without bf16 twins needs the fp32 input rows");
         rc = launch_gather_segments_bf16(f->store, f->first_row, f->num_frames, f->labels, ids, f->ids_per_step, g.T, g.D,
-                                         twin ? nullptr : x + row0 * g.D, labels_out, twin, s);
+                                         twin ? nullptr : x + row0 * g.D, labels_out, twin, s, g.pair_delta);
     } else {
         rc = launch_gather_segments(static_cast<const float *>(f->store), f->first_row, f->num_frames, f->labels, ids, f->ids_per_step,
-                                    g.T, g.D, x + row0 * g.D, labels_out, nullptr, twin, s);
+                                    g.T, g.D, x + row0 * g.D, labels_out, nullptr, twin, s, g.pair_delta);
     }
     return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
 }
@@ -572,7 +573,8 @@ int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, 
 int ta3n_has_fused_update(const ta3n_plan *p) {
     if (!p) return TA3N_ERR_INVALID;
     // every live parameter's gradient is produced by a tile / column-sum task of the fused step (those carry the update)
-    return ta3n_has_fused_step(p) == 1 && p->cfg.aggregation == TA3N_AGG_TRN_M ? 1 : 0;
+    // (pair twins: the fused-update epilogue keeps no lo plane of the new parameters - the separate update does)
+    return ta3n_has_fused_step(p) == 1 && p->cfg.aggregation == TA3N_AGG_TRN_M && p->geom.pair_delta == 0 ? 1 : 0;
 }
 
 int ta3n_train_steps_fused_update(ta3n_plan *p, const float *x, float *params, float *params_alt, float *grads, float *momentum, float *ws,
@@ -628,8 +630,14 @@ int ta3n_refresh_bf16(ta3n_plan *p, const float *x, const float *params, float *
     if (p->geom.o_ws16 < 0) return TA3N_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = 0;
-    if (x) rc |= launch_to_bf16(x, ws + p->geom.o_x16, (int64_t)p->geom.B * p->geom.T * p->geom.D, s);
-    if (params) rc |= launch_to_bf16(params, ws + p->geom.o_p16, p->param_floats, s);
+    const int64_t nx = (int64_t)p->geom.B * p->geom.T * p->geom.D, pd = p->geom.pair_delta;
+    if (pd) {        // pair twins (TA3N_FLAG_F32_SPLIT): the hi and the lo plane
+        if (x) rc |= launch_to_bf16_pair(x, ws + p->geom.o_x16, ws + p->geom.o_x16 + pd, nx, s);
+        if (params) rc |= launch_to_bf16_pair(params, ws + p->geom.o_p16, ws + p->geom.o_p16 + pd, p->param_floats, s);
+    } else {
+        if (x) rc |= launch_to_bf16(x, ws + p->geom.o_x16, nx, s);
+        if (params) rc |= launch_to_bf16(params, ws + p->geom.o_p16, p->param_floats, s);
+    }
     return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, "bf16 conversion launch failed");
 }
 

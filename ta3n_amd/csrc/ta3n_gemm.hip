@@ -125,7 +125,10 @@ constexpr int K_NEVER = 1 << 28;   // "k offset" of a lane whose row is out of r
 // TW: the operand is a bf16 twin (origin points into the twin region; ld, klen, rows in ELEMENTS).  The stage holds
 // 128 k: K-contiguous rows are 16 slots of 8 bf16, a k-major stage is [128][R] bf16 - the same bytes per stage, the
 // same number of 1 KiB pieces.  The plan only marks launches whose every operand moves 16 bytes at a time.
-template <int R, int NW, bool TW = false>
+// PAIR (pair twins, Geom::pair_delta): the stage holds 64 k twice - the hi plane and, pair_delta floats behind it in memory, the lo
+// plane (x = hi + lo).  K-contiguous: logical slots 0-7 of a row are the hi k-groups, 8-15 the lo ones; k-major: image rows 0-63
+// are the hi plane's k rows, 64-127 the lo plane's.  Same bytes, pieces and DMA instructions per stage as the plain twin stage.
+template <int R, int NW, bool TW = false, bool PAIR = false>
 struct OperandStream {
     static constexpr int NP = R / 4 / NW;   // 1 KiB pieces per wave per stage (16-byte path)
     static_assert((R / 4) % NW == 0, "pieces must divide over the waves");
@@ -138,8 +141,31 @@ struct OperandStream {
     bool vec;
 
     __device__ __forceinline__ void setup(const float *__restrict__ origin_, int ld_, int kmajor_, int klen, int r0_, int rvalid_,
-                                          int wave, int lane) {
+                                          int wave, int lane, int pair_delta = 0) {
         origin = origin_; ld = ld_; kmajor = kmajor_; r0 = r0_; rvalid = rvalid_;
+        if constexpr (TW && PAIR) {
+            vec = true;
+            const int ldf = ld_ >> 1;                  // floats per row of a twin plane
+            step = kmajor_ ? 64 * ldf : BKC / 2;       // 64 k per stage
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int q = wave + NW * i;
+                if (!kmajor_) {
+                    const int row = q * 4 + (lane >> 4);
+                    const int slot = (lane & 15) ^ (row & 15);            // logical slot held at physical slot (lane & 15)
+                    p[i] = origin_ + (size_t)(r0_ + row) * ldf + 4 * (slot & 7) + (slot >= 8 ? pair_delta : 0);
+                    kofs[i] = (r0_ + row < rvalid_) ? 8 * (slot & 7) : K_NEVER;
+                } else {
+                    constexpr int LPR = R / 8, KPP = 64 / LPR;
+                    const int kk = q * KPP + lane / LPR;                  // image row: 0-63 hi plane, 64-127 lo plane
+                    const int chunk = (lane % LPR) ^ (R == 64 ? ((kk >> 1) & 1) << 2 : R == 128 ? (kk & 3) << 2 : 0);
+                    const int r = r0_ + chunk * 8;
+                    p[i] = origin_ + (size_t)(kk & 63) * ldf + (r >> 1) + (kk >= 64 ? pair_delta : 0);
+                    kofs[i] = (r < rvalid_) ? (kk & 63) : K_NEVER;
+                }
+            }
+            return;
+        }
         if constexpr (TW) {
             vec = true;
             const int ldf = ld_ >> 1;                  // floats per row of the twin
@@ -297,6 +323,87 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                             accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[i][qq]),
                                                                                  __builtin_bit_cast(bf16x8, tb[j][qq]), accs[i][j], 0, 0, 0);
                 }
+        }
+        return;
+    }
+    if constexpr (BF == 4) {
+        // Pair twins: the stage holds 64 k as a hi and a lo plane (OperandStream PAIR); slot G (0-7) = k 8G .. 8G+7.  a b ~ a_lo b_hi +
+        // a_hi b_lo + a_hi b_hi (the lo lo term, ~2^-16 of the product, is dropped) with fp32 accumulation in the MFMA - the arithmetic
+        // of BF == 3 without splitting anything in the loop.  A wave owns 8 / WK slots: pairs of slots feed the 16-deep MFMA (one slot
+        // per half-wave), a single slot (WK = 8) the 8-deep one (4 k per half-wave).
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+        constexpr int SPW = 8 / WK;                     // slots per wave
+        const int lane = lh * 32 + (ra & 31);
+        const unsigned short *sa16 = reinterpret_cast<const unsigned short *>(sa);
+        const unsigned short *sb16 = reinterpret_cast<const unsigned short *>(sb);
+        const int tcol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+        const int acol = ((ra & ~31) + tcol) ^ (BM == 64 ? 32 * ((lane >> 3) & 1) : 0);
+        const int bcol = ((rb & ~31) + tcol) ^ (BN == 64 ? 32 * ((lane >> 3) & 1) : 0);
+        if constexpr (SPW >= 2) {
+            constexpr int NM = SPW / 2;
+            u32x4 ah[NM], al[NM], bh[NM], bl[NM];
+            const int trow = 8 * lh + ((lane >> 2) & 3);
+            auto rd_kc = [&](const float *img, int row, int G) {       // K-contiguous: logical slot G of `row` sits at physical slot G ^ (row & 15)
+                return *reinterpret_cast<const u32x4 *>(img + row * BKC + ((G ^ (row & 15)) << 2));
+            };
+            auto rd_km = [&](const unsigned short *img16, int R, int k0, int col) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(img16 + k0 * R + col));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(img16 + (k0 + 4) * R + col));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                return u32x4{l2[0], l2[1], h2[0], h2[1]};
+            };
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int G = wk * SPW + 2 * q + lh;
+                const int k0 = 8 * (wk * SPW + 2 * q) + trow;
+                if (!AKM) { ah[q] = rd_kc(sa, ra, G); al[q] = rd_kc(sa, ra, G + 8); }
+                else { ah[q] = rd_km(sa16, BM, k0, acol); al[q] = rd_km(sa16, BM, k0 + 64, acol); }
+                if (!BKM) { bh[q] = rd_kc(sb, rb, G); bl[q] = rd_kc(sb, rb, G + 8); }
+                else { bh[q] = rd_km(sb16, BN, k0, bcol); bl[q] = rd_km(sb16, BN, k0 + 64, bcol); }
+            }
+            if (RS) {
+#pragma unroll
+                for (int q = 0; q < NM; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rs += (__builtin_bit_cast(float, ah[q][j] << 16) + __builtin_bit_cast(float, ah[q][j] & 0xFFFF0000u)) +
+                              (__builtin_bit_cast(float, al[q][j] << 16) + __builtin_bit_cast(float, al[q][j] & 0xFFFF0000u));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NM; ++q)
+                if (FULL || 8 * (wk * SPW + 2 * q) < krem) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[q]), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[q]), __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[q]), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+                }
+        } else {
+            // one slot per wave: lanes 0-31 take k 8 wk .. + 3, lanes 32-63 k 8 wk + 4 .. + 7
+            const int trow = 4 * lh + ((lane >> 2) & 3);
+            auto rd_kc = [&](const float *img, int row, int G) {
+                return *reinterpret_cast<const u32x2 *>(img + row * BKC + ((G ^ (row & 15)) << 2) + 2 * lh);
+            };
+            auto rd_km = [&](const unsigned short *img16, int R, int k0, int col) {
+                return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(img16 + k0 * R + col)));
+            };
+            u32x2 ah, al, bh, bl;
+            if (!AKM) { ah = rd_kc(sa, ra, wk); al = rd_kc(sa, ra, wk + 8); }
+            else { ah = rd_km(sa16, BM, 8 * wk + trow, acol); al = rd_km(sa16, BM, 8 * wk + trow + 64, acol); }
+            if (!BKM) { bh = rd_kc(sb, rb, wk); bl = rd_kc(sb, rb, wk + 8); }
+            else { bh = rd_km(sb16, BN, 8 * wk + trow, bcol); bl = rd_km(sb16, BN, 8 * wk + trow + 64, bcol); }
+            if (RS) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rs += (__builtin_bit_cast(float, ah[j] << 16) + __builtin_bit_cast(float, ah[j] & 0xFFFF0000u)) +
+                          (__builtin_bit_cast(float, al[j] << 16) + __builtin_bit_cast(float, al[j] & 0xFFFF0000u));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULL || 8 * wk < krem) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, al), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bl), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
+            }
         }
         return;
     }
@@ -468,6 +575,19 @@ __device__ __forceinline__ void st_pub(void *p, u32x2 v) { asm volatile("global_
 __device__ __forceinline__ void st_pub(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_pub(unsigned short *p, unsigned v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
+// four bf16 values (two packed dwords) of one output float4 to a twin plane; nrem valid columns; vec: 8-byte aligned
+__device__ __forceinline__ void store_twin4(unsigned short *tp, unsigned w0, unsigned w1, int nrem, bool vec, bool pub) {
+    if (nrem >= 4 && vec) {
+        if (pub) st_pub(tp, u32x2{w0, w1});
+        else *reinterpret_cast<u32x2 *>(tp) = u32x2{w0, w1};
+    } else {
+        const unsigned short h[4] = {(unsigned short)(w0 & 0xFFFF), (unsigned short)(w0 >> 16), (unsigned short)(w1 & 0xFFFF), (unsigned short)(w1 >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nrem) { if (pub) st_pub(tp + e, (unsigned)h[e]); else tp[e] = h[e]; }
+    }
+}
+
 // Chained launch, consumer side: wave 0 polls the task's (counter, target) pairs, one pair per lane (relaxed agent-scope loads:
 // served by the L2 / fabric, never by this CU's L1), then one agent-scope acquire (invalidates this CU's L1) and a workgroup
 // barrier.  A producer is always a lower-indexed task of the launch, i.e. already dispatched (workgroups are dispatched in
@@ -551,12 +671,13 @@ namespace ta3n {
 // which only the tile size lowers.
 template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
 __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__ segs, const Ptrs &ptrs, int hyper_off, int zeros_off,
-                                          int twin_off, const SgdSide &side) {
+                                          int twin_off, const SgdSide &side, int pair_delta) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
     constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
-    constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128)
-    constexpr bool TW = BF == 2;
+    constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128; pair twins: 64 as hi + lo)
+    constexpr bool TW = BF == 2 || BF == 4;
+    constexpr bool PAIR = BF == 4;
     constexpr int EPI = NW * RM * RN * 32 * 36;      // epilogue staging (one padded 32x32 block per wave and register block)
     constexpr int LDS_FLOATS = NS * STAGE > EPI ? NS * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
@@ -598,8 +719,14 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
             if (side.p16_off >= 0) {
                 uint2 *tw = reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off) + i;
-                if (pub) st_pub(tw, u32x2{pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3])});
-                else *tw = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+                const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
+                if (pub) st_pub(tw, u32x2{h0, h1});
+                else *tw = make_uint2(h0, h1);
+                if (pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
+                    const u32x2 l = {pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1)};
+                    if (pub) st_pub(tw + pair_delta / 2, l);
+                    else tw[pair_delta / 2] = make_uint2(l[0], l[1]);
+                }
             }
         }
         return;
@@ -733,8 +860,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         if constexpr (NS == 2) {
             // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
             // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
-            OperandStream<BM, NW, TW> oa;
-            OperandStream<BN, NW, TW> ob;
+            OperandStream<BM, NW, TW, PAIR> oa;
+            OperandStream<BN, NW, TW, PAIR> ob;
             int klen = 0, scale = SK_ONE;
             // The descriptor of the NEXT Seg is fetched while the current one streams (scalar loads, consumed at the next
             // open): opening a Seg used to start with a dependent global load between "stage landed" and "next DMA issued" -
@@ -745,8 +872,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 if (sidx + 1 < seg_end) nx = segs[sidx + 1];
                 klen = sg.klen; scale = sg.scale_kind;
                 oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
-                         wave, lane);
-                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
+                         wave, lane, pair_delta);
+                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane, pair_delta);
             };
             auto issue = [&](int buf, int k0) {
                 const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
@@ -795,9 +922,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             } else {
             // Two cursors walk the task's Segs chunk by chunk: the issue cursor (per-lane DMA state) runs up to NS - 1
             // chunks ahead of the compute cursor (scalar state only).
-            OperandStream<BM, NW, TW> oa;
-            OperandStream<BN, NW, TW> ob;
-            constexpr int LPW = OperandStream<BM, NW, TW>::NP + OperandStream<BN, NW, TW>::NP;   // DMAs per lane and chunk (16-byte path;
+            OperandStream<BM, NW, TW, PAIR> oa;
+            OperandStream<BN, NW, TW, PAIR> ob;
+            constexpr int LPW = OperandStream<BM, NW, TW, PAIR>::NP + OperandStream<BN, NW, TW, PAIR>::NP;   // DMAs per lane and chunk (16-byte path;
                                                                                          // the 4-byte path issues more, never fewer)
             int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
             Seg nx = t.seg0;                         // descriptor of the Seg the issue cursor opens next, fetched one Seg ahead
@@ -806,8 +933,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 if (i_seg + 1 < seg_end) nx = segs[i_seg + 1];
                 i_klen = sg.klen; i_nchunks = (sg.klen + CH - 1) / CH; i_chunk = 0;
                 oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
-                         wave, lane);
-                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane);
+                         wave, lane, pair_delta);
+                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane, pair_delta);
             };
             auto issue_one = [&]() {                 // stream the chunk under the issue cursor, advance the cursor
                 const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
@@ -1039,16 +1166,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         if (epi & EPI_TWIN16) {          // bf16 twin of the stored values (TA3N_FLAG_BF16_STORE)
             unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
             const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
-            if (nrem >= 4 && c_vec) {
-                if (pub) st_pub(tp, u32x2{lo, hi});
-                else *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
-            } else {
-                const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16), (unsigned short)(hi & 0xFFFF),
-                                             (unsigned short)(hi >> 16)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nrem) { if (pub) st_pub(tp + e, (unsigned)h[e]); else tp[e] = h[e]; }
-            }
+            store_twin4(tp, lo, hi, nrem, c_vec, pub);
+            if (pair_delta)      // pair twins: the lo plane of the same four values
+                store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(v[0], v[1], lo), pack_bf16_lo(v[2], v[3], hi), nrem, c_vec, pub);
         }
         if (nfan > 0) {
             const bool fan_vec = nrem >= 4 && (t.fan_ld & 3) == 0;
@@ -1084,16 +1204,10 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                         unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) +
                                              ((size_t)t.fan_out_off[f] + (size_t)m * t.fan_ld + n);
                         const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
-                        if (nrem >= 4 && ((t.fan_out_off[f] | t.fan_ld) & 3) == 0) {
-                            if (pub) st_pub(tp, u32x2{lo, hi});
-                            else *reinterpret_cast<u32x2 *>(tp) = u32x2{lo, hi};
-                        } else {
-                            const unsigned short h[4] = {(unsigned short)(lo & 0xFFFF), (unsigned short)(lo >> 16),
-                                                         (unsigned short)(hi & 0xFFFF), (unsigned short)(hi >> 16)};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (e < nrem) { if (pub) st_pub(tp + e, (unsigned)h[e]); else tp[e] = h[e]; }
-                        }
+                        const bool fvec = ((t.fan_out_off[f] | t.fan_ld) & 3) == 0;
+                        store_twin4(tp, lo, hi, nrem, fvec, pub);
+                        if (pair_delta)
+                            store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(ov[0], ov[1], lo), pack_bf16_lo(ov[2], ov[3], hi), nrem, fvec, pub);
                     }
                 }
             }
@@ -1146,14 +1260,15 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
 template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
                                                                  Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side,
-                                                                 const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs) {
+                                                                 const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs,
+                                                                 int pair_delta) {
     const Task &t = tasks[blockIdx.x];
     int *cnt = reinterpret_cast<int *>(ptrs.ws + (chain_off >= 0 ? chain_off : 0));
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2      // tools/chain_stamps.py: [6] = workgroup entry (before the wait), [7] = after the exit bookkeeping
     GSTAMP(6);
 #endif
     if (chain_off >= 0) chain_wait(t, waits, cnt, (int)threadIdx.x, knobs);
-    gemm_tile<WM, WN, WK, BF, NS, RM, RN>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side);
+    gemm_tile<WM, WN, WK, BF, NS, RM, RN>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta);
     if (chain_off >= 0) chain_exit(t.sig, cnt, chain_n, (int)threadIdx.x, knobs);
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2
     GSTAMP(7);
@@ -1166,16 +1281,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 #define TA3N_BLOCKED_CONFIGS(X) X(2, 2, 2, 2, 2, 2) X(2, 2, 1, 2, 2, 2) X(2, 2, 2, 1, 2, 2) X(2, 2, 2, 1, 2, 3) X(2, 2, 2, 2, 1, 2) X(2, 2, 2, 2, 1, 3)
 
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
-    template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 3, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int);
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 2, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 4, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 4, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
 #define TA3N_INSTANTIATE_BLOCKED(wm, wn, wk, rm, rn, ns) \
-    template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int);
+    template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 TA3N_BLOCKED_CONFIGS(TA3N_INSTANTIATE_BLOCKED)
 
 
@@ -1206,7 +1323,7 @@ bool tile_config_ok(int cfg) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits) {
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits, int pair_delta) {
     const int chain_off = d_waits ? ph.chain_off : -1, chain_n = ph.chain_n;
     if (ph.chain_off >= 0 && !d_waits) return -4;
     // measurement knobs of the hand-off protocol (defaults = the shipped protocol): TA3N_CHAIN_SLEEP = poll back-off in units of 512
@@ -1236,7 +1353,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
 #define TA3N_LAUNCH_BLOCKED(wm, wn, wk, rm_, rn_, ns)                                                                      \
         if (!launched && cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (ph.bf16 & 15) == ns) {               \
             hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, 2, ns, rm_, rn_>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
-                               ptrs, hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs);                                                  \
+                               ptrs, hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs, pair_delta);                                      \
             launched = true;                                                                                               \
         }
         TA3N_BLOCKED_CONFIGS(TA3N_LAUNCH_BLOCKED)
@@ -1245,7 +1362,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     }
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
     hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns, 1, 1>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \
-                       hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs)
+                       hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs, pair_delta)
 #define TA3N_LAUNCH(wm, wn, wk)                                   \
     if (cfg == wm * 100 + wn * 10 + wk) {                         \
         switch (ph.bf16) {                                        \
@@ -1255,6 +1372,8 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
             case 19: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 3); break;    \
             case 34: TA3N_LAUNCH_ONE(wm, wn, wk, 3, 2); break;    \
             case 35: TA3N_LAUNCH_ONE(wm, wn, wk, 3, 3); break;    \
+            case 50: TA3N_LAUNCH_ONE(wm, wn, wk, 4, 2); break;    \
+            case 51: TA3N_LAUNCH_ONE(wm, wn, wk, 4, 3); break;    \
             default: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 2); break;    \
         }                                                         \
         launched = true;                                          \

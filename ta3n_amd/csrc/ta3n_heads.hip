@@ -521,7 +521,12 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
                     const float gh = h > 0.f ? g0 * w0[q] + g1 * w1[q] : 0.f;
                     ws[g.o_gHf + (size_t)r * F + k] = gh;
                     if (g.o_ws16 >= 0)   // bf16 twin (TA3N_FLAG_BF16_STORE): the gradient launch reads it as a GEMM operand
-                        reinterpret_cast<unsigned short *>(ws + g.o_ws16)[g.o_gHf + (size_t)r * F + k] = (unsigned short)pack_bf16(gh, 0.f);
+                    {
+                        const unsigned hb = pack_bf16(gh, 0.f);
+                        unsigned short *tw = reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_gHf + (size_t)r * F + k;
+                        *tw = (unsigned short)hb;
+                        if (g.pair_delta) tw[2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(gh, 0.f, hb);      // pair twins: the lo plane
+                    }
                 }
                 a0[q] = fmaf(g0, h, a0[q]);
                 a1[q] = fmaf(g1, h, a1[q]);

@@ -105,7 +105,8 @@ __device__ __forceinline__ Soft2 soft2(float z0, float z1) {
 
 bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side = nullptr, const Wait *d_waits = nullptr);
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side = nullptr, const Wait *d_waits = nullptr,
+                int pair_delta = 0);
 #if defined(__HIPCC__)
 // two floats -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), low half = first argument
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
@@ -114,9 +115,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// the lo halves of the split x = hi + lo (pair twins, Geom::pair_delta): lo = bf16(x - float(hi)); the subtraction is exact in fp32
+__device__ __forceinline__ unsigned pack_bf16_lo(float x0, float x1, unsigned hi) {
+    return pack_bf16(x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u));
+}
 #endif
 
 int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t stream);   // n fp32 -> n bf16 (RNE), n % 4 == 0
+int launch_to_bf16_pair(const float *src, float *dst_hi, float *dst_lo, int64_t n, hipStream_t stream);   // ... and the lo plane
 bool heads_supported(int NB, int C, int F);   // configurations the fused heads kernel (ta3n_heads.hip) covers
 int launch_heads(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream);   // TA3N_AGG_AVGPOOL: between F1 and gZ1
@@ -139,10 +145,10 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
-                           float *out_twin, hipStream_t stream);
+                           float *out_twin, hipStream_t stream, int64_t pair_delta = 0);
 
 int launch_gather_segments_bf16(const void *store16, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                                 const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, float *out_twin,
-                                hipStream_t stream);
+                                hipStream_t stream, int64_t pair_delta = 0);
 
 }  // namespace ta3n

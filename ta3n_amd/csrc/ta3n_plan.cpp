@@ -408,16 +408,28 @@ typedef std::pair<int64_t, int64_t> Span;   // [first, last) in ws floats
 void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std::vector<Span> &extra_produced,
                     const std::vector<Span> &gemm_only = {}) {
     const ta3n_config &c = p.cfg;
-    if (!((c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE))) return;
+    // (TA3N_FLAG_F32_SPLIT | _BF16_STORE: "pair twins" - every twin has a hi and a lo plane, x = hi + lo to 16 mantissa bits)
+    if (!((c.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_F32_SPLIT)) && (c.flags & TA3N_FLAG_BF16_STORE))) return;
     // bf16 twins.  A launch of the fused step reads twins when every one of its operands can be moved 16 bytes (8
     // elements) at a time and has a producer that keeps the twin current; its Segs are then re-addressed into the
     // twin regions.  Launches with odd-shaped operands (the small head weight gradients) keep rounding fp32
     // operands in registers.
     g.ws16_span = (int32_t)p.ws_floats;
+    p.ws_floats_before_twins = p.ws_floats;
     g.o_ws16 = (int32_t)b.add_region("ws16", (p.ws_floats + 1) / 2);
     g.o_p16 = (int32_t)b.add_region("p16", (p.param_floats + 1) / 2);
     g.o_x16 = (int32_t)b.add_region("x16", ((int64_t)BT * D + 1) / 2);
     g.o_p16b = (int32_t)b.add_region("p16b", (p.param_floats + 1) / 2);      // (fused-update step: twins of the second parameter buffer)
+    if (c.flags & TA3N_FLAG_F32_SPLIT) {
+        // the lo planes: the same four regions again, so ONE displacement leads from any twin element to its lo half
+        const int32_t lo_ws = (int32_t)b.add_region("ws16_lo", (p.ws_floats_before_twins + 1) / 2);
+        const int32_t lo_p = (int32_t)b.add_region("p16_lo", (p.param_floats + 1) / 2);
+        const int32_t lo_x = (int32_t)b.add_region("x16_lo", ((int64_t)BT * D + 1) / 2);
+        const int32_t lo_pb = (int32_t)b.add_region("p16b_lo", (p.param_floats + 1) / 2);
+        g.pair_delta = lo_ws - g.o_ws16;
+        if (lo_p - g.o_p16 != g.pair_delta || lo_x - g.o_x16 != g.pair_delta || lo_pb - g.o_p16b != g.pair_delta || (g.pair_delta & 3))
+            g.pair_delta = -1;      // (cannot happen: equal sizes, 64-float alignment; build_plan reports it)
+    }
     auto twin = [&](int32_t &base, int32_t &off) {
         if (base == BASE_P) { base = BASE_P16; off = off / 2; return; }      // relative to the twin region the launch is handed
         const int32_t origin = base == BASE_WS ? g.o_ws16 : g.o_x16;
@@ -596,7 +608,7 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
     g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1; g.pair_delta = 0;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_V = (int32_t)b.add_region("V", (int64_t)B * F);
     g.o_Vd = (int32_t)b.add_region("Vd", (int64_t)B * F);
@@ -743,7 +755,7 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = F; g.C = C;
     g.n_tuples = 0; g.n_rel = 0; g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1; g.pair_delta = 0;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_Hf = (int32_t)b.add_region("Hf", live_frm ? (int64_t)BT * F : 4);
     g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
@@ -946,8 +958,8 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         err = "attentive_entropy requires place_adv[0]=='Y' and place_adv[1]=='Y'";
         return TA3N_ERR_INVALID;
     }
-    if ((c.flags & TA3N_FLAG_F32_SPLIT) && (c.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_BF16_STORE))) {
-        err = "TA3N_FLAG_F32_SPLIT and TA3N_FLAG_BF16_MFMA / _STORE are different arithmetics: set one";
+    if ((c.flags & TA3N_FLAG_F32_SPLIT) && (c.flags & TA3N_FLAG_BF16_MFMA)) {
+        err = "TA3N_FLAG_F32_SPLIT and TA3N_FLAG_BF16_MFMA are different arithmetics: set one";
         return TA3N_ERR_INVALID;
     }
     auto tile_ok = [](int t) { return t == 0 || tile_config_ok(t); };
@@ -1040,7 +1052,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     std::memset(&g, 0, sizeof(g));
     g.Bs = Bs; g.Bt = Bt; g.B = B; g.T = T; g.D = D; g.F = F; g.NB = NB; g.C = C;
     g.n_tuples = NT; g.n_rel = NR; g.flags = c.flags;
-    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1; g.ws16_span = 0;
+    g.o_ws16 = g.o_p16 = g.o_x16 = g.o_p16b = -1; g.pair_delta = 0; g.ws16_span = 0;
     g.o_F1 = (int32_t)b.add_region("F1", (int64_t)BT * F);
     g.o_Hf = (int32_t)b.add_region("Hf", (int64_t)BT * F);
     g.o_Pf = (int32_t)b.add_region("Pf", (int64_t)BT * 2);
@@ -1394,14 +1406,14 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             b.colsum_pending(g.o_fh_bpart, g.n_frm_wg, 2, 2, bcd);
             // dWfd: gHf is ready after the heads kernel, so it can fill the CUs this short level leaves idle - unless the
             // next launch reads bf16 twins and this one cannot (odd-shaped head gradients): then it is cheaper there
-            const bool twins = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
+            const bool twins = (c.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_F32_SPLIT)) && (c.flags & TA3N_FLAG_BF16_STORE);
             if (!twins) push_frame_disc_wgrads(s);
             b.add_gemm_phase(4, s);
         }
         // The critical path of the backward pass is  relation level -> gradient at F1 -> shared-FC weight gradient; the TRN
         // weight gradients and dWfd feed nothing but the optimiser, so they may ride with either of the last two launches
         // (ta3n_config.wgrads_late, default 0 = with the gradient at F1: measured faster at the headline shape, ta3n_hip.h).
-        const bool twins_on = (c.flags & TA3N_FLAG_BF16_MFMA) && (c.flags & TA3N_FLAG_BF16_STORE);
+        const bool twins_on = (c.flags & (TA3N_FLAG_BF16_MFMA | TA3N_FLAG_F32_SPLIT)) && (c.flags & TA3N_FLAG_BF16_STORE);
         // wgrads_late: 0 = all with the gradient at F1, 1 = all with the shared-FC weight gradient, otherwise a mask:
         // bit 1 = the frame discriminator's first layer, bit 2 + j = TRN scale j (j = 0: all T frames)
         const unsigned late_mask = c.wgrads_late == 0 ? 0u : c.wgrads_late == 1 ? ~0u : (unsigned)c.wgrads_late;

@@ -27,6 +27,7 @@ struct ta3n_plan {
     int64_t first_floats = 0;   // size of the leading parameter block the step's first launch reads (shared frame FC weight + bias)
     std::vector<Region> regions;
     int64_t ws_floats = 0;
+    int64_t ws_floats_before_twins = 0;   // (size of the region the ws twins mirror)
     std::vector<ta3n::Seg> segs;
     std::vector<ta3n::Task> tasks;
     std::vector<ta3n::Phase> phases;

@@ -289,7 +289,11 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
         }
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+        if (g.o_p16 >= 0) {
+            const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
+            reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(h0, h1);
+            if (g.pair_delta) reinterpret_cast<uint2 *>(ws + g.o_p16 + g.pair_delta)[i] = make_uint2(pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1));
+        }
         i = nxt; p = pn; m = mn; gr = gn;
     }
 }
@@ -359,7 +363,11 @@ __global__ __launch_bounds__(256) void pool_cls_kernel(Geom g, Ptrs ptrs) {
             const size_t idx = ((size_t)b * T + t) * F + k;
             const float gz = ws[g.o_F1 + idx] > 0.f ? gf : 0.f;
             ws[g.o_gZ1 + idx] = gz;
-            if (twin) twin[g.o_gZ1 + idx] = (unsigned short)pack_bf16(gz, 0.f);
+            if (twin) {
+                const unsigned h = pack_bf16(gz, 0.f);
+                twin[g.o_gZ1 + idx] = (unsigned short)h;
+                if (g.pair_delta) twin[2 * (size_t)g.pair_delta + g.o_gZ1 + idx] = (unsigned short)pack_bf16_lo(gz, 0.f, h);
+            }
         }
     }
 }
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
                                                               const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
                                                               const int32_t *__restrict__ video_ids, int T, int D,
                                                               float *__restrict__ out, int32_t *__restrict__ labels_out,
-                                                              int32_t *__restrict__ seg_out, uint2 *__restrict__ out16) {
+                                                              int32_t *__restrict__ seg_out, uint2 *__restrict__ out16, int64_t pair_delta) {
     const int row = blockIdx.x, v = row / T, x = row - v * T;
     const int vid = video_ids[v];
     const int nf = num_frames[vid];
@@ -430,7 +438,11 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
         for (int i = threadIdx.x; i < D / 4; i += 256) {
             const float4 v4 = s4[i];
             d4[i] = v4;
-            if (t2) t2[i] = make_uint2(pack_bf16(v4.x, v4.y), pack_bf16(v4.z, v4.w));
+            if (t2) {
+                const unsigned h0 = pack_bf16(v4.x, v4.y), h1 = pack_bf16(v4.z, v4.w);
+                t2[i] = make_uint2(h0, h1);
+                if (pair_delta) t2[pair_delta / 2 + i] = make_uint2(pack_bf16_lo(v4.x, v4.y, h0), pack_bf16_lo(v4.z, v4.w, h1));   // (uint2 = 2 floats)
+            }
         }
     } else {
         for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *
                                                                    const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
                                                                    const int32_t *__restrict__ video_ids, int T, int D,
                                                                    float4 *__restrict__ out, int32_t *__restrict__ labels_out,
-                                                                   uint4 *__restrict__ out16) {
+                                                                   uint4 *__restrict__ out16, int64_t pair_delta) {
     const int row = blockIdx.x, v = row / T, x = row - v * T;
     const int vid = video_ids[v];
     const int nf = num_frames[vid];
@@ -459,7 +471,10 @@ __global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *
     const uint4 *__restrict__ src = store + (size_t)(first_row[vid] + off) * (D / 8);
     for (int i = threadIdx.x; i < D / 8; i += 256) {
         const uint4 q = src[i];
-        if (out16) out16[(size_t)row * (D / 8) + i] = q;
+        if (out16) {
+            out16[(size_t)row * (D / 8) + i] = q;
+            if (pair_delta) out16[pair_delta / 4 + (size_t)row * (D / 8) + i] = make_uint4(0u, 0u, 0u, 0u);   // bf16 rows are their own hi plane: lo = 0
+        }
         if (out) {
             out[(size_t)row * (D / 4) + 2 * i] = make_float4(__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xFFFF0000u),
                                                              __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xFFFF0000u));
@@ -552,7 +567,11 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
         }
         p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        if (g.o_p16 >= 0) reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(pack_bf16(pp[0], pp[1]), pack_bf16(pp[2], pp[3]));
+        if (g.o_p16 >= 0) {
+            const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
+            reinterpret_cast<uint2 *>(ws + g.o_p16)[i] = make_uint2(h0, h1);
+            if (g.pair_delta) reinterpret_cast<uint2 *>(ws + g.o_p16 + g.pair_delta)[i] = make_uint2(pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1));
+        }
         i = nxt; p = pn; m = mn; gr = gn;
     }
 }
@@ -597,6 +616,15 @@ __global__ void to_bf16_kernel(const float4 *__restrict__ src, uint2 *__restrict
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = src[i];
         dst[i] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    }
+}
+
+__global__ void to_bf16_pair_kernel(const float4 *__restrict__ src, uint2 *__restrict__ hi, uint2 *__restrict__ lo, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
+        hi[i] = make_uint2(h0, h1);
+        lo[i] = make_uint2(pack_bf16_lo(v.x, v.y, h0), pack_bf16_lo(v.z, v.w, h1));
     }
 }
 
@@ -777,19 +805,20 @@ int launch_sgd(const Geom &g, float *params, const float *grads, float *momentum
 
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
-                           float *out_twin, hipStream_t stream) {
+                           float *out_twin, hipStream_t stream, int64_t pair_delta) {
     if (n_videos <= 0) return 0;
     hipLaunchKernelGGL(gather_segments_kernel, dim3(n_videos * T), dim3(256), 0, stream, store, first_row, num_frames, labels, video_ids,
-                       T, D, out, labels_out, seg_out, reinterpret_cast<uint2 *>(out_twin));
+                       T, D, out, labels_out, seg_out, reinterpret_cast<uint2 *>(out_twin), out_twin ? pair_delta : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_gather_segments_bf16(const void *store16, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                                 const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, float *out_twin,
-                                hipStream_t stream) {
+                                hipStream_t stream, int64_t pair_delta) {
     if (n_videos <= 0) return 0;
     hipLaunchKernelGGL(gather_segments_bf16_kernel, dim3(n_videos * T), dim3(256), 0, stream, static_cast<const uint4 *>(store16), first_row,
-                       num_frames, labels, video_ids, T, D, reinterpret_cast<float4 *>(out), labels_out, reinterpret_cast<uint4 *>(out_twin));
+                       num_frames, labels, video_ids, T, D, reinterpret_cast<float4 *>(out), labels_out, reinterpret_cast<uint4 *>(out_twin),
+                       out_twin ? pair_delta : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -829,6 +858,15 @@ int launch_to_bf16(const float *src, float *dst_twin, int64_t n, hipStream_t str
     int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
     hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(src),
                        reinterpret_cast<uint2 *>(dst_twin), n4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_to_bf16_pair(const float *src, float *dst_hi, float *dst_lo, int64_t n, hipStream_t stream) {
+    const int64_t n4 = n / 4;
+    if (n4 <= 0) return 0;
+    int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(to_bf16_pair_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<uint2 *>(dst_hi), reinterpret_cast<uint2 *>(dst_lo), n4);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

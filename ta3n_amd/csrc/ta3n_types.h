@@ -112,6 +112,8 @@ struct Phase {
                                  // + 32: TA3N_FLAG_F32_SPLIT - operands split hi + lo in registers, three bf16 MFMAs per product block;
                                  // + 16: the operands ARE bf16 (TA3N_FLAG_BF16_STORE): the Segs' offsets address the
                                  // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
+                                 // + 16 + 32: pair twins - the stage holds the hi AND the lo plane of 64 k (Geom::pair_delta), three
+                                 // MFMAs per product block, no conversion in the loop
     int32_t rm, rn;              // 32x32 blocks per wave (0 or 1: one): block tile = 32*wm*rm x 32*wn*rn; > 1 only when bf16 >= 16
     int32_t chain_off;           // chained launch: ws offset (floats) of its int32 block {done, error, counters[chain_n]}; -1: plain launch
     int32_t chain_n;
@@ -161,6 +163,10 @@ struct Geom {
     int32_t o_Z0, o_gZ0, o_bn_batch, o_bn_run;
     int32_t p_bn_w[2], p_bn_b[2];        // [source, target]
     int32_t o_p16b;                      // second parameter-twin region (fused-update step: ping-pong with the second parameter buffer); -1: none
+    // TA3N_FLAG_F32_SPLIT with twins ("pair twins"): every twin region has a second plane holding lo = bf16(x - float(hi)) beside
+    // hi = bf16(x); the lo plane of ANY twin element lives pair_delta floats behind its hi plane (the four lo regions are laid out
+    // like the four hi regions).  0: no lo planes.
+    int32_t pair_delta;
 };
 
 }  // namespace ta3n

@@ -92,12 +92,17 @@ class TrainEngine:
                 raise ValueError("place_dis[2]: the reference itself fails on the 3-D frame features (loss.py:49)")
             flags |= _lib.FLAG_FEATURE_GRADS
             fused = False
-        if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
-            flags |= _lib.FLAG_BF16_MFMA
-        if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly
-            flags |= _lib.FLAG_BF16_STORE
-        if f32_split:            # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo in registers (ta3n_hip.h)
+        if f32_split:            # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo (ta3n_hip.h) ...
+            if bf16:
+                raise ValueError("f32_split and bf16 are different arithmetics: set one")
             flags |= _lib.FLAG_F32_SPLIT
+            if bf16_store:       # ... read from "pair twins": producers store the hi and the lo plane, nothing is split in the K loops
+                flags |= _lib.FLAG_BF16_STORE
+        else:
+            if bf16 or bf16_store:   # BASELINE configs[1]: contraction operands rounded to bf16, fp32 accumulation and fp32 state
+                flags |= _lib.FLAG_BF16_MFMA
+            if bf16_store:           # ... and the forward launches of the fused step read bf16 twins instead of rounding on the fly
+                flags |= _lib.FLAG_BF16_STORE
         self.bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
         self.bf16_store = bool(flags & _lib.FLAG_BF16_STORE)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")

@@ -21,6 +21,11 @@ GOLDEN_DRIFT_FACTOR = 2.0         # measured worst later-step tensor: 1.1e-3 (fp
 # ---- fp32-grade split arithmetic (f32x3: 16 mantissa bits per operand, ~2^-16 per product): same reference, its own bounds ----
 # logits stay within LOGIT_ATOL (measured <= 1.5e-4); gradients are 30-100x further from the reference than the fp32 MFMA's
 F32X3_GRAD_REL_L2_MEDIAN = 2e-4    # measured <= 2.0e-5
+# ... except in a step where a hidden unit of the TRN bottleneck sits within round-off of zero and lands on the other side of the ReLU
+# than in the oracle: its whole gradient row then differs, and with it every tensor upstream.  Measured once (headline shape, third step,
+# stored hi / lo planes): ONE element of Zr is 6.8e-7 instead of 0.0, 442 elements of gZ1 follow, the step's median is 4.3e-4
+# (profiles/r03_parity_floors.txt).  At most ONE step of a case may exceed the median bound, and only up to this:
+F32X3_GRAD_REL_L2_MEDIAN_TIE = 1e-3
 F32X3_GRAD_REL_L2 = 1.5e-2   # measured worst 5.3e-3
 F32X3_GRAD_MAX_SCALE = 6e-2  # measured worst 2.2e-2
 

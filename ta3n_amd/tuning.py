@@ -20,6 +20,8 @@ TUNED = {
     (202, 5, 2048, 512, "f32"): [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222],
     # the same shape, fp32-grade contractions as three bf16 MFMAs on split operands (TA3N_FLAG_F32_SPLIT): fp32 stage images
     (202, 5, 2048, 512, "f32x3"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3114, 2118, 3124, 2212, 2124],
+    # ... and with "pair twins" (TA3N_FLAG_F32_SPLIT | _BF16_STORE: the producers store the hi and the lo plane): bf16 stage images of 64 k
+    (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2114, 2124, 2122, 2122],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
     (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2222, 32222, 2222, 2214, 32222, 3222],
 }
@@ -28,7 +30,7 @@ TUNED = {
 def tuned_phase_tiles(batch: int, num_segments: int, feature_dim: int, fc_dim: int, bf16: bool, twins: bool,
                       split: bool = False) -> Optional[List[int]]:
     """The measured list for this shape, or None (the plan builder's heuristic then picks per launch)."""
-    key = (int(batch), int(num_segments), int(feature_dim), int(fc_dim), "f32x3" if split else ("bf16" if bf16 else "f32"))
+    key = (int(batch), int(num_segments), int(feature_dim), int(fc_dim), ("f32x3p" if twins else "f32x3") if split else ("bf16" if bf16 else "f32"))
     t = TUNED.get(key)
     if t is None:
         return None

@@ -57,7 +57,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
                 "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2", "o_Z0", "o_gZ0", "o_bn_batch", "o_bn_run",
-                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b"]
+                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b", "pair_delta"]
 
 
 class Geom(C.Structure):
@@ -241,8 +241,10 @@ class Interp:
                     ab, ao = (BASE_P, s.a_off * 2) if s.a_base == BASE_P16 else untwin(s.a_off)
                     bb, bo = (BASE_P, s.b_off * 2) if s.b_base == BASE_P16 else untwin(s.b_off)
                     assert s.a_base in (BASE_WS, BASE_P16) and s.b_base in (BASE_WS, BASE_P16)
-                    A = round_bf16(self.operand(ab, ao, s.a_ld, s.a_kmajor, t.m0, nr, s.klen))
-                    Bm = round_bf16(self.operand(bb, bo, s.b_ld, s.b_kmajor, t.n0, nc, s.klen))
+                    A = self.operand(ab, ao, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
+                    Bm = self.operand(bb, bo, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)
+                    if not (ph.bf16 & 32):      # (pair twins, bit 32: hi + lo planes = the original to 16 mantissa bits; modelled as exact)
+                        A, Bm = round_bf16(A), round_bf16(Bm)
                     rowsum += A.sum(1)          # the bias gradient of a twin-reading tile sums the rounded values
                     acc += A @ Bm.T
                     acc *= self.scale(s.scale_kind)

@@ -44,14 +44,21 @@ def _median(m):
 
 
 def _check(grad_m, logit_err, arith):
-    l2_tol, med_tol, mx_tol = ((tol.F32X3_GRAD_REL_L2, tol.F32X3_GRAD_REL_L2_MEDIAN, tol.F32X3_GRAD_MAX_SCALE) if arith == "f32x3" else
+    l2_tol, med_tol, mx_tol = ((tol.F32X3_GRAD_REL_L2, tol.F32X3_GRAD_REL_L2_MEDIAN, tol.F32X3_GRAD_MAX_SCALE) if arith.startswith("f32x3") else
                                (tol.F32_GRAD_REL_L2, tol.F32_GRAD_REL_L2_MEDIAN, tol.F32_GRAD_MAX_SCALE))
+    over = []
     for s, m in enumerate(grad_m):
         for k, (l2, mx, n) in m.items():
             assert l2 <= l2_tol and mx <= mx_tol, f"step {s} {k}: rel. L2 {l2:.3e}, max/scale {mx:.3e}"
-        assert _median(m) <= med_tol, f"step {s}: median rel. L2 {_median(m):.3e}"
+        if _median(m) > med_tol:
+            over.append(s)
         for key, (err, rms) in logit_err[s].items():
             assert err < tol.LOGIT_ATOL, (s, key, err)
+    # a ReLU tie that lands on the other side than in the oracle moves every upstream tensor (tolerances.py): split arithmetic only,
+    # one step per case, bounded
+    allowed = 1 if arith.startswith("f32x3") else 0
+    assert len(over) <= allowed and all(_median(grad_m[s]) <= tol.F32X3_GRAD_REL_L2_MEDIAN_TIE for s in over), \
+        "median rel. L2 per step: " + ", ".join(f"{_median(m):.3e}" for m in grad_m)
 
 
 def _worst(m, n=3):
@@ -62,7 +69,8 @@ def _steps_against_resynced_oracle(shape, arith, steps, fused=True, wseed=11, xs
     Bs, Bt, T, D, Fc, Cn = (shape[k] for k in ("Bs", "Bt", "T", "D", "F", "C"))
     cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0)
     params = synth_state(orc.param_shapes(cfg), seed=wseed, scale=wscale)
-    kw = dict(f32_split=True) if arith == "f32x3" else dict(bf16=True, bf16_store=True) if arith == "bf16" else {}
+    kw = (dict(f32_split=True) if arith == "f32x3" else dict(f32_split=True, bf16_store=True) if arith == "f32x3p" else
+          dict(bf16=True, bf16_store=True) if arith == "bf16" else {})      # f32x3p: the split arithmetic on stored hi / lo planes ("pair twins")
     eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=clip, fused=fused, **kw)
     eng.load_state(params)
     grad_m, logit_err = [], []
@@ -90,13 +98,15 @@ def _steps_against_resynced_oracle(shape, arith, steps, fused=True, wseed=11, xs
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("arith", ["f32", "f32x3"])
+@pytest.mark.parametrize("arith", ["f32", "f32x3", "f32x3p"])
 @pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9", "mid_T12", "headline"])
 def test_every_gradient_element_matches_the_oracle(name, arith, fused, capsys):
     g = Golden(name)
     c = case_config(g)
     if not fused and name not in ("tiny_T5", "headline"):
         pytest.skip("unfused launch lists checked on two cases")
+    if not fused and arith == "f32x3p":
+        pytest.skip("pair twins are read by the fused step's launches")
     shape = dict(Bs=c["Bs"], Bt=c["Bt"], T=c["T"], D=c["D"], F=c["fc_dim"], C=c["C"])
     sched = step_schedule(c)
     grad_m, logit_err = _steps_against_resynced_oracle(shape, arith, steps=max(3, len(sched)), fused=fused, wseed=c["wseed"], xseed=c["xseed"],
@@ -108,7 +118,7 @@ def test_every_gradient_element_matches_the_oracle(name, arith, fused, capsys):
     _check(grad_m, logit_err, arith)
 
 
-@pytest.mark.parametrize("arith", ["f32", "f32x3"])
+@pytest.mark.parametrize("arith", ["f32", "f32x3", "f32x3p"])
 @pytest.mark.parametrize("shape", ["config4_T9_C30_b512", "config5_T12_D1024"])
 def test_full_shape_gradients_match_the_oracle(shape, arith, capsys):
     """BASELINE configs[3] / configs[4] at full size, two steps, all gradients in full, fp32 MFMA and the split arithmetic."""

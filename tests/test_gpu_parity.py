@@ -39,7 +39,7 @@ def test_library_loaded_and_device_is_mi355x():
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x3"])
+@pytest.mark.parametrize("split", [False, True, "pairs"], ids=["fp32", "bf16x3", "bf16x3p"])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tile", [0, 114, 118, 212, 122, 214, 124, 221, 222])
 @pytest.mark.parametrize("name", CASES)
@@ -53,9 +53,11 @@ def test_train_steps_match_reference_golden(name, tile, fused, split):
         pytest.skip("fused step checked on three tile configs")
     if split and tile not in (0, 3124, 222):
         pytest.skip("split arithmetic checked on the default and two forced tiles")
+    if split == "pairs" and not fused:
+        pytest.skip("pair twins (hi / lo planes stored by the producers) are read by the fused step's launches")
     g = Golden(name)
     c = case_config(g)
-    eng = _engine(c, tile, f32_split=split)
+    eng = _engine(c, tile, f32_split=bool(split), bf16_store=(split == "pairs"))
     _load(eng, c)
     live = set(eng.live_names())
     B, Bs, T = c["Bs"] + c["Bt"], c["Bs"], c["T"]

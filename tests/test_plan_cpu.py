@@ -150,6 +150,48 @@ def test_bf16_plan_on_cpu(store):
         g.check(f"fwd/out_{dom}", out[sl], 0.0, 0.1 * rms, "bf16 operands vs fp32 reference")
 
 
+@pytest.mark.parametrize("name", ["tiny_T5", "tiny_T3", "tiny_clip"])
+def test_pair_twin_plan_on_cpu(name):
+    """TA3N_FLAG_F32_SPLIT | _BF16_STORE ("pair twins": every twin has a hi and a lo plane, the split-arithmetic launches read both
+    and split nothing in their K loops): the launch lists reproduce the fp32 goldens (the split arithmetic is fp32-grade: modelled
+    as exact products), the lo planes mirror the hi regions at ONE displacement, and the launches that qualify read them."""
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS | _lib.FLAG_F32_SPLIT | _lib.FLAG_BF16_STORE)
+    assert plan.has_fused_step and not plan.has_fused_update
+    it = Interp(plan)
+    geo = it.g
+    regions = plan.regions      # name -> (offset, size) in floats
+    assert geo.pair_delta > 0 and geo.pair_delta % 4 == 0
+    for hi_name in ("ws16", "p16", "x16", "p16b"):
+        assert regions[hi_name + "_lo"][0] - regions[hi_name][0] == geo.pair_delta and regions[hi_name + "_lo"][1] == regions[hi_name][1]
+    assert regions["ws16_lo"][0] >= regions["p16b"][0] + regions["p16b"][1]
+    gemm = [ph for ph in it.phases if ph.group == 4 and ph.kind == 0]
+    assert [ph.bf16 & 48 for ph in gemm] == [48, 48, 48, 32, 48, 48]      # launch 5 (odd-shaped head gradients) splits fp32 operands in registers
+    with pytest.raises(ValueError):
+        _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS | _lib.FLAG_F32_SPLIT | _lib.FLAG_BF16_MFMA)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        it.run_group(4)
+        raw = it.get_params(it.G)
+        it.run_group(3, fused_norm=True)
+        coef = it.ws[it.g.o_grad_norm + 1]
+        new = it.get_params()
+        for k in shapes:
+            if k in live:
+                g.check(f"step{s}/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", ["tiny_avgpool"])
 def test_avgpool_plan_reproduces_reference(name, fused):
