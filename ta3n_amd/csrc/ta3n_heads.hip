@@ -69,9 +69,9 @@ constexpr int WPV = 4 / VPW;                         // waves per video: they sp
 static_assert(VPW == 1 || VPW == 2 || VPW == 4, "1, 2 or 4 videos per workgroup");
 static_assert(64 * TROW <= NBH * WROW, "backward tile / classifier staging must fit in the weight tile");
 
-// -DTA3N_HEADS_TIMING: workgroup 0 stamps s_memtime at every stage boundary into ws["g_attn"] (debug builds only)
+// -DTA3N_HEADS_TIMING: the 101st video workgroup stamps s_memtime at every stage boundary into ws["g_attn"] (debug builds only)
 #ifdef TA3N_HEADS_TIMING
-#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<unsigned long long *>(ptrs.ws + g.o_gattn)[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define STAMP(i) do { if ((int)blockIdx.x == g.n_frm_wg + 100 && threadIdx.x == 0) { reinterpret_cast<unsigned long long *>(ptrs.ws + g.o_gattn)[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
