@@ -71,7 +71,7 @@ class TrainEngine:
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
-                 dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0):
+                 dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none"):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -91,6 +91,17 @@ class TrainEngine:
             if dis_DA == "DAN" and len(self.place_dis) > 2 and self.place_dis[2] == "Y":
                 raise ValueError("place_dis[2]: the reference itself fails on the 3-D frame features (loss.py:49)")
             flags |= _lib.FLAG_FEATURE_GRADS
+            fused = False
+        # use_bn AdaBN / AutoDIAL (models.py:194-198, 490-543, 569-570): BatchNorm1d per domain between the shared frame FC and its
+        # ReLU - batch statistics over the rows of each domain, so the step runs as the unfused launch lists with the two BN
+        # launches (TA3N_FLAG_BN_SHARED); the running statistics are buffers of this engine (state_dict names as in the reference).
+        # Single rank: the statistics are taken over the rank's own rows (what each nn.DataParallel replica of the reference
+        # does too, but not the same numbers as one GPU on the whole batch).  AutoDIAL's mixing parameter stays at its initial 1.
+        if use_bn not in ("none", "AdaBN", "AutoDIAL"):
+            raise NotImplementedError(f"use_bn {use_bn!r} (built: AdaBN, AutoDIAL)")
+        self.use_bn = use_bn
+        if use_bn != "none":
+            flags |= _lib.FLAG_BN_SHARED
             fused = False
         if f32_split:            # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo (ta3n_hip.h) ...
             if bf16:
@@ -136,6 +147,8 @@ class TrainEngine:
             self.rank = torch.distributed.get_rank(process_group)
         if self.dis_DA != "none" and self.world > 1:
             raise NotImplementedError("dis_DA with more than one rank (the discrepancy loss couples all videos of the global batch)")
+        if self.use_bn != "none" and self.world > 1:
+            raise NotImplementedError("use_bn with more than one rank (batch statistics per rank are not the single-GPU statistics)")
         p = self.plan
         with torch.cuda.device(self.device):
             self.P = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
@@ -199,6 +212,15 @@ class TrainEngine:
                 self.peer = None
                 if self.rank == 0:
                     print(f"[ta3n] peer all-reduce unavailable ({type(ex).__name__}: {ex}); using the default exchange", flush=True)
+        # use_bn: running [source, target][mean, var][F] (nn.BatchNorm1d: zeros / ones, momentum 0.1, unbiased variance) + batch counter
+        self.bn_running: Optional[torch.Tensor] = None
+        self.bn_batches = 0
+        if self.use_bn != "none":
+            self.bn_running = torch.zeros(2, 2, self.F, dtype=torch.float32, device=self.device)
+            self.bn_running[:, 1] = 1.0
+            rows = [self.Bs * self.T, self.Bt * self.T]
+            self._bn_unbias = torch.tensor([[[1.0], [r / max(r - 1, 1)]] for r in rows], dtype=torch.float32, device=self.device)
+            self._bn_rows = rows
         self._P2: Optional[torch.Tensor] = None      # second parameter buffer of the fused-update steps (train_steps)
         self.step_count = 0
         self.skip_collective = False
@@ -230,6 +252,14 @@ class TrainEngine:
         for k, v in views.items():
             if k in state:
                 v.copy_(state[k].to(device=self.device, dtype=torch.float32))
+        if self.bn_running is not None:      # BatchNorm buffers (models.py:195-198: bn_shared_S / bn_shared_T)
+            for d, dom in enumerate("ST"):
+                for j, what in enumerate(("running_mean", "running_var")):
+                    key = f"bn_shared_{dom}.{what}"
+                    if key in state:
+                        self.bn_running[d, j].copy_(state[key].to(device=self.device, dtype=torch.float32))
+            if "bn_shared_S.num_batches_tracked" in state:
+                self.bn_batches = int(state["bn_shared_S.num_batches_tracked"])
         self.refresh_bf16(params=True)
 
     def refresh_bf16(self, x: bool = False, params: bool = False) -> None:
@@ -242,7 +272,13 @@ class TrainEngine:
                    "ta3n_refresh_bf16")
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        return {k: v.detach().clone() for k, v in self.param_views().items()}
+        out = {k: v.detach().clone() for k, v in self.param_views().items()}
+        if self.bn_running is not None:
+            for d, dom in enumerate("ST"):
+                out[f"bn_shared_{dom}.running_mean"] = self.bn_running[d, 0].clone()
+                out[f"bn_shared_{dom}.running_var"] = self.bn_running[d, 1].clone()
+                out[f"bn_shared_{dom}.num_batches_tracked"] = torch.tensor(self.bn_batches, dtype=torch.int64)
+        return out
 
     def live_names(self):
         return [n for n, _, _, live in self.plan.params if live]
@@ -293,8 +329,20 @@ class TrainEngine:
 
     # ---- launches ----
     def forward(self) -> None:
+        bn = self.bn_running is not None
+        if bn and not self._hyper.train:      # eval mode: the kernel normalises with the running statistics (region bn_run [S, T][mean, var][F])
+            self.region("bn_run").copy_(self.bn_running.reshape(-1))
         _lib.check(self._L.ta3n_forward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws.data_ptr(),
                                         self._stream()), "ta3n_forward")
+        if bn and self._hyper.train:          # nn.BatchNorm1d's buffer update from the kernel's batch statistics (bn_batch [S, T][mean, biased var, 1/std][F])
+            st = self.region("bn_batch").view(2, 3, -1)[:, :2]
+            if min(self._bn_rows) > 0:
+                self.bn_running.mul_(0.9).add_(st * self._bn_unbias, alpha=0.1)
+            else:
+                for d, r in enumerate(self._bn_rows):
+                    if r > 0:
+                        self.bn_running[d].mul_(0.9).add_(st[d] * self._bn_unbias[d], alpha=0.1)
+            self.bn_batches += 1
 
     def loss(self) -> None:
         _lib.check(self._L.ta3n_loss(self.plan.handle, self.ws.data_ptr(), self._stream()), "ta3n_loss")

@@ -1,0 +1,76 @@
+"""use_bn AdaBN / AutoDIAL on TrainEngine (the native train loop: HIP forward / loss / backward launch lists with the two BatchNorm
+launches + fused clip / Nesterov update; the running statistics are engine buffers): the reference's own trajectories
+(tests/golden/tiny_adabn, tiny_autodial, mid_adabn - recorded from the unmodified reference by tests/golden/make_golden.py):
+parameters after every step, the BatchNorm buffers at the end, the eval-mode forward through them, checkpoint round trip."""
+import pytest
+import torch
+
+from golden_util import BN_CASES, Golden, case_config, step_schedule
+from ta3n_amd.engine import TrainEngine
+from ta3n_amd.synthetic import synth_batch, synth_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(c):
+    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"], use_bn=c["use_bn"])
+
+
+@pytest.mark.parametrize("name", BN_CASES)
+def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name):
+    g = Golden(name)
+    c = case_config(g)
+    T, C = c["T"], c["C"]
+    eng = _engine(c)
+    assert not eng.fused and eng.use_bn == c["use_bn"]
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    assert "bn_shared_S.weight" in shapes and "bn_shared_T.bias" in shapes
+    eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = set(eng.live_names())
+    assert live == set(str(k) for k in g.meta("live"))
+    xs0, xt0, ys0, _ = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=c["xseed"])
+    # the fixture's plain train-mode forward comes first and moves the BatchNorm buffers like any train-mode pass
+    eng.set_batch(xs0.cuda(), xt0.cuda(), ys0.cuda())
+    eng.set_hyper([0.75, 0.75, 0.5], 0.003, c["lr"], train=True)
+    eng.forward()
+    o = eng.outputs()
+    g.check("fwd/out_s", o["out"][:c["Bs"]].cpu(), 2e-4, 2e-4)
+    g.check("fwd/feat_t_v", o["feat_v"][c["Bs"]:].cpu(), 2e-4, 2e-4)
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0            # the reference's dummy rows (main.py:359-364); BatchNorm sees them too
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, st["lr"], valid_source=st["n_src"], valid_target=st["n_tgt"])
+        torch.cuda.synchronize()
+        for k, v in eng.param_views().items():
+            g.check(f"step{s}/param/{k}", v.cpu(), 2e-4, 5e-6)
+    sd = eng.state_dict()
+    for d in "ST":
+        g.check(f"final/state/bn_shared_{d}.running_mean", sd[f"bn_shared_{d}.running_mean"].cpu(), 2e-4, 2e-5)
+        g.check(f"final/state/bn_shared_{d}.running_var", sd[f"bn_shared_{d}.running_var"].cpu(), 2e-4, 2e-5)
+        assert int(sd[f"bn_shared_{d}.num_batches_tracked"]) == int(g.z[f"final/state/bn_shared_{d}.num_batches_tracked#full"])
+    # main.validate's eval-mode forward through the running statistics.  The fixture evaluated model(xs0, xs0): its target half are
+    # the SOURCE videos normalised with the target statistics; eval-mode BatchNorm is row-independent, so the first min(Bs, Bt) rows do
+    n = min(c["Bs"], c["Bt"])
+    xt_eval = torch.zeros_like(xt0)
+    xt_eval[:n] = xs0[:n]
+    eng.set_batch(xs0.cuda(), xt_eval.cuda(), ys0.cuda())
+    eng.set_hyper([0.0, 0.0, 0.0], 0.0, 0.0, train=False)
+    eng.forward()
+    torch.cuda.synchronize()
+    ev = eng.outputs()
+    for key, got in (("eval/out_t", ev["out"][c["Bs"]:c["Bs"] + n]), ("eval/feat_t_v", ev["feat_v"][c["Bs"]:c["Bs"] + n])):
+        want = torch.from_numpy(g.z[key + "#full"]).float()[:n]
+        assert torch.allclose(got.cpu().reshape(want.shape), want, rtol=3e-4, atol=3e-4), key
+    assert eng.bn_batches == len(step_schedule(c)) + 1          # the eval pass does not move the buffers
+    # a second engine restored from the state dict continues bit-identically
+    eng2 = _engine(c)
+    eng2.load_state({k: v for k, v in sd.items()})
+    eng2.M.copy_(eng.M)
+    eng2.step_count = eng.step_count
+    xs, xt, ys, yt = synth_batch(C, T, c["D"], c["Bs"], c["Bt"], seed=999)
+    for e in (eng, eng2):
+        e.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        e.train_step([0.75, 0.75, 0.5], 0.003, 1e-3, seed=5)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.P, eng2.P) and torch.equal(eng.bn_running, eng2.bn_running) and eng.bn_batches == eng2.bn_batches

@@ -22,6 +22,8 @@ def test_headline_command_line_is_accepted():
     train_ddp.validate_options(parser.parse_args(BASE))
     train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "DAN"]))      # round 3: discrepancy losses on the engine path (one rank)
     train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "JAN"]))
+    train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AdaBN"]))     # ... and the domain BatchNorm (one rank: batch statistics)
+    train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AutoDIAL"]))
     train_ddp.validate_options(parser.parse_args(["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool"]))
 
 
@@ -30,7 +32,7 @@ def test_headline_command_line_is_accepted():
                                    ["--add_loss_DA", "target_entropy"],
                                    ["--use_target", "Sv"], ["--weighted_class_loss", "Y"], ["--weighted_class_loss_DA", "Y"],
                                    ["--pred_normalize", "Y"], ["--pretrain_source"], ["--lr_adaptive", "loss"], ["--ens_DA", "MCD"],
-                                   ["--use_bn", "AdaBN"], ["--share_params", "N"], ["--frame_aggregation", "rnn"],
+                                   ["--share_params", "N"], ["--frame_aggregation", "rnn"],
                                    ["--baseline_type", "frame"], ["--use_attn", "general"], ["--place_adv", "N", "Y", "Y"]])
 def test_unimplemented_option_values_are_rejected_not_ignored(extra):
     with pytest.raises(SystemExit) as e:

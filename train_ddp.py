@@ -64,7 +64,10 @@ def validate_options(args, module_path: bool = False) -> None:
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
     else:
-        need(args.use_bn == "none", f"--use_bn {args.use_bn} (use main.py, the module path)")
+        need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
+        if args.use_bn != "none":
+            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--use_bn {args.use_bn} on more than one rank (batch statistics per rank are not the "
+                 "single-GPU statistics: one GPU, or main.py)")
     need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
     need(args.use_target in ("none", "uSv"), f"--use_target {args.use_target} (target labels in the classification loss are not built)")
     need(args.weighted_class_loss == "N", "--weighted_class_loss Y")
@@ -146,7 +149,7 @@ def main():
                       dropout_v=args.dropout_v, momentum=args.momentum, weight_decay=args.weight_decay,
                       clip=args.clip_gradient, device=dev, bf16=(args.arithmetic == "bf16"), bf16_store=(args.arithmetic == "bf16"),
                       f32_split=(args.arithmetic == "f32x3"), aggregation=args.frame_aggregation,
-                      dis_DA=args.dis_DA, place_dis=args.place_dis, alpha=max(args.alpha, 0.0))
+                      dis_DA=args.dis_DA, place_dis=args.place_dis, alpha=max(args.alpha, 0.0), use_bn=args.use_bn)
     from ta3n_amd.models import VideoModel
     torch.manual_seed(1)
     model = VideoModel(num_class, args.baseline_type, args.frame_aggregation, args.modality, train_segments=T,
