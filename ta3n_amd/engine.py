@@ -71,7 +71,8 @@ class TrainEngine:
                  phase_tiles: Optional[Sequence[int]] = None, xcd_aware: int = 0, fused: bool = True,
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
-                 dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none"):
+                 dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
+                 ens_DA: str = "none", mu: float = 0.0):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -103,6 +104,21 @@ class TrainEngine:
         if use_bn != "none":
             flags |= _lib.FLAG_BN_SHARED
             fused = False
+        # ens_DA MCD (Maximum Classifier Discrepancy; models.py:276-279, 682-684, 716-720; main.py:447-448, 548-556): a second video
+        # classifier, its cross-entropy on the source rows, and a SECOND forward with GradReverse(mu) behind dropout_v whose loss is
+        # -mean |softmax(out_target) - softmax(out_target_2)|.  Here: the unfused launch lists with the second classifier
+        # (TA3N_FLAG_MCD), a second workspace for the reversed pass, the two small logit-level losses in torch, gradients of the
+        # two passes added.  Single rank.
+        if ens_DA not in ("none", "MCD"):
+            raise NotImplementedError(f"ens_DA {ens_DA!r} (built: MCD)")
+        self.ens_DA, self.mu = ens_DA, float(mu)
+        self.loss_s = None                       # device scalar: the MCD discrepancy loss of the last step (main.py's loss_s)
+        self.loss_c2 = None                      # ... and the second classifier's cross-entropy on the source rows
+        if ens_DA == "MCD":
+            if use_bn != "none":
+                raise NotImplementedError("ens_DA MCD with use_bn (the second forward moves the BatchNorm buffers again: the module path)")
+            flags |= _lib.FLAG_MCD
+            fused = False
         if f32_split:            # fp32-grade contractions as three bf16 MFMAs on operands split hi + lo (ta3n_hip.h) ...
             if bf16:
                 raise ValueError("f32_split and bf16 are different arithmetics: set one")
@@ -129,6 +145,7 @@ class TrainEngine:
                                             self.bf16, self.bf16_store, split=bool(flags & _lib.FLAG_F32_SPLIT))
         if chain is None:        # chained launches (ta3n_config.chain): the fused trn-m step in 5 launches instead of 8
             chain = os.environ.get("TA3N_CHAIN", "0") == "1" and aggregation == "trn-m" and fused
+        self._flags = int(flags)
         self.plan = _lib.Plan(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_class, flags,
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
@@ -147,6 +164,8 @@ class TrainEngine:
             self.rank = torch.distributed.get_rank(process_group)
         if self.dis_DA != "none" and self.world > 1:
             raise NotImplementedError("dis_DA with more than one rank (the discrepancy loss couples all videos of the global batch)")
+        if self.ens_DA != "none" and self.world > 1:
+            raise NotImplementedError("ens_DA MCD with more than one rank")
         if self.use_bn != "none" and self.world > 1:
             raise NotImplementedError("use_bn with more than one rank (batch statistics per rank are not the single-GPU statistics)")
         p = self.plan
@@ -160,6 +179,13 @@ class TrainEngine:
             _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws.data_ptr(), self._stream()), "ta3n_init_workspace")
         off, n = p.region("labels")
         self._labels = self.ws[off:off + n].view(torch.int32)
+        self.ws2: Optional[torch.Tensor] = None      # ens_DA MCD: workspace and gradient buffer of the reversed second pass
+        self.G2: Optional[torch.Tensor] = None
+        if self.ens_DA == "MCD":
+            with torch.cuda.device(self.device):
+                self.ws2 = torch.zeros(p.ws_floats, dtype=torch.float32, device=self.device)
+                self.G2 = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
+                _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws2.data_ptr(), self._stream()), "ta3n_init_workspace")
         # fused: forward + loss + backward as ONE C-ABI call (ta3n_train_step, 7 launches) when the plan has it
         self.fused = bool(fused) and p.has_fused_step
         # deferred update: the optimiser step of call s is enqueued at the start of call s + 1, split so that everything but
@@ -384,6 +410,80 @@ class TrainEngine:
         _lib.check(self._L.ta3n_backward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                          self.ws.data_ptr(), self._stream()), "ta3n_backward")
 
+    def _region2(self, name: str, shape=None) -> torch.Tensor:
+        off, n = self.plan.region(name)
+        t = self.ws2[off:off + n]
+        return t.view(shape) if shape is not None else t
+
+    def mcd_source_loss(self) -> None:
+        """main.py:447-448 between ta3n_loss and ta3n_backward: + CrossEntropy(out_source_2, label) over the valid source rows - its
+        logit gradient goes to region gY2 (the loss kernel knows nothing of the second classifier)."""
+        if self.ens_DA != "MCD":
+            return
+        ns = int(self._hyper.valid_source)
+        if self._flags & _lib.FLAG_ATTN_ENTROPY:      # the attentive entropy of the TARGET rows is taken on the second pass's logits
+            # (mcd_second_forward); right after ta3n_loss those rows of gY carry nothing but that term
+            self.region("gY", (self.B, self.C))[self.Bs:] = 0
+        y2 = self.region("Y2", (self.B, self.C))
+        g2 = self.region("gY2", (self.B, self.C))
+        g2.zero_()
+        if ns > 0:
+            lab = self._labels[:ns].long()
+            lp = torch.log_softmax(y2[:ns], 1)
+            inv = float(self._hyper.inv_n_cls)
+            g = lp.exp()
+            g[torch.arange(ns, device=self.device), lab] -= 1.0
+            g2[:ns] = g * inv
+            self.loss_c2 = -(lp[torch.arange(ns, device=self.device), lab]).sum() * inv
+        else:
+            self.loss_c2 = y2.new_zeros(())
+
+    def mcd_second_forward(self) -> None:
+        """main.py:548-556: the whole model again with reverse=True (GradReverse(mu) between dropout_v and the video heads,
+        models.py:682-684; fresh dropout masks) and loss_s = -dis_MCD(out_target, out_target_2) (loss.py:29-30) over the valid target
+        rows.  The reference REBINDS out_target to this pass's logits before it assembles the attentive entropy (main.py:549 vs
+        :559-562), so the target half of that loss belongs to this pass too: its logit gradient moves from the first pass's gY to
+        this one's (where GradReverse(mu) scales it on the way to the features), and the first pass's video-domain logits, which
+        weight it, see this pass's entropies."""
+        h = _lib.Hyper.from_buffer_copy(self._hyper)
+        h.reverse, h.mu = 1, float(self.mu)
+        h.seed_i, h.seed_v = dropout_seeds(int(self._hyper.seed_i) ^ 0x5bd1e995, self.rank)
+        L, plan = self._L, self.plan
+        _lib.check(L.ta3n_set_hyper(plan.handle, self.ws2.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
+        _lib.check(L.ta3n_forward(plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws2.data_ptr(), self._stream()), "ta3n_forward")
+        nt = int(self._hyper.valid_target)
+        for name in ("gY", "gY2", "gPr", "gPv", "gPf", "g_attn", "gV_ext"):
+            if name in plan.regions:
+                self._region2(name).zero_()
+        self.loss_s = self.ws2.new_zeros(())
+        if nt == 0:
+            return
+        rows = slice(self.Bs, self.Bs + nt)
+        y = self._region2("Y", (self.B, self.C))[rows].detach().clone().requires_grad_(True)
+        y2 = self._region2("Y2", (self.B, self.C))[rows].detach().clone().requires_grad_(True)
+        loss = -torch.mean(torch.abs(torch.softmax(y, 1) - torch.softmax(y2, 1)))
+        self.loss_s = loss.detach()
+        if self._flags & _lib.FLAG_ATTN_ENTROPY:
+            def ent(z):
+                return torch.sum(-torch.softmax(z, 1) * torch.log_softmax(z, 1), 1)
+            scale = float(self._hyper.gamma) * float(self._hyper.inv_n_ent)
+            y_first = self.region("Y", (self.B, self.C))[rows].detach()
+            pv = self.region("Pv", (self.B, 2))[rows].detach().clone().requires_grad_(True)
+            w = 1.0 + ent(pv)
+            e_new, e_old = scale * torch.sum(w * ent(y)), scale * torch.sum(w * ent(y_first))
+            gpv, = torch.autograd.grad(e_new - e_old, pv, retain_graph=True)
+            self.region("gPv", (self.B, 2))[rows] += gpv   # (zero when the two passes drew the same dropout masks)
+            loss = loss + e_new
+        g1, g2 = torch.autograd.grad(loss, (y, y2))
+        self._region2("gY", (self.B, self.C))[rows] = g1
+        self._region2("gY2", (self.B, self.C))[rows] = g2
+
+    def mcd_second_backward(self) -> None:
+        _lib.check(self._L.ta3n_backward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G2.data_ptr(), self.ws2.data_ptr(),
+                                         self._stream()), "ta3n_backward")
+        n = self.plan.live_floats
+        self.G[:n].add_(self.G2[:n])
+
     def all_reduce_grads(self) -> None:
         if self.skip_collective:      # measurement only (bench.py: the step without its exchange -> exposed collective time)
             return
@@ -447,8 +547,13 @@ class TrainEngine:
         else:
             self.forward()
             self.loss()
+            self.mcd_source_loss()
             self.discrepancy()
+            if self.ens_DA == "MCD":
+                self.mcd_second_forward()
             self.backward()
+            if self.ens_DA == "MCD":
+                self.mcd_second_backward()
         self.all_reduce_grads()
         if self.fused and self.world == 1 and not self._ddp_selftest:
             self.sgd_step_fused()       # local gradients are final: their norm partials are already in ws

@@ -24,6 +24,7 @@ def test_headline_command_line_is_accepted():
     train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "JAN"]))
     train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AdaBN"]))     # ... and the domain BatchNorm (one rank: batch statistics)
     train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AutoDIAL"]))
+    train_ddp.validate_options(parser.parse_args(BASE + ["--ens_DA", "MCD", "--mu", "0.5"]))      # ... and MCD's second classifier / reversed pass
     train_ddp.validate_options(parser.parse_args(["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool"]))
 
 
@@ -31,7 +32,7 @@ def test_headline_command_line_is_accepted():
                                                                                      "--add_loss_DA", "none"],
                                    ["--add_loss_DA", "target_entropy"],
                                    ["--use_target", "Sv"], ["--weighted_class_loss", "Y"], ["--weighted_class_loss_DA", "Y"],
-                                   ["--pred_normalize", "Y"], ["--pretrain_source"], ["--lr_adaptive", "loss"], ["--ens_DA", "MCD"],
+                                   ["--pred_normalize", "Y"], ["--pretrain_source"], ["--lr_adaptive", "loss"], ["--ens_DA", "MCD", "--use_bn", "AdaBN"], ["--mu", "0.5"],
                                    ["--share_params", "N"], ["--frame_aggregation", "rnn"],
                                    ["--baseline_type", "frame"], ["--use_attn", "general"], ["--place_adv", "N", "Y", "Y"]])
 def test_unimplemented_option_values_are_rejected_not_ignored(extra):

@@ -60,7 +60,11 @@ def validate_options(args, module_path: bool = False) -> None:
             need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--dis_DA {args.dis_DA} on more than one rank (the discrepancy loss couples all "
                  "videos of the global batch: one GPU, or main.py)")
             need(args.frame_aggregation == "trn-m", f"--dis_DA {args.dis_DA} with avgpool (use main.py, the module path)")
-        need(args.ens_DA == "none", f"--ens_DA {args.ens_DA} (use main.py, the module path)")
+        need(args.ens_DA in ("none", "MCD"), f"--ens_DA {args.ens_DA}")
+        if args.ens_DA == "MCD":
+            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, "--ens_DA MCD on more than one rank (one GPU, or main.py)")
+            need(args.use_bn == "none", "--ens_DA MCD with --use_bn (use main.py, the module path)")
+            need(args.frame_aggregation == "trn-m", "--ens_DA MCD with avgpool (use main.py, the module path)")
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
     else:
@@ -80,7 +84,7 @@ def validate_options(args, module_path: bool = False) -> None:
     need(args.share_params == "Y", "--share_params N")
     need(args.add_fc == 1, f"--add_fc {args.add_fc}")
     need(args.modality == "RGB", f"modality {args.modality} (pre-extracted RGB features)")
-    need(args.mu == 0 or (module_path and args.ens_DA == "MCD"), f"--mu {args.mu} (only used by --ens_DA MCD)")
+    need(args.mu == 0 or args.ens_DA == "MCD", f"--mu {args.mu} (only used by --ens_DA MCD)")
     need(len(args.beta) == 3 and len(args.place_adv) == 3, "--beta and --place_adv take three values [relation, video, frame]")
     need(len(args.batch_size) >= 2, "-b needs at least the source and target batch sizes")
     need(args.arch in ARCH_FEATURE_DIM, f"--arch {args.arch}")
@@ -149,7 +153,8 @@ def main():
                       dropout_v=args.dropout_v, momentum=args.momentum, weight_decay=args.weight_decay,
                       clip=args.clip_gradient, device=dev, bf16=(args.arithmetic == "bf16"), bf16_store=(args.arithmetic == "bf16"),
                       f32_split=(args.arithmetic == "f32x3"), aggregation=args.frame_aggregation,
-                      dis_DA=args.dis_DA, place_dis=args.place_dis, alpha=max(args.alpha, 0.0), use_bn=args.use_bn)
+                      dis_DA=args.dis_DA, place_dis=args.place_dis, alpha=max(args.alpha, 0.0), use_bn=args.use_bn,
+                      ens_DA=args.ens_DA, mu=args.mu)
     from ta3n_amd.models import VideoModel
     torch.manual_seed(1)
     model = VideoModel(num_class, args.baseline_type, args.frame_aggregation, args.modality, train_segments=T,
