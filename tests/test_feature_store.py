@@ -112,6 +112,40 @@ def test_gather_into_writes_the_input_and_its_bf16_twin(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--use_bn", "AdaBN"], ["--ens_DA", "MCD", "--mu", "0.5"], ["--ens_DA", "MCD", "--mu", "0.5", "--dis_DA", "DAN", "--alpha", "1"],
+                                   ["--arithmetic", "f32x3"]],
+                         ids=["adabn", "mcd", "mcd_dan", "f32x3_pair_twins"])
+def test_train_script_with_the_paper_baseline_options(tmp_path, extra):
+    """train_ddp.py on one GPU with --use_bn / --ens_DA / --dis_DA (the native loop of TrainEngine: unfused launch lists + the small
+    logit-level losses) and with the split arithmetic on stored hi / lo planes: runs, validates, checkpoints and resumes."""
+    import os
+    import subprocess
+    import sys
+    lst, D, lengths = _make_dataset(tmp_path, D=512, lengths=(3, 5, 8, 13, 21, 34, 55, 9, 6, 40, 17, 25))
+    prefix = str(tmp_path / "packed")
+    feature_store.pack(lst, prefix)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "train_ddp.py"), "no_class_file", "RGB", "a", "b", "c",
+            "--frame_aggregation", "trn-m", "--baseline_type", "video", "--arch", "resnet18", "--num_segments", "5",
+            "--add_fc", "1", "--fc_dim", "64", "-b", "6", "4", "6", "--lr", "0.01", "--lr_adaptive", "dann",
+            "--use_target", "uSv", "--adv_DA", "RevGrad", "--use_attn", "TransAttn", "--add_loss_DA", "attentive_entropy",
+            "--place_adv", "Y", "Y", "Y", "--beta", "0.75", "0.75", "0.5", "--gamma", "0.003", "--print_freq", "1",
+            "--feature_store", prefix, prefix, prefix, "--exp_path", str(tmp_path / "exp") + "/", "--save_model"] + extra
+    r = subprocess.run(base + ["--epochs", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("Train: [") >= 2 and r.stdout.count("Test: [") == 2 and "nan" not in r.stdout.lower(), r.stdout[-2000:]
+    if "MCD" in extra:
+        assert "loss_s" in r.stdout
+    ck = os.path.join(str(tmp_path / "exp"), "RGB", "checkpoint.pth.tar")
+    assert os.path.exists(ck)
+    sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+    if "AdaBN" in extra:      # the engine's running statistics, not the initial buffers of the VideoModel it was initialised from
+        assert int(sd["module.bn_shared_S.num_batches_tracked"]) > 0 and sd["module.bn_shared_S.running_var"].ne(1).any()
+    r2 = subprocess.run(base + ["--epochs", "3", "--resume", ck], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "=> loaded checkpoint" in r2.stdout and r2.stdout.count("Test: [") == 1, r2.stdout[-2000:] + r2.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("arithmetic", ["f32", "bf16"])
 def test_train_script_end_to_end_from_packed_stores(tmp_path, arithmetic):
     """train_ddp.py on one GPU: batches gathered on the device from packed stores, DANN schedules, device-side

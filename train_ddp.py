@@ -238,8 +238,13 @@ def main():
                 torch.distributed.all_reduce(scal)
             if rank == 0:
                 v = scal.tolist()
+                extra = ""      # the terms the loss kernel does not know (one rank only): main.py's loss_d / loss_s
+                if eng.loss_d is not None:
+                    extra += f" loss_d {eng.loss_d.item():.4f}"
+                if eng.loss_s is not None:
+                    extra += f" loss_s {eng.loss_s.item():.4f} loss_c2 {eng.loss_c2.item():.4f}"
                 print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
-                      f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
+                      f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f}{extra} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
 
         def flush_chunk():
             if not chunk:
