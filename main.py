@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 from ta3n_amd.dataset import TSNDataSet  # noqa: E402
 from ta3n_amd.loss import JAN, attentive_entropy, dis_MCD, mmd_rbf  # noqa: E402
 from ta3n_amd.models import VideoModel  # noqa: E402
+from ta3n_amd import accel as _accel  # noqa: E402
+_accel.install()      # clip_grad_norm_ / SGD.step as passes over VideoModel's flat buffers (same arithmetic; TA3N_ACCEL=0: torch's own)
 from ta3n_amd.opts import parser  # noqa: E402
 from train_ddp import train_list_sizes, validate_options  # noqa: E402
 

@@ -1,0 +1,187 @@
+"""Single-pass gradient clipping and optimiser step for code that drives ta3n_amd.models.VideoModel with the reference's own loop
+(main.py:578-583: torch.nn.utils.clip_grad_norm_(model.parameters(), 20) then torch.optim.SGD.step()).
+
+VideoModel keeps its parameters in one flat buffer and (models._deliver_grads) hands out their gradients as views into another, so
+both calls can be a few passes over flat memory instead of ~36 per-tensor norms and ~190 per-tensor update kernels:
+
+  * install() wraps torch.nn.utils.clip_grad_norm_ and registers a global optimiser step pre-hook.  Each acts ONLY when every
+    parameter it is given belongs to one VideoModel whose .grad tensors are still the flat views, the norm is the 2-norm, and the
+    optimiser is torch.optim.SGD with one parameter group, nesterov momentum, no dampening (what main.py:83 builds); anything else
+    goes to torch's own code untouched.
+  * The arithmetic is torch's, element for element: total_norm = ||g||_2, g *= min(max_norm / (total_norm + 1e-6), 1);
+    d = g + wd p; m = mu m + d; p -= lr (d + mu m).  (The norm is one reduction over the flat buffer instead of a norm of
+    per-tensor norms: same value up to fp32 summation order.)
+  * Momentum lives in one flat buffer of the model; optimizer.state[p]['momentum_buffer'] are views into it, so
+    optimizer.state_dict() / load_state_dict() (the reference's checkpoints, main.py:266-274, 94-106) keep working.
+  * For the duration of the wrapped SGD.step() the group's parameter list is empty (it then finds nothing to do); a post-hook puts it
+    back.  The gradients are left as they are - after step() they are the clipped gradients, as with torch's own step.
+
+compat/ (the import shim under which the reference's main.py runs) and the repository's main.py call install(); TA3N_ACCEL=0 in the
+environment keeps torch's code paths."""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Optional
+
+import torch
+
+_installed = False
+_orig_clip = None
+_hook_handle = None
+_post_handle = None
+
+
+def _owner_and_items(params):
+    """The VideoModel that owns every tensor of `params` (flat storage, ta3n_amd.models._ensure_flat), else None."""
+    ref = getattr(params[0], "_ta3n_owner", None) if params else None
+    model = ref() if ref is not None else None
+    if model is None:
+        return None
+    mine = model.__dict__.get("_accel_params")           # the model's own parameter objects, in parameters() order
+    if mine is None or len(mine) != len(params):
+        mine = model.__dict__["_accel_params"] = tuple(model.parameters())
+    if len(mine) == len(params) and all(a is b for a, b in zip(mine, params)):
+        return model
+    for p in params:                                      # another order / a subset: the slow check
+        r = getattr(p, "_ta3n_owner", None)
+        if r is None or r() is not model:
+            return None
+    return model
+
+
+def _flat_range(model, params):
+    """(flat gradient buffer, n) if the gradients are exactly what models._deliver_grads handed out - every parameter of the live
+    prefix [0, n) has a .grad that is the matching view of model._grad_flat, nobody else has one - else None."""
+    flat = model._grad_flat
+    if flat is None or model._flat is None:
+        return None
+    # every parameter of the live prefix must have a gradient (one without - a discriminator whose logits feed no loss - is skipped
+    # by torch: no weight decay, no momentum; the flat passes would touch it).  The prefix may hold alignment padding between
+    # tensors (zeros in every buffer), so element counts of the tensors are compared, not the prefix length.
+    with_grad = [p for p in params if p.grad is not None]
+    if not with_grad or sum(p.numel() for p in with_grad) != model._grad_live_elems:
+        return None
+    base_g, base_p = flat.data_ptr(), model._flat.data_ptr()
+    # _deliver_grads assigned every view in one go; a .grad replaced since then is a different tensor OBJECT
+    handed = model.__dict__.get("_grad_views")
+    if handed is not None and len(handed) == len(with_grad) and all(p.grad is g for p, g in zip(with_grad, handed)):
+        return flat, model._grad_live_floats
+    for p in with_grad:
+        off = (p.data_ptr() - base_p) // 4
+        if off < 0 or off + p.numel() > flat.numel() or p.grad.data_ptr() != base_g + 4 * off or not p.grad.is_contiguous():
+            return None
+    return flat, model._grad_live_floats
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = list(parameters)
+    model = _owner_and_items(params) if (float(norm_type) == 2.0 and params) else None
+    rng = _flat_range(model, params) if model is not None else None
+    if rng is None:
+        return _orig_clip(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite, foreach=foreach)
+    flat, n = rng
+    g = flat[:n]
+    total = torch.linalg.vector_norm(g, 2.0)
+    if error_if_nonfinite and not torch.isfinite(total):
+        raise RuntimeError("The total norm of order 2.0 for gradients from `parameters` is non-finite, so it cannot be clipped.")
+    coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+    g.mul_(coef)
+    return total
+
+
+def _sgd_pre_hook(optimizer, args, kwargs):
+    if type(optimizer) is not torch.optim.SGD or len(optimizer.param_groups) != 1:
+        return None
+    grp = optimizer.param_groups[0]
+    if not grp.get("nesterov") or grp.get("dampening", 0) != 0 or grp.get("maximize") or grp.get("momentum", 0) <= 0:
+        return None
+    if (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:      # (args[0] is the optimiser itself) a closure: torch's step
+        return None
+    params = grp["params"]
+    model = _owner_and_items(params)
+    rng = _flat_range(model, params) if model is not None else None
+    if rng is None:
+        return None
+    flat, n = rng
+    P, G = model._flat[:n], flat[:n]
+    M = model._mom_flat
+    base_p = model._flat.data_ptr()
+    if M is None or M.numel() != model._flat.numel() or M.device != model._flat.device:
+        M = model._mom_flat = torch.zeros_like(model._flat)
+    # momentum buffers the optimiser already holds elsewhere (load_state_dict, or steps taken before install()) move into the flat buffer
+    base_m = M.data_ptr()
+    bound = (id(optimizer.state), base_m, len(optimizer.state))
+    for p in (params if optimizer.__dict__.get("_ta3n_bound") != bound else ()):
+        if p.grad is None:
+            continue
+        st = optimizer.state[p]
+        off = (p.data_ptr() - base_p) // 4
+        buf = st.get("momentum_buffer")
+        if buf is None or buf.data_ptr() != base_m + 4 * off:
+            view = M[off:off + p.numel()].view(p.shape)
+            if buf is not None:
+                view.copy_(buf)
+            st["momentum_buffer"] = view
+    optimizer.__dict__["_ta3n_bound"] = (id(optimizer.state), base_m, len(optimizer.state))
+    lr, mu, wd = float(grp["lr"]), float(grp["momentum"]), float(grp["weight_decay"])
+    D = model.__dict__.get("_accel_scratch")
+    if D is None or D.numel() != flat.numel() or D.device != flat.device:
+        D = model.__dict__["_accel_scratch"] = torch.empty_like(flat)
+    with torch.no_grad():          # torch.optim.SGD's operations in its order; the gradients stay as they are, like there
+        Dn, Mn = D[:n], M[:n]
+        torch.add(G, P, alpha=wd, out=Dn)
+        Mn.mul_(mu).add_(Dn)
+        Dn.add_(Mn, alpha=mu)
+        P.add_(Dn, alpha=-lr)
+    # the wrapped SGD.step() must find nothing to do: its parameter list is empty for its duration (_sgd_post_hook puts it back)
+    optimizer.__dict__["_ta3n_params"] = params
+    grp["params"] = []
+    return None
+
+
+def _sgd_post_hook(optimizer, args, kwargs):
+    params = optimizer.__dict__.pop("_ta3n_params", None)
+    if params is not None:
+        optimizer.param_groups[0]["params"] = params
+    return None
+
+
+def install() -> bool:
+    """Idempotent.  Returns whether the fast paths are active (False with TA3N_ACCEL=0)."""
+    global _installed, _orig_clip, _hook_handle, _post_handle
+    if os.environ.get("TA3N_ACCEL", "1") == "0":
+        return False
+    if _installed:
+        return True
+    from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+    _orig_clip = torch.nn.utils.clip_grad_norm_
+    torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
+    try:
+        import torch.nn.utils.clip_grad as _cg
+        _cg.clip_grad_norm_ = clip_grad_norm_
+    except Exception:      # noqa: BLE001
+        pass
+    _hook_handle = register_optimizer_step_pre_hook(_sgd_pre_hook)
+    _post_handle = register_optimizer_step_post_hook(_sgd_post_hook)
+    _installed = True
+    return True
+
+
+def uninstall() -> None:
+    global _installed, _hook_handle, _post_handle
+    if not _installed:
+        return
+    torch.nn.utils.clip_grad_norm_ = _orig_clip
+    try:
+        import torch.nn.utils.clip_grad as _cg
+        _cg.clip_grad_norm_ = _orig_clip
+    except Exception:      # noqa: BLE001
+        pass
+    for h in (_hook_handle, _post_handle):
+        if h is not None:
+            h.remove()
+    _hook_handle = _post_handle = None
+    _installed = False

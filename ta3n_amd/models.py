@@ -71,6 +71,65 @@ def _bn_after_forward(model, plan, ws, train, Bs, Bt):
                 mod.num_batches_tracked += 1
 
 
+def _backward_buffer(model, plan, dev):
+    """(flat gradient buffer for one backward pass, fresh).  fresh: no parameter holds a gradient (the usual iteration after
+    zero_grad(set_to_none=True)) - the pass writes into the model's PERSISTENT buffer, whose per-parameter views are cached, so
+    handing the gradients out costs one attribute store per parameter.  Otherwise (a second backward before zero_grad: MCD's
+    reversed pass, gradient accumulation) a temporary whose content is then added.  The alignment gaps between tensors and the
+    parameters without a gradient read as zeros in either (ta3n_backward writes every live gradient in full, nothing else)."""
+    items = model._flat_items(plan)
+    if all(p.grad is None for _, _, _, p in items):
+        buf = model._grad_buf
+        if buf is None or buf.numel() != plan.param_floats or buf.device != dev:
+            buf = model._grad_buf = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+            model._grad_buf_views = [buf[off:off + p.numel()].view(shape) for _, off, shape, p in items]
+        return buf, True
+    return torch.zeros(plan.param_floats, dtype=torch.float32, device=dev), False
+
+
+def _deliver_grads(model, plan, grads, fresh, unused, needs_grad) -> None:
+    """Hands the parameter gradients of one backward pass to autograd's consumers WITHOUT going through 48 AccumulateGrad nodes
+    (each clones what a Python Function returns: ~0.4 ms of copies per step): every parameter's .grad becomes a VIEW into one flat
+    buffer laid out like the parameters (`model._grad_flat`; what clip_grad_norm_ / the optimiser then read - ta3n_amd.accel makes
+    those two single passes over it).  Like torch with zero_grad(set_to_none=False), the buffer is reused by the next iteration.
+    Parameters whose logits fed no loss keep grad None, like in the reference (see _HipForward.backward).
+    grads, fresh: _backward_buffer's; needs_grad: per plan parameter."""
+    items = model._flat_items(plan)
+    live_n = plan.live_floats
+    if fresh:
+        model._grad_flat = target = grads
+        views = model._grad_buf_views
+    else:
+        flat = model._grad_flat
+        mine = flat is not None and flat.device == grads.device and flat.numel() == grads.numel()
+        if mine:      # do the existing .grad tensors still live in the flat buffer (nobody replaced them)?
+            base = flat.data_ptr()
+            mine = all(p.grad is None or p.grad.data_ptr() == base + 4 * off for _, off, _, p in items)
+        if mine:
+            flat[:live_n].add_(grads[:live_n])
+            target = flat
+            views = model._grad_buf_views if flat is model._grad_buf else None
+        else:         # somebody else's .grad tensors: accumulate into them one by one
+            target = views = None
+    for k, ((name, off, shape, p), (_, _, _, live), need) in enumerate(zip(items, plan.params, needs_grad)):
+        if not live or not need or name.startswith(unused):
+            continue
+        if target is None:
+            g = grads[off:off + p.numel()].view(shape)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.add_(g)
+        elif p.grad is None:
+            p.grad = views[k] if views is not None else target[off:off + p.numel()].view(shape)
+    model._grad_live_floats = live_n
+    # (ta3n_amd.accel: the tensor objects handed out, in parameters() order - a .grad somebody replaced is another object)
+    model.__dict__["_grad_views"] = [p.grad for p in model.parameters() if p.grad is not None] if target is not None else None
+    if model._grad_live_elems_plan is not plan:
+        model._grad_live_elems = sum(p.numel() for (_, _, _, p), (_, _, _, live) in zip(items, plan.params) if live)
+        model._grad_live_elems_plan = plan
+
+
 class _HipForward(torch.autograd.Function):
     """One autograd node for the whole forward; backward = ta3n_backward."""
 
@@ -136,7 +195,7 @@ class _HipForward(torch.autograd.Function):
         put("gV_ext", g_v)
         if model.ens_DA == 'MCD':
             put("gY2", g_y2)
-        grads = torch.empty(plan.param_floats, dtype=torch.float32, device=dev)     # every live gradient is written in full
+        grads, fresh = _backward_buffer(model, plan, dev)
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(L.ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
@@ -151,16 +210,8 @@ class _HipForward(torch.autograd.Function):
             unused += ["fc_feature_domain_video.", "fc_classifier_domain_video."]
         if g_pr is None and not model._attn_on:      # with TransAttn the weights are not detached (models.py:351-357): the relation
             unused += ["relation_domain_classifier_all."]      # discriminators receive a gradient through V whatever the loss uses
-        out: List[Optional[torch.Tensor]] = []
-        for name, off, shape, live in plan.params:
-            if not live or name.startswith(tuple(unused)):
-                out.append(None)            # never receives a gradient in the reference either
-                continue
-            n = 1
-            for s_ in shape:
-                n *= s_
-            out.append(grads[off:off + n].view(shape))
-        return (None, None, None, None, None, None, *out)
+        _deliver_grads(model, plan, grads, fresh, tuple(unused), ctx.needs_input_grad[6:])
+        return (None,) * (6 + ctx.n_params)
 
 
 class _HipForwardAvg(torch.autograd.Function):
@@ -190,6 +241,7 @@ class _HipForwardAvg(torch.autograd.Function):
         _lib.check(L.ta3n_forward(plan.handle, x.data_ptr(), model._flat.data_ptr(), ws.data_ptr(), stream), "ta3n_forward")
         _bn_after_forward(model, plan, ws, train, Bs, Bt)
         ctx.model, ctx.plan, ctx.x, ctx.ws = model, plan, x, ws
+        ctx.n_params = len(params)
         B, Cn = Bs + Bt, model.num_class
 
         def reg(name, shape):
@@ -215,7 +267,7 @@ class _HipForwardAvg(torch.autograd.Function):
                 ws[off:off + n].zero_()
             else:
                 ws[off:off + n].copy_(g.reshape(-1))
-        grads = torch.empty(plan.param_floats, dtype=torch.float32, device=dev)     # every live gradient is written in full
+        grads, fresh = _backward_buffer(model, plan, dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(_lib.lib().ta3n_backward(plan.handle, ctx.x.data_ptr(), model._flat.data_ptr(), grads.data_ptr(), ws.data_ptr(),
                                             stream), "ta3n_backward")
@@ -225,16 +277,8 @@ class _HipForwardAvg(torch.autograd.Function):
             unused += ["fc_feature_domain.", "fc_classifier_domain."]
         if g_pv is None:
             unused += ["fc_feature_domain_video.", "fc_classifier_domain_video."]
-        out: List[Optional[torch.Tensor]] = []
-        for name, off, shape, live in plan.params:
-            if not live or name.startswith(tuple(unused)):
-                out.append(None)
-                continue
-            n = 1
-            for s_ in shape:
-                n *= s_
-            out.append(grads[off:off + n].view(shape))
-        return (None, None, None, None, None, None, *out)
+        _deliver_grads(model, plan, grads, fresh, tuple(unused), ctx.needs_input_grad[6:])
+        return (None,) * (6 + ctx.n_params)
 
 
 class VideoModel(nn.Module):
@@ -339,6 +383,13 @@ class VideoModel(nn.Module):
         self.dropout_v = nn.Dropout(p=dropout_v)
         self._enable_pbn = partial_bn
         self._flat: Optional[torch.Tensor] = None
+        self._grad_flat: Optional[torch.Tensor] = None      # the flat buffer the parameters' .grad tensors are views of (_deliver_grads)
+        self._mom_flat: Optional[torch.Tensor] = None       # ... and the momentum buffers of ta3n_amd.accel's optimiser step
+        self._items_cache = {}
+        self._grad_live_floats = self._grad_live_elems = 0
+        self._grad_live_elems_plan = None
+        self._grad_buf: Optional[torch.Tensor] = None       # persistent flat gradient buffer and its per-parameter views (_backward_buffer)
+        self._grad_buf_views = None
         self._plans: Dict[Tuple[int, int], _lib.Plan] = {}
         self._ws_init: Dict[int, torch.Tensor] = {}
         self._ws_pool: Dict[int, list] = {}
@@ -426,11 +477,29 @@ class VideoModel(nn.Module):
         named = dict(self.named_parameters())
         return [(name, off, shape, named[name]) for name, off, shape, _ in plan.params]
 
+    def _flat_items(self, plan: _lib.Plan):
+        """[(name, offset, shape, nn.Parameter)] in the plan's order, cached per plan (walking the module tree costs ~0.1 ms per
+        forward); re-validated by identity against the owning modules' _parameters dicts (a replaced Parameter object drops it)."""
+        key = id(plan)
+        hit = self._items_cache.get(key)
+        if hit is not None and all(owner._parameters.get(leaf) is p for owner, leaf, p in hit[0]):
+            return hit[1]
+        items = self._named_flat_params(plan)
+        owners = []
+        for name, _, _, p in items:
+            mod = self
+            *path, leaf = name.split(".")
+            for part in path:
+                mod = getattr(mod, part)
+            owners.append((mod, leaf, p))
+        self._items_cache[key] = (owners, items)
+        return items
+
     def _ensure_flat(self, plan: _lib.Plan, device: torch.device) -> None:
         """Parameters are views into one flat fp32 buffer laid out as the plan wants (live
         parameters first: that prefix is the gradient all-reduce / optimiser operand).
         Re-established whenever .to()/.cuda()/load replaced the parameter storage."""
-        items = self._named_flat_params(plan)
+        items = self._flat_items(plan)
         ok = self._flat is not None and self._flat.device == device
         if ok:
             base = self._flat.data_ptr()
@@ -450,6 +519,11 @@ class VideoModel(nn.Module):
                     mod = getattr(mod, part)
                 mod._buffers[leaf] = b.to(device)
         self._flat = flat
+        self._grad_flat = self._mom_flat = self._grad_buf = self._grad_buf_views = None
+        import weakref
+        me = weakref.ref(self)
+        for q in self.parameters():      # (ta3n_amd.accel recognises the model's parameters by this)
+            q._ta3n_owner = me
         self._ws_init.clear()
         self._ws_pool.clear()
 
@@ -476,7 +550,7 @@ class VideoModel(nn.Module):
         Bs, Bt = input_source.size(0), input_target.size(0)
         plan = self._plan(Bs, Bt, num_segments if self._avg else None)
         self._ensure_flat(plan, device)
-        params = [p for _, _, _, p in self._named_flat_params(plan)]
+        params = [p for _, _, _, p in self._flat_items(plan)]
         s, t = slice(0, Bs), slice(Bs, Bs + Bt)
         if self._avg:
             with torch.cuda.device(device):

@@ -47,6 +47,9 @@ def step():
     t = tick("optimizer.step", t)
 
 
+if "--accel" in sys.argv:      # ta3n_amd.accel: clip_grad_norm_ / SGD.step as passes over the flat buffers (what compat/ and main.py install)
+    from ta3n_amd import accel
+    accel.install()
 for _ in range(10):
     step()
 acc.clear()

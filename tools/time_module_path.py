@@ -37,14 +37,22 @@ def module_step():
     opt.step()
 
 
-for name, fn in (("module path (VideoModel + torch loss + torch SGD)", module_step),):
-    for _ in range(10):
-        fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 100
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    print(f"{name}: {1e6 * (time.perf_counter() - t0) / n:.0f} us/step")
+from ta3n_amd import accel
+for name, on in (("module path (VideoModel + torch loss + torch's per-tensor clip_grad_norm_ / SGD.step)", False),
+                 ("module path with ta3n_amd.accel (flat clip + flat SGD step; what compat/ and main.py install)", True)):
+    accel.install() if on else accel.uninstall()
+    fn = module_step
+    best = 1e9
+    for rep in range(3):              # host-bound loop: best of three runs of 100 steps
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); n = 100
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        best = min(best, 1e6 * (time.perf_counter() - t0) / n)
+    print(f"{name}: {best:.0f} us/step")
+accel.uninstall()
 for bf16 in (False, True):
     eng = TrainEngine(Bs, Bt, T, D, 512, C, bf16=bf16, bf16_store=bf16)
     for v in eng.param_views().values():
