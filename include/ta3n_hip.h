@@ -120,7 +120,13 @@ typedef struct {
     int32_t cost_model;      /* how the plan orders a launch's tiles over the 8 XCD queues: 0 = by the length of their K loops; 1 = by an
                               * estimate of their TIME (fixed per-tile overhead + K, weight-gradient tiles weighted up).  Ordering only:
                               * results are bit-identical. */
-    int32_t reserved[2];
+    int32_t split_k;         /* fused step, 2: every tile of the gradient at the frame features (the longest K loops of the step: up to
+                              * 3 072 deep, and the launch lasts as long as one of them) is computed by TWO workgroups, each over half of
+                              * the tile's K segments.  Each publishes its partial tile (write-through stores) and takes a ticket; the
+                              * second to arrive adds the other's partial to its own and runs the epilogue.  a + b = b + a: the result
+                              * does not depend on who arrives last; it differs from the unsplit tile by fp32 summation order.
+                              * 0: one workgroup per tile. */
+    int32_t reserved[1];
 } ta3n_config;
 
 /* Per-step scalars; lives in device memory inside ws (region "hyper").  The host

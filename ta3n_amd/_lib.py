@@ -51,7 +51,7 @@ class Config(C.Structure):
                 ("feature_dim", C.c_int32), ("fc_dim", C.c_int32), ("num_bottleneck", C.c_int32),
                 ("num_class", C.c_int32), ("flags", C.c_uint32), ("tile_config", C.c_int32),
                 ("phase_tiles", C.c_int32 * 16), ("xcd_aware", C.c_int32), ("aggregation", C.c_int32),
-                ("wgrads_late", C.c_int32), ("chain", C.c_int32), ("cost_model", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("wgrads_late", C.c_int32), ("chain", C.c_int32), ("cost_model", C.c_int32), ("split_k", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Hyper(C.Structure):
@@ -197,7 +197,7 @@ class Plan:
     def __init__(self, batch_source: int, batch_target: int, num_segments: int, feature_dim: int, fc_dim: int,
                  num_class: int, flags: int, num_bottleneck: int = 256, tile_config: int = 0,
                  phase_tiles: Optional[List[int]] = None, xcd_aware: int = 0, aggregation: int = 0, wgrads_late: int = 0,
-                 chain: int = 0, cost_model: int = 0):
+                 chain: int = 0, cost_model: int = 0, split_k: int = 0):
         L = lib()
         self.cfg = Config(batch_source, batch_target, num_segments, feature_dim, fc_dim, num_bottleneck, num_class,
                           flags, tile_config)
@@ -208,6 +208,7 @@ class Plan:
         self.cfg.wgrads_late = int(wgrads_late)
         self.cfg.chain = int(chain)
         self.cfg.cost_model = int(cost_model)
+        self.cfg.split_k = int(split_k)
         h = C.c_void_p()
         check(L.ta3n_plan_create(C.byref(self.cfg), C.byref(h)), "ta3n_plan_create")
         self.handle = h

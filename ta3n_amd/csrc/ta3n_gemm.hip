@@ -1043,6 +1043,42 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     __syncthreads();
     GSTAMP(4);
 
+    // Split-K (EPI_SPLITK): this workgroup holds the tile's sum over ITS share of the K segments.  It publishes that partial tile
+    // (write-through stores: visible to every CU once acknowledged), takes a ticket, and if it is the first of the pair it is done;
+    // the second adds the other's partial (coherent loads) to its own in the loop below.  a + b = b + a: who finishes is immaterial.
+    const float *__restrict__ split_other = nullptr;
+    if (epi & EPI_SPLITK) {
+        __shared__ int split_ticket;
+        const int half = t.pad[2] - 1;
+        float *mine = ptrs.ws + t.pad[0] + (size_t)half * (BM * BN);
+        constexpr int ITER_S = (BM * BN / 4 + NT - 1) / NT;
+#pragma unroll
+        for (int it = 0; it < ITER_S; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < BM * BN / 4) {
+                const int r = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+                const int br = r >> 5, bc = c4 >> 5;
+                const int slot0 = ((((br / RM) * WN + (bc / RN)) * WK) * RM + (br % RM)) * RN + (bc % RN);
+                float4 v4 = zero4();
+#pragma unroll
+                for (int q = 0; q < WK; ++q) {
+                    const float4 part = *reinterpret_cast<const float4 *>(&lds[(slot0 + q * RM * RN) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
+                    v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
+                }
+                st_pub(mine + (size_t)r * BN + c4, f32x4{v4.x, v4.y, v4.z, v4.w});
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *ticket = reinterpret_cast<int *>(ptrs.ws + t.pad[1]);
+        if (tid == 0) split_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (split_ticket == 0) return;                          // (uniform) the partner finishes the tile
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next step
+        split_other = ptrs.ws + t.pad[0] + (size_t)(1 - half) * (BM * BN);
+    }
+    // ... its partial tile is read in the store loop below with agent-scope loads (coherent: never served from a stale line of this
+    // XCD's L2; compiler-managed, so nothing reads the registers before the data has landed)
     const float alpha = scale_of(t.alpha_kind);
     const float gamma = scale_of(t.gamma_kind);
     const bool drop_on = (epi & (EPI_DROP_I | EPI_DROP_V)) && h_train != 0;
@@ -1109,12 +1145,19 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 for (int e = 0; e < 4; ++e) if (e < nrem) { up[e] = ptrs.p[pi + e]; um[e] = side.momentum[pi + e]; }
             }
         }
+        float other4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (split_other != nullptr) {
+            const float *op = split_other + (size_t)r * BN + c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) other4[e] = __hip_atomic_load(op + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         float4 v4 = zero4();
 #pragma unroll
         for (int q = 0; q < WK; ++q) {
             const float4 part = *reinterpret_cast<const float4 *>(&lds[(slot0 + q * RM * RN) * (32 * 36) + (r & 31) * 36 + (c4 & 31)]);
             v4.x += part.x; v4.y += part.y; v4.z += part.z; v4.w += part.w;
         }
+        if (split_other != nullptr) { v4.x += other4[0]; v4.y += other4[1]; v4.z += other4[2]; v4.w += other4[3]; }
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -57,6 +57,7 @@ struct GemmSpec {
     int M, N;
     std::vector<Seg> segs;
     Task proto;   // epilogue fields; m0/n0/seg range filled on expansion
+    int split = 0;   // 2: two tasks per tile, each over part of the Segs (EPI_SPLITK; the Segs' order is kept: a Seg with a scale stays first)
 };
 
 Task proto(int32_t c_base, int64_t c_off, int32_t c_ld) {
@@ -94,6 +95,7 @@ struct Builder {
         return r.off;
     }
 
+    int n_split_pairs = 0;      // split-K tile pairs handed out so far (EPI_SPLITK)
     int gemm_phase_index = 0;
     int force_next = 0;         // tile code for the next add_gemm_phase only (a launch that mirrors an earlier one)
     // chained launch under construction (begin_chain .. end_chain): the levels' task lists are concatenated into ONE phase whose
@@ -228,6 +230,31 @@ struct Builder {
                     t.seg_begin = seg_begin; t.seg_count = (int)g.segs.size();
                     if (t.n0 != 0) t.epi &= ~(uint32_t)EPI_ROWSUM_A;   // the bias gradient is written once per row block
                     t.cost = cost;
+                    // split-K: the Segs [0, cut) and [cut, n) go to two tasks; cut = the boundary that balances the two K sums best.
+                    // (Not for tiles with a bias gradient or a later Seg that rescales the accumulator: that scale would have to
+                    // apply to the other half's contributions too.)
+                    bool can_split = g.split == 2 && g.segs.size() >= 2 && !(t.epi & (EPI_ROWSUM_A | EPI_SUMSQ)) && !chaining;
+                    for (size_t k = 1; k < g.segs.size(); ++k) can_split = can_split && g.segs[k].scale_kind == SK_ONE;
+                    if (can_split) {
+                        int total = 0, best_cut = 1, acc_k = 0, best_diff = 1 << 30;
+                        for (auto &sg : g.segs) total += sg.klen;
+                        for (size_t k = 0; k + 1 < g.segs.size(); ++k) {
+                            acc_k += g.segs[k].klen;
+                            const int diff = std::abs(2 * acc_k - total);
+                            if (diff < best_diff) { best_diff = diff; best_cut = (int)k + 1; }
+                        }
+                        int k0 = 0;
+                        for (int k = 0; k < best_cut; ++k) k0 += g.segs[k].klen;
+                        Task h0 = t, h1 = t;
+                        h0.epi |= EPI_SPLITK; h1.epi |= EPI_SPLITK;
+                        h0.seg_count = best_cut; h1.seg_begin = seg_begin + best_cut; h1.seg_count = (int)g.segs.size() - best_cut;
+                        h0.pad[2] = 1; h1.pad[2] = 2;
+                        h0.pad[0] = h1.pad[0] = n_split_pairs++;         // (pair id; the ws offsets are assigned once the workspace is laid out)
+                        h0.cost = cost * k0 / std::max(total, 1); h1.cost = cost - h0.cost;
+                        pn.tiles.push_back(h0); pn.tiles.push_back(h1);
+                        pn.cost += cost;
+                        continue;
+                    }
                     pn.tiles.push_back(t);
                     pn.cost += cost;
                 }
@@ -1295,6 +1322,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             }
         }
     };
+    int split_f1_grad = 0;      // (set for the fused step's launches: ta3n_config.split_k)
     auto push_f1_grad = [&](std::vector<GemmSpec> &s) {   // gradient at the frame features (TRN input gradient + frame discriminator's, reversed)
         for (int f = 0; f < T; ++f) {   // gZ1[:, f] = ( -beta2 gHf[:, f] Wfd + sum_{(t,pos): tau_t[pos]==f} gZ_t W_j[:, pos] ) * [F1>0] / keep
             GemmSpec gz;
@@ -1310,6 +1338,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             gz.proto = proto(BASE_WS, g.o_gZ1 + (int64_t)f * F, ldF);
             with_mask(gz.proto, g.o_F1 + (int64_t)f * F, ldF);
             gz.proto.gamma_kind = SK_INV_KEEP_I;
+            gz.split = split_f1_grad;
             s.push_back(gz);
         }
     };
@@ -1420,6 +1449,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         const bool late_fd = (late_mask >> 1) & 1;
         const unsigned late_trn = late_mask >> 2;
         if (chain) b.begin_chain();
+        split_f1_grad = (c.split_k == 2 && !chain) ? 2 : 0;
         {
             std::vector<GemmSpec> s;
             if (chain) {      // one launch: the tiles everything else waits for (the gradient at F1) are dispatched first
@@ -1484,6 +1514,27 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }
+    if (b.n_split_pairs > 0) {      // split-K pairs: partial tiles and tickets behind everything else (outside the span the twins mirror)
+        std::vector<int64_t> pair_off(b.n_split_pairs, -1);
+        int64_t floats = 0;
+        for (const Phase &ph : p.phases) {
+            if (ph.kind != PH_GEMM) continue;
+            const int64_t tile = (int64_t)(32 * ph.wm * std::max(ph.rm, 1)) * (32 * ph.wn * std::max(ph.rn, 1));
+            for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
+                const Task &t = p.tasks[i];
+                if ((t.epi & EPI_SPLITK) && pair_off[t.pad[0]] < 0) { pair_off[t.pad[0]] = floats; floats += 2 * tile; }
+            }
+        }
+        const int64_t o_part = b.add_region("splitk_part", floats);
+        const int64_t o_tick = b.add_region("splitk_ticket", b.n_split_pairs);
+        for (auto &t : p.tasks)
+            if (t.epi & EPI_SPLITK) {
+                const int pair = t.pad[0];
+                t.pad[0] = (int32_t)(o_part + pair_off[pair]);
+                t.pad[1] = (int32_t)(o_tick + pair);
+            }
+        if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    }
     for (auto &t : p.tasks)      // (after the twin re-addressing: the copies must be the final Segs)
         if (t.seg_count > 0) t.seg0 = p.segs[t.seg_begin];
     return TA3N_OK;

@@ -35,6 +35,10 @@ enum EpiFlags : uint32_t {
                             // which would round the partials to bf16 in the bf16 configuration); honours EPI_SUMSQ
     EPI_TWIN_ONLY = 1u << 13,      // with EPI_TWIN16: do not store the fp32 tile at all (nobody reads it: every consumer reads the twin)
     EPI_TWIN_ONLY_FAN = 1u << 14,  // same for the fan-out copies
+    EPI_SPLITK = 1u << 15,  // the tile is computed by TWO tasks of the launch, each over part of its K segments (ta3n_config.split_k): pad[2] - 1 =
+                            // this task's half, pad[0] = ws offset of the pair's partial tiles [2][BM x BN], pad[1] = ws offset of its
+                            // ticket (int32, zero between launches).  Both publish their partial and take a ticket; the second adds the
+                            // other's partial and runs the epilogue, the first is done.
     EPI_SGD = 1u << 11,     // not a tile: the workgroup applies the optimiser update to params[4 pad[0] .. 4 pad[1]) (SgdSide)
     EPI_TWIN16_FAN = 1u << 10,   // same for the fan-out copies (fan_out_off)
     EPI_TWIN16 = 1u << 9,   // also store the tile rounded to bf16 at ws16 + (c_off + m * c_ld + n) * 2 bytes (c_base == BASE_WS)

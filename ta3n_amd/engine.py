@@ -72,7 +72,7 @@ class TrainEngine:
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
                  dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
-                 ens_DA: str = "none", mu: float = 0.0):
+                 ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -150,7 +150,8 @@ class TrainEngine:
                               tile_config=tile_config, phase_tiles=list(phase_tiles or []), xcd_aware=xcd_aware,
                               aggregation=_lib.AGG_AVGPOOL if aggregation == "avgpool" else _lib.AGG_TRN_M,
                               wgrads_late=int(wgrads_late), chain=int(chain),
-                              cost_model=int(os.environ.get("TA3N_COST_MODEL", "0")))
+                              cost_model=int(os.environ.get("TA3N_COST_MODEL", "0")),
+                              split_k=int(os.environ.get("TA3N_SPLIT_K", "0")) if split_k is None else int(split_k))
         self.chain = bool(chain)
         self.Bs, self.Bt, self.T, self.D, self.C = batch_source, batch_target, num_segments, feature_dim, num_class
         self.B = batch_source + batch_target

@@ -17,6 +17,7 @@ BASE_X, BASE_P, BASE_G, BASE_WS, BASE_P16 = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_ADD, EPI_RELU, EPI_MASK, EPI_DROP_I, EPI_DROP_V, EPI_SUMROWS8, EPI_SUMSQ, EPI_ROWSUM_A = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_COLSUM = 1 << 12
 EPI_SGD = 1 << 11
+EPI_SPLITK = 1 << 15
 (PH_GEMM, PH_POOL_FWD, PH_LOSS, PH_POOL_BWD, PH_GRAD_NORM, PH_SGD, PH_HEADS, PH_POOL_CLS, PH_POOL_AVG_FWD, PH_POOL_AVG_BWD,
  PH_BN_FWD, PH_BN_BWD) = range(12)
 HEADS_RPW = 16
@@ -258,6 +259,13 @@ class Interp:
                 else:
                     acc += A @ Bm.T
                 acc *= self.scale(s.scale_kind)
+            if t.epi & EPI_SPLITK:       # two tasks per tile, each over part of the K segments: the first to run leaves its partial, the second finishes
+                part = self.__dict__.setdefault("_split_parts", {})
+                key = int(t.pad[0])
+                if key not in part:
+                    part[key] = acc
+                    return
+                acc = acc + part.pop(key)
             v = acc
             m = np.arange(t.m0, t.m0 + nr)[:, None]
             n = np.arange(t.n0, t.n0 + nc)[None, :]

@@ -271,3 +271,79 @@ def test_every_task_carries_a_copy_of_its_first_segment():
                 assert bytes(t.seg0) == bytes(it.segs[t.seg_begin])
                 n += 1
         assert n > 100
+
+
+@pytest.mark.parametrize("flags", [ALL_FLAGS, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE])
+@pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9"])
+def test_split_k_plan_on_cpu(name, flags):
+    """ta3n_config.split_k = 2: every tile of the gradient at the frame features is two tasks, each over part of the K segments, that
+    meet through a partial-tile buffer and a ticket.  Structure of the pairs, and - executed in list order AND with every pair's
+    halves swapped - the reference's golden vectors."""
+    from plan_interp import EPI_SPLITK, PH_GEMM
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, split_k=2)
+    plain = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags)
+    it = Interp(plan)
+    part_off, part_n = plan.regions["splitk_part"]
+    tick_off, tick_n = plan.regions["splitk_ticket"]
+    assert "splitk_part" not in plain.regions
+    if flags & _lib.FLAG_BF16_STORE:      # behind the span the twins mirror
+        assert part_off >= plan.regions["p16b"][0] + plan.regions["p16b"][1]
+    pairs = {}
+    for ph in it.phases:
+        if ph.kind != PH_GEMM:
+            continue
+        tile = 32 * ph.wm * max(ph.rm, 1) * 32 * ph.wn * max(ph.rn, 1)
+        for i in range(ph.task_begin, ph.task_begin + ph.task_count):
+            t = it.tasks[i]
+            if t.epi & EPI_SPLITK:
+                assert ph.group in (4, 5) and t.c_base == 3 and t.seg_count >= 1 and t.pad[2] in (1, 2)
+                assert part_off <= t.pad[0] and t.pad[0] + 2 * tile <= part_off + part_n and tick_off <= t.pad[1] < tick_off + tick_n
+                pairs.setdefault((t.pad[0], t.pad[1]), []).append((i, t))
+    assert len(pairs) == tick_n > 0
+    for (po, to), halves in pairs.items():
+        assert len(halves) == 2
+        (i0, a), (i1, b) = sorted(halves, key=lambda h: h[1].pad[2])
+        assert (a.m0, a.n0, a.c_off, a.m_valid, a.n_valid) == (b.m0, b.n0, b.c_off, b.m_valid, b.n_valid)
+        assert a.seg_begin + a.seg_count == b.seg_begin                   # consecutive shares of the tile's K segments
+        ka = sum(it.segs[k].klen for k in range(a.seg_begin, a.seg_begin + a.seg_count))
+        kb = sum(it.segs[k].klen for k in range(b.seg_begin, b.seg_begin + b.seg_count))
+        assert abs(ka - kb) <= max(it.segs[k].klen for k in range(a.seg_begin, b.seg_begin + b.seg_count))
+        assert all(it.segs[k].scale_kind == 0 for k in range(b.seg_begin, b.seg_begin + b.seg_count))    # a scaled Seg stays first in the first half
+    shapes = {n: s for n, _, s, _ in plan.params}
+    live = {n for n, _, _, lv in plan.params if lv}
+    bf16 = bool(flags & _lib.FLAG_BF16_MFMA)
+    unsplit = None
+    for swap in (None, False, True):      # None: the plan without the split (what the split must reproduce up to summation order)
+        it = Interp(plain if swap is None else plan)
+        if swap:       # the second half of every pair runs first
+            idx = {}
+            for (po, to), halves in pairs.items():
+                (i0, _), (i1, _) = halves
+                idx[i0], idx[i1] = i1, i0
+            order = list(range(len(it.tasks)))
+            tasks = [it.tasks[idx.get(i, i)] for i in order]
+            it.tasks = tasks
+        it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        st = step_schedule(c)[0]
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        it.run_group(4)
+        assert not it.__dict__.get("_split_parts")                        # every partial was picked up
+        raw = it.get_params(it.G)
+        it.run_group(3, fused_norm=True)
+        coef = it.ws[it.g.o_grad_norm + 1]
+        if swap is None:
+            unsplit = raw
+            continue
+        for k in shapes:
+            if k in live:
+                assert np.allclose(raw[k], unsplit[k], rtol=1e-9, atol=1e-12), k      # (the interpreter accumulates in fp64)
+                if not bf16:
+                    g.check(f"step0/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
