@@ -14,7 +14,7 @@ if tile == 0:                     # the bench's measured per-launch tile shapes
     phase_tiles = None      # engine default: ta3n_amd/tuning.py
 bf16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
 split = len(sys.argv) > 4 and sys.argv[4] == "f32x3"
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16, bf16_store=bf16,
+eng = TrainEngine(128, 74, 5, 2048, 512, 12, tile_config=tile, xcd_aware=xcd, phase_tiles=phase_tiles, bf16=bf16, bf16_store=(bf16 or split),
                   f32_split=split)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
