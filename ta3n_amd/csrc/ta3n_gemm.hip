@@ -679,7 +679,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     constexpr bool TW = BF == 2 || BF == 4;
     constexpr bool PAIR = BF == 4;
     constexpr int EPI = NW * RM * RN * 32 * 36;      // epilogue staging (one padded 32x32 block per wave and register block)
-    constexpr int LDS_FLOATS = NS * STAGE > EPI ? NS * STAGE : EPI;
+    constexpr int LDS_FLOATS = NS * STAGE > EPI + 4 ? NS * STAGE : EPI + 4;      // (+ 4: the split-K ticket behind the epilogue staging)
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // the ONLY LDS object of the kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -722,7 +722,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
                 if (pub) st_pub(tw, u32x2{h0, h1});
                 else *tw = make_uint2(h0, h1);
-                if (pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
+                if (BF >= 3 && pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
                     const u32x2 l = {pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1)};
                     if (pub) st_pub(tw + pair_delta / 2, l);
                     else tw[pair_delta / 2] = make_uint2(l[0], l[1]);
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // the second adds the other's partial (coherent loads) to its own in the loop below.  a + b = b + a: who finishes is immaterial.
     const float *__restrict__ split_other = nullptr;
     if (epi & EPI_SPLITK) {
-        __shared__ int split_ticket;
+        int &split_ticket = *reinterpret_cast<int *>(&lds[EPI]);
         const int half = t.pad[2] - 1;
         float *mine = ptrs.ws + t.pad[0] + (size_t)half * (BM * BN);
         constexpr int ITER_S = (BM * BN / 4 + NT - 1) / NT;
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
             const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
             store_twin4(tp, lo, hi, nrem, c_vec, pub);
-            if (pair_delta)      // pair twins: the lo plane of the same four values
+            if (BF >= 3 && pair_delta)      // pair twins (split-arithmetic launches only): the lo plane of the same four values
                 store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(v[0], v[1], lo), pack_bf16_lo(v[2], v[3], hi), nrem, c_vec, pub);
         }
         if (nfan > 0) {
@@ -1249,7 +1249,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                         const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
                         const bool fvec = ((t.fan_out_off[f] | t.fan_ld) & 3) == 0;
                         store_twin4(tp, lo, hi, nrem, fvec, pub);
-                        if (pair_delta)
+                        if (BF >= 3 && pair_delta)
                             store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(ov[0], ov[1], lo), pack_bf16_lo(ov[2], ov[3], hi), nrem, fvec, pub);
                     }
                 }
