@@ -514,7 +514,7 @@ def main():
                  "f32x3": "fp32-grade contractions on the bf16 MFMA: operands split hi + lo = bf16(x) + bf16(x - hi) " +
                           ("in registers, " if args.no_twins else "by the producing kernels (hi / lo planes in HBM, nothing converted in the K loops), ") +
                           "a_hi b_hi + a_hi b_lo + a_lo b_hi accumulated in fp32 (~2^-16 per product; not IEEE fp32 multiplication); fp32 "
-                          f"stage images, parameters, gradients, optimiser; logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, every gradient "
+                          f"parameters, gradients, optimiser; logits within {tol.LOGIT_ATOL:g} of the reference's CPU path, every gradient "
                           f"tensor rel. L2 <= {tol.F32X3_GRAD_REL_L2:g} (median <= {tol.F32X3_GRAD_REL_L2_MEDIAN:g}) (same tests, [f32x3] / [bf16x3] ids)"}
         out = {
             "metric": "src+tgt videos/sec per train step, UCF->HMDB_full 5-seg TA3N" if headline else
