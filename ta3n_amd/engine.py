@@ -87,8 +87,6 @@ class TrainEngine:
         self.dis_DA, self.place_dis, self.alpha = dis_DA, tuple(place_dis), float(alpha)
         self.loss_d = None                       # device scalar: the discrepancy loss of the last step (main.py's loss_d)
         if dis_DA != "none":
-            if aggregation != "trn-m":
-                raise NotImplementedError("dis_DA on the engine path is built for trn-m (TemPooling + DAN / JAN: the module path)")
             if dis_DA == "DAN" and len(self.place_dis) > 2 and self.place_dis[2] == "Y":
                 raise ValueError("place_dis[2]: the reference itself fails on the 3-D frame features (loss.py:49)")
             flags |= _lib.FLAG_FEATURE_GRADS

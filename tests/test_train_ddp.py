@@ -25,11 +25,13 @@ def test_headline_command_line_is_accepted():
     train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AdaBN"]))     # ... and the domain BatchNorm (one rank: batch statistics)
     train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AutoDIAL"]))
     train_ddp.validate_options(parser.parse_args(BASE + ["--ens_DA", "MCD", "--mu", "0.5"]))      # ... and MCD's second classifier / reversed pass
+    avg = ["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool", "--use_attn", "none", "--add_loss_DA", "none"]
+    for extra in (["--dis_DA", "DAN"], ["--dis_DA", "JAN"], ["--ens_DA", "MCD", "--mu", "0.5"], ["--use_bn", "AdaBN"]):      # the "TemPooling + X" rows
+        train_ddp.validate_options(parser.parse_args(avg + extra))
     train_ddp.validate_options(parser.parse_args(["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool"]))
 
 
-@pytest.mark.parametrize("extra", [["--optimizer", "Adam"], ["--dis_DA", "CORAL"], ["--dis_DA", "DAN", "--frame_aggregation", "avgpool", "--use_attn", "none",
-                                                                                     "--add_loss_DA", "none"],
+@pytest.mark.parametrize("extra", [["--optimizer", "Adam"], ["--dis_DA", "CORAL"],
                                    ["--add_loss_DA", "target_entropy"],
                                    ["--use_target", "Sv"], ["--weighted_class_loss", "Y"], ["--weighted_class_loss_DA", "Y"],
                                    ["--pred_normalize", "Y"], ["--pretrain_source"], ["--lr_adaptive", "loss"], ["--ens_DA", "MCD", "--use_bn", "AdaBN"], ["--mu", "0.5"],

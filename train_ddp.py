@@ -59,12 +59,10 @@ def validate_options(args, module_path: bool = False) -> None:
         if args.dis_DA != "none":
             need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--dis_DA {args.dis_DA} on more than one rank (the discrepancy loss couples all "
                  "videos of the global batch: one GPU, or main.py)")
-            need(args.frame_aggregation == "trn-m", f"--dis_DA {args.dis_DA} with avgpool (use main.py, the module path)")
         need(args.ens_DA in ("none", "MCD"), f"--ens_DA {args.ens_DA}")
         if args.ens_DA == "MCD":
             need(int(os.environ.get("WORLD_SIZE", "1")) == 1, "--ens_DA MCD on more than one rank (one GPU, or main.py)")
             need(args.use_bn == "none", "--ens_DA MCD with --use_bn (use main.py, the module path)")
-            need(args.frame_aggregation == "trn-m", "--ens_DA MCD with avgpool (use main.py, the module path)")
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
     else:
