@@ -16,12 +16,15 @@ from typing import List, Optional
 # (videos per step, segments, feature_dim, fc_dim, arithmetic) -> per-launch tile codes
 TUNED = {
     # BASELINE configs[1] / [2]: UCF->HMDB_full, 128 + 74 videos, 5 segments, 2048-d
-    (202, 5, 2048, 512, "bf16"): [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2118, 2124, 2222, 2222],
-    (202, 5, 2048, 512, "f32"): [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 118, 118, 124, 124, 222],
+    # (entries 10-15 by the time of the whole pipelined step, tools/tune_in_sequence.py: consecutive launches of the SAME kernel
+    # instantiation are ~1 us cheaper each than a change of kernel - 3124 for the three forward levels beats their individually
+    # fastest tiles 3124 / 2214 / 2118 by 2.7 us per step)
+    (202, 5, 2048, 512, "bf16"): [3124, 3124, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3124, 3124, 2124, 2222, 2222],
+    (202, 5, 2048, 512, "f32"): [124, 118, 118, 118, 118, 118, 118, 124, 124, 222, 124, 114, 118, 124, 124, 124],
     # the same shape, fp32-grade contractions as three bf16 MFMAs on split operands (TA3N_FLAG_F32_SPLIT): fp32 stage images
     (202, 5, 2048, 512, "f32x3"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3114, 2118, 3124, 2212, 2124],
     # ... and with "pair twins" (TA3N_FLAG_F32_SPLIT | _BF16_STORE: the producers store the hi and the lo plane): bf16 stage images of 64 k
-    (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3124, 3214, 2114, 2124, 2122, 2122],
+    (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 3214, 3214, 2124, 2122, 2122],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
     (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2222, 32222, 2222, 2214, 32222, 3222],
 }

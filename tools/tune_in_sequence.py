@@ -1,0 +1,61 @@
+"""Tile choice per GEMM launch of the fused step by the time of the WHOLE pipelined step (coordinate descent over the six launches),
+not by each launch's time in isolation (bench.py --autotune / engine.autotune_phase_tiles): a launch's tile shape also decides how its
+successor finds the caches and the CUs.  Headline shape; prints the table and the final list for ta3n_amd/tuning.py.
+usage: python tools/tune_in_sequence.py [bf16|f32|f32x3] [sweeps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ta3n_amd.engine import TrainEngine
+from ta3n_amd.synthetic import synth_batch, synth_state
+from ta3n_amd.tuning import tuned_phase_tiles
+
+arith = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+kw = dict(bf16=True, bf16_store=True) if arith == "bf16" else dict(f32_split=True, bf16_store=True) if arith == "f32x3" else {}
+Bs, Bt, T, D, F, C = 128, 74, 5, 2048, 512, 12
+base = tuned_phase_tiles(Bs + Bt, T, D, F, arith == "bf16", arith != "f32", split=(arith == "f32x3"))
+stages = (2, 3) if arith != "f32" else (0,)
+CANDS = [s * 1000 + c for c in (114, 118, 212, 122, 214, 124, 221, 222) for s in stages]
+xs, xt, ys, yt = synth_batch(C, T, D, Bs, Bt, seed=1)
+xs, xt, ys = xs.cuda(), xt.cuda(), ys.cuda()
+sched = [([0.75, 0.75, 0.5], 0.003, 1e-3)] * 200
+
+
+def step_us(tiles, reps=3):
+    eng = TrainEngine(Bs, Bt, T, D, F, C, dropout_i=0.5, dropout_v=0.5, phase_tiles=tiles, **kw)
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=7, scale="init"))
+    eng.set_batch(xs, xt, ys)
+    eng.train_steps(sched[:40]); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        eng.train_steps(sched)
+        eng.flush(); torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / len(sched) * 1e6)
+    return best
+
+
+if os.environ.get("TA3N_TUNE_COMBOS"):      # "3124,3214,2118;3124,3124,2118;...": the first fused launches' tiles, alternated three times
+    combos = [[int(v) for v in c.split(",")] for c in os.environ["TA3N_TUNE_COMBOS"].split(";")]
+    for rep in range(3):
+        for c in combos:
+            t = list(base); t[10:10 + len(c)] = c
+            print(rep, c, f"{step_us(t, reps=4):.2f} us", flush=True)
+    sys.exit(0)
+cur = list(base)
+print("base", cur[10:16], f"{step_us(cur):.2f} us", flush=True)
+for sw in range(sweeps):
+    for ph in range(10, 16):
+        table = {}
+        for c in CANDS:
+            t = list(cur); t[ph] = c
+            try:
+                table[c] = step_us(t, reps=2)
+            except Exception as ex:      # noqa: BLE001 - a tile the plan rejects for this launch
+                table[c] = float("inf")
+        best = min(table, key=table.get)
+        print(f"sweep {sw} launch {ph}: " + "  ".join(f"{c}:{v:.1f}" for c, v in table.items()) + f"  -> {best} (was {cur[ph]})", flush=True)
+        if table[best] < table.get(cur[ph], 1e9) - 0.15:      # keep the incumbent unless the gain is above the run-to-run noise
+            cur[ph] = best
+print("final", cur, f"{step_us(cur, reps=5):.2f} us vs base {step_us(base, reps=5):.2f} us")
