@@ -45,6 +45,20 @@ int ensure_uploaded(ta3n_plan *p) {
     HIP_TRY(hipMemcpy(p->d_tasks, p->tasks.data(), p->tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&p->d_waits, (p->waits.size() + 1) * sizeof(Wait)));      // (+ 1: never a zero-byte allocation)
     if (!p->waits.empty()) HIP_TRY(hipMemcpy(p->d_waits, p->waits.data(), p->waits.size() * sizeof(Wait), hipMemcpyHostToDevice));
+    p->phase_kinds.assign(p->phases.size(), 0);
+    for (size_t i = 0; i < p->phases.size(); ++i) {
+        const Phase &ph = p->phases[i];
+        if (ph.kind != PH_GEMM) continue;
+        int m = 0;
+        for (int k = ph.task_begin; k < ph.task_begin + ph.task_count; ++k) {
+            const Task &t = p->tasks[k];
+            if (t.epi & EPI_SPLITK) m |= 32;      // (optional epilogue paths: only the full kernels hold them)
+            if (t.seg_count == 0 || (t.epi & (EPI_SGD | EPI_COLSUM))) continue;
+            const int kind = t.seg0.a_kmajor * 2 + t.seg0.b_kmajor;
+            m |= kind < 3 ? (1 << kind) : ((t.epi & EPI_ROWSUM_A) ? 16 : 8);
+        }
+        p->phase_kinds[i] = m;
+    }
     p->uploaded = true;
     return TA3N_OK;
 }
@@ -64,6 +78,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
     int index = -1;
     for (const Phase &ph : p->phases) {
         if (ph.group != group) continue;
+        const int kinds = p->phase_kinds.empty() ? 0 : p->phase_kinds[&ph - p->phases.data()];
         ++index;
         if (index < first_launch || index >= first_launch + n_launches) continue;
         if (!first && join_after_first) {   // everything after the first launch also depends on work the caller put on another stream
@@ -76,7 +91,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
             case PH_GEMM:
                 rc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs,
                                  p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, stream, side, static_cast<const Wait *>(p->d_waits),
-                                 p->geom.pair_delta);
+                                 p->geom.pair_delta, kinds);
                 break;
             case PH_POOL_FWD: rc = launch_pool_fwd(p->geom, ptrs, stream); break;
             case PH_LOSS: rc = launch_loss(p->geom, ptrs, stream); break;
@@ -326,7 +341,7 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
         for (int k = 0; k < r; ++k) {
             int lrc = 0;
             switch (ph.kind) {
-                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s, nullptr, static_cast<const Wait *>(p->d_waits), p->geom.pair_delta); break;
+                case PH_GEMM: lrc = launch_gemm(ph, static_cast<const Task *>(p->d_tasks), static_cast<const Seg *>(p->d_segs), ptrs, p->geom.o_hyper, p->geom.o_zeros, p->geom.o_ws16, s, nullptr, static_cast<const Wait *>(p->d_waits), p->geom.pair_delta, p->phase_kinds.empty() ? 0 : p->phase_kinds[i]); break;
                 case PH_POOL_FWD: lrc = launch_pool_fwd(p->geom, ptrs, s); break;
                 case PH_LOSS: lrc = launch_loss(p->geom, ptrs, s); break;
                 case PH_POOL_BWD: lrc = launch_pool_bwd(p->geom, ptrs, s); break;

@@ -669,7 +669,12 @@ namespace ta3n {
 // RM x RN: 32x32 output blocks per wave (bf16 twins only): the tile is (32 WM RM) x (32 WN RN).  What bounds these launches is
 // the rate at which a CU can fill its LDS (~41 B/clk measured, tools/proto_bf16.hip), i.e. the operand bytes brought per flop -
 // which only the tile size lowers.
-template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
+// KV: which operand-kind combinations of the K loop the kernel contains (bit 0: both K-contiguous, 1: A K-contiguous x B k-major,
+// 2: A k-major x B K-contiguous, 3: both k-major, 4: both k-major with the bias-gradient row sums; bit 5: the optional epilogue
+// paths - fused update, split-K, write-through stores of chained launches); 63 = everything.  A launch whose tasks
+// use few of them can run a kernel a fraction of the size (the plan knows: ta3n_plan::phase_kinds) - less code to fetch when the
+// kernel changes between launches.
+template <int WM, int WN, int WK, int BF, int NS, int RM, int RN, int KV = 63>
 __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__ segs, const Ptrs &ptrs, int hyper_off, int zeros_off,
                                           int twin_off, const SgdSide &side, int pair_delta) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
@@ -689,7 +694,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     GSTAMP(0);
-    const bool pub = t.sig >= 0 && !(side.p16_off == -12345);    // chained launch: another task of this launch reads what this one writes -> write-through stores
+    constexpr bool OPT = (KV & 32) != 0;      // fused update / split-K / chained-launch stores compiled in
+    const bool pub = OPT && t.sig >= 0 && !(side.p16_off == -12345);    // chained launch: another task of this launch reads what this one writes -> write-through stores
     if (t.epi & EPI_SGD) {          // optimiser side job (uniform for the workgroup): arithmetic and summation order of sgd_range_kernel
         if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
         float part = 0.f;
@@ -740,7 +746,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             for (int r = 0; r < t.pad[1]; ++r) v += src[(size_t)r * t.pad[2] + n];
             dst[n] = v;
             sq = fmaf(v, v, sq);
-            if (side.p_new != nullptr && t.c_base == BASE_G) {     // fused update of these parameters (see the tile epilogue)
+            if (OPT && side.p_new != nullptr && t.c_base == BASE_G) {     // fused update of these parameters (see the tile epilogue)
                 const size_t pi = (size_t)t.c_off + n;
                 const float p0 = ptrs.p[pi];
                 float d = fmaf(side.wd, p0, v), mm = fmaf(side.mu, side.momentum[pi], d);
@@ -812,7 +818,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // 128-wide tiles) load them in the epilogue instead: 8 registers per pass are too many to carry through the K loop.
     constexpr int ITER_E = (BM * BN / 4 + NT - 1) / NT;
     constexpr bool UPD_PREFETCH = ITER_E <= 2;
-    const bool upd_early = UPD_PREFETCH && side.p_new != nullptr && t.c_base == BASE_G;
+    const bool upd_early = OPT && UPD_PREFETCH && side.p_new != nullptr && t.c_base == BASE_G;
     float up_e[UPD_PREFETCH ? ITER_E : 1][4], um_e[UPD_PREFETCH ? ITER_E : 1][4];
     if (upd_early) {
         const bool cv = ((t.c_off | t.c_ld) & 3) == 0;
@@ -1015,12 +1021,12 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     {
         const Seg &s0 = t.seg0;
         switch (s0.a_kmajor * 2 + s0.b_kmajor) {
-            case 0: k_loop(F_{}, F_{}, F_{}); break;
-            case 1: k_loop(F_{}, T_{}, F_{}); break;
-            case 2: k_loop(T_{}, F_{}, F_{}); break;
+            case 0: if constexpr (KV & 1) k_loop(F_{}, F_{}, F_{}); break;
+            case 1: if constexpr (KV & 2) k_loop(F_{}, T_{}, F_{}); break;
+            case 2: if constexpr (KV & 4) k_loop(T_{}, F_{}, F_{}); break;
             default:   // weight gradients (both operands k-major) are the only tiles that also produce a bias gradient
-                if (t.epi & EPI_ROWSUM_A) k_loop(T_{}, T_{}, T_{});
-                else k_loop(T_{}, T_{}, F_{});
+                if (t.epi & EPI_ROWSUM_A) { if constexpr (KV & 16) k_loop(T_{}, T_{}, T_{}); }
+                else { if constexpr (KV & 8) k_loop(T_{}, T_{}, F_{}); }
                 break;
         }
     }
@@ -1047,7 +1053,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // (write-through stores: visible to every CU once acknowledged), takes a ticket, and if it is the first of the pair it is done;
     // the second adds the other's partial (coherent loads) to its own in the loop below.  a + b = b + a: who finishes is immaterial.
     const float *__restrict__ split_other = nullptr;
-    if (epi & EPI_SPLITK) {
+    if (OPT && (epi & EPI_SPLITK)) {
         int &split_ticket = *reinterpret_cast<int *>(&lds[EPI]);
         const int half = t.pad[2] - 1;
         float *mine = ptrs.ws + t.pad[0] + (size_t)half * (BM * BN);
@@ -1094,7 +1100,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // nesterov and weight decay (main.py:83, 583) in the arithmetic of sgd_kernel with the clip coefficient taken as 1:
     //   d = wd p + g;  m = mu m + d;  p_new = p - lr (d + mu m)
     // (a step whose gradient norm exceeds clip_gradient is corrected afterwards by sgd_fixup_kernel: the update is linear in g).
-    const bool upd = side.p_new != nullptr && t.c_base == BASE_G;      // workgroup-uniform
+    const bool upd = OPT && side.p_new != nullptr && t.c_base == BASE_G;      // workgroup-uniform
     float sumsq = 0.f;   // EPI_SUMSQ: this thread's share of the tile's sum of squares
     // Every flag test below is workgroup-uniform: a tile without bias / mask / residual issues no load for it (the
     // bias and the per-step scalars were fetched before the K loop, so the first dependent global access of a plain
@@ -1300,7 +1306,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
 }
 
 // One workgroup = one Task of the launch's list.  chain_off >= 0: a chained launch (several dependency levels; ta3n_types.h).
-template <int WM, int WN, int WK, int BF, int NS, int RM, int RN>
+template <int WM, int WN, int WK, int BF, int NS, int RM, int RN, int KV = 63>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__restrict__ tasks, const Seg *__restrict__ segs,
                                                                  Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side,
                                                                  const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs,
@@ -1311,7 +1317,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     GSTAMP(6);
 #endif
     if (chain_off >= 0) chain_wait(t, waits, cnt, (int)threadIdx.x, knobs);
-    gemm_tile<WM, WN, WK, BF, NS, RM, RN>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta);
+    gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta);
     if (chain_off >= 0) chain_exit(t.sig, cnt, chain_n, (int)threadIdx.x, knobs);
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2
     GSTAMP(7);
@@ -1338,6 +1344,16 @@ TA3N_TILE_CONFIGS(TA3N_INSTANTIATE)
     template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 TA3N_BLOCKED_CONFIGS(TA3N_INSTANTIATE_BLOCKED)
 
+
+// kind-specialised kernels of the benchmarked bf16-twin step: (wm, wn, wk, mode, stages, KV)
+// (bf16 twins: forward levels, the head-gradient level that rounds fp32 operands, backward levels; the same three for the split
+// arithmetic on pair twins.  Measured on one MI355X, pipelined step: bf16 110.2 -> 107.8 us, split 143.7 -> 140.8 us.  The fp32-MFMA
+// kernels are MFMA-bound and got 1.2 us SLOWER specialised (216.2 -> 217.4): none built.)
+#define TA3N_KIND_CONFIGS(X) X(1, 2, 4, 2, 3, 1) X(1, 2, 4, 1, 2, 26) X(2, 2, 2, 2, 2, 26) \
+                             X(2, 1, 4, 4, 3, 1) X(1, 2, 4, 3, 2, 26) X(1, 2, 2, 4, 2, 26)
+#define TA3N_INSTANTIATE_KIND(wm, wn, wk, bf, ns, kv) \
+    template __global__ void gemm_tiles<wm, wn, wk, bf, ns, 1, 1, kv>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
+TA3N_KIND_CONFIGS(TA3N_INSTANTIATE_KIND)
 
 #ifdef TA3N_GEMM_STAMPS
 extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
@@ -1366,7 +1382,7 @@ bool tile_config_ok(int cfg) {
 }
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
-                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits, int pair_delta) {
+                int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits, int pair_delta, int kinds) {
     const int chain_off = d_waits ? ph.chain_off : -1, chain_n = ph.chain_n;
     if (ph.chain_off >= 0 && !d_waits) return -4;
     // measurement knobs of the hand-off protocol (defaults = the shipped protocol): TA3N_CHAIN_SLEEP = poll back-off in units of 512
@@ -1402,6 +1418,21 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
         TA3N_BLOCKED_CONFIGS(TA3N_LAUNCH_BLOCKED)
         if (!launched) return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    // a kernel that holds only the K-loop variants this launch's tasks use, where one is built (kinds: bit mask, 0 = unknown)
+    static const bool kind_kernels = [] { const char *e = getenv("TA3N_KIND_KERNELS"); return !(e && atoi(e) == 0); }();
+    if (kind_kernels && kinds != 0 && !(kinds & 32) && rm * rn == 1 && chain_off < 0 && sd.p_new == nullptr) {
+        // gemm_tiles' MODE and stage count as the plain dispatch below picks them
+        const int mode = ph.bf16 == 0 ? 0 : (ph.bf16 & 16) ? ((ph.bf16 & 32) ? 4 : 2) : (ph.bf16 & 32) ? 3 : 1;
+        const int ns = ph.bf16 == 0 ? 2 : ((ph.bf16 & 15) == 3 ? 3 : 2);
+#define TA3N_LAUNCH_KIND(wm, wn, wk, bf, ns_, kv)                                                                              \
+        if (!launched && cfg == wm * 100 + wn * 10 + wk && mode == bf && ns == ns_ && (kinds & ~kv) == 0) {                    \
+            hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns_, 1, 1, kv>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
+                               ptrs, hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs, pair_delta);          \
+            launched = true;                                                                                                   \
+        }
+        TA3N_KIND_CONFIGS(TA3N_LAUNCH_KIND)
+        if (launched) return hipGetLastError() == hipSuccess ? 0 : -2;
     }
 #define TA3N_LAUNCH_ONE(wm, wn, wk, bf, ns)                                                                         \
     hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns, 1, 1>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, ptrs, \

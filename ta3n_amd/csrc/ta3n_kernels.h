@@ -106,7 +106,7 @@ __device__ __forceinline__ Soft2 soft2(float z0, float z1) {
 bool tile_config_ok(int cfg);   // WM*100 + WN*10 + WK of an instantiated gemm_tiles<WM, WN, WK>
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
                 int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side = nullptr, const Wait *d_waits = nullptr,
-                int pair_delta = 0);
+                int pair_delta = 0, int kinds = 0);
 #if defined(__HIPCC__)
 // two floats -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), low half = first argument
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {

@@ -34,6 +34,7 @@ struct ta3n_plan {
     std::vector<ta3n::Wait> waits;      // wait lists of the chained launches (Task.wait_begin / wait_count)
     std::vector<int32_t> tuples, scale_len, scale_id, tuple_first;  // tuple_first[j..j+1) = tuples of scale j
     int n_tuples = 0;
+    std::vector<int32_t> phase_kinds;   // per phase: which operand-kind combinations its GEMM tasks use (gemm_tiles' KV bits; filled at upload)
     uint64_t deny_blocking = 0;   // bit i: phase i must not use register-blocked tiles (it does not read bf16 twins; build_plan's retry)
     // device copies (created lazily by the launcher)
     void *d_segs = nullptr;
