@@ -26,7 +26,7 @@ TUNED = {
     # ... and with "pair twins" (TA3N_FLAG_F32_SPLIT | _BF16_STORE: the producers store the hi and the lo plane): bf16 stage images of 64 k
     (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 3214, 3214, 2124, 2122, 2122],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
-    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2222, 32222, 2222, 2214, 32222, 3222],
+    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32222, 32222, 2222, 2222, 32222, 3222],      # (in sequence: 477.4 -> 473.3 us)
 }
 
 

@@ -52,6 +52,7 @@ def main():
     busy = [sum(e - s for s, e, _ in st) / 1e3 for st in steps]
     print(f"{len(steps)} steps in the region; step wall (start to start) us: median {statistics.median(wall):.1f}  mean {statistics.mean(wall):.1f}  "
           f"min {min(wall):.1f}  max {max(wall):.1f}")
+    print("step walls in order, us: " + " ".join(f"{w:.0f}" for w in wall))
     print(f"kernel-busy us per step: median {statistics.median(busy):.1f}; idle per step: median {statistics.median(w - b for w, b in zip(wall, busy)):.1f}")
     n = len(steps[0])
     if all(len(st) == n for st in steps):

@@ -12,10 +12,12 @@ from ta3n_amd.tuning import tuned_phase_tiles
 arith = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 kw = dict(bf16=True, bf16_store=True) if arith == "bf16" else dict(f32_split=True, bf16_store=True) if arith == "f32x3" else {}
-Bs, Bt, T, D, F, C = 128, 74, 5, 2048, 512, 12
-base = tuned_phase_tiles(Bs + Bt, T, D, F, arith == "bf16", arith != "f32", split=(arith == "f32x3"))
+Bs, Bt, T, D, F, C = (int(v) for v in os.environ.get("TA3N_TUNE_SHAPE", "128,74,5,2048,512,12").split(","))
+base = tuned_phase_tiles(Bs + Bt, T, D, F, arith == "bf16", arith != "f32", split=(arith == "f32x3")) or [0] * 16
 stages = (2, 3) if arith != "f32" else (0,)
 CANDS = [s * 1000 + c for c in (114, 118, 212, 122, 214, 124, 221, 222) for s in stages]
+if arith == "bf16" and Bs + Bt >= 512:      # register-blocked tiles of the twin kernel pay at the larger shapes
+    CANDS = [c for c in CANDS if c % 1000 in (214, 124, 221, 222)] + [12222, 13222, 22222, 23222, 32222, 32221]
 xs, xt, ys, yt = synth_batch(C, T, D, Bs, Bt, seed=1)
 xs, xt, ys = xs.cuda(), xt.cuda(), ys.cuda()
 sched = [([0.75, 0.75, 0.5], 0.003, 1e-3)] * 200
