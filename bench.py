@@ -336,8 +336,13 @@ def main():
         # Default at N = 1: the K steps are enqueued by ONE call into the library (ta3n_train_steps; the schedule of beta / lr /
         # dropout seeds is evaluated ahead of time and travels by value) - the host is then off the step's critical path, which
         # under the 20-step protocol on a slow host core was 21 % of the step.  --per-step-calls: one call per step.
-        batched = (pipelined and not side and len(engs) == 1 and not args.per_step_calls and
+        batched = (pipelined and (not side and len(engs) == 1 or n_streams > 1) and not args.per_step_calls and
                    ((world == 1 and not selftest) or (eng.comm is not None and eng._ddp_buckets == 1)))
+        two = None
+        if batched and n_streams > 1:       # configs[4]: both models' steps from ONE ta3n_train_steps_multi call (two HIP streams, or one)
+            from ta3n_amd.two_stream import TwoStreamEngine
+            two = TwoStreamEngine.__new__(TwoStreamEngine)
+            two.streams, two._hip_streams = engs, side
 
         def sched(i0, n):
             out = []
@@ -347,7 +352,9 @@ def main():
             return out
 
         def run_steps(i0, n):
-            if batched:
+            if two is not None:
+                two.train_steps(sched(i0, n))
+            elif batched:
                 eng.train_steps(sched(i0, n))
             else:
                 for i in range(i0, i0 + n):

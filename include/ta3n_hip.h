@@ -333,6 +333,27 @@ int ta3n_train_steps(ta3n_plan *plan, const float *x, float *params, float *grad
                      ta3n_comm *comm /* NULL, or: ta3n_all_reduce_sum of the live gradients after every step (fused_norm must be 0) */,
                      void *scratch_bf16 /* as in ta3n_all_reduce_sum */, void *stream);
 
+/* ta3n_train_steps for SEVERAL independent models from one call - BASELINE configs[4]: the RGB and the Flow model of a two-stream
+ * run (two VideoModel instances in the reference's terms, test_models.py sums their class logits), each with its own plan,
+ * buffers and HIP stream.  For k in [0, n_steps): for every job: step k of that job on the job's stream - so the queues of the
+ * jobs fill at the same rate and one model's launches fill the compute units the other's launch / prologue latencies leave idle,
+ * with no host call per step and stream in between.  Each job is exactly one ta3n_train_steps argument list (same requirements:
+ * a pending update per job; bit-identical to calling ta3n_train_steps once per job).  Jobs must not share buffers; ordering
+ * between the jobs' streams and the caller's is the caller's business (events / hipStreamWaitEvent). */
+typedef struct {
+    ta3n_plan *plan;
+    const float *x;
+    float *params, *grads, *momentum, *ws;
+    int32_t fused_norm;
+    float lr_pending, momentum_coef, weight_decay, clip;
+    const ta3n_hyper *hypers;       /* [n_steps] */
+    const ta3n_feed *source, *target;
+    ta3n_comm *comm;
+    void *scratch_bf16;
+    void *stream;
+} ta3n_steps_job;
+int ta3n_train_steps_multi(const ta3n_steps_job *jobs, int n_jobs, int n_steps);
+
 /* The same steps with the optimiser INSIDE the gradient launches: every gradient tile of ta3n_train_step applies the Nesterov /
  * weight-decay update (main.py:83, 583) to its own block of parameters in its epilogue - the gradient is in registers, the old
  * parameter and momentum entries are read once, the new ones written once - instead of a separate pass over 5 x 4 B per parameter

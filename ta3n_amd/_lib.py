@@ -39,7 +39,7 @@ SYMBOLS = [
     "ta3n_sgd_step", "ta3n_sgd_step_fused", "ta3n_sgd_range", "ta3n_train_step_join", "ta3n_train_step_range", "ta3n_refresh_bf16", "ta3n_sgd_step_next", "ta3n_gather_segments_into", "ta3n_has_pipelined_step", "ta3n_train_step_after_update", "ta3n_num_phases",
     "ta3n_debug_arrays", "ta3n_debug_struct_sizes", "ta3n_time_phases", "ta3n_time_update_launches", "ta3n_last_error", "ta3n_version",
     "ta3n_comm_unique_id", "ta3n_comm_create", "ta3n_comm_destroy", "ta3n_comm_world", "ta3n_all_reduce_sum", "ta3n_train_step_ddp",
-    "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_chain_status", "ta3n_debug_waits",
+    "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_train_steps_multi", "ta3n_chain_status", "ta3n_debug_waits",
     "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
     "ta3n_comm_attach_peer", "ta3n_has_fused_update", "ta3n_train_steps_fused_update",
     "ta3n_gaussian_kernel_scratch_floats", "ta3n_gaussian_kernel", "ta3n_mmd_rowdiff",
@@ -67,6 +67,14 @@ class Feed(C.Structure):
     """ta3n_feed (include/ta3n_hip.h): device-side batch assembly of a multi-step call."""
     _fields_ = [("store", C.c_void_p), ("bf16", C.c_int32), ("ids_per_step", C.c_int32), ("first_row", C.c_void_p),
                 ("num_frames", C.c_void_p), ("labels", C.c_void_p), ("video_ids", C.c_void_p)]
+
+
+class StepsJob(C.Structure):
+    """ta3n_steps_job (include/ta3n_hip.h): the argument list of one ta3n_train_steps call, as an element of ta3n_train_steps_multi."""
+    _fields_ = [("plan", C.c_void_p), ("x", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p), ("momentum", C.c_void_p),
+                ("ws", C.c_void_p), ("fused_norm", C.c_int32), ("lr_pending", C.c_float), ("momentum_coef", C.c_float),
+                ("weight_decay", C.c_float), ("clip", C.c_float), ("hypers", C.POINTER(Hyper)), ("source", C.POINTER(Feed)),
+                ("target", C.POINTER(Feed)), ("comm", C.c_void_p), ("scratch_bf16", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class Ta3nError(RuntimeError):
@@ -120,6 +128,7 @@ def lib() -> C.CDLL:
     L.ta3n_train_step_after_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ta3n_train_steps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
                                    C.POINTER(Feed), C.POINTER(Feed), vp, vp, vp]
+    L.ta3n_train_steps_multi.argtypes = [C.POINTER(StepsJob), C.c_int, C.c_int]
     L.ta3n_has_fused_update.argtypes = [vp]
     L.ta3n_train_steps_fused_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
                                                 C.POINTER(Feed), C.POINTER(Feed), vp]

@@ -549,39 +549,80 @@ static int feed_step(ta3n_plan *p, const ta3n_feed *f, int step, int first_video
     return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
 }
 
-int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
-                     float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
-                     const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm, void *scratch_bf16, void *stream) {
+// One pipelined step of a multi-step call: optional batch assembly, the update that opens the step (learning rate `lr` of the step
+// before, scalars `next` of this one), the step's launches, optional gradient exchange.
+static int enqueue_pipelined_step(ta3n_plan *p, const Ptrs &ptrs, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                                  float lr, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *next, int k,
+                                  const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm, void *scratch_bf16, hipStream_t s) {
+    const Geom &g = p->geom;
+    int rc;
+    // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued)
+    if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(ptrs.x), ws,
+                                  reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
+    if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(ptrs.x), ws, nullptr, s)) != TA3N_OK) return rc;
+    if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+    if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                         reinterpret_cast<const Hyper *>(next), s) != 0)
+        return fail(TA3N_ERR_HIP, "sgd launch failed");
+    SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
+                 fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
+    if ((rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;
+    if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30)) != TA3N_OK) return rc;
+    // data parallel: the step's single exchange, on the step's stream, between the last gradient launch and the update
+    if (comm && (rc = ta3n_all_reduce_sum(comm, grads, p->live_floats, scratch_bf16, s)) != TA3N_OK) return rc;
+    return TA3N_OK;
+}
+
+static int check_steps_job(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, const ta3n_hyper *hypers,
+                           int fused_norm, const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm) {
     if (!p || !x || !params || !grads || !momentum || !ws || !hypers) return fail(TA3N_ERR_INVALID, "null argument");
-    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
     if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(momentum) || !aligned16(ws))
         return fail(TA3N_ERR_INVALID, "buffers must be 16-byte aligned");
     if (ta3n_has_pipelined_step(p) != 1) return fail(TA3N_ERR_INVALID, "no pipelined step for this configuration");
-    int rc = ensure_uploaded(p);
+    if ((source || target) && (p->geom.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
+    if (comm && fused_norm) return fail(TA3N_ERR_INVALID, "with a communicator the norm is taken from the REDUCED gradients: fused_norm must be 0");
+    return ensure_uploaded(p);
+}
+
+int ta3n_train_steps(ta3n_plan *p, const float *x, float *params, float *grads, float *momentum, float *ws, int fused_norm,
+                     float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
+                     const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm, void *scratch_bf16, void *stream) {
+    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
+    int rc = check_steps_job(p, x, params, grads, momentum, ws, hypers, fused_norm, source, target, comm);
     if (rc != TA3N_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const Geom &g = p->geom;
-    if ((source || target) && (g.D & 7) != 0) return fail(TA3N_ERR_INVALID, "ta3n_feed: feature_dim % 8 required");
-    if (comm && fused_norm) return fail(TA3N_ERR_INVALID, "with a communicator the norm is taken from the REDUCED gradients: fused_norm must be 0");
     Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
     float lr = lr_pending;
     for (int k = 0; k < n_steps; ++k) {
-        // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued)
-        if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(x), ws,
-                                      reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
-        if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(x), ws, nullptr, s)) != TA3N_OK) return rc;
-        if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
-        if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
-                             reinterpret_cast<const Hyper *>(&hypers[k]), s) != 0)
-            return fail(TA3N_ERR_HIP, "sgd launch failed");
-        SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
-                     fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
-        if ((rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;
-        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, 1 << 30)) != TA3N_OK) return rc;
-        // data parallel: the step's single exchange, on the step's stream, between the last gradient launch and the update
-        if (comm && (rc = ta3n_all_reduce_sum(comm, grads, p->live_floats, scratch_bf16, stream)) != TA3N_OK) return rc;
+        if ((rc = enqueue_pipelined_step(p, ptrs, params, grads, momentum, ws, fused_norm, lr, momentum_coef, weight_decay, clip, &hypers[k], k,
+                                         source, target, comm, scratch_bf16, s)) != TA3N_OK) return rc;
         lr = hypers[k].lr;
     }
+    return TA3N_OK;
+}
+
+int ta3n_train_steps_multi(const ta3n_steps_job *jobs, int n_jobs, int n_steps) {
+    if (!jobs || n_jobs < 1) return fail(TA3N_ERR_INVALID, "null argument");
+    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
+    std::vector<Ptrs> ptrs;
+    for (int j = 0; j < n_jobs; ++j) {
+        const ta3n_steps_job &b = jobs[j];
+        for (int i = 0; i < j; ++i)
+            if (jobs[i].ws == b.ws || jobs[i].grads == b.grads || jobs[i].params == b.params)
+                return fail(TA3N_ERR_INVALID, "ta3n_train_steps_multi: jobs must not share buffers");
+        int rc = check_steps_job(b.plan, b.x, b.params, b.grads, b.momentum, b.ws, b.hypers, b.fused_norm, b.source, b.target, b.comm);
+        if (rc != TA3N_OK) return rc;
+        ptrs.push_back(make_ptrs(b.plan, b.x, b.params, b.grads, b.ws));
+    }
+    // step k of every job before step k + 1 of any: the jobs' queues fill at the same rate, so their launches interleave on the GPU
+    for (int k = 0; k < n_steps; ++k)
+        for (int j = 0; j < n_jobs; ++j) {
+            const ta3n_steps_job &b = jobs[j];
+            const int rc = enqueue_pipelined_step(b.plan, ptrs[j], b.params, b.grads, b.momentum, b.ws, b.fused_norm,
+                                                  k == 0 ? b.lr_pending : b.hypers[k - 1].lr, b.momentum_coef, b.weight_decay, b.clip,
+                                                  &b.hypers[k], k, b.source, b.target, b.comm, b.scratch_bf16, static_cast<hipStream_t>(b.stream));
+            if (rc != TA3N_OK) return rc;
+        }
     return TA3N_OK;
 }
 

@@ -702,14 +702,38 @@ class TrainEngine:
             self._hyper = self.hyper_for(*schedule[-1], step=self.step_count + n - 1)
             self.step_count += n
             return
-        if not self.fused or not self._side_update or (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)):
-            if feeds is not None:
-                raise _lib.Ta3nError("train_steps: device-side batch feeds need the pipelined step")
-            for beta, gamma, lr in schedule:
+        if not self.can_batch_steps():
+            # no single library call for this configuration (torch.distributed fallback, two buckets, TA3N_SIDE_UPDATE=0, unfused):
+            # the same steps one by one, the batch of each assembled on the device before it
+            for k, (beta, gamma, lr) in enumerate(schedule):
+                if feeds is not None:
+                    for (store, ids), first in zip(feeds, (0, self.Bs)):
+                        if store is not None:
+                            store.gather_into(self, ids[k], first, labels_out=self._labels[: self.Bs] if first == 0 else None)
                 (self.train_step_pipelined if self.fused else self.train_step)(beta, gamma, lr)
             return
-        k0 = 0
-        if self._pending is None:            # the very first step has no update to open with
+        job, keep, n_run = self._steps_job(schedule, feeds)
+        if job is None:
+            return
+        _lib.check(self._L.ta3n_train_steps(job.plan, job.x, job.params, job.grads, job.momentum, job.ws, job.fused_norm, job.lr_pending,
+                                            job.momentum_coef, job.weight_decay, job.clip, job.hypers, n_run, job.source, job.target,
+                                            job.comm, job.scratch_bf16, job.stream), "ta3n_train_steps")
+        self._steps_done(schedule, keep, n_run)
+
+    def can_batch_steps(self) -> bool:
+        """True when train_steps enqueues its steps through ONE library call (ta3n_train_steps / ta3n_train_steps_multi) - also the
+        condition under which device-side batch feeds are accepted."""
+        ddp = self.world > 1 or self._ddp_selftest
+        return bool(self.fused and self._side_update and
+                    not (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)))
+
+    def _steps_job(self, schedule, feeds=None):
+        """The ta3n_steps_job of `schedule` on this engine's buffers and the CURRENT stream (+ what must outlive the enqueued work, and
+        the number of steps it covers).  The very first step of an engine has no update to open with: it is enqueued here, on its
+        own; (None, ...) when nothing is left for the library call."""
+        n, k0 = len(schedule), 0
+        ddp = self.world > 1 or self._ddp_selftest
+        if self._pending is None:
             if feeds is not None:
                 for (store, ids), first in zip(feeds, (0, self.Bs)):
                     if store is not None:
@@ -717,7 +741,7 @@ class TrainEngine:
             self.train_step_pipelined(*schedule[0])
             k0 = 1
             if n == 1:
-                return
+                return None, [], 0
         hy = (_lib.Hyper * (n - k0))()
         for k in range(k0, n):
             beta, gamma, lr = schedule[k]
@@ -725,19 +749,25 @@ class TrainEngine:
             C.memmove(C.byref(hy, (k - k0) * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
         lr_p, mu, wd, clip = self._pending
         fd, keep = self._feeds(feeds, k0)
-        _lib.check(self._L.ta3n_train_steps(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
-                                            self.M.data_ptr(), self.ws.data_ptr(), 0 if ddp else 1, lr_p, mu, wd, clip, hy, n - k0,
-                                            C.byref(fd[0]) if fd[0] is not None else None,
-                                            C.byref(fd[1]) if fd[1] is not None else None,
-                                            self.comm.handle if ddp else None,
-                                            self._g16.data_ptr() if (ddp and self._g16 is not None) else None,
-                                            self._stream()), "ta3n_train_steps")
+        job = _lib.StepsJob()
+        job.plan, job.x, job.params, job.grads = self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr()
+        job.momentum, job.ws, job.fused_norm = self.M.data_ptr(), self.ws.data_ptr(), 0 if ddp else 1
+        job.lr_pending, job.momentum_coef, job.weight_decay, job.clip = lr_p, mu, wd, clip
+        job.hypers = C.cast(hy, C.POINTER(_lib.Hyper))
+        job.source = C.pointer(fd[0]) if fd[0] is not None else None
+        job.target = C.pointer(fd[1]) if fd[1] is not None else None
+        job.comm = self.comm.handle if ddp else None
+        job.scratch_bf16 = self._g16.data_ptr() if (ddp and self._g16 is not None) else None
+        job.stream = self._stream()
+        return job, keep + [hy, fd], n - k0
+
+    def _steps_done(self, schedule, keep, n_run: int) -> None:
         if keep:                              # the id tables must outlive the enqueued gathers
             self._feed_keep = keep
         last = schedule[-1]
         self._pending = (float(last[2]), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
-        self._hyper = self.hyper_for(*last, step=self.step_count + (n - k0) - 1)
-        self.step_count += n - k0
+        self._hyper = self.hyper_for(*last, step=self.step_count + n_run - 1)
+        self.step_count += n_run
 
     def chain_status(self) -> None:
         """Raises if a chained launch enqueued so far left a hand-off unserved (synchronises; tests / end of a run)."""

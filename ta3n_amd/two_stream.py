@@ -47,6 +47,40 @@ class TwoStreamEngine:
     def train_step(self, beta, gamma, lr, pipelined: bool = True, **kw) -> None:
         self._each(lambda e: (e.train_step_pipelined if (pipelined and e.fused) else e.train_step)(beta, gamma, lr, **kw))
 
+    def train_steps(self, schedule: Sequence[Sequence]) -> None:
+        """len(schedule) two-stream steps enqueued by ONE call into the library (ta3n_train_steps_multi): step k of the RGB model on
+        its HIP stream, step k of the Flow model on its own, step k + 1 of each, ... - no host call per step and stream, so a slow
+        host core cannot stall either queue (round 3: the driver's box measured 1.46 ms per step with one Python call per step and
+        stream against 0.5 ms of GPU work).  Bit-identical to train_step called once per entry."""
+        if not schedule:
+            return
+        if not all(e.can_batch_steps() for e in self.streams):
+            for beta, gamma, lr in schedule:
+                self.train_step(beta, gamma, lr)
+            return
+        import ctypes as C
+        from . import _lib
+        dev = self.streams[0].device
+        cur = torch.cuda.current_stream(dev)
+        hip = self._hip_streams or [cur] * len(self.streams)
+        jobs, keeps, runs = [], [], []
+        for e, s in zip(self.streams, hip):
+            if s is not cur:
+                s.wait_stream(cur)
+            with torch.cuda.stream(s):        # (the job records the stream that is current while it is built)
+                job, keep, n_run = e._steps_job(schedule)
+            jobs.append(job); keeps.append(keep); runs.append(n_run)
+        n_run = runs[0]
+        assert all(r == n_run for r in runs), "the models of a two-stream engine step together"
+        if n_run:
+            arr = (_lib.StepsJob * len(jobs))(*jobs)
+            _lib.check(_lib.lib().ta3n_train_steps_multi(arr, len(jobs), n_run), "ta3n_train_steps_multi")
+            for e, keep in zip(self.streams, keeps):
+                e._steps_done(schedule, keep, n_run)
+        for s in hip:
+            if s is not cur:
+                cur.wait_stream(s)
+
     def flush(self) -> None:
         self._each(lambda e: e.flush())
 

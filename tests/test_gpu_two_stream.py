@@ -53,3 +53,32 @@ def test_concurrent_streams_equal_serial_and_standalone_engines(bf16):
     want = alone[0].outputs()["out"] + alone[1].outputs()["out"]
     assert torch.equal(two[True].logits(), want)
     assert set(two[True].losses()) == set(alone[0].losses())
+
+
+@pytest.mark.parametrize("concurrent", [True, False])
+def test_one_library_call_for_both_models_equals_per_step_calls(concurrent):
+    """ta3n_train_steps_multi (TwoStreamEngine.train_steps: K steps of both models from ONE call, each on its own HIP stream) against
+    one train_step call per step and stream - bit for bit, starting both from a fresh engine (first step has no pending update) and
+    continuing from a pending one."""
+    from ta3n_amd.two_stream import TwoStreamEngine
+    kw = dict(dropout_i=0.5, dropout_v=0.5, bf16=True, bf16_store=True)
+    a = TwoStreamEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], concurrent=concurrent, **kw)
+    b = TwoStreamEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], concurrent=True, **kw)
+    _load(a.streams)
+    _load(b.streams)
+    bt = _batches(0)
+    for w in (a, b):
+        w.set_batch([x[0] for x in bt], [x[1] for x in bt], bt[0][2])
+    sched = [([0.75, 0.75, 0.5], 0.003, 1e-2 / (1 + k)) for k in range(7)]
+    a.train_steps(sched[:3])
+    a.train_steps(sched[3:])
+    for beta, gamma, lr in sched:
+        b.train_step(beta, gamma, lr)
+    a.flush()
+    b.flush()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(a.streams[k].P, b.streams[k].P), (k, (a.streams[k].P - b.streams[k].P).abs().max())
+        assert torch.equal(a.streams[k].M, b.streams[k].M)
+        assert a.streams[k].step_count == b.streams[k].step_count == 7
+    assert torch.equal(a.logits(), b.logits())

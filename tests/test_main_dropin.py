@@ -87,6 +87,69 @@ def test_own_main_trains_logs_checkpoints_and_resumes(tmp_path, name, flags):
     assert "(epoch 2)" in r2.stdout and "Train: [3][0/3]" in r2.stdout and "Train: [2]" not in r2.stdout
 
 
+def _reference_program(name):
+    """The reference's own program file: the checkout where there is one (build container, TA3N_REFERENCE_DIR), else the scratch copy
+    tools/stage_reference.sh leaves in .ref_stage/ (git-ignored; travels to the GPU box with the snapshot like the built .so)."""
+    for d in (os.environ.get("TA3N_REFERENCE_DIR"), "/root/reference", os.path.join(ROOT, ".ref_stage")):
+        if d and os.path.isfile(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_reference_program("main.py") is None, reason="no reference checkout and nothing staged (tools/stage_reference.sh)")
+@pytest.mark.parametrize("name,flags", [("ta3n", TA3N), ("configs0", CONFIGS0)])
+def test_reference_main_py_trains_on_the_gpu(tmp_path, name, flags):
+    """north_star: "main.py drops in unchanged".  The REFERENCE's main.py source file, byte for byte, run by compat/run_reference.py
+    for two epochs on the MI355X: its own main() / train() / validate() / save_checkpoint(), its DataParallel wrap, its loss assembly,
+    clip_grad_norm_ and torch.optim.SGD - over this repository's VideoModel / loss / opts / dataset modules (HIP forward and backward).
+    Then the reference's own test_models.py reads the checkpoint it wrote.  The log is kept under gpurun_out/ for profiles/."""
+    import hashlib
+    prog = _reference_program("main.py")
+    data = make_dataset(str(tmp_path / "data"))
+    exp = str(tmp_path / "exp")
+    launcher = os.path.join(ROOT, "compat", "run_reference.py")
+    argv = [data[0], "RGB", data[1], data[2], data[3], "--exp_path", exp + "/", *flags, *COMMON]
+    # the TA3N line carries the rest of script_train_val.sh:144-155 too
+    if name == "ta3n":
+        argv += ["--place_adv", "Y", "Y", "Y", "--add_fc", "1", "--gd", "20", "--val_segments", "5"]
+    env = dict(os.environ, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
+    r = subprocess.run([sys.executable, launcher, prog, *argv], cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=env)
+    keep = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(keep, exist_ok=True)
+    with open(os.path.join(keep, f"reference_main_py_on_gpu_{name}.log"), "w") as f:
+        f.write(f"# {prog} sha256 {hashlib.sha256(open(prog, 'rb').read()).hexdigest()}\n# argv: {' '.join(argv)}\n")
+        f.write(r.stdout[-20000:] + "\n# ---- stderr ----\n" + r.stderr[-5000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = exp + "/RGB/"
+    for fn in ("train.log", "train_short.log", "val.log", "val_short.log", "checkpoint.pth.tar", "model_best.pth.tar"):
+        assert os.path.exists(out + fn), fn
+    train_lines = [ln for ln in open(out + "train.log") if ln.startswith("Train:")]
+    assert len(train_lines) == 2 * 3
+    first, last = (float(ln.split("loss_c")[1].split()[0]) for ln in (train_lines[0], train_lines[-1]))
+    assert (abs(last - first) < 5e-3) if name == "configs0" else (last < first), (first, last)
+    if name == "ta3n":
+        assert "loss_a" in train_lines[-1]
+    assert "Testing Results: Prec@1" in open(out + "val.log").read()
+    ck = torch.load(out + "checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "arch", "state_dict", "optimizer", "best_prec1", "prec1"} and ck["epoch"] == 2
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    # the reference's tester on the checkpoint the reference's trainer wrote (test_models.py:85-90 loads it strictly)
+    tester = _reference_program("test_models.py")
+    trn = name == "ta3n"
+    tm = [sys.executable, launcher, tester, data[0], "RGB", data[3], out + "checkpoint.pth.tar", "--arch", "resnet18", "--test_segments", "5",
+          "--fc_dim", "64", "--baseline_type", "video", "--frame_aggregation", "trn-m" if trn else "avgpool",
+          "--use_attn", "TransAttn" if trn else "none", "--bS", "8", "-j", "0", "--top", "1", "3",
+          "--save_confusion", str(tmp_path / "cm")]      # (test_models.py:198 plots unconditionally: the option is not optional)
+    rt = subprocess.run(tm, cwd=str(tmp_path), capture_output=True, text=True, timeout=900, env=env)
+    with open(os.path.join(keep, f"reference_main_py_on_gpu_{name}.log"), "a") as f:
+        f.write("\n# ---- reference test_models.py on that checkpoint ----\n" + rt.stdout[-4000:] + "\n# ---- stderr ----\n" + rt.stderr[-3000:])
+    assert rt.returncode == 0, rt.stdout[-2000:] + rt.stderr[-3000:]
+    pred = [ln for ln in rt.stdout.splitlines() if ln.startswith("Pred@1 ") and "%" in ln]
+    assert pred, rt.stdout[-2000:]
+    assert abs(float(pred[-1].split()[1].rstrip("%")) - float(ck["prec1"])) < 1e-2, (pred[-1], ck["prec1"])
+
+
 _REF_DRIVER = r"""
 import sys, types, builtins, torch
 sys.path.insert(0, {compat!r}); sys.path.insert(1, {root!r})
