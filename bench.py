@@ -532,7 +532,8 @@ def main():
             "config": {"workload": conf["name"] + ", dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
                        "baseline_config": args.config - 1,
                        "global_batch": (SH["Bs"] + SH["Bt"]) * world, "parallelism": f"dp{world}",
-                       "launch": "hipGraph" if args.graph else ("eager, all timed steps enqueued by one ta3n_train_steps call"
+                       "launch": "hipGraph" if args.graph else (("eager, all timed steps of both models enqueued by one ta3n_train_steps_multi call, one HIP stream per model"
+                                                                 if n_streams > 1 else "eager, all timed steps enqueued by one ta3n_train_steps call")
                                                                 if main_res.get("batched") else "eager, one host call per step"),
                        "finite": main_res["finite"],
                        "step": "fused (ta3n_train_step)" if main_res["fused"] else "forward+loss+backward",

@@ -130,7 +130,7 @@ def test_reference_main_py_trains_on_the_gpu(tmp_path, name, flags):
     assert (abs(last - first) < 5e-3) if name == "configs0" else (last < first), (first, last)
     if name == "ta3n":
         assert "loss_a" in train_lines[-1]
-    assert "Testing Results: Prec@1" in open(out + "val.log").read()
+    assert r.stdout.count("Testing Results: Prec@1") == 2 and "Test: [2]" in open(out + "val.log").read()   # (main.py:745 prints the summary, :735 logs the batches)
     ck = torch.load(out + "checkpoint.pth.tar", map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "arch", "state_dict", "optimizer", "best_prec1", "prec1"} and ck["epoch"] == 2
     assert all(k.startswith("module.") for k in ck["state_dict"])
