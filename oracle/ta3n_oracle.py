@@ -254,15 +254,27 @@ class _BiasBf16Sum(torch.autograd.Function):
         return g, rne_bf16(g).sum(0)
 
 
+# Experiment switch (tools/bf16_relation_disc_deviation.py): True = the relation discriminator's hidden layer
+# rounds the SUM of its scale's tuple activations once, the way a literal bf16 autocast of models.py:475-479 would, instead of each
+# tuple activation on its own.  Never set by the tests: the product reads the tuple activations as separate K segments.
+SEGSUM_ROUND_AFTER_SUM = False
+
+
 class _SegSumMatmulBf16(torch.autograd.Function):
     """(sum_t z_t) W^T computed as sum_t bf16(z_t) bf16(W)^T: the relation discriminator's hidden layer reads the
     tuple activations of its scale as separate K segments (each rounded on its own), never their sum.  Backward:
-    every z_t receives bf16(g) bf16(W); dW = bf16(g)^T bf16(sum_t z_t) (the weight-gradient launch reads R_j)."""
+    every z_t receives bf16(g) bf16(W); dW = bf16(g)^T bf16(sum_t z_t) (the weight-gradient launch reads R_j).
+    THIS FUNCTION RESTATES PRODUCT STRUCTURE (see the note above BF16_POLICY)."""
 
     @staticmethod
     def forward(ctx, w, *zs):
         ctx.save_for_backward(w, *zs)
         w16 = rne_bf16(w).double().t()
+        if SEGSUM_ROUND_AFTER_SUM:
+            r = zs[0]
+            for z in zs[1:]:
+                r = r + z
+            return (rne_bf16(r).double() @ w16).float()
         out = None
         for z in zs:
             y = rne_bf16(z).double() @ w16
@@ -279,6 +291,24 @@ class _SegSumMatmulBf16(torch.autograd.Function):
         return (_mm16(g.t(), r),) + tuple(gz for _ in zs)
 
 
+# What in this bf16 mode is INDEPENDENT of the product and what RESTATES it (VERDICT r03 weak #2a).  The reference has no bf16 mode
+# and ships no fixtures for one, so this mode cannot be pinned the way the fp32 mode is (tests/golden/*.npz from the reference itself):
+# it is a model of "the reference's layers with bf16 matrix-core operands", and three of its choices are the product's, not the
+# reference's:
+#   (1) WHICH contractions round their operands (BF16_POLICY below): the nn.Linear layers that run on the MFMA tile kernel do, the
+#       2-wide / C-wide output layers and the video discriminator's 256x256 layer inside the heads kernel do not - a different
+#       kernel partition would give a different, equally legitimate table;
+#   (2) _SegSumMatmulBf16: the relation discriminator's hidden layer rounds each tuple activation z_t on its own (K segments of one
+#       tile) instead of their sum R_j - the plan's segment structure;
+#   (3) bias16 / _BiasBf16Sum: bias gradients as column sums of ROUNDED upstream gradients - what a weight-gradient launch that reads
+#       bf16 twins has.
+# Independent of the product: the rounding itself (RNE on the fp32 bit pattern), exact products, fp64 accumulation (no summation
+# order of any kernel), autograd through the reference's own formulas, everything outside the contractions in fp32.
+# Consequently tests/test_gpu_bf16.py (HIP bf16 vs this mode) checks that the kernels IMPLEMENT this contract, not that the contract
+# is the reference's; the distance of the contract from the reference is measured separately against the fp32 mode
+# (tests/test_gpu_gradients.py::test_bf16_distance_from_the_fp32_reference_*, tests/test_gpu_training_equivalence.py), and
+# tools/bf16_relation_disc_deviation.py attributes it to the three choices above.
+#
 # The arithmetic contract of the bf16 configuration, per reference layer: which of (forward x W^T, input gradient g W,
 # weight gradient g^T x) run on the bf16 matrix cores, and whether the bias gradient sums rounded values.  Everything
 # else - the 2-wide / C-wide output layers and the 256x256 video-discriminator layer inside the fused heads kernel,

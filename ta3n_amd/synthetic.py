@@ -48,3 +48,27 @@ def synth_batch(num_class: int, num_segments: int, feature_dim: int, batch_sourc
     yt = rng.integers(0, num_class, size=(batch_target,))
     return (torch.tensor(xs, dtype=dtype), torch.tensor(xt, dtype=dtype),
             torch.tensor(ys, dtype=torch.long), torch.tensor(yt, dtype=torch.long))
+
+
+def task_batch(num_class: int, num_segments: int, feature_dim: int, batch_source: int, batch_target: int, step: int,
+               task_seed: int = 0, dtype=torch.float32):
+    """A LEARNABLE synthetic domain-adaptation task (tests/test_gpu_training_equivalence.py): every class has a mean pattern over the
+    feature channels (fixed by task_seed); a video's frames are |mean * (0.5 + t / T) + noise| (non-negative, like ResNet pool5
+    features, with a mild temporal trend for the relation module to see); the target domain is the same classes seen through a fixed
+    per-channel gain and offset.  `step` selects the batch.  Returns (xs [Bs,T,D], xt [Bt,T,D], ys, yt)."""
+    task = np.random.default_rng(1_000_003 * (task_seed + 1))
+    means = task.standard_normal((num_class, feature_dim)) * 0.6
+    gain = 1.0 + 0.3 * task.standard_normal(feature_dim)
+    offset = 0.2 * task.standard_normal(feature_dim)
+    rng = np.random.default_rng([task_seed, step])
+    trend = (0.5 + np.arange(num_segments) / num_segments)[None, :, None]
+
+    def draw(n, target):
+        y = rng.integers(0, num_class, size=(n,))
+        x = means[y][:, None, :] * trend + rng.standard_normal((n, num_segments, feature_dim))
+        if target:
+            x = x * gain + offset
+        return np.abs(x), y
+    xs, ys = draw(batch_source, False)
+    xt, yt = draw(batch_target, True)
+    return (torch.tensor(xs, dtype=dtype), torch.tensor(xt, dtype=dtype), torch.tensor(ys, dtype=torch.long), torch.tensor(yt, dtype=torch.long))

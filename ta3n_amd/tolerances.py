@@ -37,5 +37,23 @@ BF16_GRAD_MAX_SCALE = 1e-1
 # ---- bf16 arithmetic: distance from the fp32 REFERENCE (what rounding the contraction operands to bf16 costs) ----
 BF16_REF_LOGIT_REL_RMS = 2.5e-2          # measured 1.1e-2 .. 1.7e-2 of rms at the three benchmarked shapes
 BF16_REF_GRAD_REL_L2_MEDIAN = 2e-2       # measured 3.4e-3 .. 6.4e-3
-BF16_REF_GRAD_REL_L2 = 0.25              # per weight-gradient tensor; measured 0.8 - 1.3 % at the headline shape, up to 15 % for single
+BF16_REF_GRAD_REL_L2 = 0.25              # absolute cap per weight-gradient tensor; measured 0.8 - 1.3 % at the headline shape, up to 15 % for single
                                          # relation-discriminator hidden layers at 1024 videos / 12 segments (ReLU-masked, few active rows)
+# ... and, per tensor, relative to what the bf16 CONTRACT costs on the very same inputs (the oracle's bf16-operand mode against its fp32
+# mode, computed in the test): rel. L2(HIP bf16, fp32 reference) <= FACTOR x rel. L2(oracle bf16, fp32 reference) + FLOOR.  The contract's
+# cost is the ReLU on/off pattern (0.08 % of the hidden units land on the other side of zero; profiles/r04_bf16_gradient_deviation_attribution.txt):
+# two implementations of the contract flip different units of the same population, hence a factor and not equality.
+BF16_REF_GRAD_CONTRACT_FACTOR = 3.0
+BF16_REF_GRAD_FLOOR = 1e-2
+
+# ---- training equivalence over 300 steps on a learnable synthetic task (tests/test_gpu_training_equivalence.py) ----
+# early: total loss step by step over the first 20 steps, relative (the trajectories coincide up to the arithmetic's rounding; from
+# ~step 25 on ReLU flips decorrelate ANY two arithmetics - the oracle's own bf16-operand mode is 3.1e-2 from its fp32 mode there);
+# late: medians over the last 100 steps; accuracy: held-out top-1, points, both domains.
+# PROVISIONAL until the first GPU run records the floors (profiles/r04_training_equivalence.json).
+TRAIN_EARLY_REL_F32 = 0.01
+TRAIN_EARLY_REL_BF16 = 0.08
+TRAIN_LATE_REL = 0.10           # total and adversarial loss medians
+TRAIN_LATE_LOSS_C = 0.05        # classification loss median (learnt task: -> 0)
+TRAIN_LATE_LOSS_E = 0.15        # attentive-entropy median
+TRAIN_ACC_POINTS = 3.0

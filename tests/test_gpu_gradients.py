@@ -65,7 +65,8 @@ def _worst(m, n=3):
     return f"median L2 {_median(m):.1e}; worst " + ", ".join(f"{k} L2 {v[0]:.1e} max {v[1]:.1e}" for k, v in sorted(m.items(), key=lambda kv: -kv[1][0])[:n])
 
 
-def _steps_against_resynced_oracle(shape, arith, steps, fused=True, wseed=11, xseed=21, lr=2e-3, wscale="trained", n_valid=None, clip=20.0):
+def _steps_against_resynced_oracle(shape, arith, steps, fused=True, wseed=11, xseed=21, lr=2e-3, wscale="trained", n_valid=None, clip=20.0,
+                                   contract_m=None):
     Bs, Bt, T, D, Fc, Cn = (shape[k] for k in ("Bs", "Bt", "T", "D", "F", "C"))
     cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0)
     params = synth_state(orc.param_shapes(cfg), seed=wseed, scale=wscale)
@@ -84,9 +85,16 @@ def _steps_against_resynced_oracle(shape, arith, steps, fused=True, wseed=11, xs
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
         eng.train_step([0.75, 0.75, 0.5], 0.003, lr, valid_source=ns, valid_target=nt, seed=s)
         torch.cuda.synchronize()
+        if contract_m is not None:      # what the bf16 CONTRACT itself costs on these inputs: the oracle's bf16-operand mode against its fp32 mode
+            st16 = orc.TrainState(params={k: v.clone() for k, v in state.params.items()}, lr=lr)
+            st16.momentum = {k: v.clone() for k, v in state.momentum.items()}
+            cfg16 = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, arithmetic="bf16")
+            res16 = orc.train_step(st16, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg16, clip=clip, n_src=ns, n_tgt=nt)
         res = orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, clip=clip, n_src=ns, n_tgt=nt)
         got_g = {k: v for k, v in eng.param_views(eng.G).items() if k in res["grads"]}
         grad_m.append(_metrics(got_g, res["grads"]))
+        if contract_m is not None:
+            contract_m.append(_metrics(res16["grads"], res["grads"]))
         o = eng.outputs()
         errs = {}
         for key, pick in (("out", lambda r: r["out"]), ("pred_rel", lambda r: r["pred_domain"][0]), ("pred_vid", lambda r: r["pred_domain"][1]),
@@ -133,16 +141,23 @@ def test_full_shape_gradients_match_the_oracle(shape, arith, capsys):
 def test_bf16_distance_from_the_fp32_reference_logits_and_gradients(shape, capsys):
     """What rounding the contraction operands to bf16 costs against the REFERENCE's fp32 arithmetic, for the logits and for every
     gradient tensor, at the benchmarked shapes (the gate against the bf16-operand oracle is tests/test_gpu_bf16.py)."""
-    grad_m, logit_err = _steps_against_resynced_oracle(SHAPES[shape], "bf16", steps=2)
+    contract_m = []
+    grad_m, logit_err = _steps_against_resynced_oracle(SHAPES[shape], "bf16", steps=2, contract_m=contract_m)
     with capsys.disabled():
         for s, m in enumerate(grad_m):
             big = {k: v for k, v in m.items() if v[2] >= 4096}
+            ratio = max(v[0] / (tol.BF16_REF_GRAD_CONTRACT_FACTOR * contract_m[s][k][0] + tol.BF16_REF_GRAD_FLOOR) for k, v in big.items())
             print(f"\n[bf16 vs fp32 reference] {shape} step {s}: {_worst(big)} | median L2 {np.median([v[0] for v in m.values()]):.1e} | "
-                  f"logits max/rms {max(e[0] / (e[1] + 1e-30) for e in logit_err[s].values()):.1e}")
+                  f"logits max/rms {max(e[0] / (e[1] + 1e-30) for e in logit_err[s].values()):.1e} | the contract itself (oracle bf16 mode vs fp32 mode): "
+                  f"{_worst({k: v for k, v in contract_m[s].items() if v[2] >= 4096})} | worst fraction of the per-tensor bound {ratio:.2f}")
     for s, m in enumerate(grad_m):
         for k, (l2, mx, n) in m.items():
             if n >= 4096:
-                assert l2 <= tol.BF16_REF_GRAD_REL_L2, f"step {s} {k}: rel. L2 {l2:.3e}"
+                # no further from the reference than a small multiple of what the arithmetic contract itself costs on these very inputs
+                # (profiles/r04_bf16_gradient_deviation_attribution.txt: that cost is the ReLU on/off pattern - 0.08 % of the hidden units
+                # land on the other side of zero - not the rounding of the products), and never beyond the absolute cap
+                bound = min(tol.BF16_REF_GRAD_REL_L2, tol.BF16_REF_GRAD_CONTRACT_FACTOR * contract_m[s][k][0] + tol.BF16_REF_GRAD_FLOOR)
+                assert l2 <= bound, f"step {s} {k}: rel. L2 {l2:.3e} > {bound:.3e} (contract: {contract_m[s][k][0]:.3e})"
         assert np.median([v[0] for v in m.values()]) <= tol.BF16_REF_GRAD_REL_L2_MEDIAN
         for key, (err, rms) in logit_err[s].items():
             assert err <= tol.BF16_REF_LOGIT_REL_RMS * rms + 1e-7, (s, key, err, rms)
