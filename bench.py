@@ -184,7 +184,25 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=40):
                     break
     except OSError:
         pass
+    # The port's time relative to the REFERENCE's own (main.train + models.VideoModel, timed beside the port in the build container -
+    # the GPU box has no reference checkout): profiles/reference_vs_port_cpu.json, written by tools/time_reference_cpu.py
+    ref = {"file": None}
+    try:
+        import hashlib
+        with open(os.path.join(ROOT, "profiles", "reference_vs_port_cpu.json"), "rb") as f:
+            raw = f.read()
+        tbl = json.loads(raw)
+        cnum = next(k for k, v in CONFIGS.items() if v is conf)
+        e = tbl["configs"][f"configs[{cnum - 1}]"]
+        with open(os.path.join(ROOT, "oracle", "ta3n_oracle.py"), "rb") as f:
+            fresh = hashlib.sha256(f.read()).hexdigest()[:16] == tbl.get("oracle_sha256")
+        ref = {"file": "profiles/reference_vs_port_cpu.json", "file_sha256": hashlib.sha256(raw).hexdigest()[:16],
+               "reference_over_port": e["reference_over_port"], "measured_on": tbl["host"], "port_unchanged_since": fresh,
+               "reference_ms_per_step_there": e["reference_ms_per_step"], "port_ms_per_step_there": e["port_ms_per_step"]}
+    except Exception as ex:      # noqa: BLE001 - no table for this configuration
+        ref = {"file": None, "error": f"{type(ex).__name__}: {ex}"[:120]}
     return dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port",
+                reference_over_port=ref.get("reference_over_port"), reference=ref,
                 sample=f"{n} full train steps ({CFG['Bs']}+{CFG['Bt']} videos, fp32, dropout 0.5" + (", both streams" if conf["streams"] > 1 else "") + f") of oracle/ta3n_oracle.py on {cores} "
                        f"torch threads (best of a bounded probe; {avail} hw threads visible) of '{model}' = "
                        f"{1e3 * dt / n:.1f} ms/step",

@@ -430,7 +430,9 @@ int ta3n_all_reduce_sum(ta3n_comm *comm, float *buf, int64_t count, void *scratc
  * device memory, for up to max_count elements, transport fp32 or bf16) on the current device; ta3n_peer_handle fills 128 bytes
  * (two HIP IPC handles) that the launcher gathers from every rank, in rank order, and hands to ta3n_peer_connect as world x 128
  * bytes.  ta3n_peer_all_reduce_sum: in-place SUM over the ranks, enqueued on `stream` (three kernels); every rank receives
- * bit-identical results; every cross-rank wait is bounded (3 s) and failures are reported by ta3n_peer_status (synchronises).
+ * bit-identical results; every cross-rank wait is bounded (120 s; TA3N_PEER_TIMEOUT_S in the environment, 0 = unbounded): a wait that gives
+ * up sets a sticky error word, every exchange from then on delivers NaN instead of partial sums, and ta3n_peer_status (synchronises)
+ * reports it - a host checks it wherever it synchronises anyway (TrainEngine.check_exchange).
  * ta3n_comm_attach_peer routes ta3n_all_reduce_sum / ta3n_train_step_ddp / ta3n_train_steps of a communicator through it. */
 typedef struct ta3n_peer ta3n_peer;
 int ta3n_peer_create(int rank, int world, int64_t max_count, int bf16_transport, ta3n_peer **out);

@@ -101,15 +101,25 @@ class _TrnStandalone(torch.autograd.Function):
             t0 += len(tuples)
         ctx.mod, ctx.dev, ctx.dims = mod, dev, (B, T, D, NB)
         ctx.in_device, ctx.in_dtype = input.device, input.dtype
+        # What backward needs is kept PER CALL: the module's workspace is shared by every call with this batch size, and the reference
+        # calls the module twice per forward - TRN(source), TRN(target), models.py:636-651 - before one backward (with
+        # equal batch sizes the second call used to overwrite the first one's activations, silently).
+        ctx.save_for_backward(ws[o_f1:o_f1 + n_f1].clone(), z.clone(), *[t.detach() for t in params])
         return torch.cat(out, 1)
 
     @staticmethod
     def backward(ctx, g_out):
         import ctypes as C
         mod, dev, (B, T, D, NB) = ctx.mod, ctx.dev, ctx.dims
-        plan, ws, flat, grads, x = mod._hip_state(B, T, D, NB, dev)      # (the forward's activations are still in this workspace)
-        o_z, n_z = plan.region("Zr")
-        z = ws[o_z:o_z + n_z].view(B, -1, NB)
+        plan, ws, flat, grads, x = mod._hip_state(B, T, D, NB, dev)
+        f1, z, *params = ctx.saved_tensors                                # this call's own activations and parameters back into the workspace
+        o_f1, n_f1 = plan.region("F1")
+        ws[o_f1:o_f1 + n_f1].copy_(f1)
+        offs = {n: (o, sh) for n, o, sh, _ in plan.params}
+        for j in range(len(mod.fc_fusion_scales)):
+            for nm, t in (("weight", params[2 * j]), ("bias", params[2 * j + 1])):
+                o, sh = offs[f"TRN.fc_fusion_scales.{j}.1.{nm}"]
+                flat[o:o + t.numel()].copy_(t.reshape(-1))
         o_gz, n_gz = plan.region("gZ")
         gz = ws[o_gz:o_gz + n_gz].view(B, -1, NB)
         g = g_out.to(dev, torch.float32)

@@ -164,10 +164,24 @@ def install() -> bool:
         _cg.clip_grad_norm_ = clip_grad_norm_
     except Exception:      # noqa: BLE001
         pass
+    # A program that ran `from torch.nn.utils import clip_grad_norm_` BEFORE this call holds the original by name (the reference's
+    # main.py:10 precedes its `from models import VideoModel` at :13, which is what triggers install() under compat/): rebind the name
+    # in every already-imported module where it IS the original, the running program first.
+    import sys
+    for mod in list(sys.modules.values()):
+        try:
+            if mod is not None and getattr(mod, "clip_grad_norm_", None) is _orig_clip and mod.__name__ not in ("torch.nn.utils", "torch.nn.utils.clip_grad"):
+                _rebound.append(mod)
+                mod.clip_grad_norm_ = clip_grad_norm_
+        except Exception:      # noqa: BLE001 - modules with exotic __getattr__
+            pass
     _hook_handle = register_optimizer_step_pre_hook(_sgd_pre_hook)
     _post_handle = register_optimizer_step_post_hook(_sgd_post_hook)
     _installed = True
     return True
+
+
+_rebound = []
 
 
 def uninstall() -> None:
@@ -180,6 +194,10 @@ def uninstall() -> None:
         _cg.clip_grad_norm_ = _orig_clip
     except Exception:      # noqa: BLE001
         pass
+    for mod in _rebound:
+        if getattr(mod, "clip_grad_norm_", None) is clip_grad_norm_:
+            mod.clip_grad_norm_ = _orig_clip
+    _rebound.clear()
     for h in (_hook_handle, _post_handle):
         if h is not None:
             h.remove()

@@ -27,6 +27,7 @@
 // device, tests/test_gpu_peer.py); TA3N_DDP_PEER=1 selects it, ncclAllReduce stays the default exchange.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -40,7 +41,18 @@ namespace {
 
 constexpr int MAXR = 16;
 enum { F_READY_IN = 0, F_READY_RED = 1, F_DONE = 2 };
-constexpr unsigned long long SPIN_TICKS = 3ull * 100000000ull;     // wall_clock64 runs at 100 MHz: 3 s
+// Bound of one cross-rank wait in wall_clock64 ticks (100 MHz).  Default 120 s - ranks legitimately arrive seconds apart (a slow data
+// loader, a checkpoint written by rank 0); TA3N_PEER_TIMEOUT_S overrides it (0 = wait for ever, like a blocking RCCL collective).  A wait
+// that does give up sets the sticky error word, and from then on every exchange POISONS its output (NaN) instead of delivering partial
+// sums: divergence between ranks is loud, never silent; ta3n_peer_status reports it at the host's next check.
+unsigned long long spin_ticks() {
+    static const unsigned long long t = [] {
+        const char *e = getenv("TA3N_PEER_TIMEOUT_S");
+        const double s = e ? atof(e) : 120.0;
+        return s <= 0.0 ? ~0ull : (unsigned long long)(s * 1e8);
+    }();
+    return t;
+}
 
 struct PeerView {
     const void *in[MAXR];       // every rank's stage_in (own entry = own buffer)
@@ -63,7 +75,7 @@ __device__ __forceinline__ float ld_elem(const void *base, int64_t i, int bf16) 
 // every peer's flag block, then wait until every rank's epoch in MY block has reached it.  Stream order puts it behind this rank's
 // previous phase (whose stores the kernel boundary has written back) and in front of the next; the data kernels themselves never
 // spin, so a waiting rank occupies one wave, not the device (two processes may share a GPU in tests).  The wait is bounded.
-__global__ __launch_bounds__(64) void peer_sync_kernel(PeerView v, int which, unsigned epoch, unsigned *err) {
+__global__ __launch_bounds__(64) void peer_sync_kernel(PeerView v, int which, unsigned epoch, unsigned *err, unsigned long long SPIN_TICKS) {
     const int p = threadIdx.x;
     if (p < v.world) {
         __threadfence_system();
@@ -135,6 +147,13 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerView v, float *__r
                                                           unsigned *err) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n4 = count / 4;                        // chunk is a multiple of 4: a group of four never straddles two owners
+    // a wait of this or an earlier exchange gave up (sticky error word): what the staging buffers hold is stale or partial - deliver NaN,
+    // so that the ranks cannot drift apart silently (the optimiser turns every parameter into NaN and the run stops being "finite")
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        const float nan = __builtin_nanf("");
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += stride) buf[i] = nan;
+        return;
+    }
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += stride) {
         const int64_t i = 4 * q;
         reinterpret_cast<float4 *>(buf)[q] = ld4(v.red[(int)(i / chunk)], i, v.bf16);
@@ -239,13 +258,13 @@ int ta3n_peer_all_reduce_sum(ta3n_peer *p, float *buf, int64_t count, void *stre
     unsigned *err = p->flags + 3 * MAXR;
     const int blocks = (int)std::min<int64_t>((count / 4 + 255) / 256 + 1, 1024);
     // "I am done reading everybody's buffers of the previous exchange" / wait until everybody is: the staging buffers may be overwritten
-    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_DONE, epoch - 1, err);
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_DONE, epoch - 1, err, spin_ticks());
     hipLaunchKernelGGL(peer_pack_kernel, dim3(blocks), dim3(256), 0, s, v, buf, static_cast<void *>(p->stage), count, epoch, err);
-    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_IN, epoch, err);
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_IN, epoch, err, spin_ticks());
     const int rblocks = (int)std::max<int64_t>(1, std::min<int64_t>((c1 - c0 + 255) / 256, 1024));
     hipLaunchKernelGGL(peer_reduce_kernel, dim3(rblocks), dim3(256), 0, s, v, static_cast<void *>(p->stage + (size_t)p->cap * sizeof(float)), c0, c1,
                        epoch, err);
-    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_RED, epoch, err);
+    hipLaunchKernelGGL(peer_sync_kernel, dim3(1), dim3(64), 0, s, v, (int)F_READY_RED, epoch, err, spin_ticks());
     hipLaunchKernelGGL(peer_gather_kernel, dim3(blocks), dim3(256), 0, s, v, buf, count, chunk, epoch, err);
     if (hipGetLastError() != hipSuccess) return fail(TA3N_ERR_HIP, "peer all-reduce launch failed");
     return TA3N_OK;

@@ -112,6 +112,8 @@ class TrainEngine:
         self.ens_DA, self.mu = ens_DA, float(mu)
         self.loss_s = None                       # device scalar: the MCD discrepancy loss of the last step (main.py's loss_s)
         self.loss_c2 = None                      # ... and the second classifier's cross-entropy on the source rows
+        self.loss_e_shift = None                 # MCD + attentive entropy: (d total, d loss_e) that moving the target rows' entropy term to the
+                                                 # second pass's logits adds to what the loss kernel logged (main.py:549 vs :559-562)
         if ens_DA == "MCD":
             if use_bn != "none":
                 raise NotImplementedError("ens_DA MCD with use_bn (the second forward moves the BatchNorm buffers again: the module path)")
@@ -471,6 +473,8 @@ class TrainEngine:
             w = 1.0 + ent(pv)
             e_new, e_old = scale * torch.sum(w * ent(y)), scale * torch.sum(w * ent(y_first))
             gpv, = torch.autograd.grad(e_new - e_old, pv, retain_graph=True)
+            de = (e_new - e_old).detach()
+            self.loss_e_shift = (de, de / float(self._hyper.gamma) if float(self._hyper.gamma) != 0.0 else de * 0)
             self.region("gPv", (self.B, 2))[rows] += gpv   # (zero when the two passes drew the same dropout masks)
             loss = loss + e_new
         g1, g2 = torch.autograd.grad(loss, (y, y2))
@@ -499,6 +503,13 @@ class TrainEngine:
             w = parallel.all_reduce_sum_async(self.G[: self.plan.live_floats], self.pg, True)
             if w is not None:
                 w.wait()
+
+    def check_exchange(self) -> None:
+        """Raise if the peer all-reduce (TA3N_DDP_PEER=1) ever gave up waiting for a rank: its error word is sticky and every later
+        exchange delivers NaN (csrc/ta3n_peer.hip).  Synchronises the stream - call it where the host synchronises anyway (a log line,
+        before validation / a checkpoint, the end of an epoch).  RCCL needs no such check: its collectives block."""
+        if self.peer is not None:
+            self.peer.status(self.device)
 
     def sgd_step_fused(self) -> None:
         """Update with the global norm taken from the fused step's per-tile partials (single rank only)."""

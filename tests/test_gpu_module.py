@@ -166,3 +166,36 @@ def test_standalone_relation_module_backward_matches_autograd_of_the_reference_m
         assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=2e-4, atol=2e-5 * xr.grad.abs().max().item()), (xg.grad.cpu() - xr.grad).abs().max()
         for p, r in zip(m.parameters(), ref_params):
             assert torch.allclose(p.grad.cpu(), r.grad, rtol=2e-4, atol=2e-5 * r.grad.abs().max().item()), (p.grad.cpu() - r.grad).abs().max()
+
+
+def test_standalone_relation_module_called_twice_before_one_backward():
+    """The reference calls the module for the source and for the target batch and backpropagates once (models.py:636-651).  With
+    EQUAL batch sizes both calls share the module's cached workspace: each call must keep what its own backward needs."""
+    import torch.nn.functional as Fn
+    from ta3n_amd.TRNmodule import RelationModuleMultiScale
+    torch.manual_seed(9)
+    T, D, B = 5, 128, 6
+    m = RelationModuleMultiScale(D, 256, T, verbose=False)
+    xs, xt = torch.randn(B, T, D), torch.randn(B, T, D)
+    ref_params = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    xr = [xs.clone().requires_grad_(True), xt.clone().requires_grad_(True)]
+
+    def ref(x):
+        out = []
+        for j, tuples in enumerate(m.relations_selected):
+            w, b = ref_params[2 * j], ref_params[2 * j + 1]
+            acc = 0
+            for tup in tuples:
+                acc = acc + torch.relu(Fn.linear(torch.relu(x[:, list(tup), :]).reshape(B, -1), w, b))
+            out.append(acc.unsqueeze(1))
+        return torch.cat(out, 1)
+    gs, gt = torch.randn(B, T - 1, 256), torch.randn(B, T - 1, 256)
+    ((ref(xr[0]) * gs).sum() + (ref(xr[1]) * gt).sum()).backward()
+    m = m.cuda()
+    xg = [xs.cuda().requires_grad_(True), xt.cuda().requires_grad_(True)]
+    os_, ot = m(xg[0]), m(xg[1])                       # two forwards ...
+    ((os_ * gs.cuda()).sum() + (ot * gt.cuda()).sum()).backward()      # ... one backward
+    for a, b in zip(xg, xr):
+        assert torch.allclose(a.grad.cpu(), b.grad, rtol=2e-4, atol=2e-5 * b.grad.abs().max().item()), (a.grad.cpu() - b.grad).abs().max()
+    for p, r in zip(m.parameters(), ref_params):
+        assert torch.allclose(p.grad.cpu(), r.grad, rtol=2e-4, atol=2e-5 * r.grad.abs().max().item()), (p.grad.cpu() - r.grad).abs().max()

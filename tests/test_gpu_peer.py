@@ -155,3 +155,44 @@ def test_engine_data_parallel_step_through_the_peer_all_reduce_matches_the_globa
     torch.cuda.synchronize()
     want = ref.P.detach().cpu()
     assert torch.allclose(got[0], want, rtol=2e-4, atol=2e-6), (got[0] - want).abs().max()
+
+
+def _absent_rank_worker(rank, world, port, q):
+    """rank 1 never joins the second exchange: rank 0's wait must give up after TA3N_PEER_TIMEOUT_S, deliver NaN (never a partial sum),
+    keep delivering NaN (sticky), and status() / TrainEngine.check_exchange must raise."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TA3N_PEER_TIMEOUT_S="0.5")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from ta3n_amd import _lib, parallel
+        dev = torch.device("cuda", 0)
+        pc = parallel.PeerComm(None, dev, 4096)
+        x = torch.full((4096,), float(rank + 1), device=dev)
+        pc.all_reduce_sum_(x)                      # both ranks: fine
+        torch.cuda.synchronize()
+        assert torch.equal(x.cpu(), torch.full((4096,), 3.0))
+        pc.status(dev)
+        dist.barrier()
+        if rank == 0:
+            for _ in range(2):                      # alone: gives up, poisons; and again (sticky)
+                y = torch.ones(4096, device=dev)
+                pc.all_reduce_sum_(y)
+                torch.cuda.synchronize()
+                assert bool(torch.isnan(y).all()), "a timed-out exchange must deliver NaN, not stale or partial sums"
+            try:
+                pc.status(dev)
+                raise AssertionError("status() must report the rank that never arrived")
+            except _lib.Ta3nError as ex:
+                assert "gave up waiting for rank 1" in str(ex), str(ex)
+        dist.barrier()
+        q.put(("ok", rank))
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        q.put(("fail", rank, traceback.format_exc()[-1500:]))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_a_rank_that_never_arrives_poisons_the_exchange_and_is_reported():
+    _run(_absent_rank_worker)

@@ -186,3 +186,36 @@ def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path,
     # everything before the first forward ran on the reference's own code: parser, ctor, DataParallel, SGD, loaders, train()
     assert "start training" in r.stdout, r.stdout[-2000:]
     assert "STOPPED Ta3nError" in r.stdout and "HIP device" in r.stdout, r.stdout[-2000:]      # loud: no CPU fallback
+
+
+@pytest.mark.gpu
+def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path):
+    """main.py's train() takes the fused step (TrainEngine) where the options allow it; TA3N_MAIN_FAST=0 keeps the module path
+    (VideoModel.forward + torch loss assembly + autograd + clip + SGD).  Same arithmetic up to fp32 summation order: with dropout off the
+    logged losses agree line by line and the checkpoints hold the same parameters and momentum buffers."""
+    import re
+    data = make_dataset(str(tmp_path / "data"))
+    common = [c if c != "0.5" else "0" for c in COMMON]      # dropout_i / dropout_v 0: the two paths draw different masks
+    outs, cks = [], []
+    for fast in ("1", "0"):
+        exp = str(tmp_path / f"exp{fast}")
+        cmd = [sys.executable, os.path.join(ROOT, "main.py"), data[0], "RGB", data[1], data[2], data[3], "--exp_path", exp + "/", *TA3N, *common]
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, TA3N_MAIN_FAST=fast))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append([ln for ln in open(exp + "/RGB/train.log") if ln.startswith("Train:")])
+        cks.append(torch.load(exp + "/RGB/checkpoint.pth.tar", map_location="cpu", weights_only=False))
+    assert len(outs[0]) == len(outs[1]) == 6
+    num = re.compile(r"(Loss|loss_c|loss_a|loss_e|Prec@1|lr:) ([0-9.]+)")
+    for a, b in zip(*outs):
+        fa, fb = num.findall(a), num.findall(b)
+        assert [k for k, _ in fa] == [k for k, _ in fb]
+        for (k, x), (_, y) in zip(fa, fb):
+            assert abs(float(x) - float(y)) <= 2e-3 * max(1.0, abs(float(y))), (k, x, y, a, b)
+    sa, sb = cks[0]["state_dict"], cks[1]["state_dict"]
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert torch.allclose(sa[k].float(), sb[k].float(), rtol=2e-3, atol=2e-5), (k, (sa[k].float() - sb[k].float()).abs().max())
+    ma = [st["momentum_buffer"] for st in cks[0]["optimizer"]["state"].values()]
+    mb = [st["momentum_buffer"] for st in cks[1]["optimizer"]["state"].values()]
+    assert len(ma) == len(mb) and all(torch.allclose(x, y, rtol=5e-3, atol=1e-5) for x, y in zip(ma, mb))
+    assert cks[0]["prec1"] == cks[1]["prec1"]

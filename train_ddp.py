@@ -224,6 +224,8 @@ def main():
         # With packed stores and full, evenly sharded batches the steps between two log lines go to the GPU in ONE call
         # (TrainEngine.train_steps: the library gathers each step's batch on the device, runs the step, exchanges the gradients and
         # opens the next step with the update) - same arithmetic as one call per step, bit for bit.
+        # (when the engine has no single library call for its configuration - torch.distributed fallback, TA3N_DDP_BUCKETS=2,
+        # TA3N_SIDE_UPDATE=0 - train_steps itself runs the chunk step by step, gathering each batch on the device: ADVICE r03)
         chunked = (bool(stores) and eng.fused and not args.graph and Bs_g % world == 0 and Bt_g % world == 0 and
                    os.environ.get("TA3N_TRAIN_CHUNKS", "1") == "1")
         chunk = []
@@ -231,16 +233,24 @@ def main():
         def log_line(i, lr_used, beta):
             # one host sync every print_freq steps (the reference syncs 5-6x per step).  A rank's loss scalars are its
             # shard's sums divided by the GLOBAL counts: the job's losses are their sum over ranks.
+            eng.check_exchange()                 # (peer all-reduce only: a rank that gave up waiting is reported here, not silently ignored)
             scal = eng.region("losses")[:6].clone()
             if world > 1:
                 torch.distributed.all_reduce(scal)
             if rank == 0:
                 v = scal.tolist()
-                extra = ""      # the terms the loss kernel does not know (one rank only): main.py's loss_d / loss_s
+                extra = ""      # the terms the loss kernel does not know (one rank only): main.py's loss_d / loss_s - printed AND, like in
+                # the reference's log (main.py:564-571: `loss` is everything that was backpropagated), part of the logged total
                 if eng.loss_d is not None:
                     extra += f" loss_d {eng.loss_d.item():.4f}"
+                    v[0] += eng.alpha * eng.loss_d.item()
                 if eng.loss_s is not None:
                     extra += f" loss_s {eng.loss_s.item():.4f} loss_c2 {eng.loss_c2.item():.4f}"
+                    v[0] += eng.loss_s.item() + eng.loss_c2.item()
+                    v[1] += eng.loss_c2.item()          # main.py:447-450: loss_c is the sum of the two classifiers' cross-entropies
+                if eng.loss_e_shift is not None:        # MCD: the target rows' entropy term is the SECOND pass's (main.py:549, 559-562)
+                    v[0] += eng.loss_e_shift[0].item()
+                    v[5] += eng.loss_e_shift[1].item()
                 print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
                       f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f}{extra} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
 
@@ -294,6 +304,7 @@ def main():
                 log_line(i, lr_used, beta)
         flush_chunk()
         eng.flush()                                                                   # the epoch's last update, before validation / checkpoint
+        eng.check_exchange()
         if epoch % max(args.eval_freq, 1) == 0 or epoch == args.epochs:                   # main.py:252-274
             prec1 = validate(epoch) if (stores and len(stores) > 2) else 0.0
             is_best = prec1 > best_prec1
