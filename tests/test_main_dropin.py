@@ -215,7 +215,8 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path):
     assert set(sa) == set(sb)
     for k in sa:
         assert torch.allclose(sa[k].float(), sb[k].float(), rtol=2e-3, atol=2e-5), (k, (sa[k].float() - sb[k].float()).abs().max())
-    ma = [st["momentum_buffer"] for st in cks[0]["optimizer"]["state"].values()]
-    mb = [st["momentum_buffer"] for st in cks[1]["optimizer"]["state"].values()]
-    assert len(ma) == len(mb) and all(torch.allclose(x, y, rtol=5e-3, atol=1e-5) for x, y in zip(ma, mb))
+    ma, mb = cks[0]["optimizer"]["state"], cks[1]["optimizer"]["state"]      # keyed by the parameter's index in the optimiser's group
+    assert set(ma) == set(mb), (sorted(ma), sorted(mb))
+    for k in ma:
+        assert torch.allclose(ma[k]["momentum_buffer"], mb[k]["momentum_buffer"], rtol=5e-3, atol=1e-5), k
     assert cks[0]["prec1"] == cks[1]["prec1"]
