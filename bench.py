@@ -423,7 +423,11 @@ def main():
         if brief:
             return res
         res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
-        if eng.peer is not None:
+        if eng._sharded:
+            res["gradient_exchange"] = ("sharded update: RCCL reduce-scatter (region B beside the last launch), own-shard clip + SGD, all-gather of the parameters "
+                                        "(region B beside the next step's first launch); " + ("bf16" if eng._g16 is not None else "fp32") + " gradient transport"
+                                        if eng.comm is not None else "sharded update over torch.distributed")
+        elif eng.peer is not None:
             res["gradient_exchange"] = ("two-shot all-reduce over peer-mapped buffers (csrc/ta3n_peer.hip), " +
                                         ("bf16" if eng.peer.bf16 else "fp32") + " transport")
         elif eng.comm is not None:
@@ -432,6 +436,7 @@ def main():
         else:
             res["gradient_exchange"] = ("torch.distributed all_reduce (backend nccl = RCCL), fp32" +
                                         (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
+        res["rccl_ranks"] = int(eng._L.ta3n_comm_world(eng.comm.handle)) if eng.comm is not None else None
         res["deferred"] = deferred
         res["batched"] = batched
         res["pipelined"] = pipelined
@@ -559,6 +564,7 @@ def main():
                        ("opens the next step, carrying its scalars; all but the shared frame FC's part rides in that step's first GEMM "
                         "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
                        "gradient_exchange": None if (world == 1 and not selftest) else main_res.get("gradient_exchange"),
+                       "rccl_ranks": main_res.get("rccl_ranks"),
                        "collective": main_res.get("collective"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],

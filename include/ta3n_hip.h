@@ -443,6 +443,37 @@ int ta3n_peer_status(ta3n_peer *peer, void *stream);
 void ta3n_peer_destroy(ta3n_peer *peer);
 int ta3n_comm_attach_peer(ta3n_comm *comm, ta3n_peer *peer);
 
+/* ---- sharded optimiser step (the data-parallel exchange as reduce-scatter + all-gather instead of one all-reduce) ----------------
+ * What nn.DataParallel's backward + optimizer.step() (main.py:79, 576-583) amount to when every rank updates only ITS share of the
+ * parameters: the flat gradient prefix is reduce-scattered (rank r receives the job-wide SUM of its shards), every rank takes the
+ * sum of squares of its shards, one float per rank is all-gathered - clip_grad_norm_'s global norm, identical on every rank -, the
+ * clip + Nesterov / weight-decay update runs on the own shards only (1 / world of the optimiser's 20 bytes per parameter) and the
+ * updated parameters are all-gathered.  Same bytes over xGMI as the all-reduce (which is these two collectives back to back); the
+ * optimiser pass shrinks by the number of ranks and the all-gather of everything the step's first launch does not read can run
+ * beside that launch.  Two regions, each dealt to the ranks in equal 4-float-aligned chunks: A = [0, a_end) holds the parameters
+ * the first launch reads (the shared frame FC, whose gradient is the LAST launch's output), B = [a_end, b_end) everything else.
+ * ta3n_shard_ranges: own4 = this rank's [a_lo, a_hi, b_lo, b_hi) clipped to the live prefix; layout4 = a_chunk, a_end, b_chunk, b_end.
+ * ta3n_shard_sumsq: the own shards' sum of squares into slot `rank` of ws["norm_part"], every other slot zeroed (gather one float per
+ * rank into slots [0, world) next).  ta3n_sgd_shard: the update on the own shards with the norm = sqrt(sum of ws["norm_part"]),
+ * leaving `next` (may be NULL) as the next step's scalars.  These two need no communicator (a host may do the exchanges itself).
+ * ta3n_shard_reduce_scatter / ta3n_sharded_update: the collectives (RCCL) + the pieces above on one stream; the bf16 twins of the
+ * gathered parameters are rebuilt locally.  scratch_bf16 (2 bytes per element up to b_end): gradients travel as bf16. */
+int ta3n_shard_ranges(const ta3n_plan *plan, int rank, int world, int64_t *own4, int64_t *layout4);
+int ta3n_shard_sumsq(ta3n_plan *plan, const float *grads, float *ws, int rank, int world, void *stream);
+int ta3n_sgd_shard(ta3n_plan *plan, float *params, float *grads, float *momentum, float *ws, int rank, int world, float lr,
+                   float momentum_coef, float weight_decay, float clip, const ta3n_hyper *next, void *stream);
+int ta3n_shard_reduce_scatter(ta3n_plan *plan, ta3n_comm *comm, float *grads, void *scratch_bf16, void *stream);
+int ta3n_sharded_update(ta3n_plan *plan, ta3n_comm *comm, float *params, float *grads, float *momentum, float *ws, float lr,
+                        float momentum_coef, float weight_decay, float clip, const ta3n_hyper *next, void *stream);
+/* ta3n_train_steps with the sharded update: for every step { batch assembly; update of the step before (its gradients must already
+ * be reduce-scattered: a previous call of this function or ta3n_shard_reduce_scatter) carrying hypers[k]; all-gather of region A on
+ * `stream`, of region B on `comm_stream` under the step's first launch; the step's launches; reduce-scatter of region B on
+ * `comm_stream` beside the last launch, of region A behind it }.  comm_stream == NULL or == stream: everything in order on one
+ * stream.  The update of step n_steps - 1 stays pending, reduce-scattered (finish with ta3n_sharded_update, next = NULL). */
+int ta3n_train_steps_sharded(ta3n_plan *plan, ta3n_comm *comm, const float *x, float *params, float *grads, float *momentum, float *ws,
+                             float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
+                             const ta3n_feed *source, const ta3n_feed *target, void *scratch_bf16, void *stream, void *comm_stream);
+
 /* ta3n_train_step followed by the all-reduce of the live gradient prefix - the data-parallel step up to the optimiser
  * (continue with ta3n_sgd_step, whose norm pass reads the reduced gradients).  Losses must be normalised by GLOBAL row
  * counts (ta3n_hyper.inv_n_*), so the summed gradients are the global-batch gradients.

@@ -163,6 +163,10 @@ def _fast_engine(model, optimizer, num_class):
     torch.optim state as before."""
     from ta3n_amd.engine import TrainEngine, flags_from_options
     m = model.module
+    needed = ("frame_aggregation", "dis_DA", "ens_DA", "use_bn", "save_attention", "add_loss_DA", "use_attn", "use_target", "place_adv", "adv_DA",
+              "batch_size", "num_segments", "fc_dim", "dropout_i", "dropout_v", "clip_gradient", "no_partialbn", "print_freq", "lr_adaptive", "epochs")
+    if any(not hasattr(args, k) for k in needed):      # a caller that drives train() with a hand-made namespace: the module path
+        return None
     if (os.environ.get("TA3N_MAIN_FAST", "1") == "0" or args.frame_aggregation != "trn-m" or args.dis_DA != "none" or args.ens_DA != "none" or
             args.use_bn != "none" or args.save_attention >= 0 or type(optimizer) is not torch.optim.SGD or len(optimizer.param_groups) != 1):
         return None

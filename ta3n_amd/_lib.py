@@ -43,6 +43,7 @@ SYMBOLS = [
     "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
     "ta3n_comm_attach_peer", "ta3n_has_fused_update", "ta3n_train_steps_fused_update",
     "ta3n_gaussian_kernel_scratch_floats", "ta3n_gaussian_kernel", "ta3n_mmd_rowdiff",
+    "ta3n_shard_ranges", "ta3n_shard_sumsq", "ta3n_sgd_shard", "ta3n_shard_reduce_scatter", "ta3n_sharded_update", "ta3n_train_steps_sharded",
 ]
 
 
@@ -130,6 +131,13 @@ def lib() -> C.CDLL:
                                    C.POINTER(Feed), C.POINTER(Feed), vp, vp, vp]
     L.ta3n_train_steps_multi.argtypes = [C.POINTER(StepsJob), C.c_int, C.c_int]
     L.ta3n_has_fused_update.argtypes = [vp]
+    L.ta3n_shard_ranges.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.ta3n_shard_sumsq.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    L.ta3n_sgd_shard.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), vp]
+    L.ta3n_shard_reduce_scatter.argtypes = [vp, vp, vp, vp, vp]
+    L.ta3n_sharded_update.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), vp]
+    L.ta3n_train_steps_sharded.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
+                                           C.POINTER(Feed), C.POINTER(Feed), vp, vp, vp]
     L.ta3n_train_steps_fused_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.POINTER(Hyper), C.c_int,
                                                 C.POINTER(Feed), C.POINTER(Feed), vp]
     L.ta3n_gather_segments_into.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]

@@ -626,6 +626,171 @@ int ta3n_train_steps_multi(const ta3n_steps_job *jobs, int n_jobs, int n_steps) 
     return TA3N_OK;
 }
 
+// ---- sharded optimiser step of a data-parallel rank (reduce-scatter -> per-shard norm -> clip + SGD on the own shard -> all-gather) ----
+namespace {
+// Two regions of the flat prefix, each dealt to the ranks in equal 4-float-aligned chunks: A = the parameters the step's FIRST launch
+// reads (shared frame FC; its gradient is the LAST launch's output), B = everything else.  A ends at a multiple of 4 * world at or
+// behind first_floats, B may run past live_floats into parameters that never receive a gradient (zeros are reduced, identical values
+// are gathered) but never past the buffer.
+struct Shards { int64_t a_chunk = 0, a_end = 0, b_chunk = 0, b_end = 0; };
+int shard_layout(const ta3n_plan *p, int world, Shards &s) {
+    if (!p || world < 1) return fail(TA3N_ERR_INVALID, "bad shard arguments");
+    if (p->first_floats <= 0 || p->first_floats >= p->live_floats) return fail(TA3N_ERR_INVALID, "no pipelined step for this configuration");
+    const int64_t q = 4 * (int64_t)world;
+    s.a_end = (p->first_floats + q - 1) / q * q;
+    s.a_chunk = s.a_end / world;
+    const int64_t rest = p->live_floats > s.a_end ? p->live_floats - s.a_end : 0;
+    s.b_chunk = (rest + q - 1) / q * 4;
+    s.b_end = s.a_end + s.b_chunk * world;
+    if (s.b_end > p->param_floats) return fail(TA3N_ERR_INVALID, "the flat buffers are too short to shard over this many ranks");
+    return TA3N_OK;
+}
+void own_ranges(const ta3n_plan *p, const Shards &s, int rank, int64_t *r4) {
+    r4[0] = std::min<int64_t>(s.a_chunk * rank, p->live_floats);
+    r4[1] = std::min<int64_t>(s.a_chunk * (rank + 1), p->live_floats);
+    r4[2] = std::min<int64_t>(s.a_end + s.b_chunk * rank, p->live_floats);
+    r4[3] = std::min<int64_t>(s.a_end + s.b_chunk * (rank + 1), p->live_floats);
+}
+int refresh_param_twins(ta3n_plan *p, const float *params, float *ws, int64_t lo, int64_t hi, hipStream_t s) {
+    const Geom &g = p->geom;
+    if (g.o_p16 < 0 || hi <= lo) return TA3N_OK;
+    hi = std::min<int64_t>(hi, p->param_floats);
+    int rc;
+    if (g.pair_delta) rc = launch_to_bf16_pair(params + lo, ws + g.o_p16 + lo / 2, ws + g.o_p16 + g.pair_delta + lo / 2, hi - lo, s);
+    else rc = launch_to_bf16(params + lo, ws + g.o_p16 + lo / 2, hi - lo, s);
+    return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, "bf16 conversion launch failed");
+}
+}  // namespace
+
+int ta3n_shard_ranges(const ta3n_plan *p, int rank, int world, int64_t *own4, int64_t *layout4) {
+    Shards s;
+    int rc = shard_layout(p, world, s);
+    if (rc != TA3N_OK) return rc;
+    if (rank < 0 || rank >= world) return fail(TA3N_ERR_INVALID, "rank outside the group");
+    if (own4) own_ranges(p, s, rank, own4);
+    if (layout4) { layout4[0] = s.a_chunk; layout4[1] = s.a_end; layout4[2] = s.b_chunk; layout4[3] = s.b_end; }
+    return TA3N_OK;
+}
+
+int ta3n_shard_sumsq(ta3n_plan *p, const float *grads, float *ws, int rank, int world, void *stream) {
+    if (!p || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    Shards s;
+    int rc = shard_layout(p, world, s);
+    if (rc != TA3N_OK) return rc;
+    if (rank < 0 || rank >= world || world > p->geom.n_norm_blocks) return fail(TA3N_ERR_INVALID, "rank outside the group");
+    if ((rc = ensure_uploaded(p)) != TA3N_OK) return rc;
+    int64_t r[4];
+    own_ranges(p, s, rank, r);
+    return launch_shard_sumsq(p->geom, grads, ws, r[0], r[1], r[2], r[3], rank, static_cast<hipStream_t>(stream)) == 0
+               ? TA3N_OK : fail(TA3N_ERR_HIP, "shard norm launch failed");
+}
+
+int ta3n_sgd_shard(ta3n_plan *p, float *params, float *grads, float *momentum, float *ws, int rank, int world, float lr, float momentum_coef,
+                   float weight_decay, float clip, const ta3n_hyper *next, void *stream) {
+    if (!p || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    Shards s;
+    int rc = shard_layout(p, world, s);
+    if (rc != TA3N_OK) return rc;
+    if (rank < 0 || rank >= world) return fail(TA3N_ERR_INVALID, "rank outside the group");
+    if ((rc = ensure_uploaded(p)) != TA3N_OK) return rc;
+    int64_t r[4];
+    own_ranges(p, s, rank, r);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Hyper *nx = reinterpret_cast<const Hyper *>(next);
+    // the norm is the sum of the ranks' shard partials in region norm_part (slots [0, world), the rest zero): fused_norm = false
+    if (r[1] > r[0]) {
+        if (launch_sgd_range(p->geom, params, grads, momentum, ws, r[0], r[1], false, lr, momentum_coef, weight_decay, clip, nx, st) != 0)
+            return fail(TA3N_ERR_HIP, "sgd launch failed");
+    } else if (nx) {      // (a rank without a share of region A still needs the next step's scalars)
+        if (launch_set_hyper(ws + p->geom.o_hyper, *nx, st) != 0) return fail(TA3N_ERR_HIP, "set_hyper launch failed");
+    }
+    if (r[3] > r[2] && launch_sgd_range(p->geom, params, grads, momentum, ws, r[2], r[3], false, lr, momentum_coef, weight_decay, clip, nullptr, st) != 0)
+        return fail(TA3N_ERR_HIP, "sgd launch failed");
+    return TA3N_OK;
+}
+
+int ta3n_shard_reduce_scatter(ta3n_plan *p, ta3n_comm *c, float *grads, void *scratch_bf16, void *stream) {
+    if (!p || !c || !grads) return fail(TA3N_ERR_INVALID, "null argument");
+    Shards s;
+    int rc = shard_layout(p, comm_world_size(c), s);
+    if (rc != TA3N_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = comm_reduce_scatter_sum(c, grads, s.a_end, s.b_chunk, scratch_bf16, st)) != TA3N_OK) return rc;
+    return comm_reduce_scatter_sum(c, grads, 0, s.a_chunk, scratch_bf16, st);
+}
+
+// everything between "the own shards hold the summed gradients" and "every rank holds the updated parameters", on ONE stream
+int ta3n_sharded_update(ta3n_plan *p, ta3n_comm *c, float *params, float *grads, float *momentum, float *ws, float lr, float momentum_coef,
+                        float weight_decay, float clip, const ta3n_hyper *next, void *stream) {
+    if (!p || !c || !params || !grads || !momentum || !ws) return fail(TA3N_ERR_INVALID, "null argument");
+    const int rank = comm_rank(c), world = comm_world_size(c);
+    Shards s;
+    int rc = shard_layout(p, world, s);
+    if (rc != TA3N_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = ta3n_shard_sumsq(p, grads, ws, rank, world, stream)) != TA3N_OK) return rc;
+    if ((rc = comm_all_gather(c, ws, p->geom.o_norm_part, 1, st)) != TA3N_OK) return rc;
+    if ((rc = ta3n_sgd_shard(p, params, grads, momentum, ws, rank, world, lr, momentum_coef, weight_decay, clip, next, stream)) != TA3N_OK) return rc;
+    if ((rc = comm_all_gather(c, params, 0, s.a_chunk, st)) != TA3N_OK) return rc;
+    if ((rc = comm_all_gather(c, params, s.a_end, s.b_chunk, st)) != TA3N_OK) return rc;
+    return refresh_param_twins(p, params, ws, 0, s.b_end, st);
+}
+
+int ta3n_train_steps_sharded(ta3n_plan *p, ta3n_comm *c, const float *x, float *params, float *grads, float *momentum, float *ws,
+                             float lr_pending, float momentum_coef, float weight_decay, float clip, const ta3n_hyper *hypers, int n_steps,
+                             const ta3n_feed *source, const ta3n_feed *target, void *scratch_bf16, void *stream, void *comm_stream) {
+    if (!c) return fail(TA3N_ERR_INVALID, "null communicator");
+    if (n_steps < 0) return fail(TA3N_ERR_INVALID, "n_steps must be >= 0");
+    int rc = check_steps_job(p, x, params, grads, momentum, ws, hypers, 0, source, target, nullptr);
+    if (rc != TA3N_OK) return rc;
+    const int rank = comm_rank(c), world = comm_world_size(c);
+    Shards sh;
+    if ((rc = shard_layout(p, world, sh)) != TA3N_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream), cs = static_cast<hipStream_t>(comm_stream);
+    const bool two = cs && cs != s;
+    hipEvent_t fork = comm_event(c, 0), join = comm_event(c, 1), fork2 = comm_event(c, 2), join2 = comm_event(c, 3);
+    if (two && (!fork || !join || !fork2 || !join2)) return fail(TA3N_ERR_HIP, "hipEventCreate failed");
+    const Geom &g = p->geom;
+    const int n = ta3n_num_phases(p, 4);
+    if (n < 3) return fail(TA3N_ERR_INVALID, "no fused step for this configuration");
+    // with wgrads_late the last launch also produces gradients of region B: its reduce-scatter then cannot start before that launch
+    const bool early_b = two && p->cfg.wgrads_late == 0;
+    Ptrs ptrs = make_ptrs(p, x, params, grads, ws);
+    float lr = lr_pending;
+    for (int k = 0; k < n_steps; ++k) {
+        if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(x), ws, reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
+        if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(x), ws, nullptr, s)) != TA3N_OK) return rc;
+        // -- update of the step before (its gradients are reduce-scattered): norm of the own shards, one float per rank gathered,
+        //    clip + Nesterov SGD on the own shards (1 / world of the optimiser pass), carrying this step's scalars
+        if ((rc = ta3n_shard_sumsq(p, grads, ws, rank, world, stream)) != TA3N_OK) return rc;
+        if ((rc = comm_all_gather(c, ws, g.o_norm_part, 1, s)) != TA3N_OK) return rc;
+        if ((rc = ta3n_sgd_shard(p, params, grads, momentum, ws, rank, world, lr, momentum_coef, weight_decay, clip, &hypers[k], stream)) != TA3N_OK) return rc;
+        // -- the parameters the first launch reads come back on the step's stream; everything else on the second stream, under that launch
+        if ((rc = comm_all_gather(c, params, 0, sh.a_chunk, s)) != TA3N_OK) return rc;
+        if ((rc = refresh_param_twins(p, params, ws, 0, sh.a_end, s)) != TA3N_OK) return rc;
+        hipStream_t bs = two ? cs : s;
+        if (two && (hipEventRecord(fork2, s) != hipSuccess || hipStreamWaitEvent(cs, fork2, 0) != hipSuccess)) return fail(TA3N_ERR_HIP, "event fork failed");
+        if ((rc = comm_all_gather(c, params, sh.a_end, sh.b_chunk, bs)) != TA3N_OK) return rc;
+        if ((rc = refresh_param_twins(p, params, ws, sh.a_end, sh.b_end, bs)) != TA3N_OK) return rc;
+        if (two && hipEventRecord(join2, cs) != hipSuccess) return fail(TA3N_ERR_HIP, "event record failed");
+        // -- step k
+        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 0, 1)) != TA3N_OK) return rc;
+        if (two && hipStreamWaitEvent(s, join2, 0) != hipSuccess) return fail(TA3N_ERR_HIP, "event join failed");
+        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, 1, n - 2)) != TA3N_OK) return rc;
+        if (early_b) {      // region B's gradients are complete: their reduce-scatter runs beside the last launch
+            if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(cs, fork, 0) != hipSuccess) return fail(TA3N_ERR_HIP, "event fork failed");
+            if ((rc = comm_reduce_scatter_sum(c, grads, sh.a_end, sh.b_chunk, scratch_bf16, cs)) != TA3N_OK) return rc;
+            if (hipEventRecord(join, cs) != hipSuccess) return fail(TA3N_ERR_HIP, "event record failed");
+        }
+        if ((rc = run_group(p, 4, ptrs, nullptr, nullptr, s, nullptr, n - 1, 1)) != TA3N_OK) return rc;
+        if (!early_b && (rc = comm_reduce_scatter_sum(c, grads, sh.a_end, sh.b_chunk, scratch_bf16, s)) != TA3N_OK) return rc;
+        if ((rc = comm_reduce_scatter_sum(c, grads, 0, sh.a_chunk, scratch_bf16, s)) != TA3N_OK) return rc;
+        if (early_b && hipStreamWaitEvent(s, join, 0) != hipSuccess) return fail(TA3N_ERR_HIP, "event join failed");
+        lr = hypers[k].lr;
+    }
+    return TA3N_OK;
+}
+
 int ta3n_has_fused_update(const ta3n_plan *p) {
     if (!p) return TA3N_ERR_INVALID;
     // every live parameter's gradient is produced by a tile / column-sum task of the fused step (those carry the update)

@@ -31,6 +31,8 @@ struct Rccl {
     int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;      // (send, recv, recvcount, type, op, ...)
+    int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;               // (send, recv, sendcount, type, ...)
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -54,6 +56,8 @@ Rccl &rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+    r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(dlsym(r.handle, "ncclReduceScatter"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.error = "librccl.so lacks the ncclAllReduce entry points";
     return r;
@@ -79,7 +83,55 @@ struct ta3n_comm {
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork2 = nullptr, join2 = nullptr;      // sharded update: the parameter all-gather that overlaps the next step's first launch
 };
+
+// ---- pieces of the sharded update (ta3n_api.hip: ta3n_train_steps_sharded composes them with the step's launches) ----
+namespace ta3n {
+int comm_rank(const ta3n_comm *c) { return c->rank; }
+int comm_world_size(const ta3n_comm *c) { return c->world; }
+hipEvent_t comm_event(ta3n_comm *c, int which) {
+    hipEvent_t *e[4] = {&c->fork, &c->join, &c->fork2, &c->join2};
+    if (!*e[which] && hipEventCreateWithFlags(e[which], hipEventDisableTiming) != hipSuccess) return nullptr;
+    return *e[which];
+}
+
+// In place: buf[begin + r chunk, + chunk) of rank r receives the SUM over ranks of that range; the other ranges of buf hold junk
+// afterwards.  chunk % 4 == 0.  scratch_bf16 (covering the same element offsets, 2 bytes each): bf16 transport.
+int comm_reduce_scatter_sum(ta3n_comm *c, float *buf, int64_t begin, int64_t chunk, void *scratch_bf16, hipStream_t s) {
+    if (chunk <= 0) return TA3N_OK;
+    if (c->peer) return fail(TA3N_ERR_INVALID, "the sharded update runs on RCCL (no peer transport attached)");
+    Rccl &r = rccl();
+    if (!r.ReduceScatter || !r.AllGather) return fail(TA3N_ERR_HIP, "librccl.so lacks ncclReduceScatter / ncclAllGather");
+    int rc;
+    if (scratch_bf16) {
+        char *s16 = static_cast<char *>(scratch_bf16) + 2 * begin;
+        if (launch_to_bf16(buf + begin, reinterpret_cast<float *>(s16), chunk * c->world, s) != 0) return fail(TA3N_ERR_HIP, "bf16 pack launch failed");
+        rc = r.ReduceScatter(s16, s16 + 2 * chunk * c->rank, (size_t)chunk, kNcclBfloat16, kNcclSum, c->comm, s);
+        if (rc == 0) {
+            const int64_t n4 = chunk / 4;
+            const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+            hipLaunchKernelGGL(from_bf16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint2 *>(s16 + 2 * chunk * c->rank),
+                               reinterpret_cast<float4 *>(buf + begin + chunk * c->rank), n4);
+            if (hipGetLastError() != hipSuccess) return fail(TA3N_ERR_HIP, "bf16 unpack launch failed");
+        }
+    } else {
+        rc = r.ReduceScatter(buf + begin, buf + begin + chunk * c->rank, (size_t)chunk, kNcclFloat32, kNcclSum, c->comm, s);
+    }
+    if (rc != 0) return fail(TA3N_ERR_HIP, std::string("ncclReduceScatter: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"));
+    return TA3N_OK;
+}
+
+// In place: every rank's buf[begin + r chunk, + chunk) to everybody.
+int comm_all_gather(ta3n_comm *c, float *buf, int64_t begin, int64_t chunk, hipStream_t s) {
+    if (chunk <= 0) return TA3N_OK;
+    Rccl &r = rccl();
+    if (!r.AllGather) return fail(TA3N_ERR_HIP, "librccl.so lacks ncclAllGather");
+    const int rc = r.AllGather(buf + begin + chunk * c->rank, buf + begin, (size_t)chunk, kNcclFloat32, c->comm, s);
+    if (rc != 0) return fail(TA3N_ERR_HIP, std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"));
+    return TA3N_OK;
+}
+}  // namespace ta3n
 
 extern "C" {
 
@@ -121,6 +173,8 @@ void ta3n_comm_destroy(ta3n_comm *c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
+    if (c->fork2) (void)hipEventDestroy(c->fork2);
+    if (c->join2) (void)hipEventDestroy(c->join2);
     delete c;
 }
 

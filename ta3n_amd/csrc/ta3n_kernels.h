@@ -142,6 +142,7 @@ int launch_sgd_fixup(const Geom &g, float *params, const float *grads, float *mo
                      float clip, const Hyper *next, hipStream_t stream);
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
                      bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream);
+int launch_shard_sumsq(const Geom &g, const float *grads, float *ws, int64_t a0, int64_t a1, int64_t b0, int64_t b1, int rank, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,
                            const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, int32_t *seg_out,
@@ -151,4 +152,15 @@ int launch_gather_segments_bf16(const void *store16, const int64_t *first_row, c
                                 const int32_t *video_ids, int n_videos, int T, int D, float *out, int32_t *labels_out, float *out_twin,
                                 hipStream_t stream, int64_t pair_delta = 0);
 
+
+}  // namespace ta3n
+
+// pieces of the sharded update that live beside the RCCL binding (csrc/ta3n_comm.hip)
+struct ta3n_comm;
+namespace ta3n {
+int comm_rank(const ta3n_comm *c);
+int comm_world_size(const ta3n_comm *c);
+hipEvent_t comm_event(ta3n_comm *c, int which);      // 0 fork, 1 join, 2 fork2, 3 join2 (created on first use)
+int comm_reduce_scatter_sum(ta3n_comm *c, float *buf, int64_t begin, int64_t chunk, void *scratch_bf16, hipStream_t s);
+int comm_all_gather(ta3n_comm *c, float *buf, int64_t begin, int64_t chunk, hipStream_t s);
 }  // namespace ta3n

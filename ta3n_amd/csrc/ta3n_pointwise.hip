@@ -544,8 +544,8 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && i0 == 0) {
-        ws[g.o_grad_norm] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (i0 == 0 || has_next)) {      // (every existing caller passes `next` with the range that starts at 0;
+        ws[g.o_grad_norm] = total;                                            // the sharded update passes it with each rank's own first range)
         ws[g.o_grad_norm + 1] = coef;
     }
     // the per-step scalars of the NEXT step ride along (this kernel takes its own by value and never reads ws.hyper)
@@ -790,6 +790,42 @@ int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 int launch_grad_norm(const Geom &g, const float *grads, float *ws, hipStream_t stream) {
     hipLaunchKernelGGL(grad_norm_kernel, dim3(g.n_norm_blocks), dim3(256), 0, stream, grads, ws + g.o_norm_part,
                        g.live_floats / 4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Sharded update (ta3n_sharded_update): sum of squares of the REDUCED gradients this rank owns - two index ranges [a0, a1) and
+// [b0, b1) in float4 units - per block, then (shard_norm_finish_kernel, one block) added up in a fixed order into slot `rank` of the
+// norm_part region with every other slot zeroed: an all-gather of one float per rank into slots [0, world) completes it, and
+// sgd_range_kernel adds the region up the way it always does.
+__global__ __launch_bounds__(256) void shard_sumsq_kernel(const float *__restrict__ grads, float *__restrict__ part, int a0, int a1, int b0, int b1) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
+    const int stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = a0 + t; i < a1; i += stride) {
+        const float4 v = g4[i];
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+    for (int i = b0 + t; i < b1; i += stride) {
+        const float4 v = g4[i];
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void shard_norm_finish_kernel(float *__restrict__ part, int n, int rank) {
+    __shared__ float red[8];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) acc += part[k];
+    const float s = block_sum(acc, red);      // (broadcast to every thread; also a barrier: all reads above are done)
+    for (int k = threadIdx.x; k < n; k += blockDim.x) part[k] = (k == rank) ? s : 0.f;
+}
+
+int launch_shard_sumsq(const Geom &g, const float *grads, float *ws, int64_t a0, int64_t a1, int64_t b0, int64_t b1, int rank, hipStream_t stream) {
+    hipLaunchKernelGGL(shard_sumsq_kernel, dim3(g.n_norm_blocks), dim3(256), 0, stream, grads, ws + g.o_norm_part, (int)(a0 / 4), (int)(a1 / 4),
+                       (int)(b0 / 4), (int)(b1 / 4));
+    hipLaunchKernelGGL(shard_norm_finish_kernel, dim3(1), dim3(256), 0, stream, ws + g.o_norm_part, g.n_norm_blocks, rank);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -72,7 +72,7 @@ class TrainEngine:
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
                  dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
-                 ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None):
+                 ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None, sharded_update: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -248,6 +248,19 @@ class TrainEngine:
             rows = [self.Bs * self.T, self.Bt * self.T]
             self._bn_unbias = torch.tensor([[[1.0], [r / max(r - 1, 1)]] for r in rows], dtype=torch.float32, device=self.device)
             self._bn_rows = rows
+        # Sharded update (TA3N_DDP_SHARDED=1 / sharded_update=True; N > 1 or the 1-rank self-test, fused step): the gradient exchange as
+        # reduce-scatter + all-gather around an optimiser pass that touches only this rank's 1 / world of the parameters
+        # (include/ta3n_hip.h: ta3n_sharded_update).  Every rank must make the same choice.
+        want_sh = (os.environ.get("TA3N_DDP_SHARDED", "0") == "1") if sharded_update is None else bool(sharded_update)
+        self._sharded = bool(want_sh and (self.world > 1 or self._ddp_selftest) and self.fused and self.peer is None and
+                             self._L.ta3n_has_pipelined_step(self.plan.handle) == 1)
+        self._shard_own = self._shard_layout = None
+        if self._sharded:
+            own, lay = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+            _lib.check(self._L.ta3n_shard_ranges(p.handle, self.rank, self.world, own, lay), "ta3n_shard_ranges")
+            self._shard_own, self._shard_layout = list(own), list(lay)
+            if self._g16 is not None:      # bf16 gradient transport: the scratch covers the padded end of region B
+                self._g16 = torch.zeros(max(p.live_floats, self._shard_layout[3]), dtype=torch.bfloat16, device=self.device)
         self._P2: Optional[torch.Tensor] = None      # second parameter buffer of the fused-update steps (train_steps)
         self.step_count = 0
         self.skip_collective = False
@@ -548,6 +561,12 @@ class TrainEngine:
                 w.wait()
 
     def _enqueue_step(self) -> None:
+        if self._sharded:
+            self.fused_step()
+            self._shard_reduce_scatter()
+            h = self._hyper
+            self._sharded_update(float(h.lr), float(h.momentum), float(h.weight_decay), float(h.clip), None)
+            return
         if self.fused and (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2:
             self._fused_step_overlapped_allreduce()
             self.sgd_step()
@@ -600,7 +619,46 @@ class TrainEngine:
 
     def flush(self) -> None:
         """Apply a deferred update (train_step(defer_update=True)) so that the parameters are current."""
+        if self._sharded and self._pending is not None:
+            lr, mu, wd, clip = self._pending
+            self._pending = None
+            self._sharded_update(lr, mu, wd, clip, None)
+            return
         self._apply_pending(overlap=False)
+
+    # ---- sharded update (reduce-scatter / own-shard optimiser / all-gather) ----
+    def _shard_reduce_scatter(self) -> None:
+        """The own shards of self.G receive the job-wide sum (RCCL reduce-scatter from the C ABI; over a torch.distributed group
+        without RCCL - gloo tests - an all-reduce, of which only the own shards are then read)."""
+        if self.skip_collective:
+            return
+        if self.comm is not None:
+            _lib.check(self._L.ta3n_shard_reduce_scatter(self.plan.handle, self.comm.handle, self.G.data_ptr(),
+                                                         self._g16.data_ptr() if self._g16 is not None else None, self._stream()),
+                       "ta3n_shard_reduce_scatter")
+        elif self.world > 1:
+            parallel.all_reduce_sum_(self.G[: self._shard_layout[3]], self.pg)
+
+    def _sharded_update(self, lr: float, mu: float, wd: float, clip: float, nxt) -> None:
+        """clip + Nesterov SGD on this rank's shards with the job-wide gradient norm, then everybody's updated shards gathered."""
+        h, L = self.plan.handle, self._L
+        nx = C.byref(nxt) if nxt is not None else None
+        if self.comm is not None and not self.skip_collective:
+            _lib.check(L.ta3n_sharded_update(h, self.comm.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.ws.data_ptr(),
+                                             lr, mu, wd, clip, nx, self._stream()), "ta3n_sharded_update")
+            return
+        _lib.check(L.ta3n_shard_sumsq(h, self.G.data_ptr(), self.ws.data_ptr(), self.rank, self.world, self._stream()), "ta3n_shard_sumsq")
+        if self.world > 1 and not self.skip_collective:      # one float per rank; every other slot is zero: a sum is the gather
+            off, _ = self.plan.region("norm_part")
+            parallel.all_reduce_sum_(self.ws[off:off + self.world], self.pg)
+        _lib.check(L.ta3n_sgd_shard(h, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.ws.data_ptr(), self.rank, self.world,
+                                    lr, mu, wd, clip, nx, self._stream()), "ta3n_sgd_shard")
+        if self.world > 1 and not self.skip_collective:
+            a_chunk, a_end, b_chunk, b_end = self._shard_layout
+            for base, chunk in ((0, a_chunk), (a_end, b_chunk)):
+                parts = [self.P[base + r * chunk: base + (r + 1) * chunk] for r in range(self.world)]
+                torch.distributed.all_gather(parts, parts[self.rank].clone(), group=self.pg)
+        self.refresh_bf16(params=True)
 
     def train_step_deferred(self, beta: Sequence[float], gamma: float, lr: float, **hyper_kw) -> None:
         """train_step whose optimiser update is postponed to the start of the next call, where all of it except the shared
@@ -624,6 +682,16 @@ class TrainEngine:
             raise _lib.Ta3nError("pipelined updates need the fused step")
         first = self._pending is None
         self.set_hyper(beta, gamma, lr, train=True, upload=first, **hyper_kw)
+        if self._sharded:
+            if not first:
+                lr_p, mu, wd, clip = self._pending
+                self._pending = None
+                self._sharded_update(lr_p, mu, wd, clip, self._hyper)
+            self.fused_step()
+            self._shard_reduce_scatter()
+            self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
+            self.step_count += 1
+            return
         two_buckets = (self.world > 1 or self._ddp_selftest) and self._ddp_buckets == 2
         stepped = False
         if not first:
@@ -726,6 +794,16 @@ class TrainEngine:
         job, keep, n_run = self._steps_job(schedule, feeds)
         if job is None:
             return
+        if self._sharded:      # the same steps with the sharded update; region B's collectives on a second stream
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.device)
+            two = os.environ.get("TA3N_DDP_SHARDED_STREAMS", "2") == "2"
+            _lib.check(self._L.ta3n_train_steps_sharded(job.plan, job.comm, job.x, job.params, job.grads, job.momentum, job.ws, job.lr_pending,
+                                                        job.momentum_coef, job.weight_decay, job.clip, job.hypers, n_run, job.source, job.target,
+                                                        job.scratch_bf16, job.stream,
+                                                        C.c_void_p(self._comm_stream.cuda_stream) if two else None), "ta3n_train_steps_sharded")
+            self._steps_done(schedule, keep, n_run)
+            return
         _lib.check(self._L.ta3n_train_steps(job.plan, job.x, job.params, job.grads, job.momentum, job.ws, job.fused_norm, job.lr_pending,
                                             job.momentum_coef, job.weight_decay, job.clip, job.hypers, n_run, job.source, job.target,
                                             job.comm, job.scratch_bf16, job.stream), "ta3n_train_steps")
@@ -735,6 +813,8 @@ class TrainEngine:
         """True when train_steps enqueues its steps through ONE library call (ta3n_train_steps / ta3n_train_steps_multi) - also the
         condition under which device-side batch feeds are accepted."""
         ddp = self.world > 1 or self._ddp_selftest
+        if self._sharded:
+            return bool(self.comm is not None and not self.skip_collective)
         return bool(self.fused and self._side_update and
                     not (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)))
 

@@ -30,13 +30,13 @@ def _engine(Bs, Bt, mode):
     from ta3n_amd.engine import TrainEngine
     c = CFG
     return TrainEngine(Bs, Bt, c["T"], c["D"], c["fc"], c["C"], dropout_i=0.0, dropout_v=0.0, fused=(mode != "unfused"),
-                       bf16=(mode == "bf16"), bf16_store=(mode == "bf16"))
+                       bf16=mode.endswith("bf16"), bf16_store=mode.endswith("bf16"))
 
 
 def _run(eng, xs, xt, ys, steps, mode, **kw):
     for i in range(steps):
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
-        if mode == "bf16":
+        if mode.endswith("bf16"):
             eng.train_step_pipelined([0.75, 0.75, 0.5], 0.003, 1e-2, seed=i, **kw)
         else:
             eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-2, seed=i, **kw)
@@ -47,7 +47,8 @@ def _run(eng, xs, xt, ys, steps, mode, **kw):
 
 def _worker(rank, world, port, out, mode):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      TA3N_DDP_BUCKETS="2" if mode == "fused" else "1")      # cover both gradient bucketings
+                      TA3N_DDP_BUCKETS="2" if mode == "fused" else "1",      # cover both gradient bucketings
+                      TA3N_DDP_SHARDED="1" if mode.startswith("sharded") else "0")      # ... and the sharded update (own-shard optimiser)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ta3n_amd import parallel
@@ -56,7 +57,7 @@ def _worker(rank, world, port, out, mode):
     lo, hi = parallel.shard_range(c["Bs"], world, rank)
     lo_t, hi_t = parallel.shard_range(c["Bt"], world, rank)
     eng = _engine(hi - lo, hi_t - lo_t, mode)
-    assert eng.world == world
+    assert eng.world == world and eng._sharded == mode.startswith("sharded")
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=3))
     P = _run(eng, xs[lo:hi], xt[lo_t:hi_t], ys[lo:hi], 3, mode, global_source=c["Bs"], global_target=c["Bt"])
@@ -65,7 +66,7 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16"])
+@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16", "sharded", "sharded_bf16"])
 def test_two_ranks_equal_single_process_global_batch(tmp_path, mode):
     c = CFG
     out = str(tmp_path / "P")
@@ -78,7 +79,7 @@ def test_two_ranks_equal_single_process_global_batch(tmp_path, mode):
     ref = _run(eng, xs, xt, ys, 3, mode)
     assert torch.equal(p0, p1)                                    # every rank applies the identical update
     # bf16: the sharded weight gradients sum the same bf16 products in another order; a sum-order ulp can flip a bf16 rounding
-    rtol, atol = (2e-4, 2e-6) if mode != "bf16" else (5e-3, 5e-5)
+    rtol, atol = (2e-4, 2e-6) if not mode.endswith("bf16") else (5e-3, 5e-5)
     assert torch.allclose(p0, ref, rtol=rtol, atol=atol), (p0 - ref).abs().max()
     moved = (ref - synth_flat(eng, shapes)).abs().max()
     assert moved > 1e-4                                           # the steps actually changed the parameters

@@ -55,6 +55,40 @@ def test_one_rank_rccl_step_equals_the_plain_step(monkeypatch, buckets):
     assert not torch.equal(got, synth_flat(eng))
 
 
+@pytest.mark.parametrize("how", ["per_step", "pipelined", "one_call_two_streams", "one_call_one_stream", "bf16_arithmetic"])
+def test_one_rank_sharded_update_equals_the_plain_step(monkeypatch, how):
+    """TA3N_DDP_SHARDED=1: reduce-scatter -> per-shard sum of squares -> all-gather of one float per rank -> clip + SGD on the own
+    shards -> all-gather of the parameters (ta3n_sharded_update / ta3n_train_steps_sharded), in a 1-rank communicator: the
+    collectives are identities, the shard bookkeeping, the event edges between the two streams and the twin refresh are real.  Same
+    gradients as the plain step; the norm is summed in another order (allclose, as for the all-reduce path)."""
+    bf16 = how == "bf16_arithmetic"
+    ref = _steps(_engine(monkeypatch, selftest=False, bf16=bf16), n=5)
+    monkeypatch.setenv("TA3N_DDP_SHARDED", "1")
+    monkeypatch.setenv("TA3N_DDP_SHARDED_STREAMS", "1" if how == "one_call_one_stream" else "2")
+    eng = _engine(monkeypatch, transport="0", bf16=bf16)
+    assert eng._sharded and eng.comm is not None and eng._shard_own == [0, eng._n_first, eng._shard_layout[1], eng.plan.live_floats]
+    c = CFG
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    sched = [([0.75, 0.75, 0.5], 0.003, 1e-2)] * 5
+    if how == "per_step":
+        for i, (b, g, lr) in enumerate(sched):
+            eng.train_step(b, g, lr, seed=i)
+    elif how == "pipelined":
+        for i, (b, g, lr) in enumerate(sched):
+            eng.train_step_pipelined(b, g, lr, seed=i)
+    else:
+        eng.train_steps(sched[:2])
+        eng.train_steps(sched[2:])
+    eng.flush()
+    torch.cuda.synchronize()
+    assert torch.allclose(eng.P, ref, rtol=1e-5, atol=1e-7), (eng.P - ref).abs().max()
+    if bf16:      # the twins of the gathered parameters were rebuilt locally: bit for bit the rounding of the fp32 parameters
+        off, n = eng.plan.region("p16")
+        tw = eng.ws[off:off + n].view(torch.bfloat16)[: eng.plan.param_floats]
+        assert torch.equal(tw, eng.P.to(torch.bfloat16))
+
+
 def test_bf16_transport_rounds_each_ranks_gradient_to_bf16(monkeypatch):
     assert _engine(monkeypatch, bf16=True, transport=None)._g16 is None      # default: fp32 transport in every arithmetic (ADVICE r02)
     eng = _engine(monkeypatch, bf16=True, transport="1")           # opt-in (TA3N_DDP_BF16=1 / TrainEngine(grad_transport="bf16"))
