@@ -45,6 +45,11 @@ enum { F_READY_IN = 0, F_READY_RED = 1, F_DONE = 2 };
 // loader, a checkpoint written by rank 0); TA3N_PEER_TIMEOUT_S overrides it (0 = wait for ever, like a blocking RCCL collective).  A wait
 // that does give up sets the sticky error word, and from then on every exchange POISONS its output (NaN) instead of delivering partial
 // sums: divergence between ranks is loud, never silent; ta3n_peer_status reports it at the host's next check.
+// The flag block is 128 bytes, but it is exported with hipIpcGetMemHandle, which wants the BASE of an allocation: a request this small
+// may be carved out of a larger block the runtime already holds (seen once in round 4: "hipIpcGetMemHandle: invalid argument" on one
+// rank of a test that had passed for two rounds).  2 MiB - the allocation granularity - always is an allocation of its own.
+constexpr size_t FLAGS_ALLOC_BYTES = 2u << 20;
+
 unsigned long long spin_ticks() {
     static const unsigned long long t = [] {
         const char *e = getenv("TA3N_PEER_TIMEOUT_S");
@@ -183,7 +188,7 @@ int ta3n_peer_create(int rank, int world, int64_t max_count, int bf16_transport,
     p->rank = rank; p->world = world; p->cap = max_count; p->bf16 = bf16_transport ? 1 : 0;
     const size_t bytes = 2 * (size_t)max_count * sizeof(float);
     if (hipExtMallocWithFlags(reinterpret_cast<void **>(&p->stage), bytes, hipDeviceMallocFinegrained) != hipSuccess ||
-        hipExtMallocWithFlags(reinterpret_cast<void **>(&p->flags), 4 * MAXR * sizeof(unsigned), hipDeviceMallocFinegrained) != hipSuccess) {
+        hipExtMallocWithFlags(reinterpret_cast<void **>(&p->flags), FLAGS_ALLOC_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
         const std::string e = hipGetErrorString(hipGetLastError());
         if (p->stage) (void)hipFree(p->stage);
         delete p;

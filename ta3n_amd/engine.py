@@ -797,7 +797,7 @@ class TrainEngine:
         if self._sharded:      # the same steps with the sharded update; region B's collectives on a second stream
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(self.device)
-            two = os.environ.get("TA3N_DDP_SHARDED_STREAMS", "2") == "2"
+            two = os.environ.get("TA3N_DDP_SHARDED_STREAMS", "1") == "2"
             _lib.check(self._L.ta3n_train_steps_sharded(job.plan, job.comm, job.x, job.params, job.grads, job.momentum, job.ws, job.lr_pending,
                                                         job.momentum_coef, job.weight_decay, job.clip, job.hypers, n_run, job.source, job.target,
                                                         job.scratch_bf16, job.stream,

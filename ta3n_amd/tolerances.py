@@ -43,17 +43,23 @@ BF16_REF_GRAD_REL_L2 = 0.25              # absolute cap per weight-gradient tens
 # mode, computed in the test): rel. L2(HIP bf16, fp32 reference) <= FACTOR x rel. L2(oracle bf16, fp32 reference) + FLOOR.  The contract's
 # cost is the ReLU on/off pattern (0.08 % of the hidden units land on the other side of zero; profiles/r04_bf16_gradient_deviation_attribution.txt):
 # two implementations of the contract flip different units of the same population, hence a factor and not equality.
-BF16_REF_GRAD_CONTRACT_FACTOR = 3.0
-BF16_REF_GRAD_FLOOR = 1e-2
+BF16_REF_GRAD_CONTRACT_FACTOR = 1.5      # measured: the HIP path's distances ARE the contract's to two digits (ratio 0.98 .. 1.02 at the three shapes,
+BF16_REF_GRAD_FLOOR = 5e-3                # profiles/r04_parity_floors.txt), e.g. 6.5e-2 / 6.5e-2 and 1.5e-1 / 1.5e-1 for relation_domain_classifier_all.6.0.weight
 
 # ---- training equivalence over 300 steps on a learnable synthetic task (tests/test_gpu_training_equivalence.py) ----
 # early: total loss step by step over the first 20 steps, relative (the trajectories coincide up to the arithmetic's rounding; from
 # ~step 25 on ReLU flips decorrelate ANY two arithmetics - the oracle's own bf16-operand mode is 3.1e-2 from its fp32 mode there);
 # late: medians over the last 100 steps; accuracy: held-out top-1, points, both domains.
-# PROVISIONAL until the first GPU run records the floors (profiles/r04_training_equivalence.json).
+# Measured (profiles/r04_training_equivalence.json; one MI355X run): early 9.4e-7 (fp32 MFMA), 4.2e-3 (f32x3), 1.2e-2 (bf16); late medians
+# within 1.3e-2 (total), 1.1e-2 (adversarial) of the oracle's; classification-loss medians <= 4.6e-3, entropy <= 4.7e-2; accuracies
+# 98.5-100 % against the oracle's 99.5 / 98.5 %.
 TRAIN_EARLY_REL_F32 = 0.01
-TRAIN_EARLY_REL_BF16 = 0.08
-TRAIN_LATE_REL = 0.10           # total and adversarial loss medians
+TRAIN_EARLY_REL_BF16 = 0.05
+TRAIN_LATE_REL = 0.05           # total and adversarial loss medians
 TRAIN_LATE_LOSS_C = 0.05        # classification loss median (learnt task: -> 0)
 TRAIN_LATE_LOSS_E = 0.15        # attentive-entropy median
 TRAIN_ACC_POINTS = 3.0
+# with dropout 0.5 / 0.5 (bf16 engine against the fp32 engine on identical masks): classification loss and entropy stay well above zero
+TRAIN_ACC_POINTS_DROPOUT = 5.0
+TRAIN_LATE_DROPOUT_REL = 0.5
+TRAIN_LATE_DROPOUT_ABS = 0.05

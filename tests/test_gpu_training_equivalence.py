@@ -48,8 +48,9 @@ def _heldout():
     return [task_batch(SH["C"], SH["T"], SH["D"], 100, 100, step=10_000 + k, task_seed=3) for k in range(2)]
 
 
-def _engine_run(arith, dropout):
-    eng = TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=dropout, dropout_v=dropout, clip=20.0, **KW[arith])
+def _engine_run(arith, dropout, F=None):
+    F = SH["F"] if F is None else F
+    eng = TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], F, SH["C"], dropout_i=dropout, dropout_v=dropout, clip=20.0, **KW[arith])
     eng.load_state(synth_state({n: s for n, _, s, _ in eng.plan.params}, seed=5, scale="trained"))
     curve = {"loss": [], "loss_c": [], "loss_a": [], "loss_e": []}
     for i in range(STEPS):
@@ -61,7 +62,7 @@ def _engine_run(arith, dropout):
         curve["loss_a"].append(l["loss_adv_rel"] + l["loss_adv_vid"] + l["loss_adv_frm"])
     # held-out accuracy, both domains (main.validate's bookkeeping on the device; at most batch_source videos per call)
     acc = []
-    ev = TrainEngine(100, 1, SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.0, dropout_v=0.0, **KW[arith])
+    ev = TrainEngine(100, 1, SH["T"], SH["D"], F, SH["C"], dropout_i=0.0, dropout_v=0.0, **KW[arith])
     ev.load_state(eng.state_dict())
     for dom in (0, 1):
         first = True
@@ -137,15 +138,23 @@ def test_300_steps_track_the_fp32_oracle_trajectory():
 
 
 def test_300_steps_with_dropout_bf16_tracks_the_fp32_engine():
-    """The reference's configuration trains with dropout 0.5 / 0.5: bf16 against the fp32 MFMA engine on identical dropout masks."""
-    ref_curve, ref_acc = _engine_run("f32", 0.5)
-    curve, acc = _engine_run("bf16", 0.5)
+    """The reference's configuration trains with dropout 0.5 / 0.5: bf16 against the fp32 MFMA engine on identical dropout masks, with a
+    128-wide shared layer (at 64 channels half of them dropped leave the task unlearnt in 300 steps - in the fp32 oracle too)."""
+    ref_curve, ref_acc = _engine_run("f32", 0.5, F=128)
+    curve, acc = _engine_run("bf16", 0.5, F=128)
     dist = _curve_distance(curve, ref_curve)
-    report = {"f32_engine": {"acc_source_target": ref_acc}, "bf16": {"acc_source_target": acc, "distance_from_f32_engine": dist}}
+    med = lambda c, k: float(np.median(c[k][-100:]))
+    late = {k: (med(curve, k), med(ref_curve, k)) for k in ("loss_c", "loss_e")}
+    report = {"f32_engine": {"acc_source_target": ref_acc, "loss_c_windows": _windows(ref_curve["loss_c"]).round(4).tolist()},
+              "bf16": {"acc_source_target": acc, "distance_from_f32_engine": dist, "late_medians_bf16_f32": late,
+                       "loss_c_windows": _windows(curve["loss_c"]).round(4).tolist()}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "training_equivalence_300_steps_dropout.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
-    assert _windows(ref_curve["loss_c"])[-1] < 0.5 * _windows(ref_curve["loss_c"])[0]
-    dist["late_loss_c_max"] *= 0.25; dist["late_loss_e_max"] *= 0.25      # (dropout 0.5 keeps both losses higher: four times the bound)
-    _assert_tracks(dist, "bf16", acc, ref_acc)
+    assert min(ref_acc) > 90.0 and min(acc) > 90.0, (ref_acc, acc)
+    assert all(abs(a - b) <= tol.TRAIN_ACC_POINTS_DROPOUT for a, b in zip(acc, ref_acc)), (acc, ref_acc)
+    assert dist["early"] <= tol.TRAIN_EARLY_REL_BF16, dist
+    assert dist["late_loss_rel"] <= tol.TRAIN_LATE_REL and dist["late_loss_a_rel"] <= tol.TRAIN_LATE_REL, dist
+    for k, (a, b) in late.items():      # under dropout both losses stay well above zero: compared relatively
+        assert abs(a - b) <= tol.TRAIN_LATE_DROPOUT_REL * b + tol.TRAIN_LATE_DROPOUT_ABS, (k, a, b)
