@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import torch  # noqa: F401
 
 _LIB: Optional[C.CDLL] = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libta3n_hip.so")
+LIB_PATH = os.path.join(os.environ.get("TA3N_LIBDIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), "libta3n_hip.so")
 
 FLAG_ADV_RELATION = 1 << 0
 FLAG_ADV_VIDEO = 1 << 1

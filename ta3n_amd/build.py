@@ -9,10 +9,12 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIBDIR = os.path.join(PKG, "lib")
+# TA3N_LIBDIR: another build directory (A/B builds with other -D flags, e.g. ta3n_amd/lib_ab/ built with TA3N_EXTRA_FLAGS="-DTA3N_DMA_INTERLEAVE=0");
+# _lib.py loads from the same place
+LIBDIR = os.environ.get("TA3N_LIBDIR") or os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libta3n_hip.so")
-SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_mmd.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
-HEADERS = ["ta3n_types.h", "ta3n_kernels.h", "ta3n_plan.h", os.path.join("..", "..", "include", "ta3n_hip.h")]
+SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_gemm_i0.hip", "ta3n_gemm_i1.hip", "ta3n_gemm_i2.hip", "ta3n_gemm_i3.hip", "ta3n_gemm_i4.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_mmd.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
+HEADERS = ["ta3n_types.h", "ta3n_kernels.h", "ta3n_plan.h", "ta3n_gemm_kernel.h", os.path.join("..", "..", "include", "ta3n_hip.h")]
 
 
 def _hipcc() -> str:
@@ -77,5 +79,5 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, extra_flags=tuple(os.environ.get("TA3N_EXTRA_FLAGS", "").split()))
     print(LIB)

@@ -1,0 +1,6 @@
+// Explicit instantiations of ta3n::gemm_tiles, part 0 of 5 (ta3n_gemm_kernel.h; split so that the parts compile in parallel).
+#include "ta3n_gemm_kernel.h"
+namespace ta3n {
+#define TA3N_PART_CONFIGS(X) X(1, 1, 4) X(1, 1, 8)
+TA3N_PART_CONFIGS(TA3N_INSTANTIATE)
+}  // namespace ta3n

@@ -1,0 +1,6 @@
+// Explicit instantiations of ta3n::gemm_tiles, part 1 of 5 (ta3n_gemm_kernel.h; split so that the parts compile in parallel).
+#include "ta3n_gemm_kernel.h"
+namespace ta3n {
+#define TA3N_PART_CONFIGS(X) X(2, 1, 2) X(1, 2, 2)
+TA3N_PART_CONFIGS(TA3N_INSTANTIATE)
+}  // namespace ta3n

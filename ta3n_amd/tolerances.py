@@ -61,5 +61,6 @@ TRAIN_LATE_LOSS_E = 0.15        # attentive-entropy median
 TRAIN_ACC_POINTS = 3.0
 # with dropout 0.5 / 0.5 (bf16 engine against the fp32 engine on identical masks): classification loss and entropy stay well above zero
 TRAIN_ACC_POINTS_DROPOUT = 5.0
+TRAIN_LATE_REL_DROPOUT = 0.10    # total / adversarial loss medians (measured 5.4e-2 / 3.6e-3)
 TRAIN_LATE_DROPOUT_REL = 0.5
 TRAIN_LATE_DROPOUT_ABS = 0.05

@@ -207,6 +207,9 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append([ln for ln in open(exp + "/RGB/train.log") if ln.startswith("Train:")])
         cks.append(torch.load(exp + "/RGB/checkpoint.pth.tar", map_location="cpu", weights_only=False))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "main_fast_vs_module_path.txt"), "w") as f:
+        f.write("# train.log of main.py with the fused step (TA3N_MAIN_FAST=1), then with the module path (=0); dropout 0\n" + "".join(outs[0]) + "# ----\n" + "".join(outs[1]))
     assert len(outs[0]) == len(outs[1]) == 6
     # (Prec@1 is not compared: from the 0.001-std initialisation the five class logits of a video differ in the sixth digit, so the
     # argmax is decided by fp32 summation order)
