@@ -270,9 +270,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // mid(slot, nslots): called once after each of the stage's `nslots` groups of matrix instructions (slot = 0 .. nslots - 1, compile-time
 // constants once the loops are unrolled) - the K loop hangs the NEXT stage's LDS-DMA pieces there, a share per group, so that they
 // issue in the shadow of the MFMAs instead of in a block in front of the fragment reads.
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1, class Mid>
+// pre(): called once, when the stage's LAST fragment read has been issued and before the matrix instructions that consume it (the early-
+// refill loop waits there for the reads, meets the other waves and streams the chunk after next into the very buffer just read).
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1, class Mid, class Pre>
 __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rss)[RM], const float *__restrict__ sa,
-                                              const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem, Mid &&mid) {
+                                              const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem, Mid &&mid, Pre &&pre) {
     constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
     constexpr int NQ = GPW / 2;
     static_assert(BF == 2 || (RM == 1 && RN == 1), "register blocking exists on the bf16-twin path only");
@@ -332,6 +334,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                             rss[i] += __builtin_bit_cast(float, ta[i][qq][j] << 16) + __builtin_bit_cast(float, ta[i][qq][j] & 0xFFFF0000u);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (q0 + QG >= NQ) pre();
 #pragma unroll
             for (int qq = 0; qq < QG; ++qq) {
                 if (FULL || 8 * (wk * GPW + 2 * (q0 + qq)) < krem) {
@@ -392,6 +395,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                               (__builtin_bit_cast(float, al[q][j] << 16) + __builtin_bit_cast(float, al[q][j] & 0xFFFF0000u));
             }
             __builtin_amdgcn_sched_barrier(0);
+            pre();
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 if (FULL || 8 * (wk * SPW + 2 * q) < krem) {
@@ -422,6 +426,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                           (__builtin_bit_cast(float, al[j] << 16) + __builtin_bit_cast(float, al[j] & 0xFFFF0000u));
             }
             __builtin_amdgcn_sched_barrier(0);
+            pre();
             if (FULL || 8 * wk < krem) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, al), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bl), acc, 0, 0, 0);
@@ -476,6 +481,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     rs += __builtin_bit_cast(float, ta[q][j] << 16) + __builtin_bit_cast(float, ta[q][j] & 0xFFFF0000u);
         }
         __builtin_amdgcn_sched_barrier(0);
+        pre();
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (FULL || 8 * (wk * GPW + 2 * q) < krem)
@@ -509,6 +515,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         for (int q = 0; q < NQ; ++q) rs += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
+    pre();
     if constexpr (BF == 3) {
         // fp32-grade on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi
         // (the a_lo b_lo term, ~2^-16 of the product, is dropped); fp32 accumulation in the MFMA
@@ -893,16 +900,98 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
 #pragma unroll
     for (int i = 0; i < RM; ++i) rs[i] = 0.f;
 #ifndef TA3N_DMA_INTERLEAVE
-#define TA3N_DMA_INTERLEAVE 1
+#define TA3N_DMA_INTERLEAVE 0
 #endif
-    // 0 (build with -DTA3N_DMA_INTERLEAVE=0): every chunk's DMAs in a block in front of the fragment reads, as in round 3.  A compile-time
+    // 1 (build with -DTA3N_DMA_INTERLEAVE=1): the next chunk's DMA pieces issue BETWEEN the current chunk's matrix instructions instead of
+    // in a block in front of its fragment reads.  Built on the guide's figure (a piece costs ~60 cycles of issue among bare MFMAs against
+    // 100-185 in a block); bit-identical; measured SLOWER on every configuration (profiles/r04_dma_interleave_ab.txt: bf16 112.1 vs 109.5
+    // us, fp32 237 vs 221, configs[3] 522 vs 505, configs[4] 542 vs 494): the loop is bound by how EARLY a chunk's DMAs leave, not by
+    // the issue slots they take - spreading them over the compute phase delays the chunk's arrival.  Off.  A compile-time
     // choice on purpose: with both variants in one kernel the loop-invariant fragment addresses of both stay live (+20-40 VGPRs measured:
     // the 32x64 fp32 tile went from 111 to 131 and lost its second resident workgroup, the 128x128 tile spilled).
     constexpr bool interleave = TA3N_DMA_INTERLEAVE != 0;
+#ifndef TA3N_EARLY_REFILL
+#define TA3N_EARLY_REFILL 0
+#endif
+    // the blocked tiles whose fragments do not all fit in registers at once (QG < NQ in compute_stage) read the buffer in two
+    // rounds: the hook fires before the last round's MFMAs, which is still correct (all reads issued), just later
+    constexpr bool EARLY = TA3N_EARLY_REFILL != 0 && NS == 2;
     (void)knobs;
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
-        if constexpr (NS == 2) {
+        if constexpr (EARLY) {
+            // Early refill (build with -DTA3N_EARLY_REFILL=1; two LDS stages): a stage's fragments are all in registers before its first
+            // matrix instruction, so its buffer is free as soon as every wave's reads have returned - chunk c + 2 streams into the buffer
+            // of chunk c while chunk c is still being MULTIPLIED.  Two chunks in flight on two buffers (the third "stage" is the register
+            // file), at the price of a second barrier per chunk.  Same products in the same order: bit-identical results.
+            OperandStream<BM, NW, TW, PAIR> oa;
+            OperandStream<BN, NW, TW, PAIR> ob;
+            constexpr int LPW = OperandStream<BM, NW, TW, PAIR>::NP + OperandStream<BN, NW, TW, PAIR>::NP;
+            static_assert(LPW <= 63, "vmcnt is a 6-bit counter");
+            int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
+            Seg nx = t.seg0;
+            auto open_issue_seg = [&]() {
+                const Seg sg = nx;
+                if (i_seg + 1 < seg_end) nx = segs[i_seg + 1];
+                i_klen = sg.klen; i_nchunks = (sg.klen + CH - 1) / CH; i_chunk = 0;
+                oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
+                         wave, lane, pair_delta);
+                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane, pair_delta);
+            };
+            auto issue_one = [&]() {
+                const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
+                const int k0 = i_chunk * CH;
+                oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
+                ob.issue(k0, i_klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                i_buf ^= 1;
+                ++ahead;
+                if (++i_chunk == i_nchunks) {
+                    if (++i_seg < seg_end) open_issue_seg();
+                }
+            };
+            open_issue_seg();
+    #pragma unroll 1
+            for (int sidx = 0; sidx < 2 && i_seg < seg_end; ++sidx) issue_one();
+            int c_buf = 0;
+            int c_klen_nx = t.seg0.klen, c_scale_nx = t.seg0.scale_kind;
+            auto refill = [&]() {      // pre(): this chunk's fragment reads are issued
+                if (i_seg < seg_end) {                                 // (workgroup-uniform: every wave walks the same Seg list)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... have returned
+                    __builtin_amdgcn_s_barrier();                      // ... everybody's: the buffer under the compute cursor is free
+                    asm volatile("" ::: "memory");
+                    issue_one();                                       // (i_buf == c_buf here: two buffers, two chunks ahead)
+                }
+            };
+            for (;;) {
+                const int klen = c_klen_nx, c_scale = c_scale_nx;
+                if (cseg + 1 < seg_end) { c_klen_nx = segs[cseg + 1].klen; c_scale_nx = segs[cseg + 1].scale_kind; }
+                const int n_chunks = (klen + CH - 1) / CH;
+    #pragma unroll 1
+                for (int c = 0; c < n_chunks; ++c) {
+                    if (ahead > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");      // the older of the two chunks in flight has landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    --ahead;
+                    const float *sa = lds + c_buf * STAGE;
+                    if (c < n_chunks - 1)
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, refill);
+                    else
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, refill);
+                    c_buf ^= 1;
+                }
+                if (c_scale != SK_ONE) {
+                    const float sc = scale_of(c_scale);
+    #pragma unroll
+                    for (int i = 0; i < RM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < RN; ++j)
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+                }
+                if (++cseg >= seg_end) break;
+            }
+        } else if constexpr (NS == 2) {
             // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
             // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
             OperandStream<BM, NW, TW, PAIR> oa;
@@ -951,10 +1040,10 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     const float *sa = lds + buf * STAGE;
                     if constexpr (interleave) {       // the next chunk's DMAs between this chunk's matrix instructions
                         compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH,
-                                                                                  [&](int slot, int nslots) { issue_share(buf ^ 1, (c + 1) * CH, slot, nslots); });
+                                                                                  [&](int slot, int nslots) { issue_share(buf ^ 1, (c + 1) * CH, slot, nslots); }, [] {});
                     } else {
                         issue(buf ^ 1, (c + 1) * CH);
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {});
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                     }
                     buf ^= 1;
                 }
@@ -970,7 +1059,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const float *sa = lds + buf * STAGE;
                 // (ONE instance of the tail stage: the hook issues nothing when no Seg follows)
                 compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem,
-                                                                           [&](int slot, int nslots) { if (interleave && more) issue_share(buf ^ 1, 0, slot, nslots); });
+                                                                           [&](int slot, int nslots) { if (interleave && more) issue_share(buf ^ 1, 0, slot, nslots); }, [] {});
                 if (c_scale != SK_ONE) {
                     const float sc = scale_of(c_scale);
     #pragma unroll
@@ -1048,11 +1137,11 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                                     else if (slot == 0) oa.issue(k0, klen - k0, st, wave, lane, zeros);
                                     if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * BKC * 4, wave, zeros);
                                     else if (slot == 0) ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
-                                });
+                                }, [] {});
                         } else {
                             oa.issue(k0, klen - k0, st, wave, lane, zeros);
                             ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
-                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {});
+                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                         }
                         i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                         c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
@@ -1067,9 +1156,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     if (i_seg < seg_end) issue_one();
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {});
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH, [](int, int) {});
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, [] {});
                     c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     --ahead;
                 }
