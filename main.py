@@ -216,7 +216,10 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
         data_time.update(time.time() - end)
         eng.set_batch(source_data.to(dev, non_blocking=True), target_data.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
         lr = optimizer.param_groups[0]["lr"]
-        eng.train_step(beta_new, gamma, lr, valid_source=batch_source_ori, valid_target=batch_target_ori)
+        # the dropout seeds come from the global torch RNG exactly as VideoModel.forward draws them (one draw of two per train forward):
+        # the same masks as the module path, and the same RNG state for the samplers of the next epoch
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,))
+        eng.train_step(beta_new, gamma, lr, valid_source=batch_source_ori, valid_target=batch_target_ori, raw_seeds=(int(seeds[0]), int(seeds[1])))
         l = eng.losses()                                                # (one host sync per step; the reference has five .item() calls)
         out = eng.outputs()["out"][:batch_source_ori]
         losses_c.update(l["loss_c"], batch_source_ori)

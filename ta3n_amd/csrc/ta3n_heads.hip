@@ -45,6 +45,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP float4 are demoted to scratch by hipcc)
 
+#ifndef TA3N_HEADS_EARLY_A
+#define TA3N_HEADS_EARLY_A 1
+#endif
+constexpr bool EARLY_A = TA3N_HEADS_EARLY_A != 0;      // 0: stage A's first loads behind the weight burst, as in round 3 (A/B builds)
 constexpr int NBH = 256;           // num_bottleneck of trn-m (models.py:223); thread t <-> channel t
 constexpr int VPW = HEADS_VPW;
 constexpr int RPW = HEADS_RPW;
@@ -118,7 +122,31 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const float *__restrict__ Wcv = P + g.p_Wcv;
     float l_cls = 0.f, l_rel = 0.f, l_vid = 0.f, l_ent = 0.f;
 
-    // ---- address-independent loads, issued first ----
+    // ---- stage A's operands for this wave's FIRST relation, requested before anything else ----
+    // Vector loads return in order: behind the 256 KB weight burst below, the first relation's 24 values per lane used to arrive last
+    // and stage A - which needs nothing else - waited 4-5 k cycles for them (tools/heads_timing.py).  The tuple range comes by
+    // SCALAR loads (their own counter), so the addresses are known at once; at 5 segments (4 relations, 4 waves per video) this is
+    // the wave's ONLY relation.
+    const int j_first = __builtin_amdgcn_readfirstlane(sub < NR ? sub : 0);
+    const int tf_lo0 = __builtin_amdgcn_readfirstlane(tf[j_first]), tf_hi0 = __builtin_amdgcn_readfirstlane(tf[j_first + 1]);
+    float a_hr[4] = {0.f, 0.f, 0.f, 0.f}, a_w0[4] = {0.f, 0.f, 0.f, 0.f}, a_w1[4] = {0.f, 0.f, 0.f, 0.f}, a_zr[3][4];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_zr[tt][q] = 0.f;
+    if (EARLY_A && have && sub < NR) {
+        const float *__restrict__ W2f = P + g.p_W2_0 + (size_t)j_first * g.p_W2_stride;
+        const float *__restrict__ hrf = wsr + g.o_Hr + ((size_t)b * NR + j_first) * NBH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a_hr[q] = hrf[q * 64 + lane]; a_w0[q] = W2f[q * 64 + lane]; a_w1[q] = W2f[NBH + q * 64 + lane]; }
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)           // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num)
+            if (tf_lo0 + tt < tf_hi0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_zr[tt][q] = wsr[g.o_Zr + ((size_t)b * NT + tf_lo0 + tt) * NBH + q * 64 + lane];
+            }
+    }
+    // ---- address-independent loads ----
     f32x4 cw[16];                                  // classifier weights [C][256]: float4 i*256+tid of the flat array
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -146,8 +174,6 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // wave handles the tuple range and the output-layer bias
     const float bcv_c = (tid >> 2) < C ? P[g.p_bcv + (tid >> 2)] : 0.f;
     const float bdv_n = P[g.p_bdv + (tid >> 4) + 16 * (tid & 15)];
-    const int j_first = sub < NR ? sub : 0;
-    const int tf_lo0 = tf[j_first], tf_hi0 = tf[j_first + 1];
     const float b2_00 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride], b2_01 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride + 1];
 
     STAMP(0);
@@ -160,18 +186,32 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                 const float *__restrict__ b2 = P + g.p_b2_0 + (size_t)j * g.p_b2_stride;
                 const float *__restrict__ hr = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
                 float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = q * 64 + lane;
-                    const float h = hr[c];
-                    d0 = fmaf(h, W2[c], d0);
-                    d1 = fmaf(h, W2[NBH + c], d1);
-                }
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
-                const int t_lo = j == j_first ? tf_lo0 : tf[j], t_hi = j == j_first ? tf_hi0 : tf[j + 1];
-                for (int t = t_lo; t < t_hi; ++t) {
+                if (EARLY_A && j == j_first) {         // (wave-uniform) the operands requested at the top of the kernel
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
+                    for (int q = 0; q < 4; ++q) {
+                        d0 = fmaf(a_hr[q], a_w0[q], d0);
+                        d1 = fmaf(a_hr[q], a_w1[q], d1);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt)     // (tuples past the relation's range were left at zero; same order of additions)
+                        if (tf_lo0 + tt < tf_hi0) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) r[q] += a_zr[tt][q];
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = q * 64 + lane;
+                        const float h = hr[c];
+                        d0 = fmaf(h, W2[c], d0);
+                        d1 = fmaf(h, W2[NBH + c], d1);
+                    }
+                    const int t_lo = tf[j], t_hi = tf[j + 1];
+                    for (int t = t_lo; t < t_hi; ++t) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
+                    }
                 }
                 d0 = wave_allreduce_sum(d0) + (j == j_first ? b2_00 : b2[0]);
                 d1 = wave_allreduce_sum(d1) + (j == j_first ? b2_01 : b2[1]);

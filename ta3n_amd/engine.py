@@ -345,7 +345,7 @@ class TrainEngine:
     def set_hyper(self, beta: Sequence[float], gamma: float, lr: float, train: bool = True,
                   valid_source: Optional[int] = None, valid_target: Optional[int] = None,
                   global_source: Optional[int] = None, global_target: Optional[int] = None,
-                  seed: Optional[int] = None, upload: bool = True) -> None:
+                  seed: Optional[int] = None, upload: bool = True, raw_seeds: Optional[Sequence[int]] = None) -> None:
         """Per-step scalars.  global_* are the job-wide valid video counts (all ranks):
         losses are means over the GLOBAL batch like the reference's DataParallel gather
         (main.py:446, 533; loss.py:24), so ranks divide by global counts and gradients are SUMMED."""
@@ -360,6 +360,8 @@ class TrainEngine:
         h.clip = float(self.clip) if self.clip is not None else 0.0
         h.p_drop_i, h.p_drop_v = float(self.dropout_i), float(self.dropout_v)
         h.seed_i, h.seed_v = dropout_seeds(self.step_count if seed is None else seed, self.rank)
+        if raw_seeds is not None:      # the two dropout stream seeds as given (a caller that draws them itself, like VideoModel.forward does)
+            h.seed_i, h.seed_v = int(raw_seeds[0]) & 0xFFFFFFFF, int(raw_seeds[1]) & 0xFFFFFFFF
         for k, v in parallel.loss_normalisers(gs, gt, self.T).items():
             setattr(h, k, v)
         h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))
