@@ -17,6 +17,9 @@ SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_gemm_i0.hip", "ta3n_gemm_i1.hi
 HEADERS = ["ta3n_types.h", "ta3n_kernels.h", "ta3n_plan.h", "ta3n_gemm_kernel.h", os.path.join("..", "..", "include", "ta3n_hip.h")]
 
 
+COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -34,8 +37,14 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def needs_build() -> bool:
+def needs_build(extra_flags=()) -> bool:
     if not os.path.exists(LIB):
+        return True
+    try:                                  # another set of -D flags than the library was built with (A/B build directories)
+        with open(os.path.join(LIBDIR, ".flags")) as f:
+            if f.read() != " ".join([*COMMON_FLAGS, *extra_flags]):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
@@ -44,12 +53,12 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     """Compile what is out of date (an object is rebuilt when its source or any header is newer), in parallel, and link."""
-    if not force and not needs_build():
+    if not force and not needs_build(extra_flags):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+    common = list(COMMON_FLAGS)
     t_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     flags_file = os.path.join(LIBDIR, ".flags")
     flags_now = " ".join([*common, *extra_flags])

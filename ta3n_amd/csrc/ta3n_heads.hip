@@ -14,7 +14,7 @@
 // It replaces seven launches of the unfused path (pool_fwd, two small GEMM levels, loss,
 // two small GEMM levels, pool_bwd).
 //
-// Grid: n_vid_wg video workgroups (HEADS_VPW videos each: one wave per video for the
+// Grid: n_vid_wg video workgroups (Geom::heads_vpw videos each: one wave per video for the
 // per-video reductions, thread t <-> channel t for the 256-wide layers) followed by
 // n_frm_wg frame workgroups (HEADS_RPW frame rows each, 4 rows per wave).
 //
@@ -26,7 +26,7 @@
 //   * the 256x256 video-discriminator layer is a VALU mini-GEMM over LDS-staged weight
 //     tiles (forward: 256 outputs x 64 k per tile, backward: 64 outputs x 256 k), the
 //     next tile travelling in registers while the current one is multiplied, shared by
-//     the HEADS_VPW videos of the workgroup;
+//     the videos of the workgroup;
 //   * a frame wave keeps its 4 rows in registers: one round trip for the forward dots,
 //     none for the backward.
 // Cross-workgroup sums made here (dWcd, dbcd, the logging scalars) are written as
@@ -50,28 +50,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP flo
 #endif
 constexpr bool EARLY_A = TA3N_HEADS_EARLY_A != 0;      // 0: stage A's first loads behind the weight burst, as in round 3 (A/B builds)
 constexpr int NBH = 256;           // num_bottleneck of trn-m (models.py:223); thread t <-> channel t
-constexpr int VPW = HEADS_VPW;
 constexpr int RPW = HEADS_RPW;
 constexpr int WROW = 68;           // padded row of the forward tile [256 n][64 k] (conflict-free b128 row reads)
 constexpr int TROW = 260;          // padded row of the backward tile [64 n][256 k] and of the classifier weights [C][256]
 
-// LDS carve-up (floats)
-constexpr int S_W = 0;                               // weight tile (17408 floats)
-constexpr int S_VD = S_W + NBH * WROW;               // [VPW][256] dropped-out video feature
-constexpr int S_HV = S_VD + VPW * NBH;               // [VPW][256] video-discriminator hidden
-constexpr int S_GHV = S_HV + VPW * NBH;              // [VPW][256] its gradient
-constexpr int S_GVT = S_GHV + VPW * NBH;             // [VPW][256] gradient at the pooled feature
-constexpr int S_GY = S_GVT + VPW * NBH;              // [VPW][64]  class-logit gradients
-constexpr int S_PR = S_GY + VPW * 64;                // [VPW][64][2] relation logits
-constexpr int S_GPV = S_PR + VPW * 128;              // [VPW][2]
-constexpr int S_Y = S_GPV + 8;                       // [64] class logits
-constexpr int S_FPART = S_Y + 64;                    // [16][256] partial sums of the backward mini-GEMM
-constexpr int S_VPART = S_FPART + 16 * NBH;                   // [4 waves][256] per-wave partial sums of V
-constexpr int S_LOSS = S_VPART + 4 * NBH;            // [4 waves][8] loss partials
-constexpr int S_TOTAL = S_LOSS + 32;
-constexpr int WPV = 4 / VPW;                         // waves per video: they split the relations of the per-video stages
-static_assert(VPW == 1 || VPW == 2 || VPW == 4, "1, 2 or 4 videos per workgroup");
+// LDS carve-up (floats) of a workgroup that handles VPW videos at once (Geom::heads_vpw: 1 where every video can have a compute unit of
+// its own - the headline shape - and 2 or 4 for larger batches: a video workgroup owns its CU (256 registers of weights per lane), so
+// with more videos than CUs the launch ran in ROUNDS of one video per CU, each a ~26-30 k-cycle chain of dependent single-wave stages
+// (tools/heads_timing.py, round 4: 7-11 k of it in the relation stages A and G, ~13 k in B-F whatever the shape).  With VPW videos per
+// workgroup the per-video stages run one video per wave (or per wave pair) side by side and the 256x256 layer multiplies VPW vectors
+// from the one register copy of its weights.)
+template <int VPW>
+struct Lds {
+    static_assert(VPW == 1 || VPW == 2 || VPW == 4, "1, 2 or 4 videos per workgroup");
+    static constexpr int W = 0;                                 // weight tile (17408 floats)
+    static constexpr int VD = W + NBH * WROW;                   // [VPW][256] dropped-out video feature
+    static constexpr int HV = VD + VPW * NBH;                   // [VPW][256] video-discriminator hidden
+    static constexpr int GHV = HV + VPW * NBH;                  // [VPW][256] its gradient
+    static constexpr int GVT = GHV + VPW * NBH;                 // [VPW][256] gradient at the pooled feature
+    static constexpr int GY = GVT + VPW * NBH;                  // [VPW][64]  class-logit gradients
+    static constexpr int PR = GY + VPW * 64;                    // [VPW][64][2] relation logits
+    static constexpr int GPV = PR + VPW * 128;                  // [VPW][2]
+    static constexpr int Y = GPV + 8;                           // [VPW][64] class logits
+    static constexpr int FPART = Y + VPW * 64;                  // [16][256] partial sums of the backward mini-GEMM (one video at a time)
+    static constexpr int VPART = FPART + 16 * NBH;              // [4 waves][256] per-wave partial sums of V
+    static constexpr int LOSS = VPART + 4 * NBH;                // [4 waves][8] loss partials
+    static constexpr int TOTAL = LOSS + 32;
+    static constexpr int WPV = 4 / VPW;                         // waves per video: they split the relations of the per-video stages
+};
 static_assert(64 * TROW <= NBH * WROW, "backward tile / classifier staging must fit in the weight tile");
+constexpr int S_LOSS_MIN = Lds<1>::LOSS;                        // (the frame workgroups' staging must stay below the loss slots of every variant)
 
 // -DTA3N_HEADS_TIMING: the 101st video workgroup stamps s_memtime at every stage boundary into ws["g_attn"] (debug builds only)
 #ifdef TA3N_HEADS_TIMING
@@ -85,7 +93,7 @@ __device__ __forceinline__ bool video_valid(int Bs, const Hyper *hy, int b) {
 }
 
 // this workgroup's loss partials -> ws["loss_part"][wg][8] = {total, cls, rel, vid, frm, ent, 0, 0}
-__device__ __forceinline__ void write_loss_part(float *smem, float *ws, int o_loss_part, int wg, float gamma) {
+__device__ __forceinline__ void write_loss_part(float *smem, float *ws, int o_loss_part, int wg, float gamma, int S_LOSS) {
     const int tid = threadIdx.x;
     __syncthreads();
     float v = 0.f;
@@ -99,7 +107,11 @@ __device__ __forceinline__ void write_loss_part(float *smem, float *ws, int o_lo
     }
 }
 
+template <int VPW>
 __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *smem) {
+    using L = Lds<VPW>;
+    constexpr int S_W = L::W, S_VD = L::VD, S_HV = L::HV, S_GHV = L::GHV, S_GVT = L::GVT, S_GY = L::GY, S_PR = L::PR, S_GPV = L::GPV, S_Y = L::Y,
+                  S_FPART = L::FPART, S_VPART = L::VPART, S_LOSS = L::LOSS, WPV = L::WPV;
     float *__restrict__ ws = ptrs.ws;
     const float *__restrict__ wsr = ptrs.ws;       // regions this kernel only reads (Hr, Zr): their loads may move over stores
     const float *__restrict__ P = ptrs.p;
@@ -258,60 +270,65 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     __syncthreads();
 
     STAMP(2);
-    // ---- B: class logits: 4 threads per class, each a quarter of K; combined on the DPP quad network ----
+    // ---- B: class logits: 4 threads per class, each a quarter of K; combined on the DPP quad network; one video after the other ----
     {
         const int c = tid >> 2, part = tid & 3;
-        float acc = 0.f;
-        if (c < C) {
-            const float *wr = &smem[S_W + c * TROW + part * 64];
-            const float *vd = &smem[S_VD + part * 64];
 #pragma unroll
-            for (int k4 = 0; k4 < 64; k4 += 4) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
-                const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
-                acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
+        for (int v = 0; v < VPW; ++v) {
+            float acc = 0.f;
+            if (c < C) {
+                const float *wr = &smem[S_W + c * TROW + part * 64];
+                const float *vd = &smem[S_VD + v * NBH + part * 64];
+#pragma unroll
+                for (int k4 = 0; k4 < 64; k4 += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
+                    const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
+                    acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
+                }
             }
-        }
-        acc += dpp_move<0xB1, 0xF>(0.f, acc);      // quad_perm [1,0,3,2]
-        acc += dpp_move<0x4E, 0xF>(0.f, acc);      // quad_perm [2,3,0,1]: every lane of the quad holds the class logit
-        if (c < C && part == 0) {
-            const float yc = acc + bcv_c;
-            smem[S_Y + c] = yc;
-            if (have) ws[g.o_Y + (size_t)b * C + c] = yc;
+            acc += dpp_move<0xB1, 0xF>(0.f, acc);      // quad_perm [1,0,3,2]
+            acc += dpp_move<0x4E, 0xF>(0.f, acc);      // quad_perm [2,3,0,1]: every lane of the quad holds the class logit
+            if (c < C && part == 0) {
+                const float yc = acc + bcv_c;
+                smem[S_Y + v * 64 + c] = yc;
+                if (v < nv) ws[g.o_Y + (size_t)(b0 + v) * C + c] = yc;
+            }
         }
     }
     __syncthreads();   // logits visible; done with the classifier tile
-    const float y = (lane < C) ? smem[S_Y + lane] : -INFINITY;
+    const float y = (lane < C) ? smem[S_Y + vloc * 64 + lane] : -INFINITY;
 
     STAMP(3);
-    // ---- C: Hv = relu(Wdv Vd + bdv) straight from the register copy of Wdv ----
+    // ---- C: Hv = relu(Wdv Vd + bdv) straight from the register copy of Wdv, for the workgroup's VPW videos ----
     // Thread (srow, c16) holds W[srow + 16 i][64 kc + 4 c16 .. +3]: 16 partial dot products over its 16 k, then a sum over the
     // 16 lanes of its DPP row (they share srow and cover all 256 k).  Lane c16 keeps output channel srow + 16 c16.
     {
-        static_assert(VPW == 1, "stages C and F are written for one video per workgroup");
         const int c16 = tid & 15;
-        f32x4 xk[4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) xk[kc] = *reinterpret_cast<const f32x4 *>(&smem[S_VD + kc * 64 + sk4]);
-        float hv = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float p = 0.f;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const f32x4 w4 = wreg[kc * 16 + i];
-                p = fmaf(w4.x, xk[kc].x, p); p = fmaf(w4.y, xk[kc].y, p); p = fmaf(w4.z, xk[kc].z, p); p = fmaf(w4.w, xk[kc].w, p);
-            }
-            p += dpp_move<0xB1, 0xF>(0.f, p);      // quad_perm [1,0,3,2]
-            p += dpp_move<0x4E, 0xF>(0.f, p);      // quad_perm [2,3,0,1]
-            p += dpp_move<0x141, 0xF>(0.f, p);     // row_half_mirror
-            p += dpp_move<0x140, 0xF>(0.f, p);     // row_mirror: all 16 lanes of the row hold the sum
-            if (c16 == i) hv = p;
-        }
         const int n = srow + 16 * c16;
-        const float h = fmaxf(hv + bdv_n, 0.f);
-        smem[S_HV + n] = h;
-        if (have) ws[g.o_Hv + (size_t)b * NBH + n] = h;
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) {
+            f32x4 xk[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) xk[kc] = *reinterpret_cast<const f32x4 *>(&smem[S_VD + v * NBH + kc * 64 + sk4]);
+            float hv = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const f32x4 w4 = wreg[kc * 16 + i];
+                    p = fmaf(w4.x, xk[kc].x, p); p = fmaf(w4.y, xk[kc].y, p); p = fmaf(w4.z, xk[kc].z, p); p = fmaf(w4.w, xk[kc].w, p);
+                }
+                p += dpp_move<0xB1, 0xF>(0.f, p);      // quad_perm [1,0,3,2]
+                p += dpp_move<0x4E, 0xF>(0.f, p);      // quad_perm [2,3,0,1]
+                p += dpp_move<0x141, 0xF>(0.f, p);     // row_half_mirror
+                p += dpp_move<0x140, 0xF>(0.f, p);     // row_mirror: all 16 lanes of the row hold the sum
+                if (c16 == i) hv = p;
+            }
+            const float h = fmaxf(hv + bdv_n, 0.f);
+            smem[S_HV + v * NBH + n] = h;
+            if (v < nv) ws[g.o_Hv + (size_t)(b0 + v) * NBH + n] = h;
+        }
     }
     __syncthreads();
 
@@ -385,13 +402,14 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
-    // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ) from the register copy of Wdv ----
+    // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ) from the register copy of Wdv, one video after the other ----
     // Thread (srow, c16) multiplies its 16 rows n = srow + 16 i into partial sums for its 16 input channels
     // k = 64 kc + 4 c16 + e; the 16 threads that share c16 (one per srow) are added through LDS, thread t <-> channel t.
-    {
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
         float gh[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gh[i] = smem[S_GHV + srow + 16 * i];
+        for (int i = 0; i < 16; ++i) gh[i] = smem[S_GHV + v * NBH + srow + 16 * i];
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             f32x4 p = {0.f, 0.f, 0.f, 0.f};
@@ -408,14 +426,15 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         for (int r = 0; r < 16; ++r) acc += smem[S_FPART + r * NBH + tid];
         acc *= -hy->beta[1];
         // classifier weights column-wise: the [C][TROW] tile staged for stage B is still in place
-        for (int c = 0; c < C; ++c) acc = fmaf(smem[S_GY + c], smem[S_W + c * TROW + tid], acc);
+        for (int c = 0; c < C; ++c) acc = fmaf(smem[S_GY + v * 64 + c], smem[S_W + c * TROW + tid], acc);
         float gv = acc;
-        if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)(b * NBH + tid), hy->p_drop_v);
+        if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v);
         gv *= inv_keep_v;
-        smem[S_GVT + tid] = gv;
-        if (have) ws[g.o_gVt + (size_t)b * NBH + tid] = gv;
+        smem[S_GVT + v * NBH + tid] = gv;
+        if (v < nv) ws[g.o_gVt + (size_t)(b0 + v) * NBH + tid] = gv;
+        if (VPW > 1) __syncthreads();      // (the partial-sum block is reused by the next video)
     }
-    __syncthreads();
+    if (VPW == 1) __syncthreads();
 
     STAMP(6);
     // ---- G: backward of the attention pooling + relation adversarial loss (WPV waves per video) ----
@@ -481,7 +500,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         }
     }
     STAMP(7);
-    write_loss_part(smem, ws, g.o_loss_part, (int)blockIdx.x - g.n_frm_wg, hy->gamma);
+    write_loss_part(smem, ws, g.o_loss_part, (int)blockIdx.x - g.n_frm_wg, hy->gamma, S_LOSS);
     STAMP(8);
 }
 
@@ -582,7 +601,7 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
         smem[(wv * 2 + 1) * FP + q * 64 + lane] = a1[q];
     }
     if (lane == 0) { smem[8 * FP + wv * 2] = sg0; smem[8 * FP + wv * 2 + 1] = sg1; }
-    if (lane < 8) smem[S_LOSS + wv * 8 + lane] = lane == 4 ? l_frm : 0.f;
+    if (lane < 8) smem[S_LOSS_MIN + wv * 8 + lane] = lane == 4 ? l_frm : 0.f;
     __syncthreads();
     float *__restrict__ part = ws + g.o_fh_part + (size_t)wg * 2 * F;
     for (int i = tid; i < 2 * F; i += 256) {
@@ -591,28 +610,35 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
     }
     if (tid < 2)
         ws[g.o_fh_bpart + (size_t)wg * 2 + tid] = (smem[8 * FP + tid] + smem[8 * FP + 2 + tid]) + (smem[8 * FP + 4 + tid] + smem[8 * FP + 6 + tid]);
-    write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hy->gamma);
+    write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hy->gamma, S_LOSS_MIN);
 }
 
-template <int FQ>
+template <int FQ, int VPW>
 __global__ __launch_bounds__(256) void heads_kernel(Geom g, Ptrs ptrs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // the (short) frame workgroups come first in the grid: if the grid does not fit on the chip at once, the workgroups that
     // start late are video workgroups behind finished frame workgroups, not frame workgroups behind finished video ones
     if ((int)blockIdx.x < g.n_frm_wg) frame_wg<FQ>(g, ptrs, smem, (int)blockIdx.x);
-    else video_wg(g, ptrs, smem);
+    else video_wg<VPW>(g, ptrs, smem);
+}
+
+template <int FQ, int VPW>
+int launch_fq_vpw(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    static_assert(8 * FQ * 64 + 16 <= S_LOSS_MIN, "the frame partials must stay below the loss slots");
+    static std::once_flag attr_once;   // > 64 KiB of dynamic LDS needs the opt-in once per process; callers may be DataParallel's
+                                       // one-thread-per-replica workers (SURVEY 8b: re-entrancy), hence call_once and no plain flag
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ, VPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((heads_kernel<FQ, VPW>), dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)Lds<VPW>::TOTAL * sizeof(float), stream, g, ptrs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int FQ>
 int launch_fq(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    static_assert(8 * FQ * 64 + 16 <= S_LOSS, "the frame partials must stay below the loss slots");
-    static std::once_flag attr_once;   // > 64 KiB of dynamic LDS needs the opt-in once per process; callers may be DataParallel's
-                                       // one-thread-per-replica workers (SURVEY 8b: re-entrancy), hence call_once and no plain flag
-    std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    hipLaunchKernelGGL(heads_kernel<FQ>, dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)S_TOTAL * sizeof(float), stream, g, ptrs);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    if (g.heads_vpw == 4) return launch_fq_vpw<FQ, 4>(g, ptrs, stream);
+    if (g.heads_vpw == 2) return launch_fq_vpw<FQ, 2>(g, ptrs, stream);
+    return launch_fq_vpw<FQ, 1>(g, ptrs, stream);
 }
 
 }  // namespace

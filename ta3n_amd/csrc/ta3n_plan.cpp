@@ -14,6 +14,7 @@
 #include "ta3n_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -1130,7 +1131,12 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_hyper = (int32_t)b.add_region("hyper", 32);
     g.o_labels = (int32_t)b.add_region("labels", B);
     g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
-    g.n_vid_wg = (B + HEADS_VPW - 1) / HEADS_VPW;
+    // Videos per video workgroup: one while every video can have a compute unit (the headline shape: the shortest chain), two or four
+    // once there are more videos than CUs - a video workgroup owns its CU, so the launch would otherwise run in rounds (ta3n_heads.hip).
+    // TA3N_HEADS_VPW in the environment forces 1 / 2 / 4 (A/B runs).
+    g.heads_vpw = B <= 224 ? 1 : (B <= 448 ? 2 : 4);
+    if (const char *e = std::getenv("TA3N_HEADS_VPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) g.heads_vpw = v; }
+    g.n_vid_wg = (B + g.heads_vpw - 1) / g.heads_vpw;
     g.heads_rpw = HEADS_RPW;      // all workgroups of the heads kernel resident at once if the chip (256 CUs) can hold them
     while (g.n_vid_wg + (BT + g.heads_rpw - 1) / g.heads_rpw > 256 && g.heads_rpw < 8 * HEADS_RPW) g.heads_rpw *= 2;
     g.n_frm_wg = (BT + g.heads_rpw - 1) / g.heads_rpw;

@@ -104,7 +104,6 @@ enum PhaseKind : int32_t {
 };
 
 // work split of the fused heads kernel (ta3n_heads.hip); the plan builder sizes its partial-sum regions from these
-constexpr int HEADS_VPW = 1;    // videos per video workgroup (one wave each for the per-video parts; 1, 2 or 4)
 constexpr int HEADS_RPW = 16;   // frame rows per row group of a frame workgroup (Geom.heads_rpw rows per workgroup, a multiple of this)
 
 struct Phase {
@@ -171,6 +170,7 @@ struct Geom {
     // hi = bf16(x); the lo plane of ANY twin element lives pair_delta floats behind its hi plane (the four lo regions are laid out
     // like the four hi regions).  0: no lo planes.
     int32_t pair_delta;
+    int32_t heads_vpw;                   // videos per video workgroup of the fused heads kernel (1, 2 or 4; 0 = 1)
 };
 
 }  // namespace ta3n

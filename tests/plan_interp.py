@@ -58,7 +58,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
                 "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2", "o_Z0", "o_gZ0", "o_bn_batch", "o_bn_run",
-                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b", "pair_delta"]
+                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b", "pair_delta", "heads_vpw"]
 
 
 class Geom(C.Structure):

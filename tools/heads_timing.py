@@ -7,10 +7,14 @@ from ta3n_amd import _lib
 # a library whose ta3n_heads.o was compiled with -DTA3N_HEADS_TIMING (build it where hipcc is, it travels with the tree):
 #   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DTA3N_HEADS_TIMING -x hip -c ta3n_amd/csrc/ta3n_heads.hip -o tools/lib_timing/ta3n_heads.o
 #   hipcc -shared -fPIC --offload-arch=gfx950 -o tools/lib_timing/libta3n_hip.so <the other objects of ta3n_amd/lib> tools/lib_timing/ta3n_heads.o -ldl
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_timing", "libta3n_hip.so")
+# (round 4: TA3N_LIBDIR=ta3n_amd/lib_ab TA3N_EXTRA_FLAGS=-DTA3N_HEADS_TIMING python -m ta3n_amd.build, then run with the same TA3N_LIBDIR)
+if not os.environ.get("TA3N_LIBDIR"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_timing", "libta3n_hip.so")
 from ta3n_amd.engine import TrainEngine
 BF16 = "--bf16" in sys.argv
-eng = TrainEngine(128, 74, 5, 2048, 512, 12, bf16=BF16, bf16_store=BF16)
+shape = [int(v) for v in sys.argv[1:7]] if len(sys.argv) >= 7 and sys.argv[1].isdigit() else [128, 74, 5, 2048, 512, 12]
+print("shape", shape, "bf16" if BF16 else "f32")
+eng = TrainEngine(*shape, bf16=BF16, bf16_store=BF16)
 eng.X.uniform_(0, 1)
 for v in eng.param_views().values(): v.normal_(0, 0.02)
 eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3)
