@@ -1131,10 +1131,14 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_hyper = (int32_t)b.add_region("hyper", 32);
     g.o_labels = (int32_t)b.add_region("labels", B);
     g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
-    // Videos per video workgroup: one while every video can have a compute unit (the headline shape: the shortest chain), two or four
-    // once there are more videos than CUs - a video workgroup owns its CU, so the launch would otherwise run in rounds (ta3n_heads.hip).
-    // TA3N_HEADS_VPW in the environment forces 1 / 2 / 4 (A/B runs).
-    g.heads_vpw = B <= 224 ? 1 : (B <= 448 ? 2 : 4);
+    // Videos per video workgroup (ta3n_heads.hip; TA3N_HEADS_VPW in the environment forces 1 / 2 / 4 for A/B runs).  A video workgroup owns
+    // its compute unit, so what matters is how many ROUNDS the launch needs and how long a workgroup lives - and a workgroup's life is
+    // dominated by the relation stages, whose per-wave chain grows with the relations a wave handles.  Measured (profiles/r04_heads_vpw_ab.txt):
+    // 128+128 videos x 12 segments (configs[4]): 2 per workgroup turns 1.2 rounds into one, launch 40.6 -> 29.1 us, two-stream step 477 -> 470;
+    // 512+512 x 9 (configs[3]): the video workgroups alone fill the chip whatever the packing - 4 per workgroup 79.5 -> 79.5 us on one box and
+    // +40 us per step on another, 2 per workgroup -7 us on the launch and +6 on the step: left at one; 128+74 x 5 (headline): 2 per
+    // workgroup 15.5 -> 20.1 us (every video has a compute unit already).
+    g.heads_vpw = (B > 224 && B <= 448) ? 2 : 1;
     if (const char *e = std::getenv("TA3N_HEADS_VPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) g.heads_vpw = v; }
     g.n_vid_wg = (B + g.heads_vpw - 1) / g.heads_vpw;
     g.heads_rpw = HEADS_RPW;      // all workgroups of the heads kernel resident at once if the chip (256 CUs) can hold them
