@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 # _lib.py loads from the same place
 LIBDIR = os.environ.get("TA3N_LIBDIR") or os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libta3n_hip.so")
-SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_gemm_i0.hip", "ta3n_gemm_i1.hip", "ta3n_gemm_i2.hip", "ta3n_gemm_i3.hip", "ta3n_gemm_i4.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_mmd.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
+SOURCES = ["ta3n_api.hip", "ta3n_gemm.hip", "ta3n_gemm_i0.hip", "ta3n_gemm_i1.hip", "ta3n_gemm_i2.hip", "ta3n_gemm_i3.hip", "ta3n_gemm_i4.hip", "ta3n_gemm_i5.hip", "ta3n_pointwise.hip", "ta3n_heads.hip", "ta3n_comm.hip", "ta3n_peer.hip", "ta3n_mmd.hip", "ta3n_plan.cpp", "ta3n_index.cpp"]
 HEADERS = ["ta3n_types.h", "ta3n_kernels.h", "ta3n_plan.h", "ta3n_gemm_kernel.h", os.path.join("..", "..", "include", "ta3n_hip.h")]
 
 

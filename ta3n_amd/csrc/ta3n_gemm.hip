@@ -20,6 +20,9 @@ TA3N_BLOCKED_CONFIGS(TA3N_EXTERN_BLOCKED)
 #define TA3N_EXTERN_KIND(wm, wn, wk, bf, ns, kv) \
     extern template __global__ void gemm_tiles<wm, wn, wk, bf, ns, 1, 1, kv>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 TA3N_KIND_CONFIGS(TA3N_EXTERN_KIND)
+#define TA3N_EXTERN_HS(wm, wn, wk, rm, rn, ns) \
+    extern template __global__ void gemm_tiles<wm, wn, wk, 5, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
+TA3N_HS_CONFIGS(TA3N_EXTERN_HS)
 
 #ifdef TA3N_GEMM_STAMPS
 extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
@@ -31,8 +34,16 @@ bool tile_config_ok(int cfg) {
     // optional ten-thousands digit: register blocking of the bf16-twin kernel (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2)
     const int blk = cfg / 10000;
     cfg %= 10000;
-    const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice)
+    const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice); 6 / 7: HALF stages (64 k), 3 / 4 of them
     cfg %= 1000;
+    if (stages == 6 || stages == 7) {
+        if (blk < 0 || blk > 5) return false;
+        const int rm = blk_rm(blk), rn = blk_rn(blk);
+#define TA3N_CHECK_HS(wm, wn, wk, rm_, rn_, ns) \
+        if (cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && stages - 3 == ns) return true;
+        TA3N_HS_CONFIGS(TA3N_CHECK_HS)
+        return false;
+    }
     if (stages != 0 && stages != 2 && stages != 3) return false;
     if (blk != 0) {
         if (blk < 0 || blk > 3) return false;
@@ -73,6 +84,18 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
     const int rm = ph.rm > 0 ? ph.rm : 1, rn = ph.rn > 0 ? ph.rn : 1;
+    if (ph.bf16 & 64) {        // half stages (the plan only sets the bit on launches that read plain bf16 twins)
+        if ((ph.bf16 & 48) != 16) return -3;
+#define TA3N_LAUNCH_HS(wm, wn, wk, rm_, rn_, ns)                                                                           \
+        if (!launched && cfg == wm * 100 + wn * 10 + wk && rm == rm_ && rn == rn_ && (ph.bf16 & 15) == ns) {               \
+            hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, 5, ns, rm_, rn_>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
+                               ptrs, hyper_off, zeros_off, twin_off, sd, d_waits, chain_off, chain_n, knobs, pair_delta);   \
+            launched = true;                                                                                               \
+        }
+        TA3N_HS_CONFIGS(TA3N_LAUNCH_HS)
+        if (!launched) return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (rm * rn > 1) {
         if (!(ph.bf16 & 16)) return -3;     // (the plan builder never emits this: blocked tiles read bf16 twins)
 #define TA3N_LAUNCH_BLOCKED(wm, wn, wk, rm_, rn_, ns)                                                                      \

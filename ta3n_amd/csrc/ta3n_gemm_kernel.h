@@ -80,8 +80,16 @@ __device__ __forceinline__ void glds16_batch(const float *const (&src)[NP], unsi
         const float *const lo[4] = {src[0], src[1], src[2], src[3]}, *const hi[4] = {src[4], src[5], src[6], src[7]};
         glds16_batch<4>(lo, lds_byte_addr, stride);
         glds16_batch<4>(hi, lds_byte_addr + 4 * stride, stride);
+    } else if constexpr (NP == 3) {
+        const float *const lo[2] = {src[0], src[1]}, *const hi[1] = {src[2]};
+        glds16_batch<2>(lo, lds_byte_addr, stride);
+        glds16_batch<1>(hi, lds_byte_addr + 2 * stride, stride);
+    } else if constexpr (NP == 6) {
+        const float *const lo[4] = {src[0], src[1], src[2], src[3]}, *const hi[2] = {src[4], src[5]};
+        glds16_batch<4>(lo, lds_byte_addr, stride);
+        glds16_batch<2>(hi, lds_byte_addr + 4 * stride, stride);
     } else {
-        static_assert(NP == 4, "1, 2, 4 or 8 pieces per wave");
+        static_assert(NP == 4, "1, 2, 3, 4, 6 or 8 pieces per wave");
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                      "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
                      "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
@@ -131,10 +139,15 @@ constexpr int K_NEVER = 1 << 28;   // "k offset" of a lane whose row is out of r
 // PAIR (pair twins, Geom::pair_delta): the stage holds 64 k twice - the hi plane and, pair_delta floats behind it in memory, the lo
 // plane (x = hi + lo).  K-contiguous: logical slots 0-7 of a row are the hi k-groups, 8-15 the lo ones; k-major: image rows 0-63
 // are the hi plane's k rows, 64-127 the lo plane's.  Same bytes, pieces and DMA instructions per stage as the plain twin stage.
-template <int R, int NW, bool TW = false, bool PAIR = false>
+// HS ("half stages", bf16 twins only): the stage holds 64 k in HALF the bytes - K-contiguous rows are 8 slots of 8 bf16 (128-byte rows: a
+// 1 KiB piece is 8 rows; slot s of row r holds k-group s ^ ((r >> 1) & 7), conflict-free for ds_read_b128: the 16 lanes of a read group
+// cover all sixteen 16-byte bank quads), a k-major stage is [64][R] bf16.  Half the bytes per stage = twice the stages in the same LDS:
+// a 128x128 tile keeps four (three in flight) where it kept two (one in flight) - the K loops wait for LDS-DMA round trips, not for
+// bandwidth (profiles/r04_pmc_per_launch.txt).
+template <int R, int NW, bool TW = false, bool PAIR = false, bool HS = false>
 struct OperandStream {
-    static constexpr int NP = R / 4 / NW;   // 1 KiB pieces per wave per stage (16-byte path)
-    static_assert((R / 4) % NW == 0, "pieces must divide over the waves");
+    static constexpr int NP = HS ? R / 8 / NW : R / 4 / NW;   // 1 KiB pieces per wave per stage (16-byte path)
+    static_assert(HS ? (R / 8) % NW == 0 && TW && !PAIR : (R / 4) % NW == 0, "pieces must divide over the waves");
     const float *p[NP];     // this lane's source address in the current chunk
     int kofs[NP];           // this lane's k offset inside a chunk (K_NEVER: row out of range)
     int step;               // floats between consecutive chunks
@@ -165,6 +178,29 @@ struct OperandStream {
                     const int r = r0_ + chunk * 8;
                     p[i] = origin_ + (size_t)(kk & 63) * ldf + (r >> 1) + (kk >= 64 ? pair_delta : 0);
                     kofs[i] = (r < rvalid_) ? (kk & 63) : K_NEVER;
+                }
+            }
+            return;
+        }
+        if constexpr (TW && HS) {
+            vec = true;
+            const int ldf = ld_ >> 1;                  // floats per row of the twin
+            step = kmajor_ ? 64 * ldf : BKC / 2;       // 64 k per stage
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int q = wave + NW * i;
+                if (!kmajor_) {                        // piece = 8 rows x 128 B; slot s of row r holds k = 8 (s ^ ((r >> 1) & 7)) .. + 7
+                    const int row = q * 8 + (lane >> 3);
+                    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+                    p[i] = origin_ + (size_t)(r0_ + row) * ldf + 4 * slot;
+                    kofs[i] = (r0_ + row < rvalid_) ? 8 * slot : K_NEVER;
+                } else {                               // [64][R] bf16: the image rows and their chunk swizzle are those of the 128-k image
+                    constexpr int LPR = R / 8, KPP = 64 / LPR;
+                    const int k = q * KPP + lane / LPR;
+                    const int chunk = (lane % LPR) ^ (R == 64 ? ((k >> 1) & 1) << 2 : R == 128 ? (k & 3) << 2 : 0);
+                    const int r = r0_ + chunk * 8;
+                    p[i] = origin_ + (size_t)k * ldf + (r >> 1);
+                    kofs[i] = (r < rvalid_) ? k : K_NEVER;
                 }
             }
             return;
@@ -275,12 +311,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1, class Mid, class Pre>
 __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rss)[RM], const float *__restrict__ sa,
                                               const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem, Mid &&mid, Pre &&pre) {
-    constexpr int GPW = 16 / WK;                   // 4-deep k groups per wave per stage
+    constexpr bool HS = BF == 5;                   // bf16 twins in 64-k stages (128-byte image rows)
+    constexpr int GPW = (HS ? 8 : 16) / WK;        // k groups per wave per stage (4-deep fp32 groups; 8-deep bf16 groups on the twin paths)
     constexpr int NQ = GPW / 2;
-    static_assert(BF == 2 || (RM == 1 && RN == 1), "register blocking exists on the bf16-twin path only");
+    constexpr int ROWF = HS ? BKC / 2 : BKC;       // floats per row of a K-contiguous stage image
+    static_assert(GPW >= 2, "the K split leaves every wave a pair of k groups");
+    static_assert(BF == 2 || BF == 5 || (RM == 1 && RN == 1), "register blocking exists on the bf16-twin path only");
+    auto swz = [](int row) { return HS ? ((row >> 1) & 7) : (row & 15); };      // physical slot = logical k group ^ swz(row)
     f32x16 &acc = accs[0][0];
     float &rs = rss[0];
-    if constexpr (BF == 2 && RM * RN > 1) {
+    if constexpr ((BF == 2 || BF == 5) && RM * RN > 1) {
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
         constexpr int QG = (RM + RN) * NQ <= 16 ? NQ : NQ / 2;   // k groups whose fragments are in registers together (<= 64 VGPRs)
@@ -289,6 +329,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         const int tcol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
         const unsigned short *sa16 = reinterpret_cast<const unsigned short *>(sa);
         const unsigned short *sb16 = reinterpret_cast<const unsigned short *>(sb);
+        static_assert(!AKM || BM <= 128, "k-major A images exist for 32-, 64- and 128-row tiles (the plan keeps taller tiles off such launches)");
         const int swa = BM == 64 ? 32 * ((lane >> 3) & 1) : BM == 128 ? 32 * ((lane >> 2) & 3) : 0;
         const int swb = BN == 64 ? 32 * ((lane >> 3) & 1) : BN == 128 ? 32 * ((lane >> 2) & 3) : 0;
 #pragma unroll
@@ -302,7 +343,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
 #pragma unroll
                 for (int i = 0; i < RM; ++i) {
                     if (!AKM) {
-                        ta[i][qq] = *reinterpret_cast<const u32x4 *>(sa + (ra + 32 * i) * BKC + ((G ^ (ra & 15)) << 2));
+                        ta[i][qq] = *reinterpret_cast<const u32x4 *>(sa + (ra + 32 * i) * ROWF + ((G ^ swz(ra + 32 * i)) << 2));
                     } else {
                         const int acol = ((ra & ~31) + 32 * i + tcol) ^ swa;
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + k0 * BM + acol));
@@ -314,7 +355,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
 #pragma unroll
                 for (int j = 0; j < RN; ++j) {
                     if (!BKM) {
-                        tb[j][qq] = *reinterpret_cast<const u32x4 *>(sb + (rb + 32 * j) * BKC + ((G ^ (rb & 15)) << 2));
+                        tb[j][qq] = *reinterpret_cast<const u32x4 *>(sb + (rb + 32 * j) * ROWF + ((G ^ swz(rb + 32 * j)) << 2));
                     } else {
                         const int bcol = ((rb & ~31) + 32 * j + tcol) ^ swb;
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + k0 * BN + bcol));
@@ -436,8 +477,8 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         }
         return;
     }
-    if constexpr (BF == 2) {
-        // stage of 128 k; slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): two transpose
+    if constexpr (BF == 2 || BF == 5) {
+        // stage of 128 k (64 with half stages); slot G = k 8G .. 8G+7.  K-contiguous: one 16-byte slot read.  k-major ([k][R] bf16): two transpose
         // reads (ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 rows] block, 8 contiguous bytes per lane, and lane i
         // receives row i's four k) - k 8G .. 8G+3 and 8G+4 .. 8G+7 of this lane's row.  For R = 64 the 16-byte chunks of image
         // rows k with (k >> 1) & 1 are stored swapped by 4 chunks (OperandStream::setup), which makes the reads conflict-free.
@@ -455,7 +496,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         for (int q = 0; q < NQ; ++q) {
             const int G = wk * GPW + 2 * q + lh;
             if (!AKM) {
-                ta[q] = *reinterpret_cast<const u32x4 *>(sa + ra * BKC + ((G ^ (ra & 15)) << 2));
+                ta[q] = *reinterpret_cast<const u32x4 *>(sa + ra * ROWF + ((G ^ swz(ra)) << 2));
             } else {
                 const int k0 = 8 * (wk * GPW + 2 * q) + trow;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sa16 + k0 * BM + acol));
@@ -464,7 +505,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                 ta[q] = u32x4{l2[0], l2[1], h2[0], h2[1]};
             }
             if (!BKM) {
-                tb[q] = *reinterpret_cast<const u32x4 *>(sb + rb * BKC + ((G ^ (rb & 15)) << 2));
+                tb[q] = *reinterpret_cast<const u32x4 *>(sb + rb * ROWF + ((G ^ swz(rb)) << 2));
             } else {
                 const int k0 = 8 * (wk * GPW + 2 * q) + trow;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(sb16 + k0 * BN + bcol));
@@ -717,9 +758,11 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                                           int twin_off, const SgdSide &side, int pair_delta, int knobs) {
     constexpr int NW = WM * WN * WK, NT = 64 * NW;
     constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
-    constexpr int STAGE = (BM + BN) * BKC;           // floats per stage
-    constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128; pair twins: 64 as hi + lo)
-    constexpr bool TW = BF == 2 || BF == 4;
+    constexpr bool HS = BF == 5;                     // bf16 twins in 64-k stages (OperandStream HS): half the bytes per stage
+    constexpr int ROWF = HS ? BKC / 2 : BKC;         // floats per row of a K-contiguous stage image
+    constexpr int STAGE = (BM + BN) * ROWF;          // floats per stage
+    constexpr int CH = BF == 2 ? 2 * BKC : BKC;      // K elements per stage (bf16 twins: 128; pair twins: 64 as hi + lo; half stages: 64)
+    constexpr bool TW = BF == 2 || BF == 4 || BF == 5;
     constexpr bool PAIR = BF == 4;
     constexpr int EPI = NW * RM * RN * 32 * 36;      // epilogue staging (one padded 32x32 block per wave and register block)
     constexpr int LDS_FLOATS = NS * STAGE > EPI + 4 ? NS * STAGE : EPI + 4;      // (+ 4: the split-K ticket behind the epilogue staging)
@@ -766,7 +809,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
                 if (pub) st_pub(tw, u32x2{h0, h1});
                 else *tw = make_uint2(h0, h1);
-                if (BF >= 3 && pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
+                if ((BF == 3 || BF == 4) && pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
                     const u32x2 l = {pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1)};
                     if (pub) st_pub(tw + pair_delta / 2, l);
                     else tw[pair_delta / 2] = make_uint2(l[0], l[1]);
@@ -917,6 +960,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // rounds: the hook fires before the last round's MFMAs, which is still correct (all reads issued), just later
     constexpr bool EARLY = TA3N_EARLY_REFILL != 0 && NS == 2;
     (void)knobs;
+    constexpr int KVE = BM > 128 ? (KV & (1 | 2 | 32)) : KV;      // tiles taller than 128 rows: K-contiguous A only (the plan keeps them off other launches)
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
         if constexpr (EARLY) {
@@ -924,9 +968,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             // matrix instruction, so its buffer is free as soon as every wave's reads have returned - chunk c + 2 streams into the buffer
             // of chunk c while chunk c is still being MULTIPLIED.  Two chunks in flight on two buffers (the third "stage" is the register
             // file), at the price of a second barrier per chunk.  Same products in the same order: bit-identical results.
-            OperandStream<BM, NW, TW, PAIR> oa;
-            OperandStream<BN, NW, TW, PAIR> ob;
-            constexpr int LPW = OperandStream<BM, NW, TW, PAIR>::NP + OperandStream<BN, NW, TW, PAIR>::NP;
+            OperandStream<BM, NW, TW, PAIR, HS> oa;
+            OperandStream<BN, NW, TW, PAIR, HS> ob;
+            constexpr int LPW = OperandStream<BM, NW, TW, PAIR, HS>::NP + OperandStream<BN, NW, TW, PAIR, HS>::NP;
             static_assert(LPW <= 63, "vmcnt is a 6-bit counter");
             int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
             Seg nx = t.seg0;
@@ -942,7 +986,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
                 const int k0 = i_chunk * CH;
                 oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
-                ob.issue(k0, i_klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                ob.issue(k0, i_klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
                 i_buf ^= 1;
                 ++ahead;
                 if (++i_chunk == i_nchunks) {
@@ -975,9 +1019,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     --ahead;
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, refill);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, refill);
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, refill);
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, refill);
                     c_buf ^= 1;
                 }
                 if (c_scale != SK_ONE) {
@@ -994,8 +1038,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         } else if constexpr (NS == 2) {
             // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
             // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
-            OperandStream<BM, NW, TW, PAIR> oa;
-            OperandStream<BN, NW, TW, PAIR> ob;
+            OperandStream<BM, NW, TW, PAIR, HS> oa;
+            OperandStream<BN, NW, TW, PAIR, HS> ob;
             int klen = 0, scale = SK_ONE;
             // The descriptor of the NEXT Seg is fetched while the current one streams (scalar loads, consumed at the next
             // open): opening a Seg used to start with a dependent global load between "stage landed" and "next DMA issued" -
@@ -1012,18 +1056,18 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             auto issue = [&](int buf, int k0) {
                 const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
                 oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
             };
             // the same chunk, a share of its pieces per call: slot s of n issues pieces [s PT / n, (s + 1) PT / n) of the PT = NPa + NPb
             // this wave owns (an operand on the 4-byte path goes out whole with slot 0)
             auto issue_share = [&](int buf, int k0, int slot, int nslots) {
-                constexpr int PA = OperandStream<BM, NW, TW, PAIR>::NP, PB = OperandStream<BN, NW, TW, PAIR>::NP, PT = PA + PB;
+                constexpr int PA = OperandStream<BM, NW, TW, PAIR, HS>::NP, PB = OperandStream<BN, NW, TW, PAIR, HS>::NP, PT = PA + PB;
                 const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
                 const int lo = slot * PT / nslots, hi = (slot + 1) * PT / nslots;
                 if (oa.vec) oa.issue_pieces(lo, hi, klen - k0, st, wave, zeros);
                 else if (slot == 0) oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * BKC * 4, wave, zeros);
-                else if (slot == 0) ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * ROWF * 4, wave, zeros);
+                else if (slot == 0) ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
             };
             auto stage_ready = [&]() {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
@@ -1039,11 +1083,11 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     stage_ready();
                     const float *sa = lds + buf * STAGE;
                     if constexpr (interleave) {       // the next chunk's DMAs between this chunk's matrix instructions
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH,
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH,
                                                                                   [&](int slot, int nslots) { issue_share(buf ^ 1, (c + 1) * CH, slot, nslots); }, [] {});
                     } else {
                         issue(buf ^ 1, (c + 1) * CH);
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                     }
                     buf ^= 1;
                 }
@@ -1058,7 +1102,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 }
                 const float *sa = lds + buf * STAGE;
                 // (ONE instance of the tail stage: the hook issues nothing when no Seg follows)
-                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, krem,
+                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, krem,
                                                                            [&](int slot, int nslots) { if (interleave && more) issue_share(buf ^ 1, 0, slot, nslots); }, [] {});
                 if (c_scale != SK_ONE) {
                     const float sc = scale_of(c_scale);
@@ -1075,9 +1119,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             } else {
             // Two cursors walk the task's Segs chunk by chunk: the issue cursor (per-lane DMA state) runs up to NS - 1
             // chunks ahead of the compute cursor (scalar state only).
-            OperandStream<BM, NW, TW, PAIR> oa;
-            OperandStream<BN, NW, TW, PAIR> ob;
-            constexpr int LPW = OperandStream<BM, NW, TW, PAIR>::NP + OperandStream<BN, NW, TW, PAIR>::NP;   // DMAs per lane and chunk (16-byte path;
+            OperandStream<BM, NW, TW, PAIR, HS> oa;
+            OperandStream<BN, NW, TW, PAIR, HS> ob;
+            constexpr int LPW = OperandStream<BM, NW, TW, PAIR, HS>::NP + OperandStream<BN, NW, TW, PAIR, HS>::NP;   // DMAs per lane and chunk (16-byte path;
                                                                                          // the 4-byte path issues more, never fewer)
             int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
             Seg nx = t.seg0;                         // descriptor of the Seg the issue cursor opens next, fetched one Seg ahead
@@ -1093,7 +1137,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
                 const int k0 = i_chunk * CH;
                 oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
-                ob.issue(k0, i_klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                ob.issue(k0, i_klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
                 i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                 ++ahead;
                 if (++i_chunk == i_nchunks) {
@@ -1129,19 +1173,19 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                         const int k0 = (c + NS - 1) * CH;
                         const float *sa = lds + c_buf * STAGE;
                         if constexpr (interleave) {      // the chunk's DMAs between the matrix instructions of the chunk being computed
-                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH,
+                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH,
                                 [&](int slot, int nslots) {
-                                    constexpr int PA = OperandStream<BM, NW, TW, PAIR>::NP, PT = LPW;
+                                    constexpr int PA = OperandStream<BM, NW, TW, PAIR, HS>::NP, PT = LPW;
                                     const int lo = slot * PT / nslots, hi = (slot + 1) * PT / nslots;
                                     if (oa.vec) oa.issue_pieces(lo, hi, klen - k0, st, wave, zeros);
                                     else if (slot == 0) oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                                    if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * BKC * 4, wave, zeros);
-                                    else if (slot == 0) ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
+                                    if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * ROWF * 4, wave, zeros);
+                                    else if (slot == 0) ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
                                 }, [] {});
                         } else {
                             oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                            ob.issue(k0, klen - k0, st + BM * BKC * 4, wave, lane, zeros);
-                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
+                            ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
+                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                         }
                         i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                         c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
@@ -1156,9 +1200,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     if (i_seg < seg_end) issue_one();
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * BKC, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, [] {});
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, [] {});
                     c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     --ahead;
                 }
@@ -1180,12 +1224,12 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     {
         const Seg &s0 = t.seg0;
         switch (s0.a_kmajor * 2 + s0.b_kmajor) {
-            case 0: if constexpr (KV & 1) k_loop(F_{}, F_{}, F_{}); break;
-            case 1: if constexpr (KV & 2) k_loop(F_{}, T_{}, F_{}); break;
-            case 2: if constexpr (KV & 4) k_loop(T_{}, F_{}, F_{}); break;
+            case 0: if constexpr (KVE & 1) k_loop(F_{}, F_{}, F_{}); break;
+            case 1: if constexpr (KVE & 2) k_loop(F_{}, T_{}, F_{}); break;
+            case 2: if constexpr (KVE & 4) k_loop(T_{}, F_{}, F_{}); break;
             default:   // weight gradients (both operands k-major) are the only tiles that also produce a bias gradient
-                if (t.epi & EPI_ROWSUM_A) { if constexpr (KV & 16) k_loop(T_{}, T_{}, T_{}); }
-                else { if constexpr (KV & 8) k_loop(T_{}, T_{}, F_{}); }
+                if (t.epi & EPI_ROWSUM_A) { if constexpr (KVE & 16) k_loop(T_{}, T_{}, T_{}); }
+                else { if constexpr (KVE & 8) k_loop(T_{}, T_{}, F_{}); }
                 break;
         }
     }
@@ -1375,7 +1419,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             unsigned short *tp = reinterpret_cast<unsigned short *>(ptrs.ws + twin_off) + ((size_t)t.c_off + (size_t)m * t.c_ld + n);
             const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
             store_twin4(tp, lo, hi, nrem, c_vec, pub);
-            if (BF >= 3 && pair_delta)      // pair twins (split-arithmetic launches only): the lo plane of the same four values
+            if ((BF == 3 || BF == 4) && pair_delta)      // pair twins (split-arithmetic launches only): the lo plane of the same four values
                 store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(v[0], v[1], lo), pack_bf16_lo(v[2], v[3], hi), nrem, c_vec, pub);
         }
         if (nfan > 0) {
@@ -1414,7 +1458,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                         const unsigned lo = pack_bf16(ov[0], ov[1]), hi = pack_bf16(ov[2], ov[3]);
                         const bool fvec = ((t.fan_out_off[f] | t.fan_ld) & 3) == 0;
                         store_twin4(tp, lo, hi, nrem, fvec, pub);
-                        if (BF >= 3 && pair_delta)
+                        if ((BF == 3 || BF == 4) && pair_delta)
                             store_twin4(tp + 2 * (size_t)pair_delta, pack_bf16_lo(ov[0], ov[1], lo), pack_bf16_lo(ov[2], ov[3], hi), nrem, fvec, pub);
                     }
                 }
@@ -1498,6 +1542,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     template __global__ void gemm_tiles<wm, wn, wk, 3, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 4, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 4, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
+// half-stage kernels (MODE 5: bf16 twins in 64-k stages, OperandStream HS): (wm, wn, wk, rm, rn, stages) - the 128x128 and 64x64 tiles
+// and - four waves, no K split inside the workgroup, 3 x 2 / 4 x 2 blocks per wave - the 192x128 and the 256x128 tile (A K-contiguous only)
+#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 2, 2, 4) X(2, 2, 2, 1, 1, 3) X(2, 2, 2, 1, 1, 4) X(2, 2, 1, 3, 2, 3) X(2, 2, 1, 4, 2, 3)
+#define TA3N_INSTANTIATE_HS(wm, wn, wk, rm, rn, ns) \
+    template __global__ void gemm_tiles<wm, wn, wk, 5, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
+
 #define TA3N_INSTANTIATE_BLOCKED(wm, wn, wk, rm, rn, ns) \
     template __global__ void gemm_tiles<wm, wn, wk, 2, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 

@@ -151,6 +151,13 @@ struct Builder {
         if (!twins_flags || (p.deny_blocking >> (p.phases.size() & 63)) & 1) blk = 0;
         int forced_stages = forced / 1000;
         forced %= 1000;
+        // thousands digit 6 / 7: HALF stages (64 k per stage: gemm_tiles MODE 5), 3 / 4 of them - for launches that read plain bf16 twins;
+        // dropped again (with the blocking) where a launch turns out not to (build_plan's retry loop)
+        bool half_stages = false;
+        if (forced_stages == 6 || forced_stages == 7) {
+            half_stages = twins_flags && !(p.cfg.flags & TA3N_FLAG_F32_SPLIT) && !((p.deny_blocking >> (p.phases.size() & 63)) & 1);
+            forced_stages = half_stages ? forced_stages - 3 : 0;
+        }
         if (forced != 0) {
             wm = forced / 100; wn = (forced / 10) % 10; wk = forced % 10;
         } else {
@@ -170,8 +177,20 @@ struct Builder {
             else if (count(32, 32) >= 512) { wm = 1; wn = 1; wk = 4; }
             else { wm = 1; wn = 1; wk = 8; }
         }
-        const int rm = 1 + (blk & 1), rn = 1 + (blk >> 1);
-        if (forced_stages == 3 && rm * rn == 4) forced_stages = 2;   // three 64 KiB stages do not fit
+        if (blk >= 4) {
+            // 192x128 / 256x128 tiles: half-stage kernels of four waves, and only where every A operand is K-contiguous (forward levels,
+            // gradients at activations); anywhere else the launch falls back to the plan's own choice
+            bool a_kcontig = true;
+            for (auto &g : specs) for (auto &sg : g.segs) a_kcontig = a_kcontig && !sg.a_kmajor;
+            if (!(half_stages && forced == 221 && forced_stages == 3 && a_kcontig)) {
+                const int64_t n128 = [&] { int64_t n = 0; for (auto &g : specs) n += (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128); return n; }();
+                half_stages = false; forced_stages = 0;
+                if (twins_flags && !((p.deny_blocking >> (p.phases.size() & 63)) & 1) && n128 >= 256) { wm = 2; wn = 2; wk = 2; blk = 3; }
+                else { wm = 2; wn = 2; wk = 2; blk = 0; }
+            }
+        }
+        const int rm = blk_rm(blk), rn = blk_rn(blk);
+        if (forced_stages == 3 && rm * rn == 4 && !half_stages) forced_stages = 2;   // three 64 KiB stages do not fit
         const int BM = 32 * wm * rm, BN = 32 * wn * rn;
         Phase ph;
         std::memset(&ph, 0, sizeof(ph));
@@ -184,8 +203,20 @@ struct Builder {
                 for (auto &sg : g.segs) k += sg.klen;
                 min_k = std::min(min_k, k);
             }
-            ph.bf16 = forced_stages ? forced_stages : (min_k >= 1024 && rm * rn < 4 ? 3 : 2);
+            // ... and the twin kernel's third 128-k stage of a 64x64 tile (3 x 32 KB) costs the CU its second resident workgroup: with
+            // more than one tile per CU two workgroups on two stages each are faster (measured at 512+512 videos x 9 segments,
+            // shared-FC product, 1 152 tiles: 113 -> 86 us unfused, and at 128+128 x 12, 384 tiles: 20.7 -> 15.1 us), with at most one
+            // tile per CU the third stage is (shared-FC weight gradient, 256 tiles: 46.8 vs 53.5 us) - profiles/r04_half_stage_ab.txt
+            int64_t n_tiles = 0;
+            for (auto &g : specs) n_tiles += (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+            const int64_t twin_stage = (int64_t)(BM + BN) * 256;
+            const bool third_costs_a_workgroup = twins_flags && !(p.cfg.flags & TA3N_FLAG_F32_SPLIT) &&
+                                                 2 * 3 * twin_stage > 160 * 1024 && 2 * 2 * twin_stage <= 160 * 1024;
+            static const bool third_always = [] { const char *e = getenv("TA3N_THIRD_STAGE"); return e && std::strcmp(e, "always") == 0; }();   // (A/B: the rule before round 4)
+            const bool third = min_k >= 1024 && rm * rn < 4 && (third_always || !(third_costs_a_workgroup && n_tiles > 256));
+            ph.bf16 = forced_stages ? forced_stages : (third ? 3 : 2);
             if (p.cfg.flags & TA3N_FLAG_F32_SPLIT) ph.bf16 |= 32;      // split (hi + lo) operands, three MFMAs per product block
+            if (half_stages) ph.bf16 |= 64;
         }
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all
@@ -1486,8 +1517,8 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             const Phase *f1 = nullptr;
             for (const Phase &ph : p.phases)
                 if (ph.group == 4 && ph.kind == PH_GEMM) { f1 = &ph; break; }
-            b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * (f1->bf16 & 15) +
-                           10000 * ((f1->rm > 1 ? 1 : 0) + (f1->rn > 1 ? 2 : 0));
+            b.force_next = f1->wm * 100 + f1->wn * 10 + f1->wk + 1000 * ((f1->bf16 & 15) + ((f1->bf16 & 64) ? 3 : 0)) +
+                           10000 * blk_code(f1->rm, f1->rn);
             const int64_t i0 = p.first_floats / 4, i1 = p.live_floats / 4;
             const int n_side = 256;
             const int64_t per = (i1 - i0 + n_side - 1) / n_side;
@@ -1564,7 +1595,7 @@ int ta3n::build_plan(ta3n_plan &p, std::string &err) {
         uint64_t bad = 0;
         for (size_t i = 0; i < p.phases.size(); ++i) {
             const Phase &ph = p.phases[i];
-            if (ph.kind == PH_GEMM && ph.rm * ph.rn > 1 && !(ph.bf16 & 16)) bad |= 1ull << (i & 63);
+            if (ph.kind == PH_GEMM && (ph.rm * ph.rn > 1 || (ph.bf16 & 64)) && !(ph.bf16 & 16)) bad |= 1ull << (i & 63);
         }
         if (bad == 0) return TA3N_OK;
         deny |= bad;

@@ -173,4 +173,10 @@ struct Geom {
     int32_t heads_vpw;                   // videos per video workgroup of the fused heads kernel (1, 2 or 4; 0 = 1)
 };
 
+// Register-blocking digit of a tile code (ten-thousands): 32x32 blocks per wave, rows x columns.
+// 0: 1 x 1, 1: 2 x 1, 2: 1 x 2, 3: 2 x 2, 4: 3 x 2, 5: 4 x 2 (the last two: half-stage kernels of four waves, tile codes 46221 / 56221).
+inline int blk_rm(int blk) { return blk == 4 ? 3 : blk == 5 ? 4 : 1 + (blk & 1); }
+inline int blk_rn(int blk) { return blk >= 4 ? 2 : 1 + (blk >> 1); }
+inline int blk_code(int rm, int rn) { return rm == 3 ? 4 : rm == 4 ? 5 : (rm > 1 ? 1 : 0) + (rn > 1 ? 2 : 0); }
+
 }  // namespace ta3n

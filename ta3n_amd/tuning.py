@@ -2,8 +2,8 @@
 engine.autotune_phase_tiles does the measurement: every candidate tile for every launch, HIP events on the launch stream).
 
 A tile code is WM*100 + WN*10 + WK (waves of the workgroup in M, N and the in-workgroup K split), + 1000 * LDS stages for the
-bf16 kernels, + 10000 / 20000 / 30000 for 2 row / 2 column / 2 x 2 32x32 blocks per wave (bf16-twin kernel: 128x64, 64x128,
-128x128 tiles).  Entries 0-9 are the forward / loss / backward launches of the unfused sequence, 10-15 the six GEMM launches of
+bf16 kernels (6000 / 7000: three / four HALF stages of 64 k, bf16-twin kernel), + 10000 / 20000 / 30000 for 2 row / 2 column / 2 x 2
+32x32 blocks per wave (bf16-twin kernel: 128x64, 64x128, 128x128 tiles; 46221 / 56221: 192x128 / 256x128, four waves, half stages).  Entries 0-9 are the forward / loss / backward launches of the unfused sequence, 10-15 the six GEMM launches of
 the fused step (ta3n_train_step); 0 = the plan builder's own choice (ta3n_plan.cpp: add_gemm_phase).
 
 What decides a launch ("tile choice"): a CU fills its LDS at ~41 B/clk whatever the tile, so a launch wants (a) at
@@ -26,7 +26,10 @@ TUNED = {
     # ... and with "pair twins" (TA3N_FLAG_F32_SPLIT | _BF16_STORE: the producers store the hi and the lo plane): bf16 stage images of 64 k
     (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 3214, 3214, 2124, 2122, 2122],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
-    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32222, 32222, 2222, 2222, 32222, 3222],      # (in sequence: 477.4 -> 473.3 us)
+    # (round 4: the shared-FC launch - 1 152 64x64 tiles, K = 2 048, both operands K-contiguous - on the half-stage kernel, four 64-k stages:
+    # 7222 = two resident workgroups with three 16 KB stages in flight each; 62.6 -> 46.1 us alone, the step 451.6 -> 445.8 and 449.8 ->
+    # 432.4 us on two boxes, tools/half_stage_ab.py, profiles/r04_half_stage_ab.txt)
+    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7222, 32222, 2222, 2222, 32222, 3222],
     # BASELINE configs[4] (128 + 128 videos, 12 segments, 1024-d, two streams): NO entry - the plan's heuristic.  Round 3 shipped a list
     # chosen on a single-stream 200-step sweep (277.2 -> 271.7 us, one run each); under the protocol the configuration is judged by
     # (two concurrent streams, 20 steps after 5, five processes each: profiles/r04_config5_protocol.txt) it measures 0.516-0.523 ms

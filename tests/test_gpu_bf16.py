@@ -384,8 +384,48 @@ def test_register_blocked_tiles_are_bit_identical_to_one_block_per_wave(name, bl
         assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [32222, 22222, 12222])
+HALF_STAGE = [(6222, 2222), (7222, 2222), (36222, 32222), (37222, 32222), (46221, 32222), (56221, 32222)]
+
+
+@pytest.mark.parametrize("half,full", HALF_STAGE, ids=[str(h) for h, _ in HALF_STAGE])
+@pytest.mark.parametrize("name", ["headline", "tiny_T9", "mid_T12"])
+def test_half_stage_kernels_agree_with_the_full_stage_kernels(name, half, full):
+    """64-k LDS stages (gemm_tiles MODE 5) give each of the tile's K-split waves another slice of every stage (and the four-wave
+    192x128 / 256x128 tiles have no K split at all): the same bf16 products, the fp32 accumulation in another order.  The shared-FC
+    output - the first launch, fp32 sums of bf16 products over K = D, nothing rounded to bf16 before it - must agree to fp32 rounding
+    of the sums (1e-5 of its largest element, every element).  Downstream an fp32 sum that differs in its last bit can round to the
+    other bf16 neighbour where a producer stores a twin, so the logits are held to a few such flips (2^-7 of the largest logit) here;
+    what bounds logits and every gradient element against the oracle is test_bf16_oracle_gate_with_register_blocked_tiles, which
+    runs every one of these tile codes.  With dropout on; the plan under test must contain half-stage launches."""
+    from ta3n_amd.engine import TrainEngine
+    c = case_config(Golden(name))
+    st = step_schedule(c)[0]
+    out = []
+    for tile in (half, full):
+        eng = TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.5, dropout_v=0.5, clip=c["clip"],
+                          bf16=True, bf16_store=True, tile_config=tile)
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, st["lr"], valid_source=st["n_src"], valid_target=st["n_tgt"])
+        torch.cuda.synchronize()
+        o = {k: v.detach().clone() for k, v in eng.outputs().items()}
+        n_half = sum(1 for ph in eng.plan.description.get("phases", []) if ph["kind"] == 0 and ph.get("half_stages", 0))
+        out.append((o, n_half))
+    (a, nh), (b, nf) = out
+    assert nh > 0 and nf == 0, (nh, nf)
+    for k, rel in (("feat_f1", 1e-5), ("out", 2.0 ** -7)):
+        scale = max(b[k].abs().max().item(), 1e-30)
+        d = (a[k].double() - b[k].double()).abs().max().item()
+        assert d <= rel * scale + 1e-9, (k, scale, d)
+
+
+@pytest.mark.parametrize("tile", [32222, 22222, 12222, 6222, 7222, 36222, 37222, 46221, 56221])
 def test_bf16_oracle_gate_with_register_blocked_tiles(tile, capsys):
+    """(6xxx / 7xxx: the half-stage kernels - 64-k stages, three / four of them - of the 64x64 and the 128x128 tile; 46221 / 56221: the
+    192x128 and 256x128 tiles - four waves of 3 x 2 / 4 x 2 blocks, three half stages - on the launches whose A operands are
+    K-contiguous, the plan's own choice on the others.)"""
     shape = dict(Bs=128, Bt=128, T=12, D=1024, F=512, C=12)
     rep, bad = _oracle_gate(shape, wseed=11, wscale="trained", xseed=21, lr=1e-3, clip=20.0, tile_config=tile)
     with capsys.disabled():

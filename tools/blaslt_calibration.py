@@ -1,6 +1,9 @@
 """Calibration, not product: how long does the vendor GEMM (hipBLASLt through torch.mm) take for the step's big products at the
 headline shape?  Tells whether ta3n::gemm_tiles' per-launch times are near what this GPU does for such small GEMMs at all.
-Usage (GPU box): python tools/blaslt_calibration.py > gpurun_out/blaslt.txt"""
+Usage (GPU box): python tools/blaslt_calibration.py [configs3] > gpurun_out/blaslt.txt
+(configs3: the products of BASELINE configs[3] - 512+512 videos x 9 segments = 9 216 frame rows - the only shape large enough for
+kernel quality, not launch structure, to decide; round 4)"""
+import sys
 import torch
 
 SHAPES = [  # (name, M, N, K, transA, transB)  C[M,N] = op(A) op(B)
@@ -12,6 +15,18 @@ SHAPES = [  # (name, M, N, K, transA, transB)  C[M,N] = op(A) op(B)
     ("Hr      R[202,256] . W1^T[256,256]", 202, 256, 256, False, True),
     ("dWtrn   gZ^T[256,202] . cat[202,2560]", 256, 2560, 202, True, False),
 ]
+
+
+SHAPES_CONFIGS3 = [
+    ("F1      X[9216,2048] . Wsh^T[2048,512]", 9216, 512, 2048, False, True),
+    ("dWsh    gZ1^T[512,9216] . X[9216,2048]", 512, 2048, 9216, True, False),
+    ("gF1-ish gZ[9216,256] . W[256,4608]", 9216, 4608, 256, False, False),
+    ("Z_t     cat[1024,4608] . W^T[4608,256]", 1024, 256, 4608, False, True),
+    ("Z_t x22 batched cat[22,1024,2560] . W^T", 22528, 256, 2560, False, True),
+    ("dWtrn   gZ^T[256,1024] . cat[1024,4608]", 256, 4608, 1024, True, False),
+]
+if len(sys.argv) > 1 and sys.argv[1] == "configs3":
+    SHAPES = SHAPES_CONFIGS3
 
 
 def graphed(fn, inner):
