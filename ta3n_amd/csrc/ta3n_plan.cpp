@@ -203,17 +203,23 @@ struct Builder {
                 for (auto &sg : g.segs) k += sg.klen;
                 min_k = std::min(min_k, k);
             }
-            // ... and the twin kernel's third 128-k stage of a 64x64 tile (3 x 32 KB) costs the CU its second resident workgroup: with
-            // more than one tile per CU two workgroups on two stages each are faster (measured at 512+512 videos x 9 segments,
-            // shared-FC product, 1 152 tiles: 113 -> 86 us unfused, and at 128+128 x 12, 384 tiles: 20.7 -> 15.1 us), with at most one
-            // tile per CU the third stage is (shared-FC weight gradient, 256 tiles: 46.8 vs 53.5 us) - profiles/r04_half_stage_ab.txt
+            // ... and the twin kernel's third 128-k stage of a 64x64 tile (3 x 32 KB) costs the CU its second resident workgroup.  For the
+            // launches of the UNFUSED sequence (ta3n_forward / ta3n_backward: what the module path runs, each launch on its own) two
+            // workgroups on two stages each are faster once there is more than one tile per CU (512+512 videos x 9 segments, shared-FC
+            // product, 1 152 tiles: 113 -> 86 us; TRN gradient level: 391 -> 260 us; 128+128 x 12, 384 tiles: 29.5 -> 19.7 us), with at
+            // most one tile per CU the third stage is (shared-FC weight gradient, 256 tiles: 46.8 vs 53.5 us).  The launches of the
+            // pipelined fused step keep the third stage: the same change measured SLOWER there under bench.py's protocol (configs[4]
+            // two-stream 0.497 -> 0.504 ms, three alternating processes each: profiles/r04_half_stage_ab.txt) - a launch timed alone
+            // and the same launch between its neighbours with the update's side workgroups aboard are different experiments.
+            // TA3N_THIRD_STAGE=always / =residency applies one rule to every launch (A/B).
             int64_t n_tiles = 0;
             for (auto &g : specs) n_tiles += (int64_t)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
             const int64_t twin_stage = (int64_t)(BM + BN) * 256;
             const bool third_costs_a_workgroup = twins_flags && !(p.cfg.flags & TA3N_FLAG_F32_SPLIT) &&
                                                  2 * 3 * twin_stage > 160 * 1024 && 2 * 2 * twin_stage <= 160 * 1024;
-            static const bool third_always = [] { const char *e = getenv("TA3N_THIRD_STAGE"); return e && std::strcmp(e, "always") == 0; }();   // (A/B: the rule before round 4)
-            const bool third = min_k >= 1024 && rm * rn < 4 && (third_always || !(third_costs_a_workgroup && n_tiles > 256));
+            static const int third_rule = [] { const char *e = getenv("TA3N_THIRD_STAGE"); return !e ? 0 : std::strcmp(e, "always") == 0 ? 1 : std::strcmp(e, "residency") == 0 ? 2 : 0; }();
+            const bool by_residency = third_rule == 2 || (third_rule == 0 && group < 4);
+            const bool third = min_k >= 1024 && rm * rn < 4 && !(by_residency && third_costs_a_workgroup && n_tiles > 256);
             ph.bf16 = forced_stages ? forced_stages : (third ? 3 : 2);
             if (p.cfg.flags & TA3N_FLAG_F32_SPLIT) ph.bf16 |= 32;      // split (hi + lo) operands, three MFMAs per product block
             if (half_stages) ph.bf16 |= 64;

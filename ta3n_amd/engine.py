@@ -143,6 +143,11 @@ class TrainEngine:
             from .tuning import tuned_phase_tiles
             phase_tiles = tuned_phase_tiles(batch_source + batch_target, num_segments, feature_dim, min(fc_dim, feature_dim),
                                             self.bf16, self.bf16_store, split=bool(flags & _lib.FLAG_F32_SPLIT))
+        if os.environ.get("TA3N_PHASE_TILES") and tile_config == 0:      # measurement aid: "i:code,i:code" replaces entries of the list (A/B of one launch's tile under bench.py's protocol)
+            phase_tiles = list(phase_tiles or []) + [0] * (16 - len(phase_tiles or []))
+            for item in os.environ["TA3N_PHASE_TILES"].split(","):
+                i, code = item.split(":")
+                phase_tiles[int(i)] = int(code)
         if chain is None:        # chained launches (ta3n_config.chain): the fused trn-m step in 5 launches instead of 8
             chain = os.environ.get("TA3N_CHAIN", "0") == "1" and aggregation == "trn-m" and fused
         self._flags = int(flags)

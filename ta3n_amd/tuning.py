@@ -26,10 +26,11 @@ TUNED = {
     # ... and with "pair twins" (TA3N_FLAG_F32_SPLIT | _BF16_STORE: the producers store the hi and the lo plane): bf16 stage images of 64 k
     (202, 5, 2048, 512, "f32x3p"): [3124, 3114, 2118, 2118, 2118, 2118, 2118, 2124, 2122, 2124, 3214, 3214, 3214, 2124, 2122, 2122],
     # BASELINE configs[3]: 512 + 512 videos, 9 segments, 2048-d, 30 classes
-    # (round 4: the shared-FC launch - 1 152 64x64 tiles, K = 2 048, both operands K-contiguous - on the half-stage kernel, four 64-k stages:
-    # 7222 = two resident workgroups with three 16 KB stages in flight each; 62.6 -> 46.1 us alone, the step 451.6 -> 445.8 and 449.8 ->
-    # 432.4 us on two boxes, tools/half_stage_ab.py, profiles/r04_half_stage_ab.txt)
-    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7222, 32222, 2222, 2222, 32222, 3222],
+    # (round 4: entry 10, the shared-FC launch, measured on the half-stage kernel 7222 - 62.6 -> 46.1 us timed alone, 451.6 -> 445.8 / 449.8 ->
+    # 432.4 us per forward+backward step on two boxes - and then under bench.py's protocol, the pipelined step whose first launch also
+    # carries the update's side workgroups: 0.492-0.504 ms against 0.493-0.496 for 32222, three alternating processes each.  Not adopted:
+    # profiles/r04_half_stage_ab.txt.)
+    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32222, 32222, 2222, 2222, 32222, 3222],      # (in sequence: 477.4 -> 473.3 us)
     # BASELINE configs[4] (128 + 128 videos, 12 segments, 1024-d, two streams): NO entry - the plan's heuristic.  Round 3 shipped a list
     # chosen on a single-stream 200-step sweep (277.2 -> 271.7 us, one run each); under the protocol the configuration is judged by
     # (two concurrent streams, 20 steps after 5, five processes each: profiles/r04_config5_protocol.txt) it measures 0.516-0.523 ms
