@@ -168,12 +168,11 @@ class TrainEngine:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
             self.rank = torch.distributed.get_rank(process_group)
-        if self.dis_DA != "none" and self.world > 1:
-            raise NotImplementedError("dis_DA with more than one rank (the discrepancy loss couples all videos of the global batch)")
-        if self.ens_DA != "none" and self.world > 1:
-            raise NotImplementedError("ens_DA MCD with more than one rank")
-        if self.use_bn != "none" and self.world > 1:
-            raise NotImplementedError("use_bn with more than one rank (batch statistics per rank are not the single-GPU statistics)")
+        # The DA options under more than one rank follow what the reference's nn.DataParallel does with them (main.py:79): the discrepancy
+        # loss is taken on the gathered global batch (discrepancy()); MCD's discrepancy is a mean over the global target batch
+        # (mcd_second_forward()); BatchNorm statistics are PER REPLICA - each replica normalises its own slice of the batch with its own
+        # batch statistics (torch's DataParallel replicates the module; nothing synchronises the statistics) - and the running
+        # buffers that persist are replica 0's (sync_buffers()).
         p = self.plan
         with torch.cuda.device(self.device):
             self.P = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
@@ -370,6 +369,7 @@ class TrainEngine:
         for k, v in parallel.loss_normalisers(gs, gt, self.T).items():
             setattr(h, k, v)
         h.valid_source, h.valid_target, h.train = int(ns), int(nt), int(bool(train))
+        self._global_source, self._global_target = int(gs), int(gt)
         if not upload:      # the caller delivers self._hyper another way (ta3n_sgd_step_next)
             return
         _lib.check(self._L.ta3n_set_hyper(self.plan.handle, self.ws.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
@@ -399,33 +399,27 @@ class TrainEngine:
         videos; JAN: the joint kernel of logits and video feature) on the first min(Bs, Bt) valid rows of each domain; its gradient
         is added to the logit gradient (region gY) and written to the feature-gradient entry (gV_ext).  HIP kernels through
         ta3n_amd.loss (ta3n_gaussian_kernel / ta3n_mmd_rowdiff); torch only differentiates the O(n^2) glue."""
-        from . import loss as L
         if self.dis_DA == "none":
             return
         ns, nt = int(self._hyper.valid_source), int(self._hyper.valid_target)
-        size = min(ns, nt)
-        y = self.region("Y", (self.B, self.C)).detach().clone().requires_grad_(True)
-        v = self.region("V", (self.B, -1)).detach().clone().requires_grad_(True)
-        feat_s, feat_t = [y[:size], v[:size]], [y[self.Bs:self.Bs + size], v[self.Bs:self.Bs + size]]
-        muls, nums = [2.0, 2.0], [2, 5]
-        loss = y.new_zeros(())
-        if self.dis_DA == "JAN":
-            loss = L.JAN(feat_s, feat_t, kernel_muls=muls, kernel_nums=nums, fix_sigma_list=[None, None], ver=2)
-        else:
-            for l in range(2):
-                if self.place_dis[l] != "Y":
-                    continue
-                sb = min(256, size)
-                fs = feat_s[l].view((-1, sb) + feat_s[l].shape[1:])
-                ft = feat_t[l].view((-1, sb) + feat_t[l].shape[1:])
-                parts = [L.mmd_rbf(fs[t], ft[t], kernel_mul=muls[l], kernel_num=nums[l], fix_sigma=None, ver=2) for t in range(fs.size(0))]
-                loss = loss + sum(parts) / len(parts)
-        self.loss_d = loss.detach()
-        gy, gv = torch.autograd.grad(self.alpha * loss, (y, v), allow_unused=True)
-        if gy is not None:
-            self.region("gY", (self.B, self.C)).add_(gy)
-        gve = self.region("gV_ext", (self.B, -1))
-        gve.zero_() if gv is None else gve.copy_(gv)
+        y, v = self.region("Y", (self.B, self.C)), self.region("V", (self.B, -1))
+        # more than one rank: the reference takes this loss after DataParallel's gather, on the global batch - the ranks' valid rows are
+        # all-gathered in rank order and every rank keeps its own gradient rows (parallel.discrepancy_over_ranks)
+        self.loss_d, gy, gv = parallel.discrepancy_over_ranks(self.dis_DA, self.place_dis, self.alpha, y, v, self.Bs, ns, nt,
+                                                               self.pg if self.world > 1 else None)
+        self.region("gY", (self.B, self.C)).add_(gy)
+        self.region("gV_ext", (self.B, -1)).copy_(gv)
+
+    def sync_buffers(self, src: int = 0) -> None:
+        """use_bn under more than one rank: the BatchNorm running statistics that persist are replica `src`'s - nn.DataParallel re-creates
+        its replicas from the module on device 0 before every forward and only that module's buffers survive it (main.py:79) - so before
+        a validation pass or a checkpoint every rank takes rank src's.  A collective: every rank calls it (no-op on one rank / without BN)."""
+        if self.bn_running is None or self.world == 1:
+            return
+        packed = torch.cat((self.bn_running.reshape(-1), self.bn_running.new_tensor([float(self.bn_batches)])))
+        parallel.broadcast_(packed, src=src, group=self.pg)
+        self.bn_running.copy_(packed[:-1].view_as(self.bn_running))
+        self.bn_batches = int(packed[-1].item())
 
     def backward(self) -> None:
         _lib.check(self._L.ta3n_backward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
@@ -482,7 +476,9 @@ class TrainEngine:
         rows = slice(self.Bs, self.Bs + nt)
         y = self._region2("Y", (self.B, self.C))[rows].detach().clone().requires_grad_(True)
         y2 = self._region2("Y2", (self.B, self.C))[rows].detach().clone().requires_grad_(True)
-        loss = -torch.mean(torch.abs(torch.softmax(y, 1) - torch.softmax(y2, 1)))
+        # loss.py:29-30 torch.mean over (target videos x classes) of the GLOBAL batch: ranks divide by the job-wide count and their
+        # gradients are summed like every other term (set_hyper)
+        loss = -torch.sum(torch.abs(torch.softmax(y, 1) - torch.softmax(y2, 1))) / float(max(self._global_target, 1) * self.C)
         self.loss_s = loss.detach()
         if self._flags & _lib.FLAG_ATTN_ENTROPY:
             def ent(z):

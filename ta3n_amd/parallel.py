@@ -13,7 +13,7 @@ parameters never need to be broadcast after initialisation."""
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -90,6 +90,67 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+
+def discrepancy_over_ranks(dis_DA: str, place_dis: Sequence[str], alpha: float, y: torch.Tensor, v: torch.Tensor, batch_source: int,
+                           valid_source: int, valid_target: int, group=None):
+    """The discrepancy loss of main.py:452-505 (DAN: mmd_rbf per selected feature in chunks of <= 256 videos; JAN: the joint kernel of
+    logits and video feature) on the GLOBAL batch, and the gradient of alpha * loss with respect to THIS rank's rows.
+
+    y [B, C], v [B, Fv]: this rank's logits and video features, source rows first (batch_source of them, valid_source real), then the
+    target rows.  The reference computes the loss after nn.DataParallel has gathered every replica's outputs in replica order, on the
+    first min(#source, #target) videos of each domain (main.py:467, 482): with more than one rank the valid rows of all ranks are
+    gathered in rank order (one collective), every rank evaluates the same global loss and keeps
+    the gradient rows that are its own - the parameter gradients the ranks then SUM (the step's all-reduce) are the global-batch ones.
+    Returns (loss, gy, gv): the loss value (detached, identical on every rank) and [B, .] gradients (zero rows where a video takes no part)."""
+    from . import loss as L
+    B = y.size(0)
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    feat = torch.cat((y.detach(), v.detach()), 1)
+    counts = [(int(valid_source), int(valid_target))]
+    feats = [feat]
+    if world > 1:
+        # gathered as a SUM over slots that are zero except the owner's (the counts ride in one extra row): all_reduce is the one
+        # collective every backend has for device tensors (gloo cannot all_gather CUDA tensors; the shared-GPU tests run on gloo), and
+        # the features are small - B x (C + Fv) floats per rank
+        slots = feat.new_zeros((world, B + 1, feat.size(1)))
+        slots[rank, :B] = feat
+        slots[rank, B, 0], slots[rank, B, 1] = float(valid_source), float(valid_target)
+        dist.all_reduce(slots, op=dist.ReduceOp.SUM, group=group)
+        counts = [(int(round(slots[r, B, 0].item())), int(round(slots[r, B, 1].item()))) for r in range(world)]
+        feats = [slots[r, :B] for r in range(world)]
+    src = torch.cat([f[:ns] for f, (ns, _) in zip(feats, counts)]).requires_grad_(True)
+    tgt = torch.cat([f[batch_source:batch_source + nt] for f, (_, nt) in zip(feats, counts)]).requires_grad_(True)
+    size = min(src.size(0), tgt.size(0))
+    C = y.size(1)
+    feat_s, feat_t = [src[:size, :C], src[:size, C:]], [tgt[:size, :C], tgt[:size, C:]]
+    muls, nums = [2.0, 2.0], [2, 5]
+    loss = src.new_zeros(())
+    if size > 0:
+        if dis_DA == "JAN":
+            loss = L.JAN(feat_s, feat_t, kernel_muls=muls, kernel_nums=nums, fix_sigma_list=[None, None], ver=2)
+        else:
+            for l in range(2):
+                if place_dis[l] != "Y":
+                    continue
+                sb = min(256, size)
+                fs = feat_s[l].reshape((-1, sb) + feat_s[l].shape[1:])
+                ft = feat_t[l].reshape((-1, sb) + feat_t[l].shape[1:])
+                parts = [L.mmd_rbf(fs[t], ft[t], kernel_mul=muls[l], kernel_num=nums[l], fix_sigma=None, ver=2) for t in range(fs.size(0))]
+                loss = loss + sum(parts) / len(parts)
+    gy, gv = torch.zeros_like(y), torch.zeros_like(v)
+    if loss.requires_grad:
+        gs, gt = torch.autograd.grad(alpha * loss, (src, tgt), allow_unused=True)
+        s0 = sum(ns for ns, _ in counts[:rank])
+        t0 = sum(nt for _, nt in counts[:rank])
+        ns, nt = counts[rank]
+        if gs is not None and ns:
+            gy[:ns], gv[:ns] = gs[s0:s0 + ns, :C], gs[s0:s0 + ns, C:]
+        if gt is not None and nt:
+            gy[batch_source:batch_source + nt], gv[batch_source:batch_source + nt] = gt[t0:t0 + nt, :C], gt[t0:t0 + nt, C:]
+    return loss.detach(), gy, gv
 
 
 class NativeComm:

@@ -90,3 +90,74 @@ def synth_flat(eng, shapes):
     e2 = TrainEngine(eng.Bs, eng.Bt, eng.T, eng.D, CFG["fc"], eng.C, dropout_i=0.0, dropout_v=0.0)
     e2.load_state(synth_state(shapes, seed=3))
     return e2.P.detach().cpu().clone()
+
+
+# ---- the DA options under two ranks (round 4): nn.DataParallel's semantics ----
+DA_OPTS = {
+    "mcd": dict(ens_DA="MCD", mu=0.7),
+    "dan": dict(dis_DA="DAN", place_dis=("Y", "Y", "N"), alpha=0.5),
+    "jan_mcd": dict(dis_DA="JAN", place_dis=("Y", "Y", "N"), alpha=0.5, ens_DA="MCD", mu=0.7),
+    "adabn": dict(use_bn="AdaBN"),
+}
+
+
+def _engine_da(Bs, Bt, opt):
+    from ta3n_amd.engine import TrainEngine
+    c = CFG
+    return TrainEngine(Bs, Bt, c["T"], c["D"], c["fc"], c["C"], dropout_i=0.0, dropout_v=0.0, **DA_OPTS[opt])
+
+
+def _run_da(eng, xs, xt, ys, steps, **kw):
+    for i in range(steps):
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        eng.train_step([0.75, 0.75, 0.5], 0.003, 1e-2, seed=i, **kw)
+    eng.flush()
+    eng.sync_buffers()
+    torch.cuda.synchronize()
+    extra = eng.bn_running.detach().cpu().clone() if eng.bn_running is not None else torch.zeros(0)
+    return eng.P.detach().cpu().clone(), extra, float(eng.loss_d) if eng.loss_d is not None else 0.0
+
+
+def _worker_da(rank, world, port, out, opt):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ta3n_amd import parallel
+    c = CFG
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    lo, hi = parallel.shard_range(c["Bs"], world, rank)
+    lo_t, hi_t = parallel.shard_range(c["Bt"], world, rank)
+    eng = _engine_da(hi - lo, hi_t - lo_t, opt)
+    assert eng.world == world and not eng.fused
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=3))
+    res = _run_da(eng, xs[lo:hi], xt[lo_t:hi_t], ys[lo:hi], 2, global_source=c["Bs"], global_target=c["Bt"])
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("opt", sorted(DA_OPTS))
+def test_two_ranks_with_da_options(tmp_path, opt):
+    """dis_DA / ens_DA: two ranks end on the parameters of one process that stepped the whole batch (the reference's DataParallel
+    takes those losses on the gathered global batch, main.py:446-562).  use_bn: statistics are per replica there, so the two-rank
+    result is NOT the one-process result by design - the ranks must agree with each other, move the parameters, and hold replica
+    0's running statistics after sync_buffers()."""
+    c = CFG
+    out = str(tmp_path / "P")
+    mp.spawn(_worker_da, args=(2, _free_port(), out, opt), nprocs=2, join=True)
+    (p0, b0, d0), (p1, b1, d1) = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(p0, p1) and torch.equal(b0, b1) and d0 == d1
+    assert torch.isfinite(p0).all()
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    eng = _engine_da(c["Bs"], c["Bt"], opt)
+    shapes = {n: s for n, _, s, _ in eng.plan.params}
+    eng.load_state(synth_state(shapes, seed=3))
+    start = eng.P.detach().cpu().clone()
+    ref, bref, dref = _run_da(eng, xs, xt, ys, 2)
+    assert (p0 - start).abs().max() > 1e-4
+    if opt == "adabn":
+        assert b0.numel() > 0 and not torch.equal(b0, bref)      # half-batch statistics of replica 0, not whole-batch ones
+        return
+    assert torch.allclose(p0, ref, rtol=2e-4, atol=2e-6), (p0 - ref).abs().max()
+    assert abs(d0 - dref) <= 1e-5 * max(abs(dref), 1e-3)

@@ -20,9 +20,9 @@ BASE = ["classInd.txt", "RGB", "s.txt", "t.txt", "v.txt", "--baseline_type", "vi
 
 def test_headline_command_line_is_accepted():
     train_ddp.validate_options(parser.parse_args(BASE))
-    train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "DAN"]))      # round 3: discrepancy losses on the engine path (one rank)
+    train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "DAN"]))      # round 3: discrepancy losses on the engine path (round 4: on any number of ranks)
     train_ddp.validate_options(parser.parse_args(BASE + ["--dis_DA", "JAN"]))
-    train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AdaBN"]))     # ... and the domain BatchNorm (one rank: batch statistics)
+    train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AdaBN"]))     # ... and the domain BatchNorm (per-replica batch statistics, as under nn.DataParallel)
     train_ddp.validate_options(parser.parse_args(BASE + ["--use_bn", "AutoDIAL"]))
     train_ddp.validate_options(parser.parse_args(BASE + ["--ens_DA", "MCD", "--mu", "0.5"]))      # ... and MCD's second classifier / reversed pass
     avg = ["c", "RGB", "s", "t", "v", "--baseline_type", "video", "--frame_aggregation", "avgpool", "--use_attn", "none", "--add_loss_DA", "none"]
@@ -100,3 +100,11 @@ def test_engine_checkpoint_has_the_reference_format_and_resumes(tmp_path):
     assert st == {"start_epoch": 4, "best_prec1": 55.0, "lr": 7e-3}
     torch.cuda.synchronize()
     assert torch.equal(eng2.P, eng.P) and torch.equal(eng2.M, eng.M) and eng.M.abs().max().item() > 0
+
+
+def test_da_options_are_accepted_on_more_than_one_rank(monkeypatch):
+    """Round 4: dis_DA / ens_DA / use_bn under WORLD_SIZE > 1 follow nn.DataParallel's semantics (global-batch discrepancy losses,
+    per-replica BatchNorm statistics) instead of being refused."""
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    for extra in (["--dis_DA", "DAN"], ["--dis_DA", "JAN"], ["--ens_DA", "MCD", "--mu", "0.5"], ["--use_bn", "AdaBN"], ["--use_bn", "AutoDIAL"]):
+        train_ddp.validate_options(parser.parse_args(BASE + extra))

@@ -56,20 +56,13 @@ def validate_options(args, module_path: bool = False) -> None:
                  "frame features (loss.py:49 on a 3-D tensor)")
     else:
         need(args.dis_DA in ("none", "DAN", "JAN"), f"--dis_DA {args.dis_DA} (built: DAN, JAN)")
-        if args.dis_DA != "none":
-            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--dis_DA {args.dis_DA} on more than one rank (the discrepancy loss couples all "
-                 "videos of the global batch: one GPU, or main.py)")
         need(args.ens_DA in ("none", "MCD"), f"--ens_DA {args.ens_DA}")
         if args.ens_DA == "MCD":
-            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, "--ens_DA MCD on more than one rank (one GPU, or main.py)")
             need(args.use_bn == "none", "--ens_DA MCD with --use_bn (use main.py, the module path)")
     if module_path:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
     else:
         need(args.use_bn in ("none", "AdaBN", "AutoDIAL"), f"--use_bn {args.use_bn}")
-        if args.use_bn != "none":
-            need(int(os.environ.get("WORLD_SIZE", "1")) == 1, f"--use_bn {args.use_bn} on more than one rank (batch statistics per rank are not the "
-                 "single-GPU statistics: one GPU, or main.py)")
     need(args.add_loss_DA in ("none", "attentive_entropy"), f"--add_loss_DA {args.add_loss_DA} (built: attentive_entropy)")
     need(args.use_target in ("none", "uSv"), f"--use_target {args.use_target} (target labels in the classification loss are not built)")
     need(args.weighted_class_loss == "N", "--weighted_class_loss Y")
@@ -234,7 +227,12 @@ def main():
             # one host sync every print_freq steps (the reference syncs 5-6x per step).  A rank's loss scalars are its
             # shard's sums divided by the GLOBAL counts: the job's losses are their sum over ranks.
             eng.check_exchange()                 # (peer all-reduce only: a rank that gave up waiting is reported here, not silently ignored)
-            scal = eng.region("losses")[:6].clone()
+            # (the MCD terms the engine keeps outside the loss kernel are partial sums too; the discrepancy loss is the global value on every rank)
+            zero = eng.ws.new_zeros(())
+            es = eng.loss_e_shift if eng.loss_e_shift is not None else (zero, zero)
+            scal = torch.cat((eng.region("losses")[:6], torch.stack([eng.loss_s if eng.loss_s is not None else zero,
+                                                                     eng.loss_c2 if eng.loss_c2 is not None else zero,
+                                                                     es[0], es[1]]).to(torch.float32)))
             if world > 1:
                 torch.distributed.all_reduce(scal)
             if rank == 0:
@@ -245,12 +243,12 @@ def main():
                     extra += f" loss_d {eng.loss_d.item():.4f}"
                     v[0] += eng.alpha * eng.loss_d.item()
                 if eng.loss_s is not None:
-                    extra += f" loss_s {eng.loss_s.item():.4f} loss_c2 {eng.loss_c2.item():.4f}"
-                    v[0] += eng.loss_s.item() + eng.loss_c2.item()
-                    v[1] += eng.loss_c2.item()          # main.py:447-450: loss_c is the sum of the two classifiers' cross-entropies
+                    extra += f" loss_s {v[6]:.4f} loss_c2 {v[7]:.4f}"
+                    v[0] += v[6] + v[7]
+                    v[1] += v[7]                        # main.py:447-450: loss_c is the sum of the two classifiers' cross-entropies
                 if eng.loss_e_shift is not None:        # MCD: the target rows' entropy term is the SECOND pass's (main.py:549, 559-562)
-                    v[0] += eng.loss_e_shift[0].item()
-                    v[5] += eng.loss_e_shift[1].item()
+                    v[0] += v[8]
+                    v[5] += v[9]
                 print(f"Train: [{epoch}][{i}/{steps_per_epoch}] lr {lr_used:.5f} loss {v[0]:.4f} loss_c {v[1]:.4f} "
                       f"loss_a {v[2] + v[3] + v[4]:.4f} loss_e {v[5]:.4f}{extra} beta {beta[0]:.3f},{beta[1]:.3f},{beta[2]:.3f}", flush=True)
 
@@ -305,6 +303,7 @@ def main():
         flush_chunk()
         eng.flush()                                                                   # the epoch's last update, before validation / checkpoint
         eng.check_exchange()
+        eng.sync_buffers()                                                            # use_bn: every rank evaluates and saves replica 0's running statistics
         if epoch % max(args.eval_freq, 1) == 0 or epoch == args.epochs:                   # main.py:252-274
             prec1 = validate(epoch) if (stores and len(stores) > 2) else 0.0
             is_best = prec1 > best_prec1
