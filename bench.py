@@ -79,6 +79,24 @@ def measured_traffic(dtype):
         return None, {"file": None, "error": str(ex)[:80]}
 
 
+def gemm_launch_table(eng, phases, bf16, split):
+    """Per GEMM launch of the fused step, timed ALONE (ta3n_time_phases: HIP events on the launch stream, no optimiser riders):
+    [{tile, workgroups, us, gflop, tflops, frac_of_mfma_peak}] - gflop is what the launch computes as the plan tiled it (valid rows x
+    columns x K of every tile, from the plan description), the peak the dense MFMA peak of the arithmetic (bf16 2.5 PF, a third of it
+    for the three-product split, fp32 157.3 TF)."""
+    desc = [ph for ph in eng.plan.description["phases"] if ph["kind"] == 0 and ph["group"] == 4]
+    timed = [p for p in phases if p[0] == 0]
+    peak = (PEAK_BF16_MFMA_TFLOPS / 3 if split else PEAK_BF16_MFMA_TFLOPS) if (bf16 or split) else PEAK_FP32_MFMA_TFLOPS
+    out = []
+    for ph, t in zip(desc, timed):
+        us = 1e3 * t[3]
+        tf = ph.get("flops", 0.0) / max(us * 1e-6, 1e-12) / 1e12
+        out.append({"tile": ph["tile"] % 1000 + 1000 * ((ph["tile"] // 1000) & 15), "blocks_per_wave": [ph.get("rm", 1), ph.get("rn", 1)],
+                    "workgroups": ph["task_count"], "us": round(us, 2), "gflop": round(ph.get("flops", 0.0) / 1e9, 3),
+                    "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak, 4)})
+    return out
+
+
 def algorithmic_gemm_flops(Bs, Bt, T, D, F, C, NB):
     """SURVEY.md 8(d) without the dead frame classifier (its output feeds nothing
     for baseline_type='video'): fwd + dgrad + wgrad, no dgrad for the first layer."""
@@ -421,6 +439,8 @@ def main():
         res["whole_step"] = {**wsb, "frac": wsb["bound_us"] / (1e3 * res["ms_per_step"]),
                              "what": "SURVEY.md 8(d): max(algorithmic FLOPs / MFMA peak, algorithmic bytes / 6.3 TB/s) per step, divided by the measured step time"}
         if brief:
+            if eng.fused and conf["agg"] == "trn-m":      # per-launch figures of the tile-list GEMM for the other configurations too
+                res["gemm_launches"] = gemm_launch_table(eng, eng.time_phases(max(3, args.phase_reps // 2)), bf16, split)
             return res
         res["finite"] = all(bool(torch.isfinite(e.P).all().item()) for e in engs)
         if eng._sharded:
@@ -500,6 +520,8 @@ def main():
                 res["roofline"].update({"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                         "frac": tflops / PEAK_BF16_MFMA_TFLOPS, "hbm_gbs": gbs_plain, "hbm_frac": gbs_plain / HBM_PEAK_GBS})
         res["roofline"]["whole_step"] = res["whole_step"]
+        if eng.fused:
+            res["roofline"]["gemm_launches"] = gemm_launch_table(eng, [p for p in eng.time_phases(args.phase_reps)], bf16, split)
         # tile code per GEMM launch as the plan built it: WM WN WK + 1000 x (LDS stages, + 16: reads bf16 twins) + 100000 x blocking
         # (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2 - 128x64 / 64x128 / 128x128 tiles)
         res["phase_tiles"] = [ph["tile"] + 100000 * ((ph.get("rm", 1) > 1) + 2 * (ph.get("rn", 1) > 1))
@@ -529,6 +551,8 @@ def main():
                 configs_line[f"configs[{cnum - 1}]"] = {"workload": cf["name"], "dtype": cf["dtype"], "ms_per_step": r["ms_per_step"],
                                                         "value": r["value"], "unit": "videos/s", "steps": 20, "warmup": 5,
                                                         "bound": ws["bound"], "bound_us": ws["bound_us"], "frac_of_bound": ws["frac"]}
+                if "gemm_launches" in r:
+                    configs_line[f"configs[{cnum - 1}]"]["gemm_launches"] = r["gemm_launches"]
             except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
                 configs_line[f"configs[{cnum - 1}]"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if rank == 0:

@@ -115,6 +115,26 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
 
 void ta3n::set_error(const std::string &msg) { g_err = msg; }
 
+namespace {
+// Multiply-adds x 2 of a GEMM launch as the plan tiled it: the valid rows x columns of every tile times the K of its Segs (what the launch
+// computes, not what a tile's padding wastes; optimiser side jobs and column-sum tasks count nothing).  For "TFLOP/s of launch i".
+double phase_flops(const ta3n_plan &p, const ta3n::Phase &ph) {
+    using namespace ta3n;
+    if (ph.kind != PH_GEMM) return 0.0;
+    const int BM = 32 * ph.wm * (ph.rm > 0 ? ph.rm : 1), BN = 32 * ph.wn * (ph.rn > 0 ? ph.rn : 1);
+    double f = 0.0;
+    for (int k = ph.task_begin; k < ph.task_begin + ph.task_count; ++k) {
+        const Task &t = p.tasks[k];
+        if (t.seg_count == 0 || (t.epi & (EPI_SGD | EPI_COLSUM))) continue;
+        const int rows = std::max(0, std::min(BM, t.m_valid - t.m0)), cols = std::max(0, std::min(BN, t.n_valid - t.n0));
+        int64_t K = 0;
+        for (int sidx = t.seg_begin; sidx < t.seg_begin + t.seg_count; ++sidx) K += p.segs[sidx].klen;
+        f += 2.0 * rows * cols * (double)K;
+    }
+    return f;
+}
+}  // namespace
+
 extern "C" {
 
 const char *ta3n_last_error(void) { return g_err.c_str(); }
@@ -190,6 +210,7 @@ int64_t ta3n_plan_describe(const ta3n_plan *p, char *buf, int64_t cap) {
           << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * ph.bf16)
           << ",\"rm\":" << (ph.rm > 0 ? ph.rm : 1) << ",\"rn\":" << (ph.rn > 0 ? ph.rn : 1)
           << ",\"half_stages\":" << ((ph.bf16 & 64) ? 1 : 0)
+          << ",\"flops\":" << phase_flops(*p, ph)
           << ",\"chain_counters\":" << (ph.kind == PH_GEMM && ph.chain_off >= 0 ? ph.chain_n : -1) << "}";
     }
     o << "],\"n_tasks\":" << p->tasks.size() << ",\"n_segs\":" << p->segs.size() << "}";
