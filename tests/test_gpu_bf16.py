@@ -388,7 +388,7 @@ HALF_STAGE = [(6222, 2222), (7222, 2222), (36222, 32222), (37222, 32222), (46221
 
 
 @pytest.mark.parametrize("half,full", HALF_STAGE, ids=[str(h) for h, _ in HALF_STAGE])
-@pytest.mark.parametrize("name", ["headline", "tiny_T9", "mid_T12"])
+@pytest.mark.parametrize("name", ["headline", "mid_T12"])
 def test_half_stage_kernels_agree_with_the_full_stage_kernels(name, half, full):
     """64-k LDS stages (gemm_tiles MODE 5) give each of the tile's K-split waves another slice of every stage (and the four-wave
     192x128 / 256x128 tiles have no K split at all): the same bf16 products, the fp32 accumulation in another order.  The shared-FC
