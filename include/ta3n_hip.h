@@ -101,7 +101,11 @@ typedef struct {
     int32_t num_class;       /* C */
     uint32_t flags;          /* TA3N_FLAG_* */
     int32_t tile_config;     /* 0 = auto; otherwise WM*100+WN*10+WK (114, 118, 212, 122, 214, 124, 221, 222) for every GEMM phase;
-                              * + 2000 / 3000: LDS stages of the bf16 kernels (default: 3 when every tile streams K >= 1024) */
+                              * + 2000 / 3000: LDS stages of the bf16 kernels (default: 3 when every tile streams K >= 1024);
+                              * + 6000 / 7000: three / four HALF stages (64 k each) of the bf16-twin kernel (222 only);
+                              * + 10000 / 20000 / 30000: 2 x 1 / 1 x 2 / 2 x 2 32x32 blocks per wave (bf16-twin kernel: 128x64, 64x128,
+                              * 128x128 tiles); 46221 / 56221: 192x128 / 256x128 (four waves, three half stages; launches whose A
+                              * operands are K-contiguous, the builder's own choice elsewhere).  Codes a launch cannot use fall back. */
     int32_t phase_tiles[16]; /* per GEMM phase (in launch order) override of tile_config; 0 = use tile_config/auto */
     int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD */
     int32_t aggregation;     /* TA3N_AGG_*: frame aggregation (opts.py --frame_aggregation) */
