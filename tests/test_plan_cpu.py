@@ -344,3 +344,62 @@ def test_split_k_plan_on_cpu(name, flags):
                 assert np.allclose(raw[k], unsplit[k], rtol=1e-9, atol=1e-12), k      # (the interpreter accumulates in fp64)
                 if not bf16:
                     g.check(f"step0/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("tile", [7222, 36222, 46221, 56221])
+def test_half_stage_and_tall_tile_plans_on_cpu(tile):
+    """Tile codes of round 4 (half-stage kernels 6xxx / 7xxx; 192x128 / 256x128 tiles 46221 / 56221): the plan tiles the same
+    contractions - the numpy execution of its task lists gives the default plan's logits and gradients - marks the twin launches as
+    half-stage launches, and puts the tall tiles only on launches whose A operands are K-contiguous (their kernels hold no k-major A
+    loop); everywhere else the launch falls back to a tile its kernel exists for."""
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    T = c["T"]
+    flags = ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE
+    results = []
+    for tc in (0, tile):
+        plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, tile_config=tc)
+        it = Interp(plan)
+        shapes = {n: s for n, _, s, _ in plan.params}
+        it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        st = step_schedule(c)[0]
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        it.run_group(4)
+        results.append((plan, it, it.r(it.g.o_Y, (c["Bs"] + c["Bt"], c["C"])).copy(), it.G[: plan.live_floats].copy()))
+    (_, _, y0, g0), (plan, it, y1, g1) = results
+    assert np.allclose(y0, y1, rtol=1e-9, atol=1e-12) and np.allclose(g0, g1, rtol=1e-9, atol=1e-12)
+    assert np.abs(g0).max() > 0
+    desc = [ph for ph in plan.description["phases"] if ph["kind"] == 0 and ph["group"] == 4]
+    half = [ph for ph in desc if ph["half_stages"]]
+    assert half and all(ph["tile"] >= 16000 for ph in half)                   # only launches that read bf16 twins
+    want_rm = {46221: 3, 56221: 4}.get(tile)
+    for ph, iph in zip(desc, [p_ for p_ in it.phases if p_.kind == 0 and p_.group == 4]):
+        a_kmajor = any(it.segs[si].a_kmajor for ti in range(iph.task_begin, iph.task_begin + iph.task_count)
+                       for si in range(it.tasks[ti].seg_begin, it.tasks[ti].seg_begin + it.tasks[ti].seg_count))
+        if want_rm is None:
+            assert ph["rm"] <= 2
+        elif ph["rm"] == want_rm:
+            assert ph["half_stages"] and not a_kmajor and ph["tile"] % 1000 == 221
+        else:
+            assert ph["rm"] <= 2 and (a_kmajor or not ph["half_stages"])
+    if want_rm is not None:
+        assert any(ph["rm"] == want_rm for ph in desc)
+
+
+def test_third_stage_rule_keeps_the_second_workgroup_on_unfused_launches_only(monkeypatch):
+    """bf16-twin kernel, 64x64 tile: a third 128-k stage (96 KB) costs the CU its second resident workgroup.  The unfused launches
+    (groups 0-3) take two stages once a launch has more than one tile per CU; the fused step's launches keep the third stage (the
+    same rule measured slower under bench.py's protocol: profiles/r04_half_stage_ab.txt)."""
+    flags = ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE
+    plan = _lib.Plan(128, 128, 12, 1024, 512, 12, flags)      # one stream of BASELINE configs[4]: 384 64x64 tiles in the shared-FC product
+    ph = [p_ for p_ in plan.description["phases"] if p_["kind"] == 0]
+    stages = lambda p_: (p_["tile"] // 1000) & 15
+    first_unfused = next(p_ for p_ in ph if p_["group"] == 0)
+    first_fused = next(p_ for p_ in ph if p_["group"] == 4)
+    assert first_unfused["task_count"] == 384 and first_unfused["tile"] % 1000 == 222 and stages(first_unfused) == 2
+    assert first_fused["task_count"] == 384 and first_fused["tile"] % 1000 == 222 and stages(first_fused) == 3
