@@ -404,7 +404,7 @@ class TrainEngine:
         ns, nt = int(self._hyper.valid_source), int(self._hyper.valid_target)
         y, v = self.region("Y", (self.B, self.C)), self.region("V", (self.B, -1))
         # more than one rank: the reference takes this loss after DataParallel's gather, on the global batch - the ranks' valid rows are
-        # all-gathered in rank order and every rank keeps its own gradient rows (parallel.discrepancy_over_ranks)
+        # gathered in rank order (one sum all-reduce over per-rank slots) and every rank keeps its own gradient rows (parallel.discrepancy_over_ranks)
         self.loss_d, gy, gv = parallel.discrepancy_over_ranks(self.dis_DA, self.place_dis, self.alpha, y, v, self.Bs, ns, nt,
                                                                self.pg if self.world > 1 else None)
         self.region("gY", (self.B, self.C)).add_(gy)
