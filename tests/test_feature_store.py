@@ -59,6 +59,30 @@ def test_device_gather_is_bit_exact_with_the_dataset(tmp_path, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [3, 5, 9, 12, 25])
+def test_device_segment_indices_equal_the_reference_dataset(tmp_path, T):
+    """The fp64 index arithmetic of ta3n_gather_segments on the device against tests/golden/index_golden.npz - what the REFERENCE's
+    TSNDataSet._get_test_indices returned for 1..400 frames (tests/golden/make_index_golden.py), not a restatement of it."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "index_golden.npz"))[f"segidx_S{T}_L1"]
+    lengths = [int(r[0]) for r in gold]
+    D = 4
+    prefix = str(tmp_path / "packed")
+    starts = np.concatenate(([0], np.cumsum(lengths)[:-1]))
+    np.save(prefix + ".idx.npy", np.stack([starts, np.asarray(lengths), np.zeros(len(lengths), dtype=np.int64)], axis=1).astype(np.int64))
+    blob = np.repeat(np.arange(sum(lengths), dtype=np.float32)[:, None], D, axis=1)      # row r holds the value r
+    blob.tofile(prefix + ".f32")
+    fs = feature_store.FeatureStore(prefix, D)
+    ids = torch.arange(len(lengths), dtype=torch.int32, device="cuda")
+    seg = torch.empty(ids.numel() * T, dtype=torch.int32, device="cuda")
+    x, _ = fs.gather(ids, T, segment_ids_out=seg)
+    torch.cuda.synchronize()
+    assert seg.view(-1, T).cpu().tolist() == gold[:, 1:].tolist()
+    want_rows = torch.from_numpy(starts[:, None] + gold[:, 1:] - 1).to(torch.float32)      # 1-based frame id -> blob row
+    assert torch.equal(x[:, :, 0].cpu(), want_rows)
+
+
+@pytest.mark.gpu
 def test_gather_feeds_the_train_step_input_buffer(tmp_path):
     from ta3n_amd.engine import TrainEngine
     lst, D, lengths = _make_dataset(tmp_path, D=512)

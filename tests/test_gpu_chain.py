@@ -8,7 +8,7 @@ from golden_util import Golden, case_config
 from ta3n_amd.engine import TrainEngine
 from ta3n_amd.synthetic import synth_batch, synth_state
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.gpu_ab      # measured-and-rejected variant / opt-in transport: `pytest -m gpu_ab` on the experiments build (tests/conftest.py)
 
 ARITH = {"f32": {}, "bf16": dict(bf16=True, bf16_store=True), "bf16_cvt": dict(bf16=True), "f32x3": dict(f32_split=True)}
 

@@ -66,7 +66,8 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16", "sharded", "sharded_bf16"])
+@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16", pytest.param("sharded", marks=pytest.mark.gpu_ab),
+                                  pytest.param("sharded_bf16", marks=pytest.mark.gpu_ab)])      # (sharded update: opt-in, `-m gpu_ab`)
 def test_two_ranks_equal_single_process_global_batch(tmp_path, mode):
     c = CFG
     out = str(tmp_path / "P")

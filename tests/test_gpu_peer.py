@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.gpu_ab      # measured-and-rejected variant / opt-in transport: `pytest -m gpu_ab` on the experiments build (tests/conftest.py)
 
 
 def _free_port():

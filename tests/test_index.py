@@ -2,7 +2,9 @@
 BIT-EXACT with the reference (TRNmodule.py:30-41, 60, 68-71, 84-86;
 dataset.py:103-116).  Three implementations are compared: the product's
 combinatorial unranking (C ABI), the oracle's C enumeration and the oracle's
-Python restatement (itertools, as the reference does)."""
+Python restatement (itertools, as the reference does) - and all of them against
+tests/golden/index_golden.npz, which the REFERENCE ITSELF produced (tests/golden/make_index_golden.py: the tuples
+RelationModuleMultiScale.forward gathers for T = 2..16, TSNDataSet._get_test_indices for 1..400 frames)."""
 import ctypes as C
 import os
 import subprocess
@@ -80,3 +82,52 @@ def test_segment_indices_bit_exact(T, new_length, c_oracle):
         assert mine == list(out)
         assert mine == [int(v) for v in orc.segment_indices_test_mode(num_frames, T, new_length)]
         assert all(1 <= v <= num_frames for v in mine)
+
+
+# ---- against fixtures produced by the reference itself (tests/golden/make_index_golden.py) ----
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "index_golden.npz"))
+
+
+@pytest.mark.parametrize("T", list(range(2, 17)))
+def test_relation_tuples_equal_what_the_reference_forward_gathers(T):
+    """Rows of tuples_T{T}: (scale id, frames.., -1 padding) in the order TRNmodule.py:58-82 visits them, read back from the
+    reference module's own forward through a probe input (feature value = frame index)."""
+    rows = GOLD[f"tuples_T{T}"]
+    ref = [[] for _ in range(T - 1)]
+    for r in rows:
+        ref[int(r[0])].append(tuple(int(v) for v in r[1:] if v >= 0))
+    assert _lib.relation_table(T) == ref                                        # the product (C ABI, combinatorial unranking)
+    assert [[tuple(t) for t in s] for s in orc.selected_relations(T)] == ref    # the oracle's restatement
+    assert [len(t) for s in ref for t in s] == [T - i for i, s in enumerate(ref) for _ in s]
+
+
+@pytest.mark.parametrize("S", [3, 5, 9, 12, 25])
+@pytest.mark.parametrize("L", [1, 2, 5])
+def test_segment_indices_equal_the_reference_dataset(S, L):
+    """Rows of segidx_S{S}_L{L}: [num_frames, idx_0 .. idx_{S-1}] from the reference's TSNDataSet._get_test_indices
+    (dataset.py:103-116), num_frames = 1..400; -1 where the reference raises (no selectable frame)."""
+    rows = GOLD[f"segidx_S{S}_L{L}"]
+    assert rows.shape == (400, S + 1)
+    for r in rows:
+        n = int(r[0])
+        if r[1] < 0:
+            assert n - L + 1 <= 0
+            with pytest.raises(ValueError):
+                _lib.segment_indices(n, S, L)
+            continue
+        want = [int(v) for v in r[1:]]
+        assert _lib.segment_indices(n, S, L) == want, (n, S, L)
+        assert [int(v) for v in orc.segment_indices_test_mode(n, S, L)] == want, (n, S, L)
+
+
+def test_host_dataset_mirror_equals_the_reference_dataset():
+    """ta3n_amd.dataset.TSNDataSet._get_test_indices (what main.py's loaders call) against the same fixture."""
+    import types
+    from ta3n_amd.dataset import TSNDataSet
+    for S in (3, 5, 9, 12, 25):
+        rows = GOLD[f"segidx_S{S}_L1"]
+        ds = object.__new__(TSNDataSet)
+        ds.num_segments, ds.new_length = S, 1
+        for r in rows:
+            got = ds._get_test_indices(types.SimpleNamespace(num_frames=int(r[0])))
+            assert [int(v) for v in got] == [int(v) for v in r[1:]], (S, int(r[0]))
