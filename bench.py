@@ -19,8 +19,9 @@ accumulation and fp32 state); --dtype f32 is configs[2]'s.  At N = 1 the other
 arithmetic is timed in the same process and reported under "other_arithmetic" (at every N:
 with --gpus 8 that is configs[2], fp32 DDP).  Weak scaling: every rank processes its own 128+74 videos.  Rank 0
 prints ONE JSON line; `roofline` is measured live with HIP events on the launch
-stream, `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
-CPU path) on a bounded sample on this host.
+stream, `cpu_baseline` times the reference's own main.train (a staged, git-ignored copy
+of its module files, oracle/reference_runner.py) and the CPU oracle (the port)
+on a bounded sample on this host's cores.
 """
 import argparse
 import gc
@@ -148,7 +149,43 @@ def whole_step_bound(conf, dtype, eng):
             "bound_us": n * max(t_flop, t_bytes), "flops": n * flops, "bytes": n * nbytes}
 
 
-def cpu_baseline(conf=None, seconds=12.0, max_steps=40):
+# ---- multi-GPU projection: a stated prediction for the 8-GPU run to test -------------------------------------
+XGMI_LINK_GBS = 153.0      # MI355X_MICROARCH.md / SURVEY.md 5: 7 links x ~153 GB/s per GPU, full mesh (one link per peer)
+
+
+def scaling_projection(step_ms_by_config):
+    """Weak-scaling efficiency t_1 / (t_1 + t_norm + t_AR(N)) per BASELINE configuration: one sum all-reduce of the flat live-gradient
+    prefix per step, exposed in full (clip_grad_norm_ needs the norm of the SUMMED gradient before the first update),
+    plus the separate gradient-norm pass over the reduced buffer.  t_AR is bracketed by two models of RCCL on a full xGMI mesh:
+    `ring` - 2 (N-1)/N S bytes through ONE link per direction at 60-70 % of its 153 GB/s + 2 (N-1) hops of ~4 us;
+    `direct` - reduce-scatter + all-gather with every peer at once: 2 S/N bytes per link + 2 x ~12 us.
+    step_ms_by_config: {config number: measured single-GPU ms per step in THIS run} (entries without a measurement are left out)."""
+    from ta3n_amd import _lib
+    out = {}
+    for cnum, ms in sorted(step_ms_by_config.items()):
+        cf = CONFIGS[cnum]
+        sh = cf["shape"]
+        trn = cf["agg"] == "trn-m"
+        plan = _lib.Plan(sh["Bs"], sh["Bt"], sh["T"], sh["D"], sh["F"], sh["C"], 0x1F if trn else 0,
+                         aggregation=_lib.AGG_TRN_M if trn else _lib.AGG_AVGPOOL)
+        live = sum(math.prod(s_) for _, _, s_, lv in plan.params if lv) * cf["streams"]
+        row = {"workload": f"configs[{cnum - 1}]", "step_ms_1gpu": round(ms, 4), "message_bytes_fp32": 4 * live, "videos_per_gpu_step": sh["Bs"] + sh["Bt"]}
+        t_norm = 4 * live / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3 + 0.003          # one read of the reduced buffer + a launch
+        for transport, esz in (("fp32", 4), ("bf16", 2)):
+            S = esz * live
+            for N in (2, 4, 8):
+                ring = 2 * (N - 1) / N * S / (0.65 * XGMI_LINK_GBS * 1e9) * 1e3 + 2 * (N - 1) * 0.004
+                direct = 2 * S / N / (0.65 * XGMI_LINK_GBS * 1e9) * 1e3 + 2 * 0.012
+                conv = 0.007 if transport == "bf16" else 0.0                 # two conversion launches (measured, DESIGN.md 7)
+                row[f"{transport}_N{N}"] = {"t_allreduce_ms": [round(ring + conv, 4), round(direct + conv, 4)],
+                                            "efficiency": [round(ms / (ms + t_norm + ring + conv), 3), round(ms / (ms + t_norm + direct + conv), 3)]}
+        out[f"configs[{cnum - 1}]"] = row
+    return {"model": "efficiency = t_1gpu / (t_1gpu + gradient-norm pass + all-reduce), the all-reduce fully exposed; [pessimistic (ring), "
+                     "optimistic (direct reduce-scatter + all-gather over the mesh)], link efficiency 0.65 of 153 GB/s; the driver's N = 2, 4, 8 runs test it",
+            "configs": out}
+
+
+def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
     """The CPU path on this host: oracle train step (same ATen CPU kernels the
     reference dispatches, including the frame classifier it computes and never uses), dropout on, a bounded sample."""
     from oracle import ta3n_oracle as orc
@@ -202,29 +239,38 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=40):
                     break
     except OSError:
         pass
-    # The port's time relative to the REFERENCE's own (main.train + models.VideoModel, timed beside the port in the build container -
-    # the GPU box has no reference checkout): profiles/reference_vs_port_cpu.json, written by tools/time_reference_cpu.py
-    ref = {"file": None}
+    port = dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, ms_per_step=1e3 * dt / n,
+                sample=f"{n} full train steps of oracle/ta3n_oracle.py (the port) on {cores} torch threads = {1e3 * dt / n:.1f} ms/step")
+    # The REFERENCE ITSELF: its module files travel to the GPU box as a git-ignored staged copy (oracle/_ref/py/,
+    # made from /root/reference by oracle/reference_runner.py: stage()); its own main.train() is timed in a process of its own (the
+    # import shims patch torch.Tensor.cuda, and the CPU path must not see the GPU) on the same synthetic tensors and thread count.
+    cnum = next(k for k, v in CONFIGS.items() if v is conf)
+    ref, ref_err = None, None
     try:
-        import hashlib
-        with open(os.path.join(ROOT, "profiles", "reference_vs_port_cpu.json"), "rb") as f:
-            raw = f.read()
-        tbl = json.loads(raw)
-        cnum = next(k for k, v in CONFIGS.items() if v is conf)
-        e = tbl["configs"][f"configs[{cnum - 1}]"]
-        with open(os.path.join(ROOT, "oracle", "ta3n_oracle.py"), "rb") as f:
-            fresh = hashlib.sha256(f.read()).hexdigest()[:16] == tbl.get("oracle_sha256")
-        ref = {"file": "profiles/reference_vs_port_cpu.json", "file_sha256": hashlib.sha256(raw).hexdigest()[:16],
-               "reference_over_port": e["reference_over_port"], "measured_on": tbl["host"], "port_unchanged_since": fresh,
-               "reference_ms_per_step_there": e["reference_ms_per_step"], "port_ms_per_step_there": e["port_ms_per_step"]}
-    except Exception as ex:      # noqa: BLE001 - no table for this configuration
-        ref = {"file": None, "error": f"{type(ex).__name__}: {ex}"[:120]}
-    return dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port",
-                reference_over_port=ref.get("reference_over_port"), reference=ref,
-                sample=f"{n} full train steps ({CFG['Bs']}+{CFG['Bt']} videos, fp32, dropout 0.5" + (", both streams" if conf["streams"] > 1 else "") + f") of oracle/ta3n_oracle.py on {cores} "
-                       f"torch threads (best of a bounded probe; {avail} hw threads visible) of '{model}' = "
-                       f"{1e3 * dt / n:.1f} ms/step",
-                ms_per_step=1e3 * dt / n)
+        from oracle import reference_runner as rr
+        if not rr.available():
+            raise RuntimeError("no staged reference (oracle/_ref/py): run `python -m oracle.reference_runner --stage` in the build container")
+        import subprocess
+        env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(cores))
+        r = subprocess.run([sys.executable, "-m", "oracle.reference_runner", "--config", str(cnum), "--threads", str(cores), "--seconds", str(seconds)],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith("REFERENCE_JSON ")), None)
+        if line is None:
+            raise RuntimeError(("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-300:])
+        ref = json.loads(line[len("REFERENCE_JSON "):])
+    except Exception as ex:      # noqa: BLE001 - the port's number is still a baseline
+        ref_err = f"{type(ex).__name__}: {ex}"[:400]
+    shape = f"{CFG['Bs']}+{CFG['Bt']} videos, fp32, dropout 0.5" + (", both streams" if conf["streams"] > 1 else "")
+    host = f"{avail} hw threads visible of '{model}'"
+    if ref is not None:
+        return dict(value=ref["videos_per_s"], unit="videos/s", cores=cores, kind="reference", ms_per_step=ref["ms_per_step"],
+                    sample=f"{ref['steps']} full train steps ({shape}) of the reference's own main.train + models.VideoModel (staged copy of "
+                           f"/root/reference, sha256 main.py {ref['sha256'].get('main.py')} models.py {ref['sha256'].get('models.py')}; torch "
+                           f"{ref['torch']} CPU ops) on {cores} torch threads (the port's best of a bounded probe; {host}) = {ref['ms_per_step']:.1f} ms/step",
+                    reference_files_sha256=ref["sha256"], port=port, reference_over_port=ref["ms_per_step"] / port["ms_per_step"])
+    return dict(value=port["value"], unit="videos/s", cores=cores, kind="port", ms_per_step=port["ms_per_step"],
+                sample=f"{n} full train steps ({shape}) of oracle/ta3n_oracle.py on {cores} torch threads (best of a bounded probe; {host}) = "
+                       f"{1e3 * dt / n:.1f} ms/step", reference_unavailable=ref_err)
 
 
 def main():
@@ -263,6 +309,7 @@ def main():
                     "the exact sum up to the reduction order), or bf16 (every rank's gradients rounded to bf16 and summed in bf16: half the xGMI bytes; "
                     "stated in the line)")
     ap.add_argument("--no-other-configs", action="store_true", help="do not add the 20-step timings of configs[0] / [3] / [4] to the line")
+    ap.add_argument("--no-fresh-batch", action="store_true", help="skip the second timed loop with a new device-gathered batch per step")
     ap.add_argument("--phase-reps", type=int, default=20)
     args = ap.parse_args()
     conf = CONFIGS[args.config]
@@ -413,6 +460,34 @@ def main():
             elapsed = t.item()
         # a two-stream step processes each video through both models: videos/s counts videos, not model passes
         res = {"ms_per_step": 1e3 * elapsed / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / elapsed}
+        if batched and two is None and not brief and eng.can_batch_steps() and not args.no_fresh_batch:
+            # The same K steps once more with a DIFFERENT batch every step: a synthetic dataset resident in HBM
+            # as a packed feature store (ta3n_amd/feature_store.py: 640 videos x 16-47 frames), random video ids per step, each step's
+            # batch assembled on the device by the gather kernel that the same ta3n_train_steps call enqueues in front of it (ta3n_feed:
+            # test-mode segment indices of dataset.py:103-116 + row copy into the input buffer and its bf16 twin).  `value` keeps the
+            # resident-batch protocol of SURVEY 8(d); this is what a training loop pays.
+            from ta3n_amd.feature_store import FeatureStore
+            g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+            nf = torch.randint(16, 48, (640,), generator=g)
+            rows = torch.randn(int(nf.sum()), SH["D"], device=dev).abs_()
+            store = FeatureStore.from_tensors(rows, nf.to(dev), torch.randint(0, SH["C"], (640,), generator=g).to(dev))
+            ids = [torch.randint(0, 640, (warmup + steps, n_), generator=g, dtype=torch.int32).to(dev) for n_ in (SH["Bs"], SH["Bt"])]
+            eng.train_steps(sched(warmup + steps, warmup), feeds=((store, ids[0][:warmup]), (store, ids[1][:warmup])))
+            flush_all()
+            fence()
+            t1 = time.perf_counter()
+            eng.train_steps(sched(2 * warmup + steps, steps), feeds=((store, ids[0][warmup:]), (store, ids[1][warmup:])))
+            flush_all()
+            fence()
+            e_f = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([e_f], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                e_f = t.item()
+            res["fresh_batch"] = {"ms_per_step": 1e3 * e_f / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / e_f,
+                                  "what": "the timed loop repeated with a new batch per step, gathered on the device from a packed feature store "
+                                          "resident in HBM (640 synthetic videos, 16-47 frames each; ta3n_feed inside the same ta3n_train_steps call)"}
+            del store, rows, ids
         if (world > 1 or selftest) and not brief:
             # what the gradient exchange costs per step: the same loop once more WITHOUT the collective (every rank skips it; the
             # numbers it trains on are then wrong, the timing is what is wanted) - the difference is the exposed collective time
@@ -608,8 +683,33 @@ def main():
                                                    "ms_per_step": third["ms_per_step"], "whole_step": third["whole_step"],
                                                    **{k: third["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac",
                                                                                         "avg_launch_us", "per_phase_us")}}
+        if "fresh_batch" in main_res:
+            out["value_fresh_batch"] = main_res["fresh_batch"]["value"]
+            out["ms_per_step_fresh_batch"] = main_res["fresh_batch"]["ms_per_step"]
+            out["fresh_batch_note"] = main_res["fresh_batch"]["what"]
+            if other is not None and "fresh_batch" in other:
+                out["other_arithmetic"]["value_fresh_batch"] = other["fresh_batch"]["value"]
+                out["other_arithmetic"]["ms_per_step_fresh_batch"] = other["fresh_batch"]["ms_per_step"]
         if configs_line:
             out["configs"] = configs_line
+        try:      # projection for every configuration timed in this run (at N > 1: the benched one, from the step without the collective)
+            t1 = {}
+            if world == 1 and not selftest:
+                t1[args.config] = main_res["ms_per_step"]
+                if other is not None and headline:
+                    t1[3 if args.dtype == "bf16" else 2] = other["ms_per_step"]
+                for k_, v_ in (configs_line or {}).items():
+                    if "ms_per_step" in v_:
+                        t1[int(k_[8:-1]) + 1] = v_["ms_per_step"]
+            elif main_res.get("collective"):
+                t1[args.config] = main_res["collective"]["step_without_collective_ms"]
+            if t1:
+                out["config"]["scaling_projection"] = scaling_projection(t1)
+                if world > 1:
+                    out["config"]["scaling_projection"]["measured_here"] = {"n_gpus": world, "ms_per_step": main_res["ms_per_step"],
+                                                                           "exposed_collective_us": main_res["collective"]["exposed_us_per_step"]}
+        except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the line
+            out["config"]["scaling_projection"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)

@@ -172,10 +172,13 @@ def _fast_engine(model, optimizer, num_class):
         return None
     if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none" and list(args.place_adv) != ["Y"] * 3:
         return None      # (:560 indexes the FILTERED list of domain predictions: entry 1 is the video level only when all three are on)
-    key = (args.batch_size[0], args.batch_size[1])
+    g = optimizer.param_groups[0]
+    # everything the engine is BUILT from: a later train() call with other options must not find an engine made for these
+    key = (args.batch_size[0], args.batch_size[1], args.num_segments, args.fc_dim, num_class, tuple(args.place_adv), args.add_loss_DA,
+           args.use_attn, args.adv_DA, args.use_target, float(args.dropout_i), float(args.dropout_v), float(g["momentum"]),
+           float(g["weight_decay"]), None if args.clip_gradient is None else float(args.clip_gradient))
     eng = m.__dict__.get("_main_fast_engine", {}).get(key)
     if eng is None:
-        g = optimizer.param_groups[0]
         eng = TrainEngine(args.batch_size[0], args.batch_size[1], args.num_segments, m.feature_dim, args.fc_dim, num_class,
                           flags=flags_from_options(args.place_adv, args.add_loss_DA, args.use_attn, args.adv_DA, args.use_target),
                           dropout_i=args.dropout_i, dropout_v=args.dropout_v, momentum=g["momentum"], weight_decay=g["weight_decay"],
@@ -205,61 +208,65 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
     end = time.time()
     start_steps, total_steps = epoch * len(source_loader), args.epochs * len(source_loader)
     line = ""
-    for i, ((source_data, source_label), (target_data, target_label)) in enumerate(zip(source_loader, target_loader)):
-        p = float(i + start_steps) / total_steps
-        beta_dann = 2. / (1. + np.exp(-10 * p)) - 1
-        beta = beta_new = [beta_dann if beta[k] < 0 else beta[k] for k in range(len(beta))]      # (:352, as in train())
-        batch_source_ori, batch_target_ori = source_data.size(0), target_data.size(0)
-        source_data, target_data = _pad(source_data, args.batch_size[0]), _pad(target_data, args.batch_size[1])
-        labels = torch.zeros(args.batch_size[0], dtype=torch.long)
-        labels[:batch_source_ori] = source_label
-        data_time.update(time.time() - end)
-        eng.set_batch(source_data.to(dev, non_blocking=True), target_data.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
-        lr = optimizer.param_groups[0]["lr"]
-        # the dropout seeds come from the global torch RNG exactly as VideoModel.forward draws them (one draw of two per train forward):
-        # the same masks as the module path, and the same RNG state for the samplers of the next epoch
-        seeds = torch.randint(0, 2 ** 31 - 1, (2,))
-        eng.train_step(beta_new, gamma, lr, valid_source=batch_source_ori, valid_target=batch_target_ori, raw_seeds=(int(seeds[0]), int(seeds[1])))
-        l = eng.losses()                                                # (one host sync per step; the reference has five .item() calls)
-        out = eng.outputs()["out"][:batch_source_ori]
-        losses_c.update(l["loss_c"], batch_source_ori)
-        if args.adv_DA != "none" and args.use_target != "none":
-            last = [r for r, on in zip((args.num_segments - 1, 1, args.num_segments), args.place_adv) if on == "Y"]   # (:537 weights by the LAST enabled level's rows)
-            losses_a.update(l["loss_adv_rel"] + l["loss_adv_vid"] + l["loss_adv_frm"], (batch_source_ori + batch_target_ori) * (last[-1] if last else 1))
-        if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none":
-            losses_e.update(l["loss_e"], batch_target_ori)
-        prec1, prec5 = accuracy(out, source_label.to(dev), topk=(1, min(5, num_class)))
-        losses.update(l["loss"])
-        top1.update(prec1.item(), batch_source_ori)
-        top5.update(prec5.item(), batch_source_ori)
-        batch_time.update(time.time() - end)
-        end = time.time()
-        if i % args.print_freq == 0:
-            line = ("Train: [{0}][{1}/{2}], lr: {lr:.5f}\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t"
-                    "Prec@1 {t1.val:.3f} ({t1.avg:.3f})\tPrec@5 {t5.val:.3f} ({t5.avg:.3f})\tLoss {ls.val:.4f} ({ls.avg:.4f})   "
-                    "loss_c {lc.avg:.4f}\t").format(epoch, i, len(source_loader), bt=batch_time, dt=data_time, t1=top1, t5=top5,
-                                                    ls=losses, lc=losses_c, lr=lr)
+    try:
+        for i, ((source_data, source_label), (target_data, target_label)) in enumerate(zip(source_loader, target_loader)):
+            p = float(i + start_steps) / total_steps
+            beta_dann = 2. / (1. + np.exp(-10 * p)) - 1
+            beta = beta_new = [beta_dann if beta[k] < 0 else beta[k] for k in range(len(beta))]      # (:352, as in train())
+            batch_source_ori, batch_target_ori = source_data.size(0), target_data.size(0)
+            source_data, target_data = _pad(source_data, args.batch_size[0]), _pad(target_data, args.batch_size[1])
+            labels = torch.zeros(args.batch_size[0], dtype=torch.long)
+            labels[:batch_source_ori] = source_label
+            data_time.update(time.time() - end)
+            eng.set_batch(source_data.to(dev, non_blocking=True), target_data.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
+            lr = optimizer.param_groups[0]["lr"]
+            # the dropout seeds come from the global torch RNG exactly as VideoModel.forward draws them (one draw of two per train forward):
+            # the same masks as the module path, and the same RNG state for the samplers of the next epoch
+            seeds = torch.randint(0, 2 ** 31 - 1, (2,))
+            eng.train_step(beta_new, gamma, lr, valid_source=batch_source_ori, valid_target=batch_target_ori, raw_seeds=(int(seeds[0]), int(seeds[1])))
+            l = eng.losses()                                                # (one host sync per step; the reference has five .item() calls)
+            out = eng.outputs()["out"][:batch_source_ori]
+            losses_c.update(l["loss_c"], batch_source_ori)
             if args.adv_DA != "none" and args.use_target != "none":
-                line += "beta {:.3f}, {:.3f}, {:.3f}  loss_a {:.4f}\t".format(beta_new[0], beta_new[1], beta_new[2], losses_a.avg)
-            if args.add_loss_DA != "none" and args.use_target != "none":
-                line += "gamma {:.6f}  loss_e {:.4f}\t".format(gamma, losses_e.avg)
-            print(line)
-            log.write("%s\n" % line)
-        if args.lr_adaptive == "dann":
-            adjust_learning_rate_dann(optimizer, p)
-    # back to nn.Parameters and torch.optim state
-    views = eng.param_views()
-    with torch.no_grad():
-        for name, prm in named.items():
-            if name in views:
-                prm.copy_(views[name])
-        for name, view in mom.items():
-            st = optimizer.state[named[name]]
-            buf = st.get("momentum_buffer")
-            if buf is None:
-                st["momentum_buffer"] = view.clone()
-            else:
-                buf.copy_(view)
+                last = [r for r, on in zip((args.num_segments - 1, 1, args.num_segments), args.place_adv) if on == "Y"]   # (:537 weights by the LAST enabled level's rows)
+                losses_a.update(l["loss_adv_rel"] + l["loss_adv_vid"] + l["loss_adv_frm"], (batch_source_ori + batch_target_ori) * (last[-1] if last else 1))
+            if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none":
+                losses_e.update(l["loss_e"], batch_target_ori)
+            prec1, prec5 = accuracy(out, source_label.to(dev), topk=(1, min(5, num_class)))
+            losses.update(l["loss"])
+            top1.update(prec1.item(), batch_source_ori)
+            top5.update(prec5.item(), batch_source_ori)
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0:
+                line = ("Train: [{0}][{1}/{2}], lr: {lr:.5f}\tTime {bt.val:.3f} ({bt.avg:.3f})\tData {dt.val:.3f} ({dt.avg:.3f})\t"
+                        "Prec@1 {t1.val:.3f} ({t1.avg:.3f})\tPrec@5 {t5.val:.3f} ({t5.avg:.3f})\tLoss {ls.val:.4f} ({ls.avg:.4f})   "
+                        "loss_c {lc.avg:.4f}\t").format(epoch, i, len(source_loader), bt=batch_time, dt=data_time, t1=top1, t5=top5,
+                                                        ls=losses, lc=losses_c, lr=lr)
+                if args.adv_DA != "none" and args.use_target != "none":
+                    line += "beta {:.3f}, {:.3f}, {:.3f}  loss_a {:.4f}\t".format(beta_new[0], beta_new[1], beta_new[2], losses_a.avg)
+                if args.add_loss_DA != "none" and args.use_target != "none":
+                    line += "gamma {:.6f}  loss_e {:.4f}\t".format(gamma, losses_e.avg)
+                print(line)
+                log.write("%s\n" % line)
+            if args.lr_adaptive == "dann":
+                adjust_learning_rate_dann(optimizer, p)
+    finally:
+        # (also when the loop is left early - KeyboardInterrupt, a loader error, a Ta3nError from a step: what the engine has trained so
+        # far must reach the nn.Parameters and the optimiser state that validate(), checkpoints and --resume read)
+        # back to nn.Parameters and torch.optim state
+        views = eng.param_views()
+        with torch.no_grad():
+            for name, prm in named.items():
+                if name in views:
+                    prm.copy_(views[name])
+            for name, view in mom.items():
+                st = optimizer.state[named[name]]
+                buf = st.get("momentum_buffer")
+                if buf is None:
+                    st["momentum_buffer"] = view.clone()
+                else:
+                    buf.copy_(view)
     log_short.write("%s\n" % line)
     empty = torch.Tensor()
     return losses_c.avg, empty, empty

@@ -721,12 +721,13 @@ int ta3n_sgd_shard(ta3n_plan *p, float *params, float *grads, float *momentum, f
     const Hyper *nx = reinterpret_cast<const Hyper *>(next);
     // the norm is the sum of the ranks' shard partials in region norm_part (slots [0, world), the rest zero): fused_norm = false
     if (r[1] > r[0]) {
-        if (launch_sgd_range(p->geom, params, grads, momentum, ws, r[0], r[1], false, lr, momentum_coef, weight_decay, clip, nx, st) != 0)
+        if (launch_sgd_range(p->geom, params, grads, momentum, ws, r[0], r[1], false, lr, momentum_coef, weight_decay, clip, nx, st, true) != 0)
             return fail(TA3N_ERR_HIP, "sgd launch failed");
     } else if (nx) {      // (a rank without a share of region A still needs the next step's scalars)
         if (launch_set_hyper(ws + p->geom.o_hyper, *nx, st) != 0) return fail(TA3N_ERR_HIP, "set_hyper launch failed");
     }
-    if (r[3] > r[2] && launch_sgd_range(p->geom, params, grads, momentum, ws, r[2], r[3], false, lr, momentum_coef, weight_decay, clip, nullptr, st) != 0)
+    if (r[3] > r[2] && launch_sgd_range(p->geom, params, grads, momentum, ws, r[2], r[3], false, lr, momentum_coef, weight_decay, clip, nullptr, st,
+                                        /* records the norm when the rank has no share of region A */ r[1] <= r[0]) != 0)
         return fail(TA3N_ERR_HIP, "sgd launch failed");
     return TA3N_OK;
 }

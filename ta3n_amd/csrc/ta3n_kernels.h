@@ -141,7 +141,7 @@ int launch_set_hyper(float *ws_hyper, const Hyper &h, hipStream_t stream);   // 
 int launch_sgd_fixup(const Geom &g, float *params, const float *grads, float *momentum, float *ws, float *p16, float lr, float mu,
                      float clip, const Hyper *next, hipStream_t stream);
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
-                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream);
+                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream, bool write_norm = false);
 int launch_shard_sumsq(const Geom &g, const float *grads, float *ws, int64_t a0, int64_t a1, int64_t b0, int64_t b1, int rank, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,

@@ -27,6 +27,7 @@
 // device, tests/test_gpu_peer.py); TA3N_DDP_PEER=1 selects it, ncclAllReduce stays the default exchange.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -45,10 +46,13 @@ enum { F_READY_IN = 0, F_READY_RED = 1, F_DONE = 2 };
 // loader, a checkpoint written by rank 0); TA3N_PEER_TIMEOUT_S overrides it (0 = wait for ever, like a blocking RCCL collective).  A wait
 // that does give up sets the sticky error word, and from then on every exchange POISONS its output (NaN) instead of delivering partial
 // sums: divergence between ranks is loud, never silent; ta3n_peer_status reports it at the host's next check.
-// The flag block is 128 bytes, but it is exported with hipIpcGetMemHandle, which wants the BASE of an allocation: a request this small
-// may be carved out of a larger block the runtime already holds (seen once in round 4: "hipIpcGetMemHandle: invalid argument" on one
-// rank of a test that had passed for two rounds).  2 MiB - the allocation granularity - always is an allocation of its own.
-constexpr size_t FLAGS_ALLOC_BYTES = 2u << 20;
+// ONE fine-grained allocation per rank holds the flag block (its first FLAGS_BYTES bytes) and, behind it, the staging buffers: one
+// hipIpcGetMemHandle of an allocation BASE, one mapping per peer.  (Rounds 3-4 exported the 128-byte flag block as an allocation of
+// its own; "hipIpcGetMemHandle: invalid argument" on one rank of a test that had passed for two rounds - on the driver's box too - was
+// either that second export or a worker that set HSA_ENABLE_IPC_MODE_LEGACY=0 after the runtime had initialised; both are gone: a
+// single export, checked against hipMemGetAddressRange, and ta3n_peer_create refuses to start when the variable is not in the
+// environment.)
+constexpr size_t FLAGS_BYTES = 4096;
 
 unsigned long long spin_ticks() {
     static const unsigned long long t = [] {
@@ -186,14 +190,21 @@ int ta3n_peer_create(int rank, int world, int64_t max_count, int bf16_transport,
     if (!out || world < 1 || world > MAXR || rank < 0 || rank >= world || max_count <= 0) return fail(TA3N_ERR_INVALID, "bad peer arguments");
     ta3n_peer *p = new ta3n_peer();
     p->rank = rank; p->world = world; p->cap = max_count; p->bf16 = bf16_transport ? 1 : 0;
-    const size_t bytes = 2 * (size_t)max_count * sizeof(float);
-    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&p->stage), bytes, hipDeviceMallocFinegrained) != hipSuccess ||
-        hipExtMallocWithFlags(reinterpret_cast<void **>(&p->flags), FLAGS_ALLOC_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
+    const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    if (world > 1 && !(ipc && std::string(ipc) == "0")) {
+        delete p;
+        return fail(TA3N_ERR_INVALID, "peer transport unavailable: HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before the HIP runtime "
+                                      "initialises (these hosts only support dmabuf IPC); use the RCCL exchange (default) instead");
+    }
+    const size_t bytes = FLAGS_BYTES + 2 * (size_t)max_count * sizeof(float);
+    char *base = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&base), bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         const std::string e = hipGetErrorString(hipGetLastError());
-        if (p->stage) (void)hipFree(p->stage);
         delete p;
         return fail(TA3N_ERR_HIP, "fine-grained device allocation failed: " + e);
     }
+    p->flags = reinterpret_cast<unsigned *>(base);
+    p->stage = base + FLAGS_BYTES;
     if (hipMemset(p->flags, 0, 4 * MAXR * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         ta3n_peer_destroy(p);
         return fail(TA3N_ERR_HIP, "flag initialisation failed");
@@ -208,8 +219,20 @@ int ta3n_peer_handle(ta3n_peer *p, char *handle128) {
     if (!p || !handle128) return fail(TA3N_ERR_INVALID, "null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "two IPC handles travel in 128 bytes");
     hipIpcMemHandle_t h[2];
-    if (hipIpcGetMemHandle(&h[0], p->stage) != hipSuccess || hipIpcGetMemHandle(&h[1], p->flags) != hipSuccess)
-        return fail(TA3N_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(hipGetLastError()));
+    std::memset(h, 0, sizeof(h));            // (second slot unused since the flags moved into the same allocation; the wire format stays 128 bytes)
+    hipDeviceptr_t abase = nullptr;
+    size_t asize = 0;
+    const hipError_t er = hipMemGetAddressRange(&abase, &asize, reinterpret_cast<hipDeviceptr_t>(p->flags));
+    if (er != hipSuccess || abase != reinterpret_cast<hipDeviceptr_t>(p->flags))
+        return fail(TA3N_ERR_HIP, "peer transport unavailable: the exchange buffer is not the base of its allocation (" +
+                                      std::string(er != hipSuccess ? hipGetErrorString(er) : "offset into a larger block") + ")");
+    const hipError_t eg = hipIpcGetMemHandle(&h[0], p->flags);
+    if (eg != hipSuccess) {
+        char where[160];
+        snprintf(where, sizeof(where), " (rank %d, buffer %p, allocation %p + %zu bytes, HSA_ENABLE_IPC_MODE_LEGACY=%s)", p->rank,
+                 (void *)p->flags, (void *)abase, asize, getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
+        return fail(TA3N_ERR_HIP, std::string("peer transport unavailable: hipIpcGetMemHandle: ") + hipGetErrorString(eg) + where);
+    }
     std::memcpy(handle128, h, 128);
     return TA3N_OK;
 }
@@ -220,9 +243,11 @@ int ta3n_peer_connect(ta3n_peer *p, const char *all_handles) {
         if (r == p->rank) continue;
         hipIpcMemHandle_t h[2];
         std::memcpy(h, all_handles + 128 * (size_t)r, 128);
-        if (hipIpcOpenMemHandle(&p->peer_stage[r], h[0], hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
-            hipIpcOpenMemHandle(reinterpret_cast<void **>(&p->peer_flags[r]), h[1], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+        void *base = nullptr;
+        if (hipIpcOpenMemHandle(&base, h[0], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
             return fail(TA3N_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(r) + "): " + hipGetErrorString(hipGetLastError()));
+        p->peer_flags[r] = static_cast<unsigned *>(base);
+        p->peer_stage[r] = static_cast<char *>(base) + FLAGS_BYTES;
     }
     p->connected = true;
     return TA3N_OK;
@@ -232,11 +257,9 @@ void ta3n_peer_destroy(ta3n_peer *p) {
     if (!p) return;
     for (int r = 0; r < p->world; ++r) {
         if (r == p->rank) continue;
-        if (p->peer_stage[r]) (void)hipIpcCloseMemHandle(p->peer_stage[r]);
         if (p->peer_flags[r]) (void)hipIpcCloseMemHandle(p->peer_flags[r]);
     }
-    if (p->stage) (void)hipFree(p->stage);
-    if (p->flags) (void)hipFree(p->flags);
+    if (p->flags) (void)hipFree(p->flags);      // (the staging buffers live in the same allocation)
     delete p;
 }
 

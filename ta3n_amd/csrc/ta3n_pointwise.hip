@@ -544,12 +544,14 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (i0 == 0 || has_next)) {      // (every existing caller passes `next` with the range that starts at 0;
-        ws[g.o_grad_norm] = total;                                            // the sharded update passes it with each rank's own first range)
+    // has_next: bit 0 = `next` is valid, bit 1 = this launch records the norm / clip coefficient (one launch per rank and step does: the
+    // range that starts at 0, or - sharded update - whichever of the rank's own ranges is launched first)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (i0 == 0 || (has_next & 2))) {
+        ws[g.o_grad_norm] = total;
         ws[g.o_grad_norm + 1] = coef;
     }
     // the per-step scalars of the NEXT step ride along (this kernel takes its own by value and never reads ws.hyper)
-    if (has_next && blockIdx.x == 0 && threadIdx.x < (int)(sizeof(Hyper) / 4))
+    if ((has_next & 1) && blockIdx.x == 0 && threadIdx.x < (int)(sizeof(Hyper) / 4))
         reinterpret_cast<uint32_t *>(ws + g.o_hyper)[threadIdx.x] = reinterpret_cast<const uint32_t *>(&next)[threadIdx.x];
     while (i < i1) {
         const int nxt = i + stride;
@@ -864,7 +866,7 @@ int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t 
 }
 
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
-                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream) {
+                     bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream, bool write_norm) {
     const int i0 = (int)(begin / 4), i1 = (int)(end / 4);
     if (i1 <= i0) return 0;
     int blocks = (i1 - i0 + 255) / 256;
@@ -874,7 +876,7 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
     if (next) nh = *next;
     hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip, nh,
-                       next ? 1 : 0);
+                       (next ? 1 : 0) | (write_norm ? 2 : 0));
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -112,6 +112,7 @@ class TrainEngine:
         self.ens_DA, self.mu = ens_DA, float(mu)
         self.loss_s = None                       # device scalar: the MCD discrepancy loss of the last step (main.py's loss_s)
         self.loss_c2 = None                      # ... and the second classifier's cross-entropy on the source rows
+        self._global_source, self._global_target = int(batch_source), int(batch_target)      # job-wide valid counts of the current step (set_hyper)
         self.loss_e_shift = None                 # MCD + attentive entropy: (d total, d loss_e) that moving the target rows' entropy term to the
                                                  # second pass's logits adds to what the loss kernel logged (main.py:549 vs :559-562)
         if ens_DA == "MCD":
@@ -406,7 +407,7 @@ class TrainEngine:
         # more than one rank: the reference takes this loss after DataParallel's gather, on the global batch - the ranks' valid rows are
         # gathered in rank order (one sum all-reduce over per-rank slots) and every rank keeps its own gradient rows (parallel.discrepancy_over_ranks)
         self.loss_d, gy, gv = parallel.discrepancy_over_ranks(self.dis_DA, self.place_dis, self.alpha, y, v, self.Bs, ns, nt,
-                                                               self.pg if self.world > 1 else None)
+                                                               self.pg if self.world > 1 else None, world=self.world, rank=self.rank)
         self.region("gY", (self.B, self.C)).add_(gy)
         self.region("gV_ext", (self.B, -1)).copy_(gv)
 
@@ -460,6 +461,7 @@ class TrainEngine:
         :559-562), so the target half of that loss belongs to this pass too: its logit gradient moves from the first pass's gY to
         this one's (where GradReverse(mu) scales it on the way to the features), and the first pass's video-domain logits, which
         weight it, see this pass's entropies."""
+        self.loss_e_shift = None                  # (a rank whose target shard is empty this step must not report the previous step's shift)
         h = _lib.Hyper.from_buffer_copy(self._hyper)
         h.reverse, h.mu = 1, float(self.mu)
         h.seed_i, h.seed_v = dropout_seeds(int(self._hyper.seed_i) ^ 0x5bd1e995, self.rank)

@@ -74,6 +74,24 @@ class FeatureStore:
         self.labels = torch.from_numpy(idx[:, 2].astype(np.int32)).to(self.device)
         self._L = _lib.lib()
 
+    @classmethod
+    def from_tensors(cls, store: torch.Tensor, num_frames: torch.Tensor, labels: torch.Tensor) -> "FeatureStore":
+        """A store from tensors already on the device (synthetic datasets of bench.py / tests): `store` [total_frames, D] fp32 (or
+        int16 bit patterns of bf16 rows), videos back to back; `num_frames`, `labels` one entry per video."""
+        self = cls.__new__(cls)
+        self.device = store.device
+        self.bf16 = store.dtype == torch.int16
+        assert store.is_cuda and store.dim() == 2 and store.is_contiguous() and store.dtype in (torch.float32, torch.int16)
+        nf = num_frames.to(device=self.device, dtype=torch.int64)
+        assert int(nf.sum().item()) == store.shape[0] and int(nf.min().item()) >= 1
+        self.feature_dim, self.n_videos = int(store.shape[1]), int(nf.numel())
+        self.store = store
+        self.first_row = (torch.cumsum(nf, 0) - nf).contiguous()
+        self.num_frames = nf.to(torch.int32).contiguous()
+        self.labels = labels.to(device=self.device, dtype=torch.int32).contiguous()
+        self._L = _lib.lib()
+        return self
+
     def __len__(self) -> int:
         return self.n_videos
 

@@ -94,7 +94,7 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
 
 
 def discrepancy_over_ranks(dis_DA: str, place_dis: Sequence[str], alpha: float, y: torch.Tensor, v: torch.Tensor, batch_source: int,
-                           valid_source: int, valid_target: int, group=None):
+                           valid_source: int, valid_target: int, group=None, world: Optional[int] = None, rank: Optional[int] = None):
     """The discrepancy loss of main.py:452-505 (DAN: mmd_rbf per selected feature in chunks of <= 256 videos; JAN: the joint kernel of
     logits and video feature) on the GLOBAL batch, and the gradient of alpha * loss with respect to THIS rank's rows.
 
@@ -106,8 +106,12 @@ def discrepancy_over_ranks(dis_DA: str, place_dis: Sequence[str], alpha: float, 
     Returns (loss, gy, gv): the loss value (detached, identical on every rank) and [B, .] gradients (zero rows where a video takes no part)."""
     from . import loss as L
     B = y.size(0)
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    # world / rank: the CALLER's (TrainEngine passes its own: an engine that is single-rank while some default process group with more
+    # ranks is initialised must not reduce over that group; ADVICE r04).  None: taken from `group` (the default group if None).
+    if world is None:
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if rank is None:
+        rank = dist.get_rank(group) if world > 1 else 0
     feat = torch.cat((y.detach(), v.detach()), 1)
     counts = [(int(valid_source), int(valid_target))]
     feats = [feat]
@@ -119,7 +123,8 @@ def discrepancy_over_ranks(dis_DA: str, place_dis: Sequence[str], alpha: float, 
         slots[rank, :B] = feat
         slots[rank, B, 0], slots[rank, B, 1] = float(valid_source), float(valid_target)
         dist.all_reduce(slots, op=dist.ReduceOp.SUM, group=group)
-        counts = [(int(round(slots[r, B, 0].item())), int(round(slots[r, B, 1].item()))) for r in range(world)]
+        cnt = slots[:, B, :2].round().to(torch.int64).tolist()              # one host sync for all ranks' counts
+        counts = [(int(a), int(b)) for a, b in cnt]
         feats = [slots[r, :B] for r in range(world)]
     src = torch.cat([f[:ns] for f, (ns, _) in zip(feats, counts)]).requires_grad_(True)
     tgt = torch.cat([f[batch_source:batch_source + nt] for f, (_, nt) in zip(feats, counts)]).requires_grad_(True)
