@@ -344,18 +344,29 @@ def _linear(p, name, x, cfg: Optional["Config"] = None):
     return _BiasBf16Sum.apply(h, p[name + ".bias"]) if (bias16 and cfg.bf16_twins) else h + p[name + ".bias"]
 
 
-def trn_multiscale(p, x, cfg: Config, with_tuples: bool = False):
-    """TRNmodule.py:58-82.  x [B,T,F] -> [B,T-1,256] (with_tuples: also the per-scale lists of tuple activations)."""
+def _relu_m(x, mask=None):
+    """ReLU, or - mask-synchronised comparisons (tests/test_gpu_masked_gradients.py) - the on/off pattern of ANOTHER computation of the
+    same layer imposed on this one: x * mask, forward and backward.  With the pattern taken from the implementation under test a hidden
+    unit within round-off of zero can no longer land on different sides in the two computations, so what is left of a gradient
+    difference is arithmetic (summation order), not a flipped unit."""
+    return F.relu(x) if mask is None else x * mask.to(x.dtype)
+
+
+def trn_multiscale(p, x, cfg: Config, with_tuples: bool = False, masks=None):
+    """TRNmodule.py:58-82.  x [B,T,F] -> [B,T-1,256] (with_tuples: also the per-scale lists of tuple activations).
+    masks: optional [B, n_tuples, 256] on/off pattern of the tuple activations (tuples in visiting order), see _relu_m."""
     rel = selected_relations(cfg.num_segments)
     B = x.size(0)
     acts, parts = [], []
+    t_idx = 0
     for sid, tuples in enumerate(rel):
         scale = len(tuples[0])
         acc = None
         zs = []
         for tup in tuples:
             a = x[:, list(tup), :].reshape(B, scale * cfg.feat_dim)
-            a = F.relu(_linear(p, f"TRN.fc_fusion_scales.{sid}.1", F.relu(a), cfg))
+            a = _relu_m(_linear(p, f"TRN.fc_fusion_scales.{sid}.1", F.relu(a), cfg), None if masks is None else masks[:, t_idx])
+            t_idx += 1
             zs.append(a)
             acc = a if acc is None else acc + a
         acts.append(acc.unsqueeze(1))
@@ -370,13 +381,16 @@ def trans_attn(pred_domain):
     return 1 - ent
 
 
-def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu=None, domain="S", bn_running=None, bn_batch=None):
+def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu=None, domain="S", bn_running=None, bn_batch=None, masks=None):
     """One domain's pass through VideoModel.forward (models.py:545-722) for the
     trn-m / video / TransAttn configuration.  x [B,T,D].  drop_i / drop_v are
     optional multiplicative dropout masks already scaled by 1/(1-p)
     ([B*T,F] and [B,256]); None means dropout off (eval or p=0).
+    masks: optional dict of on/off patterns {"F1" [B*T,F], "Hf" [B*T,F], "Z" [B,n_tuples,256], "Hr" [B,T-1,256], "Hv" [B,256]} imposed
+    on the ReLUs (trn-m path; _relu_m).
     Returns dict with the reference's per-domain outputs."""
     B, T = x.size(0), cfg.num_segments
+    mk = (lambda k: None) if masks is None else (lambda k: masks.get(k))
     z0 = _linear(p, "fc_feature_shared_source", x.reshape(-1, x.size(-1)), cfg)          # :565-566
     if cfg.use_bn != "none":
         # domainAlign 'shared' (:490-543, 569-570) with alpha = 1 (self.alpha is ones(1); AutoDIAL's Parameter never receives a
@@ -389,12 +403,12 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu
             if bn_batch is not None:
                 bn_batch[domain] = (z0.detach().mean(0), z0.detach().var(0, unbiased=True), z0.size(0))
             z0 = F.batch_norm(z0, None, None, w, b_, training=True, eps=1e-5)
-    f = F.relu(z0)                                                                   # :572
+    f = _relu_m(z0, mk("F1"))                                                        # :572
     if drop_i is not None:
         f = f * drop_i                                                               # :574-575
     feat_frame = f.view(B, T, -1)                                                    # :578
     # frame-level adversarial branch (:456-462, :606-610)
-    h = F.relu(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2]), cfg))
+    h = _relu_m(_linear(p, "fc_feature_domain", _GradReverse.apply(f, beta[2]), cfg), mk("Hf"))
     pred_frame = _linear(p, "fc_classifier_domain", h, cfg).view(B, T, 2)
     if cfg.compute_dead_branches:
         _ = F.linear(f, p["fc_classifier_source.weight"], p["fc_classifier_source.bias"])       # :617-618, dead for baseline_type 'video'
@@ -412,17 +426,18 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu
             y2 = F.linear(vd, p["fc_classifier_video_source_2.weight"], p["fc_classifier_video_source_2.bias"])
         return dict(attn=v[:, 0], out=y, out2=y2, pred_domain=[pred_video, pred_video, pred_frame], feat=[y, v, feat_frame])
     # TRN (:632-636)
-    rel, rel_parts = trn_multiscale(p, feat_frame, cfg, with_tuples=True)
+    rel, rel_parts = trn_multiscale(p, feat_frame, cfg, with_tuples=True, masks=mk("Z"))
     # relation discriminators (:472-488)
-    preds = []
+    preds, hrs = [], []
     for i in range(T - 1):
         if cfg.arithmetic == "bf16":      # hidden layer on the scale's tuple activations as separate (separately rounded) K segments
             name = f"relation_domain_classifier_all.{i}.0"
             zs = [_GradReverse.apply(z, beta[0]) for z in rel_parts[i]]
-            hr = F.relu(_SegSumMatmulBf16.apply(p[name + ".weight"], *zs) + p[name + ".bias"])
+            hr = _relu_m(_SegSumMatmulBf16.apply(p[name + ".weight"], *zs) + p[name + ".bias"], None if mk("Hr") is None else mk("Hr")[:, i])
         else:
             r = _GradReverse.apply(rel[:, i, :], beta[0])
-            hr = F.relu(_linear(p, f"relation_domain_classifier_all.{i}.0", r))
+            hr = _relu_m(_linear(p, f"relation_domain_classifier_all.{i}.0", r), None if mk("Hr") is None else mk("Hr")[:, i])
+        hrs.append(hr)
         preds.append(_linear(p, f"relation_domain_classifier_all.{i}.2", hr, cfg).view(-1, 1, 2))
     pred_rel = torch.cat(preds, 1).view(-1, 2)
     # transferable attention (:379-388, :643-645)
@@ -437,14 +452,16 @@ def forward_domain(p, x, beta, cfg: Config, drop_i=None, drop_v=None, reverse_mu
     if reverse_mu is not None:                                                       # :682-684 (the MCD step's second forward)
         vd = _GradReverse.apply(vd, reverse_mu)
     y = _linear(p, "fc_classifier_video_source", vd, cfg)                            # :686
-    hv = F.relu(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg))  # :464-470
+    hv = _relu_m(_linear(p, "fc_feature_domain_video", _GradReverse.apply(vd, beta[1]), cfg), mk("Hv"))  # :464-470
     pred_video = _linear(p, "fc_classifier_domain_video", hv, cfg)
     y2 = y
     if cfg.ens_DA == "MCD":                                                          # :716-720
         y2 = F.linear(vd, p["fc_classifier_video_source_2.weight"], p["fc_classifier_video_source_2.bias"])
     return dict(attn=attn, out=y, out2=y2,
                 pred_domain=[pred_rel.view(B, T - 1, 2), pred_video, pred_frame],   # :697-707, :722 reversed
-                feat=[y, v, feat_frame])                                             # :578, :675, :690, :722
+                feat=[y, v, feat_frame],                                             # :578, :675, :690, :722
+                # the post-ReLU hidden activations (test infrastructure: mask-synchronised comparisons read their on/off patterns)
+                hidden=dict(F1=f, Hf=h, Z=torch.stack([z for zs in rel_parts for z in zs], 1), Hr=torch.stack(hrs, 1), Hv=hv))
 
 
 # ----------------------------------------------------------------------------
@@ -582,7 +599,7 @@ class TrainState:
 
 def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config,
                momentum=0.9, weight_decay=1e-4, clip=20.0, drop_i=None, drop_v=None,
-               n_src=None, n_tgt=None, grad_hook=None, alpha=0.0, mu=0.0):
+               n_src=None, n_tgt=None, grad_hook=None, alpha=0.0, mu=0.0, masks=None):
     """One optimisation step: forward both domains, total loss, backward,
     clip_grad_norm_ (main.py:578-581), Nesterov SGD with weight decay
     (main.py:83, 583; torch.optim.SGD semantics: g += wd*p; buf = mu*buf + g
@@ -594,8 +611,8 @@ def train_step(state: TrainState, xs, xt, label_source, beta, gamma, cfg: Config
         di_s, di_t = drop_i
     if drop_v is not None:
         dv_s, dv_t = drop_v
-    src = forward_domain(p, xs, beta, cfg, di_s, dv_s, domain="S")
-    tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t, domain="T")
+    src = forward_domain(p, xs, beta, cfg, di_s, dv_s, domain="S", masks=None if masks is None else masks[0])
+    tgt = forward_domain(p, xt, beta, cfg, di_t, dv_t, domain="T", masks=None if masks is None else masks[1])
     tgt_rev = None
     if cfg.ens_DA == "MCD":      # main.py:550: the whole model once more with reverse=True; only the target outputs are used
         tgt_rev = forward_domain(p, xt, beta, cfg, di_t, dv_t, reverse_mu=mu, domain="T")

@@ -207,7 +207,7 @@ int64_t ta3n_plan_describe(const ta3n_plan *p, char *buf, int64_t cap) {
     for (size_t i = 0; i < p->phases.size(); ++i) {
         const Phase &ph = p->phases[i];
         o << (i ? "," : "") << "{\"kind\":" << ph.kind << ",\"group\":" << ph.group << ",\"task_begin\":" << ph.task_begin
-          << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * ph.bf16)
+          << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * (ph.bf16 == 128 ? 3 : ph.bf16))
           << ",\"rm\":" << (ph.rm > 0 ? ph.rm : 1) << ",\"rn\":" << (ph.rn > 0 ? ph.rn : 1)
           << ",\"half_stages\":" << ((ph.bf16 & 64) ? 1 : 0)
           << ",\"flops\":" << phase_flops(*p, ph)

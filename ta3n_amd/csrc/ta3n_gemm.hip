@@ -5,6 +5,7 @@ namespace ta3n {
 // every instantiation is defined in one of ta3n_gemm_i*.hip
 #define TA3N_EXTERN(wm, wn, wk) \
     extern template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    extern template __global__ void gemm_tiles<wm, wn, wk, 0, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
@@ -60,7 +61,7 @@ bool tile_config_ok(int cfg) {
 
 int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const Ptrs &ptrs, int hyper_off,
                 int zeros_off, int twin_off, hipStream_t stream, const SgdSide *side, const Wait *d_waits, int pair_delta, int kinds) {
-    const int chain_off = d_waits ? ph.chain_off : -1, chain_n = ph.chain_n;
+    const int chain_off = d_waits ? ph.chain_off : -1;
     if (ph.chain_off >= 0 && !d_waits) return -4;
     // measurement knobs of the hand-off protocol (defaults = the shipped protocol): TA3N_CHAIN_SLEEP = poll back-off in units of 512
     // cycles; TA3N_CHAIN_NOACQ = 1: no acquire fence after the poll; TA3N_CHAIN_MEMSET = 1: counters reset by a memset before the launch
@@ -72,14 +73,19 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     }();
     const int knobs = knobs_env;
     if (chain_off >= 0 && (knobs & 512)) {
-        if (hipMemsetAsync(ptrs.ws + chain_off, 0, sizeof(int) * (size_t)(2 + chain_n), stream) != hipSuccess) return -2;
+        if (hipMemsetAsync(ptrs.ws + chain_off, 0, sizeof(int) * (size_t)(2 + ph.chain_n), stream) != hipSuccess) return -2;
     }
     if (ph.task_count == 0) return 0;
     SgdSide sd;
     std::memset(&sd, 0, sizeof(sd));
     sd.p16_off = -1;
     if (side) sd = *side;
-    const dim3 grid(ph.task_count);
+    // plain launches: chain_n = number of tasks (gemm_tiles' task loop).  TA3N_PERSIST=N (A/B, round 5): at most N workgroups (rounded down to
+    // a multiple of 8: the XCD queues), each walking the task list with that stride - "persistent workgroups over the per-XCD tile queues"
+    // without any overlap between a tile's epilogue and its successor's first stages; measured in profiles/r05_persistent_ab.txt
+    static const int persist = [] { const char *e = getenv("TA3N_PERSIST"); return e ? atoi(e) / 8 * 8 : 0; }();
+    const int chain_n = chain_off >= 0 ? ph.chain_n : ph.task_count;
+    const dim3 grid(chain_off < 0 && persist >= 8 && ph.task_count > persist ? persist : ph.task_count);
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
@@ -112,8 +118,8 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     static const bool kind_kernels = [] { const char *e = getenv("TA3N_KIND_KERNELS"); return !(e && atoi(e) == 0); }();
     if (kind_kernels && kinds != 0 && !(kinds & 32) && rm * rn == 1 && chain_off < 0 && sd.p_new == nullptr) {
         // gemm_tiles' MODE and stage count as the plain dispatch below picks them
-        const int mode = ph.bf16 == 0 ? 0 : (ph.bf16 & 16) ? ((ph.bf16 & 32) ? 4 : 2) : (ph.bf16 & 32) ? 3 : 1;
-        const int ns = ph.bf16 == 0 ? 2 : ((ph.bf16 & 15) == 3 ? 3 : 2);
+        const int mode = (ph.bf16 & 127) == 0 ? 0 : (ph.bf16 & 16) ? ((ph.bf16 & 32) ? 4 : 2) : (ph.bf16 & 32) ? 3 : 1;
+        const int ns = (ph.bf16 & 127) == 0 ? (ph.bf16 == 128 ? 3 : 2) : ((ph.bf16 & 15) == 3 ? 3 : 2);
 #define TA3N_LAUNCH_KIND(wm, wn, wk, bf, ns_, kv)                                                                              \
         if (!launched && cfg == wm * 100 + wn * 10 + wk && mode == bf && ns == ns_ && (kinds & ~kv) == 0) {                    \
             hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns_, 1, 1, kv>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
@@ -130,6 +136,7 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     if (cfg == wm * 100 + wn * 10 + wk) {                         \
         switch (ph.bf16) {                                        \
             case 0: TA3N_LAUNCH_ONE(wm, wn, wk, 0, 2); break;     \
+            case 128: TA3N_LAUNCH_ONE(wm, wn, wk, 0, 3); break;   \
             case 3: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 3); break;     \
             case 18: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 2); break;    \
             case 19: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 3); break;    \

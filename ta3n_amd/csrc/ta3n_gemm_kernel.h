@@ -1514,17 +1514,27 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                                                                  Ptrs ptrs, int hyper_off, int zeros_off, int twin_off, SgdSide side,
                                                                  const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs,
                                                                  int pair_delta) {
-    const Task &t = tasks[blockIdx.x];
     int *cnt = reinterpret_cast<int *>(ptrs.ws + (chain_off >= 0 ? chain_off : 0));
+    if (chain_off >= 0) {
+        const Task &t = tasks[blockIdx.x];
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2      // tools/chain_stamps.py: [6] = workgroup entry (before the wait), [7] = after the exit bookkeeping
-    GSTAMP(6);
+        GSTAMP(6);
 #endif
-    if (chain_off >= 0) chain_wait(t, waits, cnt, (int)threadIdx.x, knobs);
-    gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta, knobs);
-    if (chain_off >= 0) chain_exit(t.sig, cnt, chain_n, (int)threadIdx.x, knobs);
+        chain_wait(t, waits, cnt, (int)threadIdx.x, knobs);
+        gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(t, segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta, knobs);
+        chain_exit(t.sig, cnt, chain_n, (int)threadIdx.x, knobs);
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2
-    GSTAMP(7);
+        GSTAMP(7);
 #endif
+        return;
+    }
+    // Plain launch: chain_n carries the number of tasks.  The grid normally HAS that many workgroups (one task each, the loop runs once);
+    // with fewer (launch_gemm, TA3N_PERSIST: resident workgroups that walk the list with stride gridDim.x - a multiple of 8, so a workgroup
+    // stays inside the XCD queue the plan dealt its tiles to) a workgroup runs several tasks back to back.
+    for (int ti = (int)blockIdx.x; ti < chain_n; ti += (int)gridDim.x) {
+        gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(tasks[ti], segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta, knobs);
+        if (ti + (int)gridDim.x < chain_n) __syncthreads();      // the next task reuses the LDS block
+    }
 }
 
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
@@ -1534,6 +1544,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
     template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
+    template __global__ void gemm_tiles<wm, wn, wk, 0, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \

@@ -223,6 +223,12 @@ struct Builder {
             ph.bf16 = forced_stages ? forced_stages : (third ? 3 : 2);
             if (p.cfg.flags & TA3N_FLAG_F32_SPLIT) ph.bf16 |= 32;      // split (hi + lo) operands, three MFMAs per product block
             if (half_stages) ph.bf16 |= 64;
+        } else if (forced_stages == 3) {
+            // fp32 MFMA kernel with THREE LDS stages (tile code 3xxx in the fp32 arithmetic; round 5): the two-stage loop has exactly one chunk
+            // of look-ahead - ~1 000 cycles of matrix work per SIMD, about one L2 round trip - so a launch with ONE tile per compute unit
+            // (shared-FC product and its weight gradient at the headline shape: 256 tiles) stalls on every chunk; there the third stage
+            // costs nothing (its 8 VGPRs only matter where they take a resident workgroup away: the launches with > 2 tiles per CU keep two)
+            ph.bf16 = 128;
         }
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all

@@ -63,13 +63,13 @@ def _shard_grad(params, cfg, xs, xt, ys, beta, gamma, norm, T):
     return {k: gi for k, gi in zip(names, g) if gi is not None}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, c=None):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
     r, lr_, w = parallel.init_distributed("gloo")
     assert (r, w) == (rank, world)
-    c = CFG
+    c = c or CFG
     cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc"], dropout_i=0, dropout_v=0)
     params = synth_state(orc.param_shapes(cfg), seed=5)
     xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
@@ -100,6 +100,30 @@ def test_two_rank_sum_allreduce_equals_global_batch_gradient(tmp_path):
     state = orc.TrainState(params=params, lr=0.0)
     res = orc.train_step(state, xs.double(), xt.double(), ys, [0.75, 0.75, 0.5], 0.3, cfg, clip=None)
     plan = _lib.Plan(3, 2, c["T"], c["D"], c["fc"], c["C"], FLAGS)
+    ref = _flat_grads(plan, res["grads"])
+    assert ref.abs().max() > 0
+    assert torch.allclose(flat, ref, rtol=1e-9, atol=1e-12), (flat - ref).abs().max()
+
+
+CFG4 = dict(C=7, T=3, D=128, fc=16, Bs=10, Bt=74)
+
+
+def test_four_ranks_with_the_headline_target_count_equal_the_global_batch_gradient(tmp_path):
+    """74 target videos over 4 ranks -> shards of 19 / 19 / 18 / 18 inside a static 19-row buffer (zero-padded dummy rows, the
+    reference's rule main.py:366-372), 10 source videos -> 3 / 3 / 2 / 2: per-rank sum-losses over the GLOBAL counts + ONE sum
+    all-reduce reproduce the single-process global-batch gradient."""
+    c = CFG4
+    spans = [parallel.shard_range(c["Bt"], 4, r) for r in range(4)]
+    assert [e - b for b, e in spans] == [19, 19, 18, 18] and parallel.padded_shard_size(c["Bt"], 4) == 19
+    assert [e - b for b, e in (parallel.shard_range(c["Bs"], 4, r) for r in range(4))] == [3, 3, 2, 2]
+    out = str(tmp_path / "flat4.pt")
+    mp.spawn(_worker, args=(4, _free_port(), out, c), nprocs=4, join=True)
+    flat = torch.load(out)
+    cfg = orc.Config(num_class=c["C"], num_segments=c["T"], feature_dim=c["D"], fc_dim=c["fc"], dropout_i=0, dropout_v=0)
+    params = {k: v.double() for k, v in synth_state(orc.param_shapes(cfg), seed=5).items()}
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=9)
+    res = orc.train_step(orc.TrainState(params=params, lr=0.0), xs.double(), xt.double(), ys, [0.75, 0.75, 0.5], 0.3, cfg, clip=None)
+    plan = _lib.Plan(3, 19, c["T"], c["D"], c["fc"], c["C"], FLAGS)
     ref = _flat_grads(plan, res["grads"])
     assert ref.abs().max() > 0
     assert torch.allclose(flat, ref, rtol=1e-9, atol=1e-12), (flat - ref).abs().max()
