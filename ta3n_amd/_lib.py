@@ -82,6 +82,12 @@ class Ta3nError(RuntimeError):
     pass
 
 
+def has_experiments() -> bool:
+    """True when the loaded library was built with -DTA3N_EXPERIMENTS=1 (the measured-and-rejected step variants: chained launches,
+    split-K tiles, the optimiser inside the gradient tiles, the tall four-wave tiles; `pytest -m gpu_ab`)."""
+    return lib().ta3n_version().decode().endswith("+experiments")
+
+
 def lib() -> C.CDLL:
     """Load the HIP library (once).  Raises if it is missing: build it with
     `python -m ta3n_amd.build` (hipcc --offload-arch=gfx950)."""

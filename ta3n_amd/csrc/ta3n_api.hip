@@ -106,6 +106,7 @@ int run_group(ta3n_plan *p, int group, const Ptrs &ptrs, float *params_rw, float
             case PH_SGD: rc = launch_sgd(p->geom, params_rw, ptrs.g, momentum, ptrs.ws, stream); break;
             default: rc = -1;
         }
+        if (rc == -5) return TA3N_ERR_INVALID;      // (launch_gemm has set the message: an experiments-only launch list on the default library)
         if (rc != 0) return fail(TA3N_ERR_HIP, "kernel launch failed in phase kind " + std::to_string(ph.kind) + ": " +
                                                    hipGetErrorString(hipGetLastError()));
     }
@@ -138,7 +139,10 @@ double phase_flops(const ta3n_plan &p, const ta3n::Phase &ph) {
 extern "C" {
 
 const char *ta3n_last_error(void) { return g_err.c_str(); }
-const char *ta3n_version(void) { return "ta3n_hip 0.2 (gfx950, fp32 MFMA 32x32x2 | bf16 MFMA 32x32x16 with fp32 accumulation)"; }
+const char *ta3n_version(void) {
+    return TA3N_EXPERIMENTS ? "ta3n_hip 0.3 (gfx950, fp32 MFMA 32x32x2 | bf16 MFMA 32x32x16 with fp32 accumulation) +experiments"
+                            : "ta3n_hip 0.3 (gfx950, fp32 MFMA 32x32x2 | bf16 MFMA 32x32x16 with fp32 accumulation)";
+}
 
 int ta3n_plan_create(const ta3n_config *cfg, ta3n_plan **out) {
     if (!cfg || !out) return fail(TA3N_ERR_INVALID, "null argument");
@@ -207,7 +211,7 @@ int64_t ta3n_plan_describe(const ta3n_plan *p, char *buf, int64_t cap) {
     for (size_t i = 0; i < p->phases.size(); ++i) {
         const Phase &ph = p->phases[i];
         o << (i ? "," : "") << "{\"kind\":" << ph.kind << ",\"group\":" << ph.group << ",\"task_begin\":" << ph.task_begin
-          << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * (ph.bf16 == 128 ? 3 : ph.bf16))
+          << ",\"task_count\":" << ph.task_count << ",\"tile\":" << (ph.wm * 100 + ph.wn * 10 + ph.wk + 1000 * ph.bf16)
           << ",\"rm\":" << (ph.rm > 0 ? ph.rm : 1) << ",\"rn\":" << (ph.rn > 0 ? ph.rn : 1)
           << ",\"half_stages\":" << ((ph.bf16 & 64) ? 1 : 0)
           << ",\"flops\":" << phase_flops(*p, ph)
@@ -818,7 +822,8 @@ int ta3n_has_fused_update(const ta3n_plan *p) {
     if (!p) return TA3N_ERR_INVALID;
     // every live parameter's gradient is produced by a tile / column-sum task of the fused step (those carry the update)
     // (pair twins: the fused-update epilogue keeps no lo plane of the new parameters - the separate update does)
-    return ta3n_has_fused_step(p) == 1 && p->cfg.aggregation == TA3N_AGG_TRN_M && p->geom.pair_delta == 0 ? 1 : 0;
+    // (experiments build only: measured time-neutral in round 3, profiles/r03_fused_update_ab.txt)
+    return TA3N_EXPERIMENTS && ta3n_has_fused_step(p) == 1 && p->cfg.aggregation == TA3N_AGG_TRN_M && p->geom.pair_delta == 0 ? 1 : 0;
 }
 
 int ta3n_train_steps_fused_update(ta3n_plan *p, const float *x, float *params, float *params_alt, float *grads, float *momentum, float *ws,

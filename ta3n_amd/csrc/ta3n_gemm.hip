@@ -1,11 +1,11 @@
 // Launcher of the tile-list GEMM (the kernel template lives in ta3n_gemm_kernel.h, its instantiations in ta3n_gemm_i*.hip).
 #include "ta3n_gemm_kernel.h"
+#include "ta3n_plan.h"      // set_error
 
 namespace ta3n {
 // every instantiation is defined in one of ta3n_gemm_i*.hip
 #define TA3N_EXTERN(wm, wn, wk) \
     extern template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
-    extern template __global__ void gemm_tiles<wm, wn, wk, 0, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     extern template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
@@ -76,16 +76,20 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
         if (hipMemsetAsync(ptrs.ws + chain_off, 0, sizeof(int) * (size_t)(2 + ph.chain_n), stream) != hipSuccess) return -2;
     }
     if (ph.task_count == 0) return 0;
+    // chained launches, split-K tiles and the optimiser inside the gradient tiles were built, measured and rejected; their
+    // device code lives in the experiments build only (ta3n_kernels.h: TA3N_EXPERIMENTS).  The plan BUILDER still emits such launch lists
+    // (host code, checked on the CPU by tests/plan_interp.py); launching one on the default library is an error, not a silent fallback.
+    if (!TA3N_EXPERIMENTS && (chain_off >= 0 || (kinds & 32) || (side && side->p_new != nullptr))) {
+        set_error("this launch list uses ta3n_config.chain / split_k or the fused update: build with -DTA3N_EXPERIMENTS=1 "
+                  "(TA3N_LIBDIR=ta3n_amd/lib_ab TA3N_EXTRA_FLAGS=-DTA3N_EXPERIMENTS=1 python -m ta3n_amd.build)");
+        return -5;
+    }
     SgdSide sd;
     std::memset(&sd, 0, sizeof(sd));
     sd.p16_off = -1;
     if (side) sd = *side;
-    // plain launches: chain_n = number of tasks (gemm_tiles' task loop).  TA3N_PERSIST=N (A/B, round 5): at most N workgroups (rounded down to
-    // a multiple of 8: the XCD queues), each walking the task list with that stride - "persistent workgroups over the per-XCD tile queues"
-    // without any overlap between a tile's epilogue and its successor's first stages; measured in profiles/r05_persistent_ab.txt
-    static const int persist = [] { const char *e = getenv("TA3N_PERSIST"); return e ? atoi(e) / 8 * 8 : 0; }();
-    const int chain_n = chain_off >= 0 ? ph.chain_n : ph.task_count;
-    const dim3 grid(chain_off < 0 && persist >= 8 && ph.task_count > persist ? persist : ph.task_count);
+    const int chain_n = ph.chain_n;
+    const dim3 grid(ph.task_count);
     const Task *tp = d_tasks + ph.task_begin;
     const int cfg = ph.wm * 100 + ph.wn * 10 + ph.wk;
     bool launched = false;
@@ -118,8 +122,8 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     static const bool kind_kernels = [] { const char *e = getenv("TA3N_KIND_KERNELS"); return !(e && atoi(e) == 0); }();
     if (kind_kernels && kinds != 0 && !(kinds & 32) && rm * rn == 1 && chain_off < 0 && sd.p_new == nullptr) {
         // gemm_tiles' MODE and stage count as the plain dispatch below picks them
-        const int mode = (ph.bf16 & 127) == 0 ? 0 : (ph.bf16 & 16) ? ((ph.bf16 & 32) ? 4 : 2) : (ph.bf16 & 32) ? 3 : 1;
-        const int ns = (ph.bf16 & 127) == 0 ? (ph.bf16 == 128 ? 3 : 2) : ((ph.bf16 & 15) == 3 ? 3 : 2);
+        const int mode = ph.bf16 == 0 ? 0 : (ph.bf16 & 16) ? ((ph.bf16 & 32) ? 4 : 2) : (ph.bf16 & 32) ? 3 : 1;
+        const int ns = ph.bf16 == 0 ? 2 : ((ph.bf16 & 15) == 3 ? 3 : 2);
 #define TA3N_LAUNCH_KIND(wm, wn, wk, bf, ns_, kv)                                                                              \
         if (!launched && cfg == wm * 100 + wn * 10 + wk && mode == bf && ns == ns_ && (kinds & ~kv) == 0) {                    \
             hipLaunchKernelGGL((gemm_tiles<wm, wn, wk, bf, ns_, 1, 1, kv>), grid, dim3(64 * wm * wn * wk), 0, stream, tp, d_segs, \
@@ -136,7 +140,6 @@ int launch_gemm(const Phase &ph, const Task *d_tasks, const Seg *d_segs, const P
     if (cfg == wm * 100 + wn * 10 + wk) {                         \
         switch (ph.bf16) {                                        \
             case 0: TA3N_LAUNCH_ONE(wm, wn, wk, 0, 2); break;     \
-            case 128: TA3N_LAUNCH_ONE(wm, wn, wk, 0, 3); break;   \
             case 3: TA3N_LAUNCH_ONE(wm, wn, wk, 1, 3); break;     \
             case 18: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 2); break;    \
             case 19: TA3N_LAUNCH_ONE(wm, wn, wk, 2, 3); break;    \

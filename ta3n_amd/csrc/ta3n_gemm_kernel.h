@@ -254,19 +254,6 @@ struct OperandStream {
         }
     }
 
-    // pieces [lo, hi) of the chunk (16-byte path only): the same DMAs as issue(), a few at a time, so that the K loop can place them
-    // BETWEEN the matrix instructions of the stage it is computing (an LDS-DMA piece costs its wave ~60 cycles of issue among bare
-    // MFMAs against 100-185 in a block of eight pieces + sixteen LDS reads - MI355X_MICROARCH.md, "LDS-DMA piece issue cost")
-    __device__ __forceinline__ void issue_pieces(int lo, int hi, int krem, unsigned lds_addr, int wave, const float *__restrict__ zeros) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            if (i >= lo && i < hi) {
-                const float *src = kofs[i] < krem ? p[i] : zeros;
-                p[i] += step;
-                glds16(src, lds_addr + (unsigned)((wave + NW * i) * 1024));
-            }
-    }
-
     // stream the chunk starting at k0 (krem = klen - k0 valid k remain) into the stage image at lds_addr
     __device__ __forceinline__ void issue(int k0, int krem, unsigned lds_addr, int wave, int lane, const float *__restrict__ zeros) {
         if (vec) {
@@ -303,14 +290,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // BF == 2: the stage bytes are bf16 already (twins): a 16-byte slot is 8 consecutive k of one row, fed to the MFMA as is.
 // RM x RN: 32x32 blocks per wave (rows ra + 32 i, columns rb + 32 j): every fragment read feeds RN (RM) MFMAs, and the
 // workgroup's tile - what the LDS-DMA has to bring per flop - grows with it.  Twin path only.
-// mid(slot, nslots): called once after each of the stage's `nslots` groups of matrix instructions (slot = 0 .. nslots - 1, compile-time
-// constants once the loops are unrolled) - the K loop hangs the NEXT stage's LDS-DMA pieces there, a share per group, so that they
-// issue in the shadow of the MFMAs instead of in a block in front of the fragment reads.
-// pre(): called once, when the stage's LAST fragment read has been issued and before the matrix instructions that consume it (the early-
-// refill loop waits there for the reads, meets the other waves and streams the chunk after next into the very buffer just read).
-template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1, class Mid, class Pre>
+template <int BM, int BN, int WK, bool AKM, bool BKM, bool FULL, bool RS, int BF, int RM = 1, int RN = 1>
 __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rss)[RM], const float *__restrict__ sa,
-                                              const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem, Mid &&mid, Pre &&pre) {
+                                              const float *__restrict__ sb, int ra, int rb, int wk, int lh, int krem) {
     constexpr bool HS = BF == 5;                   // bf16 twins in 64-k stages (128-byte image rows)
     constexpr int GPW = (HS ? 8 : 16) / WK;        // k groups per wave per stage (4-deep fp32 groups; 8-deep bf16 groups on the twin paths)
     constexpr int NQ = GPW / 2;
@@ -375,7 +357,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                             rss[i] += __builtin_bit_cast(float, ta[i][qq][j] << 16) + __builtin_bit_cast(float, ta[i][qq][j] & 0xFFFF0000u);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (q0 + QG >= NQ) pre();
 #pragma unroll
             for (int qq = 0; qq < QG; ++qq) {
                 if (FULL || 8 * (wk * GPW + 2 * (q0 + qq)) < krem) {
@@ -386,7 +367,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                             accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[i][qq]),
                                                                                  __builtin_bit_cast(bf16x8, tb[j][qq]), accs[i][j], 0, 0, 0);
                 }
-                mid(q0 + qq, NQ);
             }
         }
         return;
@@ -436,7 +416,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                               (__builtin_bit_cast(float, al[q][j] << 16) + __builtin_bit_cast(float, al[q][j] & 0xFFFF0000u));
             }
             __builtin_amdgcn_sched_barrier(0);
-            pre();
 #pragma unroll
             for (int q = 0; q < NM; ++q) {
                 if (FULL || 8 * (wk * SPW + 2 * q) < krem) {
@@ -444,7 +423,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[q]), __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[q]), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
                 }
-                mid(q, NM);
             }
         } else {
             // one slot per wave: lanes 0-31 take k 8 wk .. + 3, lanes 32-63 k 8 wk + 4 .. + 7
@@ -467,13 +445,11 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                           (__builtin_bit_cast(float, al[j] << 16) + __builtin_bit_cast(float, al[j] & 0xFFFF0000u));
             }
             __builtin_amdgcn_sched_barrier(0);
-            pre();
             if (FULL || 8 * wk < krem) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, al), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bl), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
             }
-            mid(0, 1);
         }
         return;
     }
@@ -522,13 +498,11 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     rs += __builtin_bit_cast(float, ta[q][j] << 16) + __builtin_bit_cast(float, ta[q][j] & 0xFFFF0000u);
         }
         __builtin_amdgcn_sched_barrier(0);
-        pre();
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (FULL || 8 * (wk * GPW + 2 * q) < krem)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta[q]), __builtin_bit_cast(bf16x8, tb[q]), acc,
                                                               0, 0, 0);
-            mid(q, NQ);
         }
         return;
     }
@@ -556,7 +530,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
         for (int q = 0; q < NQ; ++q) rs += (av[q][0] + av[q][1]) + (av[q][2] + av[q][3]);
     }
     __builtin_amdgcn_sched_barrier(0);             // keep the reads above: hipcc otherwise sinks each one next to its MFMA
-    pre();
     if constexpr (BF == 3) {
         // fp32-grade on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi
         // (the a_lo b_lo term, ~2^-16 of the product, is dropped); fp32 accumulation in the MFMA
@@ -587,7 +560,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BL), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AH), __builtin_bit_cast(bf16x8, BH), acc, 0, 0, 0);
                 }
-                mid(q / 2, NQ / 2);
             }
         } else {
 #pragma unroll
@@ -604,7 +576,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, AH), __builtin_bit_cast(s16x4, BL), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, AH), __builtin_bit_cast(s16x4, BH), acc, 0, 0, 0);
                 }
-                mid(q, NQ);
             }
         }
         return;
@@ -621,7 +592,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                                   acc, 0, 0, 0);
                 }
-                mid(q / 2, NQ / 2);
             }
         } else {
 #pragma unroll
@@ -632,7 +602,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
                     acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc,
                                                                    0, 0, 0);
                 }
-                mid(q, NQ);
             }
         }
         return;
@@ -643,7 +612,6 @@ __device__ __forceinline__ void compute_stage(f32x16 (&accs)[RM][RN], float (&rs
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[q][j], acc, 0, 0, 0);
         }
-        mid(q, NQ);      // (a 64-cycle fp32 MFMA behind a dependent one leaves its issue slots free anyway)
     }
 }
 
@@ -775,7 +743,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     GSTAMP(0);
-    constexpr bool OPT = (KV & 32) != 0;      // fused update / split-K / chained-launch stores compiled in
+    constexpr bool OPT = TA3N_EXPERIMENTS != 0 && (KV & 32) != 0;      // fused update / split-K / chained-launch stores compiled in (experiments build only)
     const bool pub = OPT && t.sig >= 0 && !(side.p16_off == -12345);    // chained launch: another task of this launch reads what this one writes -> write-through stores
     if (t.epi & EPI_SGD) {          // optimiser side job (uniform for the workgroup): arithmetic and summation order of sgd_range_kernel
         if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
@@ -942,100 +910,14 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     float rs[RM];     // EPI_ROWSUM_A: K-sum of A(row ra + 32 i, this half-wave's k) over this wave's K slices
 #pragma unroll
     for (int i = 0; i < RM; ++i) rs[i] = 0.f;
-#ifndef TA3N_DMA_INTERLEAVE
-#define TA3N_DMA_INTERLEAVE 0
-#endif
-    // 1 (build with -DTA3N_DMA_INTERLEAVE=1): the next chunk's DMA pieces issue BETWEEN the current chunk's matrix instructions instead of
-    // in a block in front of its fragment reads.  Built on the guide's figure (a piece costs ~60 cycles of issue among bare MFMAs against
-    // 100-185 in a block); bit-identical; measured SLOWER on every configuration (profiles/r04_dma_interleave_ab.txt: bf16 112.1 vs 109.5
-    // us, fp32 237 vs 221, configs[3] 522 vs 505, configs[4] 542 vs 494): the loop is bound by how EARLY a chunk's DMAs leave, not by
-    // the issue slots they take - spreading them over the compute phase delays the chunk's arrival.  Off.  A compile-time
-    // choice on purpose: with both variants in one kernel the loop-invariant fragment addresses of both stay live (+20-40 VGPRs measured:
-    // the 32x64 fp32 tile went from 111 to 131 and lost its second resident workgroup, the 128x128 tile spilled).
-    constexpr bool interleave = TA3N_DMA_INTERLEAVE != 0;
-#ifndef TA3N_EARLY_REFILL
-#define TA3N_EARLY_REFILL 0
-#endif
-    // the blocked tiles whose fragments do not all fit in registers at once (QG < NQ in compute_stage) read the buffer in two
-    // rounds: the hook fires before the last round's MFMAs, which is still correct (all reads issued), just later
-    constexpr bool EARLY = TA3N_EARLY_REFILL != 0 && NS == 2;
+    // (Two bit-identical variants of this loop - the next chunk's DMA pieces issued BETWEEN the matrix instructions, and a refill of the
+    // buffer just read into registers - were built and measured slower in round 4 (profiles/r04_dma_interleave_ab.txt,
+    // r04_early_refill_ab.txt) and removed from the tree in round 5: docs/history/round4.md, git 545b5f2.)
     (void)knobs;
     constexpr int KVE = BM > 128 ? (KV & (1 | 2 | 32)) : KV;      // tiles taller than 128 rows: K-contiguous A only (the plan keeps them off other launches)
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
-        if constexpr (EARLY) {
-            // Early refill (build with -DTA3N_EARLY_REFILL=1; two LDS stages): a stage's fragments are all in registers before its first
-            // matrix instruction, so its buffer is free as soon as every wave's reads have returned - chunk c + 2 streams into the buffer
-            // of chunk c while chunk c is still being MULTIPLIED.  Two chunks in flight on two buffers (the third "stage" is the register
-            // file), at the price of a second barrier per chunk.  Same products in the same order: bit-identical results.
-            OperandStream<BM, NW, TW, PAIR, HS> oa;
-            OperandStream<BN, NW, TW, PAIR, HS> ob;
-            constexpr int LPW = OperandStream<BM, NW, TW, PAIR, HS>::NP + OperandStream<BN, NW, TW, PAIR, HS>::NP;
-            static_assert(LPW <= 63, "vmcnt is a 6-bit counter");
-            int i_seg = cseg, i_chunk = 0, i_nchunks = 0, i_klen = 0, i_buf = 0, ahead = 0;
-            Seg nx = t.seg0;
-            auto open_issue_seg = [&]() {
-                const Seg sg = nx;
-                if (i_seg + 1 < seg_end) nx = segs[i_seg + 1];
-                i_klen = sg.klen; i_nchunks = (sg.klen + CH - 1) / CH; i_chunk = 0;
-                oa.setup(base_ptr(ptrs, sg.a_base) + (size_t)sg.a_off, sg.a_ld, AKM, sg.klen, m0, sg.pad[0] > 0 ? sg.pad[0] : m_valid,
-                         wave, lane, pair_delta);
-                ob.setup(base_ptr(ptrs, sg.b_base) + (size_t)sg.b_off, sg.b_ld, BKM, sg.klen, n0, n_valid, wave, lane, pair_delta);
-            };
-            auto issue_one = [&]() {
-                const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
-                const int k0 = i_chunk * CH;
-                oa.issue(k0, i_klen - k0, st, wave, lane, zeros);
-                ob.issue(k0, i_klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
-                i_buf ^= 1;
-                ++ahead;
-                if (++i_chunk == i_nchunks) {
-                    if (++i_seg < seg_end) open_issue_seg();
-                }
-            };
-            open_issue_seg();
-    #pragma unroll 1
-            for (int sidx = 0; sidx < 2 && i_seg < seg_end; ++sidx) issue_one();
-            int c_buf = 0;
-            int c_klen_nx = t.seg0.klen, c_scale_nx = t.seg0.scale_kind;
-            auto refill = [&]() {      // pre(): this chunk's fragment reads are issued
-                if (i_seg < seg_end) {                                 // (workgroup-uniform: every wave walks the same Seg list)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... have returned
-                    __builtin_amdgcn_s_barrier();                      // ... everybody's: the buffer under the compute cursor is free
-                    asm volatile("" ::: "memory");
-                    issue_one();                                       // (i_buf == c_buf here: two buffers, two chunks ahead)
-                }
-            };
-            for (;;) {
-                const int klen = c_klen_nx, c_scale = c_scale_nx;
-                if (cseg + 1 < seg_end) { c_klen_nx = segs[cseg + 1].klen; c_scale_nx = segs[cseg + 1].scale_kind; }
-                const int n_chunks = (klen + CH - 1) / CH;
-    #pragma unroll 1
-                for (int c = 0; c < n_chunks; ++c) {
-                    if (ahead > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");      // the older of the two chunks in flight has landed
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    --ahead;
-                    const float *sa = lds + c_buf * STAGE;
-                    if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, refill);
-                    else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, refill);
-                    c_buf ^= 1;
-                }
-                if (c_scale != SK_ONE) {
-                    const float sc = scale_of(c_scale);
-    #pragma unroll
-                    for (int i = 0; i < RM; ++i)
-    #pragma unroll
-                        for (int j = 0; j < RN; ++j)
-    #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
-                }
-                if (++cseg >= seg_end) break;
-            }
-        } else if constexpr (NS == 2) {
+        if constexpr (NS == 2) {
             // Two stages: chunk c + 1 is streamed while chunk c is computed.  Per Seg, the iterations whose successor is in
             // the same Seg run in a tight loop; the iteration that computes the Seg's last chunk opens the next Seg.
             OperandStream<BM, NW, TW, PAIR, HS> oa;
@@ -1058,17 +940,6 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 oa.issue(k0, klen - k0, st, wave, lane, zeros);
                 ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
             };
-            // the same chunk, a share of its pieces per call: slot s of n issues pieces [s PT / n, (s + 1) PT / n) of the PT = NPa + NPb
-            // this wave owns (an operand on the 4-byte path goes out whole with slot 0)
-            auto issue_share = [&](int buf, int k0, int slot, int nslots) {
-                constexpr int PA = OperandStream<BM, NW, TW, PAIR, HS>::NP, PB = OperandStream<BN, NW, TW, PAIR, HS>::NP, PT = PA + PB;
-                const unsigned st = lds_base + (unsigned)(buf * STAGE * 4);
-                const int lo = slot * PT / nslots, hi = (slot + 1) * PT / nslots;
-                if (oa.vec) oa.issue_pieces(lo, hi, klen - k0, st, wave, zeros);
-                else if (slot == 0) oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * ROWF * 4, wave, zeros);
-                else if (slot == 0) ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
-            };
             auto stage_ready = [&]() {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
                 __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
@@ -1082,13 +953,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 for (int c = 0; c < n_chunks - 1; ++c) {             // chunks whose successor is in the same Seg (all full)
                     stage_ready();
                     const float *sa = lds + buf * STAGE;
-                    if constexpr (interleave) {       // the next chunk's DMAs between this chunk's matrix instructions
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH,
-                                                                                  [&](int slot, int nslots) { issue_share(buf ^ 1, (c + 1) * CH, slot, nslots); }, [] {});
-                    } else {
-                        issue(buf ^ 1, (c + 1) * CH);
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
-                    }
+                    issue(buf ^ 1, (c + 1) * CH);
+                    compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH);
                     buf ^= 1;
                 }
                 // last chunk of this Seg; the next Seg (if any) starts streaming underneath it
@@ -1098,12 +964,10 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 const bool more = cseg < seg_end;
                 if (more) {
                     open_seg(cseg);
-                    if (!interleave) issue(buf ^ 1, 0);
+                    issue(buf ^ 1, 0);
                 }
                 const float *sa = lds + buf * STAGE;
-                // (ONE instance of the tail stage: the hook issues nothing when no Seg follows)
-                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, krem,
-                                                                           [&](int slot, int nslots) { if (interleave && more) issue_share(buf ^ 1, 0, slot, nslots); }, [] {});
+                compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, krem);
                 if (c_scale != SK_ONE) {
                     const float sc = scale_of(c_scale);
     #pragma unroll
@@ -1172,21 +1036,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                         const unsigned st = lds_base + (unsigned)(i_buf * STAGE * 4);
                         const int k0 = (c + NS - 1) * CH;
                         const float *sa = lds + c_buf * STAGE;
-                        if constexpr (interleave) {      // the chunk's DMAs between the matrix instructions of the chunk being computed
-                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH,
-                                [&](int slot, int nslots) {
-                                    constexpr int PA = OperandStream<BM, NW, TW, PAIR, HS>::NP, PT = LPW;
-                                    const int lo = slot * PT / nslots, hi = (slot + 1) * PT / nslots;
-                                    if (oa.vec) oa.issue_pieces(lo, hi, klen - k0, st, wave, zeros);
-                                    else if (slot == 0) oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                                    if (ob.vec) ob.issue_pieces(lo - PA, hi - PA, klen - k0, st + BM * ROWF * 4, wave, zeros);
-                                    else if (slot == 0) ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
-                                }, [] {});
-                        } else {
-                            oa.issue(k0, klen - k0, st, wave, lane, zeros);
-                            ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
-                            compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
-                        }
+                        oa.issue(k0, klen - k0, st, wave, lane, zeros);
+                        ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH);
                         i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
                         c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     }
@@ -1200,9 +1052,9 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                     if (i_seg < seg_end) issue_one();
                     const float *sa = lds + c_buf * STAGE;
                     if (c < n_chunks - 1)
-                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH, [](int, int) {}, [] {});
+                        compute_stage<BM, BN, WK, AKM, BKM, true, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, CH);
                     else
-                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, klen - c * CH, [](int, int) {}, [] {});
+                        compute_stage<BM, BN, WK, AKM, BKM, false, RS, BF, RM, RN>(acc, rs, sa, sa + BM * ROWF, ra, rb, wk, lh, klen - c * CH);
                     c_buf = (c_buf + 1 == NS) ? 0 : c_buf + 1;
                     --ahead;
                 }
@@ -1515,7 +1367,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
                                                                  const Wait *__restrict__ waits, int chain_off, int chain_n, int knobs,
                                                                  int pair_delta) {
     int *cnt = reinterpret_cast<int *>(ptrs.ws + (chain_off >= 0 ? chain_off : 0));
-    if (chain_off >= 0) {
+    if (TA3N_EXPERIMENTS != 0 && chain_off >= 0) {
         const Task &t = tasks[blockIdx.x];
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 2      // tools/chain_stamps.py: [6] = workgroup entry (before the wait), [7] = after the exit bookkeeping
         GSTAMP(6);
@@ -1528,13 +1380,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 #endif
         return;
     }
-    // Plain launch: chain_n carries the number of tasks.  The grid normally HAS that many workgroups (one task each, the loop runs once);
-    // with fewer (launch_gemm, TA3N_PERSIST: resident workgroups that walk the list with stride gridDim.x - a multiple of 8, so a workgroup
-    // stays inside the XCD queue the plan dealt its tiles to) a workgroup runs several tasks back to back.
-    for (int ti = (int)blockIdx.x; ti < chain_n; ti += (int)gridDim.x) {
-        gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(tasks[ti], segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta, knobs);
-        if (ti + (int)gridDim.x < chain_n) __syncthreads();      // the next task reuses the LDS block
-    }
+    // One workgroup = one task.  (Round 5 measured the alternative the round-3 / round-4 verdicts asked for - resident workgroups walking
+    // the per-XCD task list with stride gridDim.x, TA3N_PERSIST - without overlap between a tile's epilogue and its successor's first
+    // stages: slower on every configuration (profiles/r05_persistent_ab.txt: fp32 259 -> 265-274 us, configs[3] 506 -> 523-592 us,
+    // headline 113.2 -> 120.9 us), because static assignment loses the hardware dispatcher's balancing of tiles whose K differs 6x, and
+    // the task loop itself cost the fp32 32x64 kernel its second resident workgroup (129 VGPRs).  Removed again)
+    gemm_tile<WM, WN, WK, BF, NS, RM, RN, KV>(tasks[blockIdx.x], segs, ptrs, hyper_off, zeros_off, twin_off, side, pair_delta, knobs);
 }
 
 #define TA3N_TILE_CONFIGS(X) X(1, 1, 4) X(1, 1, 8) X(2, 1, 2) X(1, 2, 2) X(2, 1, 4) X(1, 2, 4) X(2, 2, 1) X(2, 2, 2)
@@ -1544,7 +1395,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 
 #define TA3N_INSTANTIATE(wm, wn, wk)                                                                        \
     template __global__ void gemm_tiles<wm, wn, wk, 0, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
-    template __global__ void gemm_tiles<wm, wn, wk, 0, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 1, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 1, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
     template __global__ void gemm_tiles<wm, wn, wk, 2, 2, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int); \
@@ -1555,7 +1405,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
     template __global__ void gemm_tiles<wm, wn, wk, 4, 3, 1, 1>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 // half-stage kernels (MODE 5: bf16 twins in 64-k stages, OperandStream HS): (wm, wn, wk, rm, rn, stages) - the 128x128 and 64x64 tiles
 // and - four waves, no K split inside the workgroup, 3 x 2 / 4 x 2 blocks per wave - the 192x128 and the 256x128 tile (A K-contiguous only)
+#if TA3N_EXPERIMENTS
 #define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 2, 2, 4) X(2, 2, 2, 1, 1, 3) X(2, 2, 2, 1, 1, 4) X(2, 2, 1, 3, 2, 3) X(2, 2, 1, 4, 2, 3)
+#else       // default library: three half stages of the 128x128 and the 64x64 tile (four stages and the four-wave tall tiles measured slower)
+#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 1, 1, 3)
+#endif
 #define TA3N_INSTANTIATE_HS(wm, wn, wk, rm, rn, ns) \
     template __global__ void gemm_tiles<wm, wn, wk, 5, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 

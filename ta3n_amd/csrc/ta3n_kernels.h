@@ -1,5 +1,13 @@
 // Device-side helpers and launcher declarations shared by the .hip files.
 #pragma once
+// -DTA3N_EXPERIMENTS=1 (the A/B build: TA3N_LIBDIR=ta3n_amd/lib_ab TA3N_EXTRA_FLAGS=-DTA3N_EXPERIMENTS=1 python -m ta3n_amd.build; tests:
+// `pytest -m gpu_ab` with the same TA3N_LIBDIR) keeps the step-level variants that were built, measured and rejected - chained launches
+// (ta3n_config.chain), split-K tiles (split_k), time-based tile order (cost_model), the optimiser inside the gradient tiles
+// (ta3n_train_steps_fused_update), the four-wave 192x128 / 256x128 and four-half-stage kernels.  The default library carries only what a
+// plan can select by default; ta3n_plan_create refuses those options without the flag.  History: docs/history/.
+#ifndef TA3N_EXPERIMENTS
+#define TA3N_EXPERIMENTS 0
+#endif
 #include <hip/hip_runtime.h>
 
 #include "ta3n_types.h"

@@ -223,13 +223,10 @@ struct Builder {
             ph.bf16 = forced_stages ? forced_stages : (third ? 3 : 2);
             if (p.cfg.flags & TA3N_FLAG_F32_SPLIT) ph.bf16 |= 32;      // split (hi + lo) operands, three MFMAs per product block
             if (half_stages) ph.bf16 |= 64;
-        } else if (forced_stages == 3) {
-            // fp32 MFMA kernel with THREE LDS stages (tile code 3xxx in the fp32 arithmetic; round 5): the two-stage loop has exactly one chunk
-            // of look-ahead - ~1 000 cycles of matrix work per SIMD, about one L2 round trip - so a launch with ONE tile per compute unit
-            // (shared-FC product and its weight gradient at the headline shape: 256 tiles) stalls on every chunk; there the third stage
-            // costs nothing (its 8 VGPRs only matter where they take a resident workgroup away: the launches with > 2 tiles per CU keep two)
-            ph.bf16 = 128;
         }
+        // (fp32 MFMA kernel: two LDS stages only.  A third stage for the launches with one tile per compute unit - shared-FC product and its
+        // weight gradient, 256 tiles at the headline shape - was built and measured in round 5: 257.6 -> 260.3 us per step, 265.7 with
+        // three stages everywhere; profiles/r05_persistent_ab.txt.  The thousands digit of a tile code is ignored in the fp32 arithmetic.)
         ph.task_begin = (int32_t)p.tasks.size();
         // A "panel" is the set of tiles of one GEMM that share an operand slab: all
         // column tiles of one row tile when the A side (M*K) is the larger operand,

@@ -117,7 +117,6 @@ struct Phase {
                                  // bf16 twins (in floats, base BASE_WS); ld, klen and row counts stay in elements
                                  // + 16 + 32: pair twins - the stage holds the hi AND the lo plane of 64 k (Geom::pair_delta), three
                                  // MFMAs per product block, no conversion in the loop
-                                 // 128 (alone): fp32 MFMA kernel with three LDS stages instead of two
     int32_t rm, rn;              // 32x32 blocks per wave (0 or 1: one): block tile = 32*wm*rm x 32*wn*rn; > 1 only when bf16 >= 16
     int32_t chain_off;           // chained launch: ws offset (floats) of its int32 block {done, error, counters[chain_n]}; -1: plain launch
     int32_t chain_n;

@@ -253,7 +253,7 @@ class Interp:
                 A = self.operand(s.a_base, s.a_off, s.a_ld, s.a_kmajor, t.m0, nr, s.klen)
                 rowsum += A.sum(1)
                 Bm = self.operand(s.b_base, s.b_off, s.b_ld, s.b_kmajor, t.n0, nc, s.klen)
-                if (ph.bf16 & 127) and not (ph.bf16 & 32):      # (bit 128 alone: the fp32 kernel with three stages) TA3N_FLAG_BF16_MFMA: operands rounded to bf16, products and sums in the wide
+                if ph.bf16 and not (ph.bf16 & 32):      # TA3N_FLAG_BF16_MFMA: operands rounded to bf16, products and sums in the wide
                     # type (TA3N_FLAG_F32_SPLIT, bit 32, is fp32-grade: modelled as exact products like the fp32 MFMA)
                     acc += round_bf16(A) @ round_bf16(Bm).T
                 else:

@@ -4,7 +4,7 @@ two computations moves a first-layer discriminator gradient by ~1/rows of its no
 "ReLU flip".  Here the oracle is forced to the ENGINE's on/off patterns (read back from the workspace: F1, Hf, the TRN tuple
 activations Zr, the relation / video discriminator hidden layers Hr, Hv; oracle/ta3n_oracle.py: _relu_m), so what is left is the
 arithmetic of one step: fp32 summation order.  Every element of every gradient tensor, fp32 MFMA, per-tensor relative L2 <=
-F32_MASKED_GRAD_REL_L2 (ta3n_amd/tolerances.py) - 250 x tighter than the free-running bound; the free-running test stays beside it.
+F32_MASKED_GRAD_REL_L2 (ta3n_amd/tolerances.py) - 25 x tighter than the free-running bound, the median over a step's tensors 2e-5; the free-running test stays beside it.
 Also checked on the way: the hidden activations themselves against the oracle's (they are not outputs of VideoModel.forward, so no
 other test sees them)."""
 import numpy as np
