@@ -35,9 +35,9 @@ bool tile_config_ok(int cfg) {
     // optional ten-thousands digit: register blocking of the bf16-twin kernel (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2)
     const int blk = cfg / 10000;
     cfg %= 10000;
-    const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice); 6 / 7: HALF stages (64 k), 3 / 4 of them
+    const int stages = cfg / 1000;   // optional thousands digit: LDS stages of the bf16 kernel (0 = plan's choice); 5 / 6 / 7: HALF stages (64 k), 2 / 3 / 4 of them
     cfg %= 1000;
-    if (stages == 6 || stages == 7) {
+    if (stages >= 5 && stages <= 7) {
         if (blk < 0 || blk > 5) return false;
         const int rm = blk_rm(blk), rn = blk_rn(blk);
 #define TA3N_CHECK_HS(wm, wn, wk, rm_, rn_, ns) \

@@ -1406,9 +1406,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_tiles(const Task *__re
 // half-stage kernels (MODE 5: bf16 twins in 64-k stages, OperandStream HS): (wm, wn, wk, rm, rn, stages) - the 128x128 and 64x64 tiles
 // and - four waves, no K split inside the workgroup, 3 x 2 / 4 x 2 blocks per wave - the 192x128 and the 256x128 tile (A K-contiguous only)
 #if TA3N_EXPERIMENTS
-#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 2, 2, 4) X(2, 2, 2, 1, 1, 3) X(2, 2, 2, 1, 1, 4) X(2, 2, 1, 3, 2, 3) X(2, 2, 1, 4, 2, 3)
+#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 2, 2, 4) X(2, 2, 2, 1, 1, 3) X(2, 2, 2, 1, 1, 4) X(2, 2, 1, 3, 2, 3) X(2, 2, 1, 4, 2, 3) X(2, 2, 1, 2, 2, 2)
 #else       // default library: three half stages of the 128x128 and the 64x64 tile (four stages and the four-wave tall tiles measured slower)
-#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 1, 1, 3)
+// (2, 2, 1, 2, 2, 2), tile code 35221 (round 5): the 128x128 tile with FOUR waves (64x64 per wave, no K split inside the workgroup) on two
+// half stages - 64 KB of stages, 72 KB of epilogue staging, <= 256 registers: TWO such workgroups per compute unit, where the eight-wave
+// 128x128 tile (219 VGPRs) runs alone - one tile's epilogue and descriptor fetch under the other's K loop
+#define TA3N_HS_CONFIGS(X) X(2, 2, 2, 2, 2, 3) X(2, 2, 2, 1, 1, 3) X(2, 2, 1, 2, 2, 2)
 #endif
 #define TA3N_INSTANTIATE_HS(wm, wn, wk, rm, rn, ns) \
     template __global__ void gemm_tiles<wm, wn, wk, 5, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);

@@ -45,10 +45,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP float4 are demoted to scratch by hipcc)
 
-#ifndef TA3N_HEADS_EARLY_A
-#define TA3N_HEADS_EARLY_A 1
-#endif
-constexpr bool EARLY_A = TA3N_HEADS_EARLY_A != 0;      // 0: stage A's first loads behind the weight burst, as in round 3 (A/B builds)
 constexpr int NBH = 256;           // num_bottleneck of trn-m (models.py:223); thread t <-> channel t
 constexpr int RPW = HEADS_RPW;
 constexpr int WROW = 68;           // padded row of the forward tile [256 n][64 k] (conflict-free b128 row reads)
@@ -139,25 +135,28 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // and stage A - which needs nothing else - waited 4-5 k cycles for them (tools/heads_timing.py).  The tuple range comes by
     // SCALAR loads (their own counter), so the addresses are known at once; at 5 segments (4 relations, 4 waves per video) this is
     // the wave's ONLY relation.
-    const int j_first = __builtin_amdgcn_readfirstlane(sub < NR ? sub : 0);
-    const int tf_lo0 = __builtin_amdgcn_readfirstlane(tf[j_first]), tf_hi0 = __builtin_amdgcn_readfirstlane(tf[j_first + 1]);
-    float a_hr[4] = {0.f, 0.f, 0.f, 0.f}, a_w0[4] = {0.f, 0.f, 0.f, 0.f}, a_w1[4] = {0.f, 0.f, 0.f, 0.f}, a_zr[3][4];
+    // (round 5) ... and inside the loop the NEXT relation's operands are requested before the current one is reduced: at 9 / 12 segments a
+    // wave handles 2-3 relations (8-11 with several videos per workgroup), each of which used to be a dependent round trip of its own.
+    struct RelIn { float hr[4], w0[4], w1[4], zr[3][4], b0, b1; int nt; };
+    auto load_rel = [&](int j, RelIn &o) {
+        const float *__restrict__ W2f = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+        const float *__restrict__ hrf = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
+        const int t_lo = __builtin_amdgcn_readfirstlane(tf[j]), t_hi = __builtin_amdgcn_readfirstlane(tf[j + 1]);
+        o.nt = t_hi - t_lo;
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a_zr[tt][q] = 0.f;
-    if (EARLY_A && have && sub < NR) {
-        const float *__restrict__ W2f = P + g.p_W2_0 + (size_t)j_first * g.p_W2_stride;
-        const float *__restrict__ hrf = wsr + g.o_Hr + ((size_t)b * NR + j_first) * NBH;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a_hr[q] = hrf[q * 64 + lane]; a_w0[q] = W2f[q * 64 + lane]; a_w1[q] = W2f[NBH + q * 64 + lane]; }
+        for (int q = 0; q < 4; ++q) { o.hr[q] = hrf[q * 64 + lane]; o.w0[q] = W2f[q * 64 + lane]; o.w1[q] = W2f[NBH + q * 64 + lane]; }
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)           // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num)
-            if (tf_lo0 + tt < tf_hi0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a_zr[tt][q] = wsr[g.o_Zr + ((size_t)b * NT + tf_lo0 + tt) * NBH + q * 64 + lane];
-            }
-    }
+            for (int q = 0; q < 4; ++q) o.zr[tt][q] = tt < o.nt ? wsr[g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + q * 64 + lane] : 0.f;
+        o.b0 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride];
+        o.b1 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride + 1];
+    };
+    RelIn rel_cur;
+    rel_cur.nt = 0; rel_cur.b0 = rel_cur.b1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rel_cur.hr[q] = rel_cur.w0[q] = rel_cur.w1[q] = 0.f; rel_cur.zr[0][q] = rel_cur.zr[1][q] = rel_cur.zr[2][q] = 0.f; }
+    if (have && sub < NR) load_rel(sub, rel_cur);
     // ---- address-independent loads ----
     f32x4 cw[16];                                  // classifier weights [C][256]: float4 i*256+tid of the flat array
 #pragma unroll
@@ -186,47 +185,32 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // wave handles the tuple range and the output-layer bias
     const float bcv_c = (tid >> 2) < C ? P[g.p_bcv + (tid >> 2)] : 0.f;
     const float bdv_n = P[g.p_bdv + (tid >> 4) + 16 * (tid & 15)];
-    const float b2_00 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride], b2_01 = P[g.p_b2_0 + (size_t)j_first * g.p_b2_stride + 1];
 
     STAMP(0);
     // ---- A: relation logits, attention, R, V, Vd (WPV waves per video, relations dealt round-robin) ----
     {
         float vacc[4] = {0.f, 0.f, 0.f, 0.f};
         if (have) {
+#pragma unroll 1
             for (int j = sub; j < NR; j += WPV) {
-                const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
-                const float *__restrict__ b2 = P + g.p_b2_0 + (size_t)j * g.p_b2_stride;
-                const float *__restrict__ hr = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
+                RelIn rel_nxt = rel_cur;
+                if (j + WPV < NR) load_rel(j + WPV, rel_nxt);      // (wave-uniform) in flight while this relation is reduced
                 float d0 = 0.f, d1 = 0.f;
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (EARLY_A && j == j_first) {         // (wave-uniform) the operands requested at the top of the kernel
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        d0 = fmaf(a_hr[q], a_w0[q], d0);
-                        d1 = fmaf(a_hr[q], a_w1[q], d1);
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt)     // (tuples past the relation's range were left at zero; same order of additions)
-                        if (tf_lo0 + tt < tf_hi0) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) r[q] += a_zr[tt][q];
-                        }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = q * 64 + lane;
-                        const float h = hr[c];
-                        d0 = fmaf(h, W2[c], d0);
-                        d1 = fmaf(h, W2[NBH + c], d1);
-                    }
-                    const int t_lo = tf[j], t_hi = tf[j + 1];
-                    for (int t = t_lo; t < t_hi; ++t) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) r[q] += wsr[g.o_Zr + ((size_t)b * NT + t) * NBH + q * 64 + lane];
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    d0 = fmaf(rel_cur.hr[q], rel_cur.w0[q], d0);
+                    d1 = fmaf(rel_cur.hr[q], rel_cur.w1[q], d1);
                 }
-                d0 = wave_allreduce_sum(d0) + (j == j_first ? b2_00 : b2[0]);
-                d1 = wave_allreduce_sum(d1) + (j == j_first ? b2_01 : b2[1]);
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)     // (tuples past the relation's range were loaded as zeros... and are not added: same additions as before)
+                    if (tt < rel_cur.nt) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[q] += rel_cur.zr[tt][q];
+                    }
+                d0 = wave_allreduce_sum(d0) + rel_cur.b0;
+                d1 = wave_allreduce_sum(d1) + rel_cur.b1;
+                rel_cur = rel_nxt;
                 float w = 0.f;
                 if (attn_on) w = 1.f - soft2(d0, d1).H;
 #pragma unroll
@@ -402,6 +386,26 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     }
     __syncthreads();
 
+    // Stage G's operands for this wave's first relation (output-layer rows, Hr, R - none depends on stages B-F) are requested HERE, in
+    // front of stage F's arithmetic, and inside G the next relation's while the current one is reduced (round 5: G was 5.3 k cycles for
+    // two dependent relations at 9 segments, tools/heads_timing.py).
+    struct RelBack { float w20[4], w21[4], hrv[4], rv[4]; };
+    auto load_back = [&](int j, RelBack &o) {
+        const size_t bj = (size_t)b * NR + j;
+        const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 64 + lane;
+            o.w20[q] = W2[c]; o.w21[q] = W2[NBH + c];
+            o.hrv[q] = wsr[g.o_Hr + bj * NBH + c];
+            o.rv[q] = ws[g.o_R + bj * NBH + c];      // (R: written by THIS thread in stage A)
+        }
+    };
+    RelBack back_cur;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) back_cur.w20[q] = back_cur.w21[q] = back_cur.hrv[q] = back_cur.rv[q] = 0.f;
+    if (have && sub < NR) load_back(sub, back_cur);
+
     // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ) from the register copy of Wdv, one video after the other ----
     // Thread (srow, c16) multiplies its 16 rows n = srow + 16 i into partial sums for its 16 input channels
     // k = 64 kc + 4 c16 + e; the 16 threads that share c16 (one per srow) are added through LDS, thread t <-> channel t.
@@ -439,24 +443,21 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     STAMP(6);
     // ---- G: backward of the attention pooling + relation adversarial loss (WPV waves per video) ----
     if (have) {
-        const float *__restrict__ wsR = ptrs.ws;   // R: written in stage A, only read from here on
         const bool is_src = b < g.Bs;
         const bool valid = video_valid(g.Bs, hy, b);
         const bool adv_rel = (g.flags & TA3N_FLAG_ADV_RELATION) && valid;
         float gv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) gv[q] = smem[S_GVT + vloc * NBH + q * 64 + lane];
+#pragma unroll 1
         for (int j = sub; j < NR; j += WPV) {
             const size_t bj = (size_t)b * NR + j;
-            const float *__restrict__ W2 = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
+            RelBack back_nxt = back_cur;
+            if (j + WPV < NR) load_back(j + WPV, back_nxt);      // (wave-uniform) in flight while this relation is processed
             float w20[4], w21[4], hrv[4], rv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = q * 64 + lane;
-                w20[q] = W2[c]; w21[q] = W2[NBH + c];
-                hrv[q] = wsr[g.o_Hr + bj * NBH + c];
-                rv[q] = wsR[g.o_R + bj * NBH + c];
-            }
+            for (int q = 0; q < 4; ++q) { w20[q] = back_cur.w20[q]; w21[q] = back_cur.w21[q]; hrv[q] = back_cur.hrv[q]; rv[q] = back_cur.rv[q]; }
+            back_cur = back_nxt;
             const float z0 = smem[S_PR + (vloc * 64 + j) * 2], z1 = smem[S_PR + (vloc * 64 + j) * 2 + 1];
             const Soft2 s = soft2(z0, z1);
             float g0 = 0.f, g1 = 0.f;

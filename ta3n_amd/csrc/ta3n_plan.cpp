@@ -151,10 +151,10 @@ struct Builder {
         if (!twins_flags || (p.deny_blocking >> (p.phases.size() & 63)) & 1) blk = 0;
         int forced_stages = forced / 1000;
         forced %= 1000;
-        // thousands digit 6 / 7: HALF stages (64 k per stage: gemm_tiles MODE 5), 3 / 4 of them - for launches that read plain bf16 twins;
+        // thousands digit 5 / 6 / 7: HALF stages (64 k per stage: gemm_tiles MODE 5), 2 / 3 / 4 of them - for launches that read plain bf16 twins;
         // dropped again (with the blocking) where a launch turns out not to (build_plan's retry loop)
         bool half_stages = false;
-        if (forced_stages == 6 || forced_stages == 7) {
+        if (forced_stages >= 5 && forced_stages <= 7) {
             half_stages = twins_flags && !(p.cfg.flags & TA3N_FLAG_F32_SPLIT) && !((p.deny_blocking >> (p.phases.size() & 63)) & 1);
             forced_stages = half_stages ? forced_stages - 3 : 0;
         }

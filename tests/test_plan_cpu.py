@@ -346,7 +346,7 @@ def test_split_k_plan_on_cpu(name, flags):
                     g.check(f"step0/clipped_grad/{k}", raw[k] * coef, 1e-4, 2e-5)
 
 
-@pytest.mark.parametrize("tile", [6222, 36222, 7222, 46221, 56221])
+@pytest.mark.parametrize("tile", [6222, 36222, 35221, 7222, 46221, 56221])
 def test_half_stage_and_tall_tile_plans_on_cpu(tile):
     """Tile codes of round 4 (half-stage kernels 6xxx / 7xxx; 192x128 / 256x128 tiles 46221 / 56221): the plan tiles the same
     contractions - the numpy execution of its task lists gives the default plan's logits and gradients - marks the twin launches as
