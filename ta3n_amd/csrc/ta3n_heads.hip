@@ -103,7 +103,11 @@ __device__ __forceinline__ void write_loss_part(float *smem, float *ws, int o_lo
     }
 }
 
-template <int VPW>
+// PIPE: a wave handles MORE than one relation (n_rel > waves per video; chosen at launch): the next relation's operands are requested while
+// the current one is reduced, and stage G's first relation in front of stage F.  With one relation per wave (the headline shape: 5
+// segments, 4 relations, 4 waves) the bookkeeping of that pipeline cost 0.5 us per launch (profiles/r05_heads_tiles_ab.txt), so the
+// single-relation kernel keeps round 4's sequence: stage A's only relation requested at the top, stage G's inside stage G.
+template <int VPW, bool PIPE>
 __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *smem) {
     using L = Lds<VPW>;
     constexpr int S_W = L::W, S_VD = L::VD, S_HV = L::HV, S_GHV = L::GHV, S_GVT = L::GVT, S_GY = L::GY, S_PR = L::PR, S_GPV = L::GPV, S_Y = L::Y,
@@ -194,7 +198,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll 1
             for (int j = sub; j < NR; j += WPV) {
                 RelIn rel_nxt = rel_cur;
-                if (j + WPV < NR) load_rel(j + WPV, rel_nxt);      // (wave-uniform) in flight while this relation is reduced
+                if (PIPE && j + WPV < NR) load_rel(j + WPV, rel_nxt);      // (wave-uniform) in flight while this relation is reduced
                 float d0 = 0.f, d1 = 0.f;
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -210,7 +214,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                     }
                 d0 = wave_allreduce_sum(d0) + rel_cur.b0;
                 d1 = wave_allreduce_sum(d1) + rel_cur.b1;
-                rel_cur = rel_nxt;
+                if (PIPE) rel_cur = rel_nxt;
                 float w = 0.f;
                 if (attn_on) w = 1.f - soft2(d0, d1).H;
 #pragma unroll
@@ -404,7 +408,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     RelBack back_cur;
 #pragma unroll
     for (int q = 0; q < 4; ++q) back_cur.w20[q] = back_cur.w21[q] = back_cur.hrv[q] = back_cur.rv[q] = 0.f;
-    if (have && sub < NR) load_back(sub, back_cur);
+    if (PIPE && have && sub < NR) load_back(sub, back_cur);
 
     // ---- F: gVt = drop_v'( -beta1 * gHv Wdv + gY Wcv ) from the register copy of Wdv, one video after the other ----
     // Thread (srow, c16) multiplies its 16 rows n = srow + 16 i into partial sums for its 16 input channels
@@ -452,12 +456,13 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll 1
         for (int j = sub; j < NR; j += WPV) {
             const size_t bj = (size_t)b * NR + j;
+            if (!PIPE) load_back(j, back_cur);                           // (one relation per wave: requested here, as in round 4)
             RelBack back_nxt = back_cur;
-            if (j + WPV < NR) load_back(j + WPV, back_nxt);      // (wave-uniform) in flight while this relation is processed
+            if (PIPE && j + WPV < NR) load_back(j + WPV, back_nxt);      // (wave-uniform) in flight while this relation is processed
             float w20[4], w21[4], hrv[4], rv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { w20[q] = back_cur.w20[q]; w21[q] = back_cur.w21[q]; hrv[q] = back_cur.hrv[q]; rv[q] = back_cur.rv[q]; }
-            back_cur = back_nxt;
+            if (PIPE) back_cur = back_nxt;
             const float z0 = smem[S_PR + (vloc * 64 + j) * 2], z1 = smem[S_PR + (vloc * 64 + j) * 2 + 1];
             const Soft2 s = soft2(z0, z1);
             float g0 = 0.f, g1 = 0.f;
@@ -614,25 +619,30 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
     write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hy->gamma, S_LOSS_MIN);
 }
 
-template <int FQ, int VPW>
+template <int FQ, int VPW, bool PIPE>
 __global__ __launch_bounds__(256) void heads_kernel(Geom g, Ptrs ptrs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // the (short) frame workgroups come first in the grid: if the grid does not fit on the chip at once, the workgroups that
     // start late are video workgroups behind finished frame workgroups, not frame workgroups behind finished video ones
     if ((int)blockIdx.x < g.n_frm_wg) frame_wg<FQ>(g, ptrs, smem, (int)blockIdx.x);
-    else video_wg<VPW>(g, ptrs, smem);
+    else video_wg<VPW, PIPE>(g, ptrs, smem);
 }
 
-template <int FQ, int VPW>
-int launch_fq_vpw(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+template <int FQ, int VPW, bool PIPE>
+int launch_fq_vpw_pipe(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     static_assert(8 * FQ * 64 + 16 <= S_LOSS_MIN, "the frame partials must stay below the loss slots");
     static std::once_flag attr_once;   // > 64 KiB of dynamic LDS needs the opt-in once per process; callers may be DataParallel's
                                        // one-thread-per-replica workers (re-entrancy), hence call_once and no plain flag
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ, VPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(heads_kernel<FQ, VPW, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL((heads_kernel<FQ, VPW>), dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)Lds<VPW>::TOTAL * sizeof(float), stream, g, ptrs);
+    hipLaunchKernelGGL((heads_kernel<FQ, VPW, PIPE>), dim3(g.n_vid_wg + g.n_frm_wg), dim3(256), (size_t)Lds<VPW>::TOTAL * sizeof(float), stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int FQ, int VPW>
+int launch_fq_vpw(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
+    return g.n_rel > 4 / VPW ? launch_fq_vpw_pipe<FQ, VPW, true>(g, ptrs, stream) : launch_fq_vpw_pipe<FQ, VPW, false>(g, ptrs, stream);
 }
 
 template <int FQ>

@@ -2,7 +2,7 @@
 engine.autotune_phase_tiles does the measurement: every candidate tile for every launch, HIP events on the launch stream).
 
 A tile code is WM*100 + WN*10 + WK (waves of the workgroup in M, N and the in-workgroup K split), + 1000 * LDS stages for the
-bf16 kernels (6000 / 7000: three / four HALF stages of 64 k, bf16-twin kernel), + 10000 / 20000 / 30000 for 2 row / 2 column / 2 x 2
+bf16 kernels (5000 / 6000 / 7000: two / three / four HALF stages of 64 k, bf16-twin kernel), + 10000 / 20000 / 30000 for 2 row / 2 column / 2 x 2
 32x32 blocks per wave (bf16-twin kernel: 128x64, 64x128, 128x128 tiles; 46221 / 56221: 192x128 / 256x128, four waves, half stages).  Entries 0-9 are the forward / loss / backward launches of the unfused sequence, 10-15 the six GEMM launches of
 the fused step (ta3n_train_step); 0 = the plan builder's own choice (ta3n_plan.cpp: add_gemm_phase).
 
@@ -30,7 +30,11 @@ TUNED = {
     # 432.4 us per forward+backward step on two boxes - and then under bench.py's protocol, the pipelined step whose first launch also
     # carries the update's side workgroups: 0.492-0.504 ms against 0.493-0.496 for 32222, three alternating processes each.  Not adopted:
     # profiles/r04_half_stage_ab.txt.)
-    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32222, 32222, 2222, 2222, 32222, 3222],      # (in sequence: 477.4 -> 473.3 us)
+    # (round 5: entry 10 on 35221 - the 128x128 tile with FOUR waves on two half stages, two workgroups per compute unit: the launch's 288
+    # tiles are resident at once instead of in two rounds of 256 + 32.  Under bench.py's protocol, alternating: launch 70.3 -> 53.0 us, step
+    # 0.4658 / 0.4680 -> 0.4556 / 0.4604 ms; the same tile on launches 11 and 14 measured slower (74.6 -> 82.0, 129.5 -> 147.5 us):
+    # profiles/r05_heads_tiles_ab.txt)
+    (1024, 9, 2048, 512, "bf16"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 35221, 32222, 2222, 2222, 32222, 3222],
     # BASELINE configs[4] (128 + 128 videos, 12 segments, 1024-d, two streams): NO entry - the plan's heuristic.  Round 3 shipped a list
     # chosen on a single-stream 200-step sweep (277.2 -> 271.7 us, one run each); under the protocol the configuration is judged by
     # (two concurrent streams, 20 steps after 5, five processes each: profiles/r04_config5_protocol.txt) it measures 0.516-0.523 ms
