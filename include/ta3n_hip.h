@@ -120,7 +120,10 @@ typedef struct {
                               * frame features + weight gradients -> shared-FC weight gradient - with tile-level hand-offs inside the launch
                               * (a producer tile publishes its stores and bumps a counter, a consumer tile polls the counters of exactly
                               * the tiles it reads; derived from the tiles' read / write spans).  5 launches per step instead of 8, the
-                              * same tiles and arithmetic: bit-identical results.  0: one launch per level. */
+                              * same tiles and arithmetic: bit-identical results.  0: one launch per level.
+                              * EXPERIMENTS BUILD ONLY (round 5; measured 144-190 us against 112): the plan is built either way (and
+                              * checked on the CPU), launching it on the default library returns TA3N_ERR_INVALID with a message naming
+                              * the build flag -DTA3N_EXPERIMENTS=1.  The same holds for split_k and ta3n_train_steps_fused_update. */
     int32_t cost_model;      /* how the plan orders a launch's tiles over the 8 XCD queues: 0 = by the length of their K loops; 1 = by an
                               * estimate of their TIME (fixed per-tile overhead + K, weight-gradient tiles weighted up).  Ordering only:
                               * results are bit-identical. */
@@ -129,7 +132,7 @@ typedef struct {
                               * the tile's K segments.  Each publishes its partial tile (write-through stores) and takes a ticket; the
                               * second to arrive adds the other's partial to its own and runs the epilogue.  a + b = b + a: the result
                               * does not depend on who arrives last; it differs from the unsplit tile by fp32 summation order.
-                              * 0: one workgroup per tile. */
+                              * 0: one workgroup per tile.  Experiments build only (measured 114.8 us against 113.6). */
     int32_t reserved[1];
 } ta3n_config;
 
