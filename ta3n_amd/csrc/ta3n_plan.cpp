@@ -1178,7 +1178,10 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // 512+512 x 9 (configs[3]): the video workgroups alone fill the chip whatever the packing - 4 per workgroup 79.5 -> 79.5 us on one box and
     // +40 us per step on another, 2 per workgroup -7 us on the launch and +6 on the step: left at one; 128+74 x 5 (headline): 2 per
     // workgroup 15.5 -> 20.1 us (every video has a compute unit already).
-    g.heads_vpw = (B > 224 && B <= 448) ? 2 : 1;
+    // Round 5: with the relation loops pipelined (heads_kernel PIPE: a wave requests its next relation's operands while it reduces the current
+    // one) a wave that handles twice the relations no longer takes twice as long: 512+512 x 9 on two videos per workgroup 81.0 -> 65.8 us on
+    // the launch, 0.457 -> 0.441 ms on the step (two alternating repeats, profiles/r05_heads_vpw_tune.txt) - two per workgroup from 225 videos up.
+    g.heads_vpw = B > 224 ? 2 : 1;
     if (const char *e = std::getenv("TA3N_HEADS_VPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) g.heads_vpw = v; }
     g.n_vid_wg = (B + g.heads_vpw - 1) / g.heads_vpw;
     g.heads_rpw = HEADS_RPW;      // all workgroups of the heads kernel resident at once if the chip (256 CUs) can hold them
