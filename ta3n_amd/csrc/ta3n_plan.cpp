@@ -1182,7 +1182,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // one) a wave that handles twice the relations no longer takes twice as long: 512+512 x 9 on two videos per workgroup 81.0 -> 65.8 us on
     // the launch, 0.457 -> 0.441 ms on the step (two alternating repeats, profiles/r05_heads_vpw_tune.txt) - two per workgroup from 225 videos up.
     g.heads_vpw = B > 224 ? 2 : 1;
-    if (const char *e = std::getenv("TA3N_HEADS_VPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) g.heads_vpw = v; }
+    // (A/B override: 1 or 2.  Four per workgroup - never a plan's choice - faulted on the round-5 build at 512+512 x 9 ("memory access fault",
+    // gpurun_out of call 5) and is no longer accepted; the kernel template keeps the case.)
+    if (const char *e = std::getenv("TA3N_HEADS_VPW")) { const int v = std::atoi(e); if (v == 1 || v == 2) g.heads_vpw = v; }
     g.n_vid_wg = (B + g.heads_vpw - 1) / g.heads_vpw;
     g.heads_rpw = HEADS_RPW;      // all workgroups of the heads kernel resident at once if the chip (256 CUs) can hold them
     while (g.n_vid_wg + (BT + g.heads_rpw - 1) / g.heads_rpw > 256 && g.heads_rpw < 8 * HEADS_RPW) g.heads_rpw *= 2;

@@ -156,7 +156,10 @@ def test_oracle_parity_with_flags_and_ragged_batches():
     for (Bs, Bt, T, place, fused) in [(1, 1, 3, ("Y", "Y", "Y"), False), (33, 2, 4, ("Y", "Y", "N"), False),
                                       (7, 40, 5, ("Y", "Y", "Y"), False), (1, 1, 3, ("Y", "Y", "Y"), True),
                                       (33, 2, 4, ("Y", "Y", "N"), True), (7, 40, 5, ("Y", "Y", "Y"), True),
-                                      (5, 6, 2, ("Y", "Y", "Y"), True)]:
+                                      (5, 6, 2, ("Y", "Y", "Y"), True),
+                                      # > 224 videos: two videos per heads workgroup, an ODD count (the last workgroup holds one), 6 / 2 relations
+                                      # (more / fewer than the two waves a video gets: pipelined / plain relation loops)
+                                      (150, 77, 7, ("Y", "Y", "Y"), True), (97, 130, 3, ("Y", "Y", "Y"), True)]:
         cfg = orc.Config(num_class=7, num_segments=T, feature_dim=512, fc_dim=96, dropout_i=0.0, dropout_v=0.0,
                          place_adv=place)
         from ta3n_amd.engine import TrainEngine, flags_from_options
