@@ -471,6 +471,9 @@ def main():
                 g = torch.Generator(device="cpu").manual_seed(4321 + rank)
                 nf = torch.randint(16, 48, (640,), generator=g)
                 rows = torch.randn(int(nf.sum()), SH["D"], device=dev).abs_()
+                store_bf16 = bool(bf16 and twins)      # the bf16 arithmetic reads the input's bf16 twin only: a store packed in bf16 (feature_store.pack(dtype="bf16"))
+                if store_bf16:                         # feeds it directly - the same operands (RNE of the fp32 features), half the gather bytes
+                    rows = rows.to(torch.bfloat16).view(torch.int16)
                 store = FeatureStore.from_tensors(rows, nf.to(dev), torch.randint(0, SH["C"], (640,), generator=g).to(dev))
                 ids = [torch.randint(0, 640, (warmup + steps, n_), generator=g, dtype=torch.int32).to(dev) for n_ in (SH["Bs"], SH["Bt"])]
                 eng.train_steps(sched(warmup + steps, warmup), feeds=((store, ids[0][:warmup]), (store, ids[1][:warmup])))
@@ -487,7 +490,7 @@ def main():
                     e_f = t.item()
                 res["fresh_batch"] = {"ms_per_step": 1e3 * e_f / steps, "value": (SH["Bs"] + SH["Bt"]) * world * steps / e_f,
                                       "what": "the timed loop repeated with a new batch per step, gathered on the device from a packed feature store "
-                                              "resident in HBM (640 synthetic videos, 16-47 frames each; ta3n_feed inside the same ta3n_train_steps call)"}
+                                              "resident in HBM (640 synthetic videos, 16-47 frames each, packed as " + ("bf16: the gather writes the input's bf16 twin" if store_bf16 else "fp32") + "; ta3n_feed inside the same ta3n_train_steps call)"}
                 del store, rows, ids
             except Exception as ex:      # noqa: BLE001 - an extra figure must not cost the line (nor, at N > 1, the scaling run)
                 res["fresh_batch_error"] = f"{type(ex).__name__}: {ex}"[:200]

@@ -57,7 +57,7 @@ def test_own_main_trains_logs_checkpoints_and_resumes(tmp_path, name, flags):
     # decimals (measured on the MI355X: 1.6097 -> 1.6097 - six steps at lr 0.03 from the reference's 0.001-std classifier
     # initialisation move ln 5 in the fifth decimal; that the step LEARNS is tests/test_gpu_training_equivalence.py's job)
     ok = {"configs0": abs(last - first) < 5e-3, "ta3n_all_da": last == last and last < 2 * first,
-          "ta3n_nodrop": last <= first}.get(name, last < first + 0.05)
+          "ta3n_nodrop": last <= first + 2e-4}.get(name, last < first + 0.05)      # (2e-4: two units of the log's last decimal)
     assert ok, (first, last)
     if name != "configs0":
         assert "loss_a" in train_lines[-1]
