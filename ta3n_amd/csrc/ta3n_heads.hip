@@ -84,8 +84,25 @@ constexpr int S_LOSS_MIN = Lds<1>::LOSS;                        // (the frame wo
 #define STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ bool video_valid(int Bs, const Hyper *hy, int b) {
-    return b < Bs ? (b < hy->valid_source) : (b - Bs < hy->valid_target);
+__device__ __forceinline__ bool video_valid(int Bs, int valid_source, int valid_target, int b) {
+    return b < Bs ? (b < valid_source) : (b - Bs < valid_target);
+}
+
+// The per-step scalars a workgroup uses, read ONCE at its top.  `hy` points into the workspace the kernel also stores to, so a read of
+// hy->x inside a loop is re-issued after every store - and each such read came with s_waitcnt vmcnt(0), i.e. it also waited for the
+// operands requested ahead for the NEXT relation / row (found in the ISA in round 5: one dependent round trip per relation in stage G
+// and per frame row in the frame workgroups).
+struct StepScalars {
+    int valid_source, valid_target;
+    float inv_n_cls, inv_n_rel, inv_n_vid, inv_n_frm, inv_n_ent, gamma, beta1, p_drop_v;
+    uint32_t seed_v;
+};
+__device__ __forceinline__ StepScalars step_scalars(const Hyper *__restrict__ hy) {
+    StepScalars h;
+    h.valid_source = hy->valid_source; h.valid_target = hy->valid_target;
+    h.inv_n_cls = hy->inv_n_cls; h.inv_n_rel = hy->inv_n_rel; h.inv_n_vid = hy->inv_n_vid; h.inv_n_frm = hy->inv_n_frm;
+    h.inv_n_ent = hy->inv_n_ent; h.gamma = hy->gamma; h.beta1 = hy->beta[1]; h.p_drop_v = hy->p_drop_v; h.seed_v = hy->seed_v;
+    return h;
 }
 
 // this workgroup's loss partials -> ws["loss_part"][wg][8] = {total, cls, rel, vid, frm, ent, 0, 0}
@@ -128,8 +145,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const bool lead = sub == 0;                    // the wave that does the video's un-splittable parts (logits, losses)
     const bool attn_on = (g.flags & TA3N_FLAG_TRANS_ATTN) != 0;
     const bool train = hy->train != 0;
+    const StepScalars hs = step_scalars(hy);
     const float inv_keep_v = hyper_scale(hy, SK_INV_KEEP_V);
-    const bool drop_v = train && hy->p_drop_v > 0.f;
+    const bool drop_v = train && hs.p_drop_v > 0.f;
     const float *__restrict__ Wdv = P + g.p_Wdv;
     const float *__restrict__ Wcv = P + g.p_Wcv;
     float l_cls = 0.f, l_rel = 0.f, l_vid = 0.f, l_ent = 0.f;
@@ -141,18 +159,30 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // the wave's ONLY relation.
     // (round 5) ... and inside the loop the NEXT relation's operands are requested before the current one is reduced: at 9 / 12 segments a
     // wave handles 2-3 relations (8-11 with several videos per workgroup), each of which used to be a dependent round trip of its own.
+    // The tuple ranges of ALL relations come with ONE vector load at the very top (lane l holds tuple_first[l]; n_rel + 1 <= 64) and are
+    // read with v_readlane afterwards: a load of tuple_first[j] inside load_rel made the compiler wait for EVERYTHING outstanding
+    // (s_waitcnt vmcnt(0): the counter is in order) before it could form the next relation's addresses - a full round trip per relation
+    // at the top of each loop iteration (found in the ISA in round 5).
+    const int tfv = lane <= NR ? tf[lane] : 0;
     struct RelIn { float hr[4], w0[4], w1[4], zr[3][4], b0, b1; int nt; };
     auto load_rel = [&](int j, RelIn &o) {
         const float *__restrict__ W2f = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
         const float *__restrict__ hrf = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
-        const int t_lo = __builtin_amdgcn_readfirstlane(tf[j]), t_hi = __builtin_amdgcn_readfirstlane(tf[j + 1]);
+        const int ju = __builtin_amdgcn_readfirstlane(j);
+        const int t_lo = __builtin_amdgcn_readlane(tfv, ju), t_hi = __builtin_amdgcn_readlane(tfv, ju + 1);
         o.nt = t_hi - t_lo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o.hr[q] = hrf[q * 64 + lane]; o.w0[q] = W2f[q * 64 + lane]; o.w1[q] = W2f[NBH + q * 64 + lane]; }
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt)           // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num)
+        for (int tt = 0; tt < 3; ++tt) {         // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num); a tuple past the
+            // range is read from the block of zeros (the test selects the ADDRESS: no branch between the loads, nothing for the
+            // compiler to hang the consumer on - it used to fuse `if (tt < nt) load` with `if (tt < nt) add` and wait right there)
+            const bool on = tt < o.nt;
+            const float *__restrict__ row = on ? wsr + g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + lane : wsr + g.o_zeros + lane;
+            const int qs = on ? 64 : 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o.zr[tt][q] = tt < o.nt ? wsr[g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + q * 64 + lane] : 0.f;
+            for (int q = 0; q < 4; ++q) o.zr[tt][q] = row[q * qs];
+        }
         o.b0 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride];
         o.b1 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride + 1];
     };
@@ -183,7 +213,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     for (int q = 0; q < 4; ++q) { wc0[q] = Wcdv[q * 64 + lane]; wc1[q] = Wcdv[NBH + q * 64 + lane]; }
     const float wct0 = Wcdv[tid], wct1 = Wcdv[NBH + tid];
     const float bcdv0 = P[g.p_bcdv], bcdv1 = P[g.p_bcdv + 1];
-    const int label = (have && b < g.Bs) ? labels[b] : -1;
+    // (a SCALAR load: as a vector load at the end of the burst above, its consumer `lane == label` - which the compiler hoists up here to
+    // keep the result as a lane mask - waited for the whole 256 KB weight burst with s_waitcnt vmcnt(0) before stage A could start)
+    const int label = (have && b < g.Bs) ? labels[__builtin_amdgcn_readfirstlane(b)] : -1;
     // small operands of the later stages, requested now as well (each used to cost its stage an exposed round trip):
     // the class bias of this thread's class, the video-discriminator bias of its channel, and for the first relation this
     // wave handles the tuple range and the output-layer bias
@@ -207,11 +239,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                     d1 = fmaf(rel_cur.hr[q], rel_cur.w1[q], d1);
                 }
 #pragma unroll
-                for (int tt = 0; tt < 3; ++tt)     // (tuples past the relation's range were loaded as zeros... and are not added: same additions as before)
-                    if (tt < rel_cur.nt) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) r[q] += rel_cur.zr[tt][q];
-                    }
+                for (int tt = 0; tt < 3; ++tt)     // (tuples past the relation's range were loaded as +0: r + 0 = r exactly, r being a sum of
+#pragma unroll                                     // ReLU outputs - the same values as adding only the tuples in range)
+                    for (int q = 0; q < 4; ++q) r[q] += rel_cur.zr[tt][q];
                 d0 = wave_allreduce_sum(d0) + rel_cur.b0;
                 d1 = wave_allreduce_sum(d1) + rel_cur.b1;
                 if (PIPE) rel_cur = rel_nxt;
@@ -241,7 +271,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 #pragma unroll
         for (int s_ = 0; s_ < WPV; ++s_) val += smem[S_VPART + (v * WPV + s_) * NBH + tid];
         float vd = val;
-        if (drop_v) vd = val * keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v) * inv_keep_v;
+        if (drop_v) vd = val * keep_mask(hs.seed_v, (uint32_t)((b0 + v) * NBH + tid), hs.p_drop_v) * inv_keep_v;
         if (v < nv) {
             ws[g.o_V + (size_t)(b0 + v) * NBH + tid] = val;
             ws[g.o_Vd + (size_t)(b0 + v) * NBH + tid] = vd;
@@ -342,25 +372,25 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         float gy = 0.f, g0 = 0.f, g1 = 0.f;
         if (have && lead) {
             const bool is_src = b < g.Bs;
-            const bool valid = video_valid(g.Bs, hy, b);
+            const bool valid = video_valid(g.Bs, hs.valid_source, hs.valid_target, b);
             const bool cls_on = is_src && valid;
             const Soft2 s = soft2(d0, d1);
             const bool ent_on = (g.flags & TA3N_FLAG_ATTN_ENTROPY) && valid;
-            const float ce = hy->gamma * hy->inv_n_ent;
+            const float ce = hs.gamma * hs.inv_n_ent;
             if (cls_on) {                                                              // main.py:446
-                gy = (pr - (lane == label ? 1.f : 0.f)) * hy->inv_n_cls;
-                if (lane == label) l_cls = -lp * hy->inv_n_cls;
+                gy = (pr - (lane == label ? 1.f : 0.f)) * hs.inv_n_cls;
+                if (lane == label) l_cls = -lp * hs.inv_n_cls;
             }
             if (ent_on) {                                                              // loss.py:20-24
                 gy += ce * (1.f + s.H) * (-pr * (lp + Hc));                            // dH/dz_i = -p_i (log p_i + H)
-                if (lane == 0) l_ent = (1.f + s.H) * Hc * hy->inv_n_ent;
+                if (lane == 0) l_ent = (1.f + s.H) * Hc * hs.inv_n_ent;
             }
             if (lane >= C) gy = 0.f;
             if ((g.flags & TA3N_FLAG_ADV_VIDEO) && valid) {                           // main.py:508-538, l = 1
                 const int d = is_src ? 0 : 1;
-                if (lane == 0) l_vid = -(d ? s.lp1 : s.lp0) * hy->inv_n_vid;
-                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_vid;
-                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_vid;
+                if (lane == 0) l_vid = -(d ? s.lp1 : s.lp0) * hs.inv_n_vid;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hs.inv_n_vid;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hs.inv_n_vid;
             }
             if (ent_on) {
                 g0 += ce * Hc * (-s.p0 * (s.lp0 + s.H));
@@ -432,11 +462,11 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc += smem[S_FPART + r * NBH + tid];
-        acc *= -hy->beta[1];
+        acc *= -hs.beta1;
         // classifier weights column-wise: the [C][TROW] tile staged for stage B is still in place
         for (int c = 0; c < C; ++c) acc = fmaf(smem[S_GY + v * 64 + c], smem[S_W + c * TROW + tid], acc);
         float gv = acc;
-        if (drop_v) gv *= keep_mask(hy->seed_v, (uint32_t)((b0 + v) * NBH + tid), hy->p_drop_v);
+        if (drop_v) gv *= keep_mask(hs.seed_v, (uint32_t)((b0 + v) * NBH + tid), hs.p_drop_v);
         gv *= inv_keep_v;
         smem[S_GVT + v * NBH + tid] = gv;
         if (v < nv) ws[g.o_gVt + (size_t)(b0 + v) * NBH + tid] = gv;
@@ -448,7 +478,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // ---- G: backward of the attention pooling + relation adversarial loss (WPV waves per video) ----
     if (have) {
         const bool is_src = b < g.Bs;
-        const bool valid = video_valid(g.Bs, hy, b);
+        const bool valid = video_valid(g.Bs, hs.valid_source, hs.valid_target, b);
         const bool adv_rel = (g.flags & TA3N_FLAG_ADV_RELATION) && valid;
         float gv[4];
 #pragma unroll
@@ -468,9 +498,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
             float g0 = 0.f, g1 = 0.f;
             if (adv_rel) {                                                             // main.py:508-538, l = 0
                 const int d = is_src ? 0 : 1;
-                if (lane == 0) l_rel += -(d ? s.lp1 : s.lp0) * hy->inv_n_rel;
-                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_rel;
-                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_rel;
+                if (lane == 0) l_rel += -(d ? s.lp1 : s.lp0) * hs.inv_n_rel;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hs.inv_n_rel;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hs.inv_n_rel;
             }
             if (lane == 0) { ws[g.o_gPr + bj * 2] = g0; ws[g.o_gPr + bj * 2 + 1] = g1; }
             float w1 = 1.f;
@@ -506,7 +536,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
         }
     }
     STAMP(7);
-    write_loss_part(smem, ws, g.o_loss_part, (int)blockIdx.x - g.n_frm_wg, hy->gamma, S_LOSS);
+    write_loss_part(smem, ws, g.o_loss_part, (int)blockIdx.x - g.n_frm_wg, hs.gamma, S_LOSS);
     STAMP(8);
 }
 
@@ -519,6 +549,7 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
     const float *__restrict__ wsr = ptrs.ws;       // Hf is only read
     const float *__restrict__ P = ptrs.p;
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
+    const StepScalars hs = step_scalars(hy);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int F = g.F, T = g.T, BT = g.B * g.T;
     const float *__restrict__ W0 = P + g.p_Wcd, *__restrict__ W1 = W0 + F;
@@ -564,14 +595,14 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
         const int r = row0 + wv + 4 * i;
         if (r < BT) {   // wave-uniform
             const int b = r / T;
-            const bool valid = video_valid(g.Bs, hy, b);
+            const bool valid = video_valid(g.Bs, hs.valid_source, hs.valid_target, b);
             float g0 = 0.f, g1 = 0.f;
             if (adv && valid) {                                                        // main.py:508-538, l = 2
                 const Soft2 s = soft2(d0[i], d1[i]);
                 const int d = b < g.Bs ? 0 : 1;
-                l_frm += -(d ? s.lp1 : s.lp0) * hy->inv_n_frm;
-                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hy->inv_n_frm;
-                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hy->inv_n_frm;
+                l_frm += -(d ? s.lp1 : s.lp0) * hs.inv_n_frm;
+                g0 = (s.p0 - (d == 0 ? 1.f : 0.f)) * hs.inv_n_frm;
+                g1 = (s.p1 - (d == 1 ? 1.f : 0.f)) * hs.inv_n_frm;
             }
             if (lane == 0) {
                 ws[g.o_Pf + (size_t)r * 2] = d0[i]; ws[g.o_Pf + (size_t)r * 2 + 1] = d1[i];
@@ -616,7 +647,7 @@ __device__ __forceinline__ void frame_wg(const Geom g, const Ptrs ptrs, float *s
     }
     if (tid < 2)
         ws[g.o_fh_bpart + (size_t)wg * 2 + tid] = (smem[8 * FP + tid] + smem[8 * FP + 2 + tid]) + (smem[8 * FP + 4 + tid] + smem[8 * FP + 6 + tid]);
-    write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hy->gamma, S_LOSS_MIN);
+    write_loss_part(smem, ws, g.o_loss_part, g.n_vid_wg + wg, hs.gamma, S_LOSS_MIN);
 }
 
 template <int FQ, int VPW, bool PIPE>
