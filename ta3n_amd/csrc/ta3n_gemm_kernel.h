@@ -749,7 +749,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         if (side.params == nullptr) return;   // launched without an update to apply (ta3n_time_phases)
         float part = 0.f;
         if (tid < 256)
-            for (int k = tid; k < side.norm_n; k += 256) part += ptrs.ws[side.norm_off + k];
+            part = strided_partial_sum(ptrs.ws + side.norm_off, side.norm_n, tid, 256);
         part = wave_allreduce_sum(part);
         if (lane == 0 && wave < 4) lds[wave] = part;
         __syncthreads();
@@ -792,7 +792,21 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         float sq = 0.f;
         for (int n = t.n0 + tid; n < t.n_valid; n += NT) {
             float v = 0.f;
-            for (int r = 0; r < t.pad[1]; ++r) v += src[(size_t)r * t.pad[2] + n];
+            // rows added in order, EIGHT loads in flight per round trip (the plain loop compiled to load - s_waitcnt vmcnt(0) - add per
+            // row: 32 - 72 dependent L2 round trips, longer than every tile of the launch this task rides in; ISA pass of round 5)
+            const float *__restrict__ col = src + n;
+            const int R = t.pad[1];
+            const size_t ld = (size_t)t.pad[2];
+            int r = 0;
+#pragma unroll 1
+            for (; r + 8 <= R; r += 8) {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = col[(size_t)(r + i) * ld];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v += x[i];
+            }
+            for (; r < R; ++r) v += col[(size_t)r * ld];
             dst[n] = v;
             sq = fmaf(v, v, sq);
             if (OPT && side.p_new != nullptr && t.c_base == BASE_G) {     // fused update of these parameters (see the tile epilogue)

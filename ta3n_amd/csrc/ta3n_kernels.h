@@ -83,6 +83,28 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     v += dpp_move<0x143, 0xC>(0.f, v);   // row_bcast:31 into rows 2 and 3: lanes 48-63 hold the total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// This thread's share of  sum_{k < n} src[k]  (elements tid, tid + stride, ...), added in exactly the order of the plain loop
+//     for (k = tid; k < n; k += stride) acc += src[k];
+// but with EIGHT loads in flight per round trip: the plain loop compiled to load - s_waitcnt vmcnt(0) - add per iteration, i.e. n / stride
+// dependent L2 round trips (five to twelve for the ~1 200 - 3 000 gradient-norm partials of a step) at the top of the optimiser launch
+// that opens every step and of each of the update's side workgroups (ISA pass of round 5).  Elements past n are added as + 0.f:
+// the partial sums are sums of squares (>= +0), so acc + 0 = acc bit for bit.
+__device__ __forceinline__ float strided_partial_sum(const float *__restrict__ src, int n, int tid, int stride) {
+    float acc = 0.f;
+#pragma unroll 1
+    for (int k0 = tid; k0 < n; k0 += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + i * stride;
+            v[i] = k < n ? src[k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float wave_allreduce_max(float v) {
     const float ninf = -INFINITY;
     v = fmaxf(v, dpp_move<0xB1, 0xF>(ninf, v));

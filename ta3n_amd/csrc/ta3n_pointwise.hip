@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(Geom g, float *__restrict__ pa
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, gr = p;
     if (i < n4) { p = p4[i]; m = m4[i]; gr = g4[i]; }
     float acc = 0.f;
-    for (int k = threadIdx.x; k < norm_n; k += blockDim.x) acc += ws[norm_off + k];
+    acc = strided_partial_sum(ws + norm_off, norm_n, (int)threadIdx.x, (int)blockDim.x);
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (hy->clip > 0.f) coef = fminf(hy->clip / (total + 1e-6f), 1.f);
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, gr = p;
     if (i < i1) { p = p4[i]; m = m4[i]; gr = g4[i]; }      // in flight while the norm partials are added up
     float acc = 0.f;
-    for (int k = threadIdx.x; k < norm_n; k += blockDim.x) acc += ws[norm_off + k];
+    acc = strided_partial_sum(ws + norm_off, norm_n, (int)threadIdx.x, (int)blockDim.x);
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void sgd_fixup_kernel(Geom g, float *__restric
                                                         float lr, float mu, float clip, Hyper next, int has_next) {
     __shared__ float red[8];
     float acc = 0.f;
-    for (int k = threadIdx.x; k < g.n_sumsq; k += blockDim.x) acc += ws[g.o_sumsq + k];
+    acc = strided_partial_sum(ws + g.o_sumsq, g.n_sumsq, (int)threadIdx.x, (int)blockDim.x);
     const float total = sqrtf(block_sum(acc, red));
     float coef = 1.f;
     if (clip > 0.f) coef = fminf(clip / (total + 1e-6f), 1.f);
