@@ -329,9 +329,13 @@ struct Builder {
                 for (int x = 0; x < NX; ++x) local.push_back(d < q[x].size() ? q[x][d] : nop);
             while (!local.empty() && local.back().seg_count == 0) local.pop_back();
         }
-        if (sum8[0] >= 0 && !local.empty()) {   // local[0] is a real task: queue 0 receives the heaviest panel
-            local[0].epi |= EPI_SUMROWS8;
-            local[0].pad[0] = sum8[0]; local[0].pad[1] = sum8[1]; local[0].pad[2] = sum8[2];
+        if (sum8[0] >= 0 && !local.empty()) {
+            // on the LAST task of the list - a real tile (trailing padding was popped) and the launch's lightest, so the side job's
+            // dependent loads sit under the other tiles.  (Until round 5 it rode on local[0], the HEAVIEST tile: ~1.5 us on the critical
+            // path of the relation-level backward launch.)
+            Task &host = local.back();
+            host.epi |= EPI_SUMROWS8;
+            host.pad[0] = sum8[0]; host.pad[1] = sum8[1]; host.pad[2] = sum8[2];
             sum8[0] = -1;
         }
         // the short side tasks go right behind the first tile: they finish under the tiles instead of extending the launch's tail
