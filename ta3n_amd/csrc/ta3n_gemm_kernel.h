@@ -759,46 +759,28 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
         float4 *__restrict__ p4 = reinterpret_cast<float4 *>(side.params);
         float4 *__restrict__ m4 = reinterpret_cast<float4 *>(side.momentum);
         const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(ptrs.g);
-        // Four strides' worth of (p, m, g) are requested before the first is updated: the plain loop compiled to load - s_waitcnt vmcnt(0) -
-        // update - store per iteration, i.e. one dependent round trip to the optimiser state per 512 float4 (4-5 per side workgroup at the
-        // headline shape: the ~5 us by which the first GEMM launch is longer with the update aboard than alone; ISA pass of round 5).
-        // Element-wise independent work: the same arithmetic per element, bit-identical results.
-        constexpr int SGU = 6;
-        const int i_end = t.pad[1];
-#pragma unroll 1
-        for (int i0 = t.pad[0] + tid; i0 < i_end; i0 += SGU * NT) {
-            float4 pl[SGU], ml[SGU], gl[SGU];
+        for (int i = t.pad[0] + tid; i < t.pad[1]; i += NT) {
+            const float4 p = p4[i], m = m4[i], gr = g4[i];
+            float gg[4] = {gr.x, gr.y, gr.z, gr.w}, pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-            for (int u = 0; u < SGU; ++u) {
-                const int i = i0 + u * NT;
-                if (i < i_end) { pl[u] = p4[i]; ml[u] = m4[i]; gl[u] = g4[i]; }
+            for (int e = 0; e < 4; ++e) {
+                float d = fmaf(side.wd, pp[e], gg[e] * coef);
+                mm[e] = fmaf(side.mu, mm[e], d);
+                d = fmaf(side.mu, mm[e], d);
+                pp[e] = fmaf(-side.lr, d, pp[e]);
             }
-#pragma unroll
-            for (int u = 0; u < SGU; ++u) {
-                const int i = i0 + u * NT;
-                if (i >= i_end) break;
-                const float4 p = pl[u], m = ml[u], gr = gl[u];
-                float gg[4] = {gr.x, gr.y, gr.z, gr.w}, pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d = fmaf(side.wd, pp[e], gg[e] * coef);
-                    mm[e] = fmaf(side.mu, mm[e], d);
-                    d = fmaf(side.mu, mm[e], d);
-                    pp[e] = fmaf(-side.lr, d, pp[e]);
-                }
-                if (pub) st_pub(reinterpret_cast<float *>(p4 + i), f32x4{pp[0], pp[1], pp[2], pp[3]});
-                else p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-                m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-                if (side.p16_off >= 0) {
-                    uint2 *tw = reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off) + i;
-                    const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
-                    if (pub) st_pub(tw, u32x2{h0, h1});
-                    else *tw = make_uint2(h0, h1);
-                    if ((BF == 3 || BF == 4) && pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
-                        const u32x2 l = {pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1)};
-                        if (pub) st_pub(tw + pair_delta / 2, l);
-                        else tw[pair_delta / 2] = make_uint2(l[0], l[1]);
-                    }
+            if (pub) st_pub(reinterpret_cast<float *>(p4 + i), f32x4{pp[0], pp[1], pp[2], pp[3]});
+            else p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            if (side.p16_off >= 0) {
+                uint2 *tw = reinterpret_cast<uint2 *>(ptrs.ws + side.p16_off) + i;
+                const unsigned h0 = pack_bf16(pp[0], pp[1]), h1 = pack_bf16(pp[2], pp[3]);
+                if (pub) st_pub(tw, u32x2{h0, h1});
+                else *tw = make_uint2(h0, h1);
+                if ((BF == 3 || BF == 4) && pair_delta) {       // pair twins: the lo plane (uint2 = 2 floats)
+                    const u32x2 l = {pack_bf16_lo(pp[0], pp[1], h0), pack_bf16_lo(pp[2], pp[3], h1)};
+                    if (pub) st_pub(tw + pair_delta / 2, l);
+                    else tw[pair_delta / 2] = make_uint2(l[0], l[1]);
                 }
             }
         }
