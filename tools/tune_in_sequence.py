@@ -17,7 +17,7 @@ base = tuned_phase_tiles(Bs + Bt, T, D, F, arith == "bf16", arith != "f32", spli
 stages = (2, 3) if arith != "f32" else (0,)
 CANDS = [s * 1000 + c for c in (114, 118, 212, 122, 214, 124, 221, 222) for s in stages]
 if arith == "bf16" and Bs + Bt >= 512:      # register-blocked tiles of the twin kernel pay at the larger shapes
-    CANDS = [c for c in CANDS if c % 1000 in (214, 124, 221, 222)] + [12222, 13222, 22222, 23222, 32222, 32221]
+    CANDS = [c for c in CANDS if c % 1000 in (214, 124, 221, 222)] + [12222, 13222, 22222, 23222, 32222, 32221, 35221, 36222, 6222]
 xs, xt, ys, yt = synth_batch(C, T, D, Bs, Bt, seed=1)
 xs, xt, ys = xs.cuda(), xt.cuda(), ys.cuda()
 sched = [([0.75, 0.75, 0.5], 0.003, 1e-3)] * 200
