@@ -18,6 +18,9 @@ stages = (2, 3) if arith != "f32" else (0,)
 CANDS = [s * 1000 + c for c in (114, 118, 212, 122, 214, 124, 221, 222) for s in stages]
 if arith == "bf16" and Bs + Bt >= 512:      # register-blocked tiles of the twin kernel pay at the larger shapes
     CANDS = [c for c in CANDS if c % 1000 in (214, 124, 221, 222)] + [12222, 13222, 22222, 23222, 32222, 32221, 35221, 36222, 6222]
+if os.environ.get("TA3N_TUNE_CANDS"):         # bounded GPU time: an explicit candidate list / launch order
+    CANDS = [int(v) for v in os.environ["TA3N_TUNE_CANDS"].split(",")]
+LAUNCHES = [int(v) for v in os.environ.get("TA3N_TUNE_LAUNCHES", "10,11,12,13,14,15").split(",")]
 xs, xt, ys, yt = synth_batch(C, T, D, Bs, Bt, seed=1)
 xs, xt, ys = xs.cuda(), xt.cuda(), ys.cuda()
 sched = [([0.75, 0.75, 0.5], 0.003, 1e-3)] * 200
@@ -51,7 +54,7 @@ if os.environ.get("TA3N_TUNE_COMBOS"):      # "3124,3214,2118;3124,3124,2118;...
 cur = list(base)
 print("base", cur[10:16], f"{step_us(cur):.2f} us", flush=True)
 for sw in range(sweeps):
-    for ph in range(10, 16):
+    for ph in LAUNCHES:
         table = {}
         for c in CANDS:
             t = list(cur); t[ph] = c
