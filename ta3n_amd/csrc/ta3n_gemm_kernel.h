@@ -798,19 +798,6 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             const int R = t.pad[1];
             const size_t ld = (size_t)t.pad[2];
             int r = 0;
-#if TA3N_SIDE_BATCH32
-            // (and THIRTY-TWO while that many rows are left: at 12 segments with two videos per heads workgroup the table has 96 rows, and
-            // twelve round trips of ~1.1 us each made these tasks the longest of the relation-level backward launch - 15.5 -> 25.7 us
-            // when the frame workgroups went from 24 to 96, profiles/r05_heads_vpw_tune.txt)
-#pragma unroll 1
-            for (; r + 32 <= R; r += 32) {
-                float x[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) x[i] = col[(size_t)(r + i) * ld];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v += x[i];
-            }
-#endif
 #pragma unroll 1
             for (; r + 8 <= R; r += 8) {
                 float x[8];
@@ -847,15 +834,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     if (t.seg_count == 0) return;   // padding task of the XCD-aware ordering (uniform for the workgroup)
     if (t.epi & EPI_SUMROWS8) {   // side job of one workgroup per fused step: add up the heads kernel's loss partials in a fixed order
         const float *__restrict__ src = ptrs.ws + t.pad[1];
-#if TA3N_SIDE_BATCH32
-        // thread tid adds elements tid, tid + NT, ... of the flat [rows][8] table (row tid / 8 + k NT / 8, column tid % 8: the same elements
-        // in the same order as the plain loop below), eight loads in flight: the plain loop was one dependent round trip per 32 - 64 rows
-        // (4 - 8 for the 234 - 584 heads workgroups of a step) in front of this workgroup's own tile
-        const float sacc = strided_partial_sum(src, t.pad[2] * 8, tid, NT);
-#else
         float sacc = 0.f;
         for (int r = tid >> 3; r < t.pad[2]; r += NT / 8) sacc += src[r * 8 + (tid & 7)];
-#endif
         lds[tid] = sacc;
         __syncthreads();
         if (tid < 8) {

@@ -8,11 +8,6 @@
 #ifndef TA3N_EXPERIMENTS
 #define TA3N_EXPERIMENTS 0
 #endif
-// A/B switch of round 5's last GPU call: the side jobs of the GEMM launches (column sums of per-workgroup partials, the loss-partial sum)
-// with 32 / 8 loads in flight per round trip instead of 8 / 1
-#ifndef TA3N_SIDE_BATCH32
-#define TA3N_SIDE_BATCH32 1
-#endif
 #include <hip/hip_runtime.h>
 
 #include "ta3n_types.h"
