@@ -59,6 +59,19 @@ def dropout_seeds(step: int, rank: int = 0):
     return ((0x9E3779B1 * (2 * s + 1)) ^ r) & 0xFFFFFFFF, ((0x85EBCA77 * (2 * s + 2)) ^ ((r * 0x27D4EB2F) & 0xFFFFFFFF)) & 0xFFFFFFFF
 
 
+_HYPER_DTYPE = None
+_LEGACY_HOST_PREP = os.environ.get("TA3N_HOST_PREP", "") == "legacy"      # A/B aid (tools/r5_session16.sh): schedule arrays entry by entry, no split
+
+
+def _hyper_dtype():
+    """(numpy, the structured dtype of ta3n_hyper) - the conversion from the ctypes structure costs ~25 us, so once per process."""
+    global _HYPER_DTYPE
+    import numpy as np
+    if _HYPER_DTYPE is None:
+        _HYPER_DTYPE = np.dtype(_lib.Hyper)
+    return np, _HYPER_DTYPE
+
+
 class TrainEngine:
     """Device-resident state of one rank: flat parameters / gradients / momentum,
     workspace, static input buffers.  Source rows come first in every batch
@@ -113,6 +126,7 @@ class TrainEngine:
         self.loss_s = None                       # device scalar: the MCD discrepancy loss of the last step (main.py's loss_s)
         self.loss_c2 = None                      # ... and the second classifier's cross-entropy on the source rows
         self._global_source, self._global_target = int(batch_source), int(batch_target)      # job-wide valid counts of the current step (set_hyper)
+        self._job_last_hyper = None      # ta3n_hyper of the last step a _steps_job enqueued (becomes self._hyper in _steps_done)
         self.loss_e_shift = None                 # MCD + attentive entropy: (d total, d loss_e) that moving the target rows' entropy term to the
                                                  # second pass's logits adds to what the loss kernel logged (main.py:549 vs :559-562)
         if ens_DA == "MCD":
@@ -733,6 +747,40 @@ class TrainEngine:
         finally:
             self._hyper = keep
 
+    def hyper_array(self, entries: Sequence[Sequence], step0: int):
+        """(ta3n_hyper * len(entries)) for the steps step0, step0 + 1, ... with entries[k] = (beta, gamma, lr): byte for byte what
+        hyper_for returns entry by entry (tests/test_schedules_and_rng.py), filled column-wise.  Entry 0 comes from hyper_for - every
+        field the way set_hyper writes it - and the fields that change from step to step (beta, gamma, lr, the two dropout seeds) are
+        written for all steps at once: the per-entry loop cost 4 - 7 us of host time per step INSIDE a train_steps call, before its first
+        launch (round 5: at the 0.1 ms headline step that was 4 - 6 % of the measured step time)."""
+        m = len(entries)
+        hy = (_lib.Hyper * m)()
+        if m == 0:
+            return hy
+        h0 = self.hyper_for(*entries[0], step=step0)
+        size = C.sizeof(_lib.Hyper)
+        if m == 1:
+            C.memmove(hy, C.byref(h0), size)
+            return hy
+        if _LEGACY_HOST_PREP:              # A/B aid: the per-entry loop of rounds 3-4
+            for k in range(m):
+                h = h0 if k == 0 else self.hyper_for(*entries[k], step=step0 + k)
+                C.memmove(C.byref(hy, k * size), C.byref(h), size)
+            return hy
+        np, dt = _hyper_dtype()
+        np.frombuffer(hy, dtype=np.uint8).reshape(m, size)[:] = np.frombuffer(h0, dtype=np.uint8)      # every entry = entry 0 ...
+        a = np.frombuffer(hy, dtype=dt)
+        sched = np.array([(b_[0], b_[1], b_[2], g_, lr_) for b_, g_, lr_ in entries], dtype=np.float32)  # ... but (float -> fp32, RNE like c_float):
+        a["beta"] = sched[:, :3]
+        a["gamma"] = sched[:, 3]
+        a["lr"] = sched[:, 4]
+        # dropout_seeds(step, rank) for all steps at once, in uint32 (products wrap mod 2^32, which is what the masks there keep)
+        st2 = (np.arange(m, dtype=np.uint32) + np.uint32(step0 & 0xFFFFFFFF)) * np.uint32(2)
+        r = (0xC2B2AE3D * int(self.rank)) & 0xFFFFFFFF
+        a["seed_i"] = ((st2 + np.uint32(1)) * np.uint32(0x9E3779B1)) ^ np.uint32(r)
+        a["seed_v"] = ((st2 + np.uint32(2)) * np.uint32(0x85EBCA77)) ^ np.uint32((r * 0x27D4EB2F) & 0xFFFFFFFF)
+        return hy
+
     def _feeds(self, feeds, k0: int):
         """ta3n_feed structs (and the id tables that must outlive the enqueued gathers) of a multi-step call."""
         fd, keep = [None, None], []
@@ -749,7 +797,7 @@ class TrainEngine:
                 fd[i] = f
         return fd, keep
 
-    def train_steps(self, schedule: Sequence[Sequence], feeds=None, fused_update: Optional[bool] = None) -> None:
+    def train_steps(self, schedule: Sequence[Sequence], feeds=None, fused_update: Optional[bool] = None, _split: bool = True) -> None:
         """len(schedule) pipelined steps enqueued by ONE call into the library (ta3n_train_steps): schedule[k] = (beta, gamma, lr)
         of step k (main.py:350-352, 620-621 evaluated ahead of time).  Same launches, same results as calling
         train_step_pipelined once per entry; the host leaves the step's critical path (on a slow core the per-step ctypes call +
@@ -771,10 +819,7 @@ class TrainEngine:
             self.flush()
             if self._P2 is None:
                 self._P2 = torch.empty_like(self.P)
-            hy = (_lib.Hyper * n)()
-            for k, (beta, gamma, lr) in enumerate(schedule):
-                h = self.hyper_for(beta, gamma, lr, step=self.step_count + k)
-                C.memmove(C.byref(hy, k * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
+            hy = self.hyper_array(schedule, self.step_count)
             fd, keep = self._feeds(feeds, 0)
             _lib.check(self._L.ta3n_train_steps_fused_update(
                 self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self._P2.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
@@ -783,7 +828,7 @@ class TrainEngine:
                 "ta3n_train_steps_fused_update")
             if keep:
                 self._feed_keep = keep
-            self._hyper = self.hyper_for(*schedule[-1], step=self.step_count + n - 1)
+            self._hyper = _lib.Hyper.from_buffer_copy(hy[n - 1])
             self.step_count += n
             return
         if not self.can_batch_steps():
@@ -795,6 +840,18 @@ class TrainEngine:
                         if store is not None:
                             store.gather_into(self, ids[k], first, labels_out=self._labels[: self.Bs] if first == 0 else None)
                 (self.train_step_pipelined if self.fused else self.train_step)(beta, gamma, lr)
+            return
+        if _split and n >= 4 and not self._sharded and not _LEGACY_HOST_PREP:
+            # The first step goes out on its own and the rest of the schedule is prepared while the GPU runs it (a long schedule in two
+            # further pieces: 16 steps, then the rest): the host work in front of a call's first launch (the ta3n_hyper array: ~7 us +
+            # ~0.5 us per step) then costs the GPU one step's preparation, whatever the length of the schedule.  Same launches in the
+            # same order on the same stream; every later piece opens with the update the piece before it left pending, exactly as the
+            # next step of a single call would.
+            rows = (lambda lo, hi: None) if feeds is None else (lambda lo, hi: tuple((st, ids if st is None else ids[lo:hi]) for st, ids in feeds))
+            lo = 0
+            for hi in ((1, n) if n <= 33 else (1, 17, n)):
+                self.train_steps(schedule[lo:hi], feeds=rows(lo, hi), fused_update=fused_update, _split=False)
+                lo = hi
             return
         job, keep, n_run = self._steps_job(schedule, feeds)
         if job is None:
@@ -838,11 +895,8 @@ class TrainEngine:
             k0 = 1
             if n == 1:
                 return None, [], 0
-        hy = (_lib.Hyper * (n - k0))()
-        for k in range(k0, n):
-            beta, gamma, lr = schedule[k]
-            h = self.hyper_for(beta, gamma, lr, step=self.step_count + (k - k0))
-            C.memmove(C.byref(hy, (k - k0) * C.sizeof(_lib.Hyper)), C.byref(h), C.sizeof(_lib.Hyper))
+        hy = self.hyper_array(schedule[k0:], self.step_count)
+        self._job_last_hyper = _lib.Hyper.from_buffer_copy(hy[n - k0 - 1])      # (for _steps_done: the scalars of the last step enqueued)
         lr_p, mu, wd, clip = self._pending
         fd, keep = self._feeds(feeds, k0)
         job = _lib.StepsJob()
@@ -862,7 +916,8 @@ class TrainEngine:
             self._feed_keep = keep
         last = schedule[-1]
         self._pending = (float(last[2]), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
-        self._hyper = self.hyper_for(*last, step=self.step_count + n_run - 1)
+        self._hyper = self._job_last_hyper if self._job_last_hyper is not None else self.hyper_for(*last, step=self.step_count + n_run - 1)
+        self._job_last_hyper = None
         self.step_count += n_run
 
     def chain_status(self) -> None:

@@ -55,3 +55,32 @@ def test_dropout_streams_are_independent():
     # runs: the number of sign changes of an independent sequence is n/2 +- a few sqrt(n)/2
     changes = np.count_nonzero(np.diff(m["i0"]))
     assert abs(changes - n / 2) < 4 * np.sqrt(n) / 2
+
+
+@pytest.mark.parametrize("rank,world,step0", [(0, 1, 0), (3, 8, 17), (1, 2, 2 ** 31 - 3), (5, 8, 3_000_000_011)])
+def test_schedule_array_of_a_multi_step_call_equals_the_per_step_scalars(rank, world, step0):
+    """TrainEngine.hyper_array (the ta3n_hyper array one ta3n_train_steps call carries, filled column-wise) against hyper_for entry by
+    entry (what set_hyper uploads for a single step): the same bytes - beta / gamma / lr rounded to fp32 the same way, the dropout
+    seeds of dropout_seeds(step, rank) also where the 64-bit products wrap.  The engine's device state is not involved: the two
+    methods run on a stand-in that carries the attributes they read."""
+    import ctypes as C
+    import types
+
+    from ta3n_amd import _lib
+    from ta3n_amd.engine import TrainEngine
+
+    eng = types.SimpleNamespace(Bs=128, Bt=74, world=world, rank=rank, momentum=0.9, weight_decay=1e-4, clip=20.0, dropout_i=0.5,
+                                dropout_v=0.3, step_count=5, T=9, _hyper=_lib.Hyper(), _global_source=0, _global_target=0)
+    for name in ("set_hyper", "hyper_for", "hyper_array"):
+        setattr(eng, name, types.MethodType(getattr(TrainEngine, name), eng))
+    rng = np.random.default_rng(step0 % 1000)
+    for m in (0, 1, 2, 37):
+        entries = [([beta_dann(p), 0.75 * beta_dann(p), float(rng.random())], float(rng.random()) * 0.01, lr_dann(3e-2, p))
+                   for p in rng.random(m)]
+        hy = eng.hyper_array(entries, step0)
+        assert len(hy) == m
+        for k, (beta, gamma, lr) in enumerate(entries):
+            want = eng.hyper_for(beta, gamma, lr, step=step0 + k)
+            assert bytes(hy[k]) == bytes(want), (m, k)
+            assert (hy[k].seed_i, hy[k].seed_v) == dropout_seeds(step0 + k, rank)
+        assert C.sizeof(hy) == m * C.sizeof(_lib.Hyper)
