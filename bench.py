@@ -9,8 +9,9 @@ fp32, 4: 30 classes / 9 segments / 512+512 videos, 5: two-stream 1024-d / 12 seg
 `config.workload` names it.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          # N > 1, bare: starts its own N ranks (launch_ranks), fails if the box has < N GPUs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # the same job under a caller's launcher (WORLD_SIZE must equal N)
 
 One "step" = forward + loss + backward + (RCCL all-reduce of the flat gradient
 buffer when N > 1) + clip + Nesterov SGD on synthetic features already resident
@@ -30,6 +31,10 @@ import math
 import os
 import sys
 import time
+
+# dmabuf IPC for cross-process device memory (RCCL ranks, the opt-in peer transport): must be in the environment before the HIP runtime
+# initialises, i.e. before `import torch` (only tests/conftest.py used to set it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
@@ -208,20 +213,18 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
         for _ in range(conf["streams"]):
             orc.train_step(state, xs, xt, ys, beta, gamma, cfg, drop_i=di, drop_v=dv)
 
-    # thread count: the CPU path is many small ATen ops; on a many-core host (or under a
-    # cgroup CPU quota) all hardware threads is far slower than a moderate count, so probe a
-    # few counts (bounded) and report the best one with the count used.
+    # thread count: the CPU path is many small ATen ops; all hardware threads of a many-core host (or of a cgroup quota) is far slower
+    # than a moderate count and the best count differs from box to box (16 on some, 32 on others, a factor 2
+    # apart), so probe {16, 32, 64} (what the host has of them; 8 on a small one) - two steps each - time the best, report all.
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best_t, best_dt = None, None
-    for t in [c for c in (8, 16, 32, 64, 128) if c <= avail] or [avail]:
+    counts = [c for c in (16, 32, 64) if c <= avail] or [min(avail, 8)]
+    probe = {}
+    one()
+    for t in counts:
         torch.set_num_threads(t)
         one()
-        t1 = time.perf_counter(); one(); dt1 = time.perf_counter() - t1
-        if best_dt is None or dt1 < best_dt:
-            best_t, best_dt = t, dt1
-        if dt1 > 3.0 or (best_dt is not None and dt1 > 1.5 * best_dt):
-            break
-    cores = best_t
+        t1 = time.perf_counter(); one(); one(); probe[t] = 1e3 * (time.perf_counter() - t1) / 2
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     one()
     t0 = time.perf_counter()
@@ -239,38 +242,157 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
                     break
     except OSError:
         pass
-    port = dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, ms_per_step=1e3 * dt / n,
-                sample=f"{n} full train steps of oracle/ta3n_oracle.py (the port) on {cores} torch threads = {1e3 * dt / n:.1f} ms/step")
-    # The REFERENCE ITSELF: its module files travel to the GPU box as a git-ignored staged copy (oracle/_ref/py/,
-    # made from /root/reference by oracle/reference_runner.py: stage()); its own main.train() is timed in a process of its own (the
-    # import shims patch torch.Tensor.cuda, and the CPU path must not see the GPU) on the same synthetic tensors and thread count.
-    cnum = next(k for k, v in CONFIGS.items() if v is conf)
-    ref, ref_err = None, None
-    try:
-        from oracle import reference_runner as rr
-        if not rr.available():
-            raise RuntimeError("no staged reference (oracle/_ref/py): run `python -m oracle.reference_runner --stage` in the build container")
-        import subprocess
-        env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(cores))
-        r = subprocess.run([sys.executable, "-m", "oracle.reference_runner", "--config", str(cnum), "--threads", str(cores), "--seconds", str(seconds)],
-                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-        line = next((ln for ln in r.stdout.splitlines() if ln.startswith("REFERENCE_JSON ")), None)
-        if line is None:
-            raise RuntimeError(("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-300:])
-        ref = json.loads(line[len("REFERENCE_JSON "):])
-    except Exception as ex:      # noqa: BLE001 - the port's number is still a baseline
-        ref_err = f"{type(ex).__name__}: {ex}"[:400]
     shape = f"{CFG['Bs']}+{CFG['Bt']} videos, fp32, dropout 0.5" + (", both streams" if conf["streams"] > 1 else "")
     host = f"{avail} hw threads visible of '{model}'"
-    if ref is not None:
-        return dict(value=ref["videos_per_s"], unit="videos/s", cores=cores, kind="reference", ms_per_step=ref["ms_per_step"],
-                    sample=f"{ref['steps']} full train steps ({shape}) of the reference's own main.train + models.VideoModel (staged copy of "
-                           f"/root/reference, sha256 main.py {ref['sha256'].get('main.py')} models.py {ref['sha256'].get('models.py')}; torch "
-                           f"{ref['torch']} CPU ops) on {cores} torch threads (the port's best of a bounded probe; {host}) = {ref['ms_per_step']:.1f} ms/step",
-                    reference_files_sha256=ref["sha256"], port=port, reference_over_port=ref["ms_per_step"] / port["ms_per_step"])
-    return dict(value=port["value"], unit="videos/s", cores=cores, kind="port", ms_per_step=port["ms_per_step"],
-                sample=f"{n} full train steps ({shape}) of oracle/ta3n_oracle.py on {cores} torch threads (best of a bounded probe; {host}) = "
-                       f"{1e3 * dt / n:.1f} ms/step", reference_unavailable=ref_err)
+    out = dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port", ms_per_step=1e3 * dt / n,
+               probe_ms_per_step_by_threads={str(k): round(v, 2) for k, v in probe.items()},
+               sample=f"{n} full train steps ({shape}) of oracle/ta3n_oracle.py (the CPU restatement of the reference's main.train + VideoModel: the "
+                      f"same ATen CPU ops, incl. the frame classifier the reference computes and never uses) on {cores} torch threads (best of "
+                      f"{sorted(probe)}; {host}) = {1e3 * dt / n:.1f} ms/step")
+    # OPT-IN second figure: the reference's own main.train, when somebody staged it explicitly (oracle/reference_runner.py --stage: files
+    # verified against pinned sha256 values; never done by build()).  `value` above keeps ONE definition on every box.
+    cnum = next(k for k, v in CONFIGS.items() if v is conf)
+    try:
+        from oracle import reference_runner as rr
+        if rr.available():
+            import subprocess
+            env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+            r = subprocess.run([sys.executable, "-m", "oracle.reference_runner", "--config", str(cnum), "--threads", ",".join(map(str, counts)),
+                                "--seconds", str(seconds)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("REFERENCE_JSON ")), None)
+            if line is None:
+                raise RuntimeError(("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-300:])
+            ref = json.loads(line[len("REFERENCE_JSON "):])
+            out["reference"] = dict(value=ref["videos_per_s"], unit="videos/s", cores=ref["threads"], ms_per_step=ref["ms_per_step"], steps=ref["steps"],
+                                    probe_ms_per_step_by_threads=ref["probe_ms_per_step_by_threads"], files_sha256=ref["sha256"], torch=ref["torch"],
+                                    what="the reference's own main.train + models.VideoModel from an explicitly staged, sha256-pinned copy (oracle/_ref/py), "
+                                         "same synthetic tensors, in a process of its own")
+            out["reference_over_port"] = ref["ms_per_step"] / out["ms_per_step"]
+        else:
+            out["reference"] = None      # nothing staged (the default): profiles/reference_vs_port_cpu.json holds the ratio measured where the checkout is
+    except Exception as ex:      # noqa: BLE001 - the port's number stands
+        out["reference"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    return out
+
+
+def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, steps=12, warm=4):
+    """Times the pipelined train step under each gradient exchange ("allreduce", "sharded", "peer") and without any (every rank skips
+    it: the numbers trained on are then wrong, the time is what is wanted): `steps` steps after `warm`, fenced, MAX over ranks.
+    Returns ({candidate: {...}}, fastest candidate).  Every rank takes the same decisions: availability is what the engine
+    constructors agreed on collectively, times are all-reduced, ties go to the earlier (simpler) candidate."""
+    table, best, best_ms = {}, "allreduce", None
+
+    def timed(eng, n):
+        eng.train_steps([(beta, gamma, lr)] * warm)      # (one library call where the engine has one for its exchange, else step by step)
+        eng.flush()
+        fence()
+        t0 = time.perf_counter()
+        eng.train_steps([(beta, gamma, lr)] * n)
+        eng.flush()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return 1e3 * t.item() / n
+
+    for cand in ("allreduce", "sharded", "peer"):
+        row = {}
+        try:
+            eng = build_engines(cand)[0]
+            got = "sharded" if eng._sharded else "peer" if eng.peer is not None else "allreduce"
+            if got != cand:
+                row["unavailable"] = "the engine kept the default exchange" + (f" ({eng.comm_fallback})" if eng.comm_fallback else "")
+            else:
+                row["ms_per_step"] = timed(eng, steps)
+                row["bytes"] = eng.plan.live_floats * (2 if eng._g16 is not None else 4)
+                row["through"] = ("C-ABI RCCL communicator" if eng.comm is not None else "torch.distributed") if cand != "peer" else "csrc/ta3n_peer.hip"
+                if cand == "peer":
+                    eng.check_exchange()
+                fin = torch.tensor([float(torch.isfinite(eng.P).all().item())], device=dev)
+                if world > 1:
+                    torch.distributed.all_reduce(fin, op=torch.distributed.ReduceOp.MIN)
+                if fin.item() != 1.0:
+                    row["rejected"] = "non-finite parameters after the probe"
+                elif best_ms is None or row["ms_per_step"] < best_ms:
+                    best, best_ms = cand, row["ms_per_step"]
+                if cand == "allreduce":      # the same engine once more without its collective: what each exchange leaves exposed
+                    eng.skip_collective = True
+                    table["none"] = {"ms_per_step": timed(eng, steps), "what": "the same step with the exchange skipped on every rank"}
+                    eng.skip_collective = False
+            del eng
+        except Exception as ex:      # noqa: BLE001 - a candidate that cannot run is a row of the table, not the end of the run
+            row["error"] = f"{type(ex).__name__}: {ex}"[:200]
+        table[cand] = row
+        gc.collect()
+        torch.cuda.empty_cache()
+    base = table.get("none", {}).get("ms_per_step")
+    for cand, row in table.items():
+        if base is not None and "ms_per_step" in row and cand != "none":
+            row["exposed_us_per_step"] = round(1e3 * (row["ms_per_step"] - base), 2)
+    return {"steps": steps, "warmup": warm, "candidates": table, "chosen": best,
+            "what": "the pipelined train step under each gradient exchange, MAX over ranks; the timed region runs on `chosen`"}, best
+
+
+LAUNCH_TEST = os.environ.get("TA3N_BENCH_LAUNCH_TEST") == "1"      # tests/test_bench_launcher.py: the launcher and the rank handshake on CPU (gloo), no engine, no measurement
+
+
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: this process is not a rank, it is the launcher.  One
+    rank per GPU under torch.distributed.run (the command the docstring names), same argv, rendezvous on 127.0.0.1 and a free
+    port; returns the job's exit code.  The reference needs no launcher either (main.py:79: one process, nn.DataParallel over
+    every visible GPU), so its replacement's benchmark must not need one.  Fails before spawning anything when the box has
+    fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus and not LAUNCH_TEST:
+        print(f"[bench] --gpus {n_gpus}: this box has {have} visible GPU(s); refusing to run a {n_gpus}-rank job on fewer devices "
+              f"(one process per GPU, RCCL does not share a device between ranks)", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / peer-mapped buffers across processes (must precede HIP initialisation in every rank)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("[bench] launching " + " ".join(cmd[1:8]) + " bench.py " + " ".join(sys.argv[1:]), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rank_environment(n_gpus: int):
+    """(world, rank, local_rank) of this process, checked against --gpus: the line's n_gpus is the number of ranks that really
+    came up, so a mismatch between the flag and the job is an error, never a silently smaller run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit(f"[bench] --gpus {n_gpus} but this job has WORLD_SIZE={world}: launch `python bench.py --gpus {n_gpus}` bare (it "
+                         f"starts its own ranks) or give torch.distributed.run --nproc-per-node {n_gpus}")
+    if not LAUNCH_TEST and torch.cuda.device_count() < (world if world > 1 else 1):
+        raise SystemExit(f"[bench] rank {rank}: {torch.cuda.device_count()} visible GPU(s) for a {world}-rank job (one process per GPU)")
+    return world, rank, local_rank
+
+
+def launch_test_line(world: int, rank: int) -> None:
+    """TA3N_BENCH_LAUNCH_TEST=1 (CPU, gloo): every rank joins the group, a sum all-reduce of ones counts them, rank 0 prints what a
+    real line would say about the job's size.  No engine, no timing - `launch_test: true` and `value: null` say so."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("gloo")
+        t = torch.ones(1)
+        torch.distributed.all_reduce(t)
+        seen = int(t.item())
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    else:
+        seen = 1
+    if seen != world:
+        raise SystemExit(f"[bench] {seen} ranks answered in a job of {world}")
+    if rank == 0:
+        print(json.dumps({"launch_test": True, "value": None, "n_gpus": world, "ranks_seen": seen,
+                          "config": {"parallelism": f"dp{world}", "rccl_ranks": None}}), flush=True)
 
 
 def main():
@@ -308,6 +430,10 @@ def main():
     ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32", help="N > 1: what the gradient all-reduce moves - fp32 (default: "
                     "the exact sum up to the reduction order), or bf16 (every rank's gradients rounded to bf16 and summed in bf16: half the xGMI bytes; "
                     "stated in the line)")
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "sharded", "peer"), default="auto", help="N > 1: the gradient exchange of the timed "
+                    "region - auto (default): the fastest of the three as measured during warm-up (config.exchange_probe names all times); "
+                    "allreduce: one RCCL ncclAllReduce per step; sharded: RCCL reduce-scatter + own-shard update + all-gather; peer: the in-tree "
+                    "two-shot all-reduce over peer-mapped buffers")
     ap.add_argument("--no-other-configs", action="store_true", help="do not add the 20-step timings of configs[0] / [3] / [4] to the line")
     ap.add_argument("--no-fresh-batch", action="store_true", help="skip the second timed loop with a new device-gathered batch per step")
     ap.add_argument("--phase-reps", type=int, default=20)
@@ -319,11 +445,14 @@ def main():
     headline = args.config in (2, 3)
     n_streams = conf["streams"]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:      # bare `python bench.py --gpus N`: start the N ranks ourselves
+        raise SystemExit(launch_ranks(args.gpus))
+    world, rank, local_rank = rank_environment(args.gpus)
+    if LAUNCH_TEST:
+        launch_test_line(world, rank)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1" and "RANK" in os.environ   # N > 1 code path on 1 rank
@@ -359,22 +488,41 @@ def main():
             phase_tiles = []
         if args.plan_heuristic:
             phase_tiles = [0]
-        engs = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
-                            clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
-                            fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],
-                            f32_split=split, grad_transport=args.grad_transport)
-                for _ in range(n_streams)]
-        eng = engs[0]
-        for k, e in enumerate(engs):
-            shapes = {n: s for n, _, s, _ in e.plan.params}
-            e.load_state(synth_state(shapes, seed=7 + k, scale="init"))       # reference init: N(0, 0.001), zero bias
-            xs, xt, ys, yt = synth_batch(SH["C"], SH["T"], SH["D"], SH["Bs"], SH["Bt"], seed=1234 + rank + 100 * k)
-            e.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
         avg = conf["agg"] == "avgpool"
         lr0, gamma, beta = 3e-2, (0.0 if avg else 0.003), ([0.0, 0.0, 0.0] if avg else [0.75, 0.75, 0.5])
         total_steps = 30 * 12                                              # 30 epochs x ~11 steps (1438/128), main.py:334-335
-        for e in engs:
-            e.set_hyper(beta, gamma, lr0)
+
+        def build_engines(exchange):
+            """The engine(s) of this arithmetic with one gradient exchange (N > 1): None = whatever the environment selects (default: ONE
+            RCCL ncclAllReduce per step), "allreduce" / "sharded" (RCCL reduce-scatter, own-shard clip + SGD, all-gather) / "peer" (the
+            in-tree two-shot all-reduce over peer-mapped buffers)."""
+            kw = {} if exchange is None else dict(sharded_update=exchange == "sharded", peer_exchange=exchange == "peer")
+            es = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
+                              clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
+                              fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],
+                              f32_split=split, grad_transport=args.grad_transport, **kw)
+                  for _ in range(n_streams)]
+            for k, e in enumerate(es):
+                shapes = {n: s for n, _, s, _ in e.plan.params}
+                e.load_state(synth_state(shapes, seed=7 + k, scale="init"))       # reference init: N(0, 0.001), zero bias
+                xs, xt, ys, yt = synth_batch(SH["C"], SH["T"], SH["D"], SH["Bs"], SH["Bt"], seed=1234 + rank + 100 * k)
+                e.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
+                e.set_hyper(beta, gamma, lr0)
+            return es
+
+        # N > 1 (VERDICT r05 item 1b): which exchange?  Measured, not assumed: during warm-up every candidate runs the real step on the
+        # real message (the flat live-gradient prefix of this configuration) for a few steps, MAX over ranks; the timed region then
+        # runs on the fastest, and the line names all of them (config.exchange_probe).  A candidate that cannot be set up on every
+        # rank (the constructors agree on that collectively) or that delivers a non-finite parameter is left out; the default
+        # exchange always stands as the fallback.  --exchange pins one.
+        exchange_probe, chosen_exchange = None, None
+        if (world > 1 or selftest) and not brief and n_streams == 1 and not args.unfused and not args.graph:
+            if args.exchange == "auto":
+                exchange_probe, chosen_exchange = probe_exchanges(build_engines, beta, gamma, lr0, fence, world, dev, rank)
+            else:
+                chosen_exchange = args.exchange
+        engs = build_engines(chosen_exchange)
+        eng = engs[0]
         if args.graph:
             for e in engs:
                 e.capture()
@@ -537,7 +685,13 @@ def main():
         else:
             res["gradient_exchange"] = ("torch.distributed all_reduce (backend nccl = RCCL), fp32" +
                                         (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
-        res["rccl_ranks"] = int(eng._L.ta3n_comm_world(eng.comm.handle)) if eng.comm is not None else None
+        # the number of ranks the exchange really spans: the library's communicator, else the torch.distributed (RCCL) group
+        res["rccl_ranks"] = (int(eng._L.ta3n_comm_world(eng.comm.handle)) if eng.comm is not None else
+                             (torch.distributed.get_world_size() if (world > 1 or selftest) else None))
+        if (world > 1 or selftest) and res["rccl_ranks"] != world:
+            raise SystemExit(f"[bench] the gradient exchange spans {res['rccl_ranks']} rank(s) in a job of {world}")
+        res["exchange_probe"] = exchange_probe
+        res["exchange"] = chosen_exchange
         res["deferred"] = deferred
         res["batched"] = batched
         res["pipelined"] = pipelined
@@ -670,6 +824,8 @@ def main():
                         "launch (ta3n_train_step_after_update)" if main_res["pipelined"] else "end of step"),
                        "gradient_exchange": None if (world == 1 and not selftest) else main_res.get("gradient_exchange"),
                        "rccl_ranks": main_res.get("rccl_ranks"),
+                       "exchange": main_res.get("exchange"),
+                       "exchange_probe": main_res.get("exchange_probe"),
                        "collective": main_res.get("collective"),
                        "phase_tiles": main_res["phase_tiles"]},
             "roofline": main_res["roofline"],

@@ -1,18 +1,24 @@
 """TEST / MEASUREMENT INFRASTRUCTURE - never imported by the product (ta3n_amd/, main.py, train_ddp.py, compat/).
 
-The REFERENCE ITSELF as the CPU baseline of bench.py (`cpu_baseline.kind == "reference"`).
+OPT-IN: the reference itself timed on the GPU box's host cores, as a second figure beside bench.py's `cpu_baseline` (whose `value`
+is ALWAYS the oracle port, `kind: "port"` - one definition on every box; the reference's figure, when there is one, travels in
+`cpu_baseline.reference`).
 
-The reference is pure Python, so nothing of it "compiles into oracle/_ref/"; what can travel to the GPU box is a git-ignored STAGED
-copy of the module files the hot path lives in, made from /root/reference by `stage()` below (the recipe; `__graft_entry__.build()`
-runs it whenever /root/reference exists, i.e. in the build container) into oracle/_ref/py/ together with their sha256 - oracle/_ref/
-is listed in .gitignore and not in .gpurunignore, so it ships with the snapshot like the built .so and never enters history.
+The reference is pure Python: nothing of it compiles into oracle/_ref/, and a Python reference does not travel with the product.
+`__graft_entry__.build()` therefore does NOT stage it.  Whoever wants the reference's own `main.train` timed on a GPU box
+runs, explicitly, in a container that has the checkout:
 
-`python -m oracle.reference_runner --config N --threads T --seconds S` then times, in a process of its own (the import shims patch
-`torch.Tensor.cuda` to the identity - that must not happen inside a process that also drives the GPU), the reference's own
-`main.train()` (main.py:309-667: VideoModel.forward, the loss assembly, backward, clip_grad_norm_, SGD step, DANN LR) for one batch
-per call on the same synthetic tensors the GPU path is timed on (ta3n_amd.synthetic, in memory - TSNDataSet's per-frame file reads
-are not part of the metric), dropout 0.5 / 0.5, and prints one JSON line.  Import shims as in tests/golden/ref_shim.py (torchvision
-arch -> feature dim, colorama, tensorboardX, .cuda() -> identity, device_count -> 1, accuracy() with .reshape at main.py:820).
+    python -m oracle.reference_runner --stage        # copies the hot path's module files into oracle/_ref/py/ (git-ignored)
+
+`stage()` and `available()` verify every file against the sha256 values PINNED in this file (REFERENCE_SHA256, taken from the
+cmhungsteve/TA3N checkout this repository was built against) - a file that differs is neither staged nor ever executed, and a
+missing checkout / read-only tree is reported, not raised.  `python -m oracle.reference_runner --config N --threads T --seconds S`
+then times, in a process of its own (the import shims patch `torch.Tensor.cuda` to the identity - that must not happen inside a
+process that also drives the GPU), the reference's own `main.train()` (main.py:309-667: VideoModel.forward, the loss assembly,
+backward, clip_grad_norm_, SGD step, DANN LR) for one batch per call on the same synthetic tensors the GPU path is timed on
+(ta3n_amd.synthetic, in memory - TSNDataSet's per-frame file reads are not part of the metric), dropout 0.5 / 0.5, and prints one
+JSON line.  Import shims as in tests/golden/ref_shim.py (torchvision arch -> feature dim, colorama, tensorboardX, .cuda() ->
+identity, device_count -> 1, accuracy() with .reshape at main.py:820).
 """
 from __future__ import annotations
 
@@ -39,39 +45,69 @@ CASES = {
 }
 
 
+# sha256 of the reference's files this repository was built and pinned against (cmhungsteve/TA3N as checked out under /root/reference);
+# nothing that does not match is copied, imported or executed
+REFERENCE_SHA256 = {
+    "main.py": "1b7294d3020d36ce6968aae5351ef949e2cc255953b1907f51964646e2cd12f1",
+    "models.py": "1d3e87ff49f1a44f6ac6489289c8be5e878e22c53e381b0067a2e8eee5eefc79",
+    "TRNmodule.py": "f13c1a50ff6ed7ce9dde1068d451ac03d1e2af8479122195443506aa68109f37",
+    "loss.py": "b4bbbeea1dc6c85cbd9aad30b74e240e611951b99efea53898a37064c50924bc",
+    "opts.py": "d8206b97209bfd9c2667bb3421fa1e5f53bc59170dd7aa99fa829e170e84c99f",
+    "dataset.py": "c66ec054a1b0b8884a0f85243f9e290cbb9cba7c34496a9b03013840fc6a8d66",
+    os.path.join("utils", "utils.py"): "4a57be7cb9035b53f429e0c5509970deb92e9702824929b108f37a067063ea66",
+}
+
+
+def _sha256(path: str):
+    try:
+        with open(path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def stage() -> bool:
-    """The recipe: copy the hot path's module files from the reference checkout into oracle/_ref/py/ (git-ignored) and record their
-    sha256.  Returns False (and leaves an existing stage alone) where there is no reference checkout - the GPU box."""
-    if not os.path.isfile(os.path.join(REFERENCE, "main.py")):
+    """The explicit, opt-in recipe: copy the hot path's module files from the reference checkout into oracle/_ref/py/ (git-ignored)
+    - only files whose sha256 equals the pinned one.  Returns False, with the reason on stderr, where there is no checkout, a file
+    does not match its pin, or the tree cannot be written; never raises (an existing stage is left alone)."""
+    try:
+        for f in FILES:
+            got = _sha256(os.path.join(REFERENCE, f))
+            if got is None:
+                print(f"[reference_runner] no reference checkout at {REFERENCE} ({f} missing): nothing staged", file=sys.stderr)
+                return False
+            if got != REFERENCE_SHA256[f]:
+                print(f"[reference_runner] {os.path.join(REFERENCE, f)} does not match the pinned sha256: nothing staged", file=sys.stderr)
+                return False
+        os.makedirs(os.path.join(STAGE, "utils"), exist_ok=True)
+        for f in FILES:
+            dst = os.path.join(STAGE, f)
+            if os.path.exists(dst):
+                os.chmod(dst, 0o644)
+            shutil.copyfile(os.path.join(REFERENCE, f), dst)
+            os.chmod(dst, 0o444)
+        init = os.path.join(STAGE, "utils", "__init__.py")
+        if not os.path.exists(init):
+            open(init, "w").close()
+    except OSError as ex:
+        print(f"[reference_runner] staging failed ({ex}): nothing usable staged", file=sys.stderr)
         return False
-    os.makedirs(os.path.join(STAGE, "utils"), exist_ok=True)
-    sums = {}
-    for f in FILES:
-        src, dst = os.path.join(REFERENCE, f), os.path.join(STAGE, f)
-        if os.path.exists(dst):
-            os.chmod(dst, 0o644)
-        shutil.copyfile(src, dst)
-        os.chmod(dst, 0o444)
-        sums[f] = hashlib.sha256(open(dst, "rb").read()).hexdigest()
-    init = os.path.join(STAGE, "utils", "__init__.py")
-    if not os.path.exists(init):
-        open(init, "w").close()
-    with open(os.path.join(STAGE, "SHA256SUMS.json"), "w") as fh:
-        json.dump(sums, fh, indent=1)
-    return True
+    return available()
+
+
+def unstage() -> None:
+    shutil.rmtree(os.path.join(HERE, "_ref", "py"), ignore_errors=True)
 
 
 def available() -> bool:
-    return all(os.path.isfile(os.path.join(STAGE, f)) for f in FILES)
+    """True only when EVERY staged file is present and equals its pinned sha256 - the condition under which this module will
+    import and execute them."""
+    return all(_sha256(os.path.join(STAGE, f)) == REFERENCE_SHA256[f] for f in FILES)
 
 
 def staged_sha256() -> dict:
-    try:
-        with open(os.path.join(STAGE, "SHA256SUMS.json")) as fh:
-            want = json.load(fh)
-    except OSError:
-        return {}
-    return {f: h[:16] for f, h in want.items() if hashlib.sha256(open(os.path.join(STAGE, f), "rb").read()).hexdigest() == h}
+    """{file: first 16 hex digits} of the staged files that match their pins (all of FILES whenever available())."""
+    return {f: h[:16] for f, h in REFERENCE_SHA256.items() if _sha256(os.path.join(STAGE, f)) == h}
 
 
 def _install_shims():
@@ -126,14 +162,16 @@ class _FakeDP:
         return self.module.parameters()
 
 
-def time_reference(config: int, threads: int, seconds: float, max_steps: int = 400) -> dict:
+def time_reference(config: int, threads, seconds: float, max_steps: int = 400) -> dict:
+    """threads: one count, or several (a bounded probe - two steps each - picks the fastest; every probe time is reported)."""
     import argparse
     import importlib.util
     import io
 
     import torch
     if not available():
-        raise SystemExit("no staged reference under oracle/_ref/py (run oracle.reference_runner.stage() in the build container)")
+        raise SystemExit("no staged reference under oracle/_ref/py that matches the pinned sha256 values (opt-in: `python -m "
+                         "oracle.reference_runner --stage` in a container that has the checkout)")
     _install_shims()
     sys.path.insert(0, STAGE)                                # the reference's `import models / loss / opts / dataset / utils.utils`
     sys.path.insert(1, ROOT)
@@ -146,7 +184,8 @@ def time_reference(config: int, threads: int, seconds: float, max_steps: int = 4
     from ta3n_amd.synthetic import synth_batch, synth_state
     case = CASES[config]
     avg = case["agg"] == "avgpool"
-    torch.set_num_threads(threads)
+    counts = [int(threads)] if isinstance(threads, int) else [int(t) for t in threads]
+    torch.set_num_threads(counts[0])
     torch.manual_seed(1)
     m = ref_models.VideoModel(case["C"], "video", case["agg"], "RGB", train_segments=case["T"], val_segments=case["T"], base_model=case["arch"],
                               add_fc=1, fc_dim=case["fc_dim"], dropout_i=0.5, dropout_v=0.5, partial_bn=False, use_bn="none", ens_DA="none",
@@ -174,8 +213,18 @@ def time_reference(config: int, threads: int, seconds: float, max_steps: int = 4
             ref_main.train(case["C"], [(xs, ys)], [(xt, yt)], wrapped, crit, crit, opt, 1, log, log, 0, list(beta), gamma, 0)
 
     import contextlib
+    probe = {}
     with contextlib.redirect_stdout(io.StringIO()):
         step()
+        for c in counts:
+            torch.set_num_threads(c)
+            step()
+            t0 = time.perf_counter()
+            step()
+            step()
+            probe[c] = 1e3 * (time.perf_counter() - t0) / 2
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
         step()
         t0 = time.perf_counter()
         n = 0
@@ -183,7 +232,7 @@ def time_reference(config: int, threads: int, seconds: float, max_steps: int = 4
             step()
             n += 1
         dt = time.perf_counter() - t0
-    return {"ms_per_step": 1e3 * dt / n, "steps": n, "threads": threads, "videos_per_s": (case["Bs"] + case["Bt"]) * n / dt,
+    return {"ms_per_step": 1e3 * dt / n, "steps": n, "threads": threads, "probe_ms_per_step_by_threads": {str(k): round(v, 2) for k, v in probe.items()}, "videos_per_s": (case["Bs"] + case["Bt"]) * n / dt,
             "sha256": staged_sha256(), "torch": torch.__version__,
             "what": "the reference's own main.train (VideoModel.forward, loss assembly, backward, clip_grad_norm_, SGD step) from the staged "
                     "copy of /root/reference, in-memory synthetic features, dropout 0.5 / 0.5, fp32"}
@@ -192,12 +241,17 @@ def time_reference(config: int, threads: int, seconds: float, max_steps: int = 4
 if __name__ == "__main__":
     import argparse as _ap
     p = _ap.ArgumentParser()
-    p.add_argument("--stage", action="store_true", help="(build container) copy the reference's module files into oracle/_ref/py/")
+    p.add_argument("--stage", action="store_true", help="(opt-in, build container) copy the reference's module files into oracle/_ref/py/ after "
+                   "checking them against the pinned sha256 values")
+    p.add_argument("--unstage", action="store_true", help="remove oracle/_ref/py/")
     p.add_argument("--config", type=int, default=2)
-    p.add_argument("--threads", type=int, default=8)
+    p.add_argument("--threads", type=str, default="8", help="torch thread count, or a comma list to probe (the fastest is timed)")
     p.add_argument("--seconds", type=float, default=12.0)
     ns = p.parse_args()
-    if ns.stage:
-        print("staged" if stage() else "no reference checkout here", STAGE)
+    if ns.unstage:
+        unstage()
+        print("removed", STAGE)
+    elif ns.stage:
+        print("staged (every file matches its pinned sha256)" if stage() else "nothing staged", STAGE)
     else:
-        print("REFERENCE_JSON " + json.dumps(time_reference(ns.config, ns.threads, ns.seconds)), flush=True)
+        print("REFERENCE_JSON " + json.dumps(time_reference(ns.config, [int(t) for t in ns.threads.split(",")], ns.seconds)), flush=True)

@@ -97,6 +97,18 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise Ta3nError(f"{LIB_PATH} not found: the HIP extension is required (python -m ta3n_amd.build); "
                         "there is no CPU fallback")
+    # The binary must be the one these sources build: the hash of csrc/ + include/ stored beside it at link time (ta3n_amd/build.py)
+    # against the hash of the tree that is loading it.  A stale or hand-placed library fails here, loudly (TA3N_ALLOW_STALE_LIB=1: A/B
+    # runs of an older build directory on purpose).
+    try:
+        from .build import source_hash
+        with open(os.path.join(os.path.dirname(LIB_PATH), ".source_hash")) as fh:
+            linked_from = fh.read().strip()
+        if linked_from != source_hash() and os.environ.get("TA3N_ALLOW_STALE_LIB") != "1":
+            raise Ta3nError(f"{LIB_PATH} was linked from sources {linked_from}, this tree is {source_hash()}: rebuild "
+                            "(python -m ta3n_amd.build), or TA3N_ALLOW_STALE_LIB=1 to load it anyway")
+    except OSError:
+        pass                              # (a library without a recorded hash: built by hand; nothing to compare)
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.ta3n_num_relation_tuples.argtypes = [C.c_int]

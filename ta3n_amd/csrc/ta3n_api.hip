@@ -381,7 +381,11 @@ int ta3n_time_phases(ta3n_plan *p, const float *x, float *params, float *grads, 
                 case PH_SGD: lrc = launch_sgd(p->geom, params, grads, momentum, ws, s); break;
                 default: lrc = -1;
             }
-            if (lrc != 0) return fail(TA3N_ERR_HIP, "launch failed while timing");
+            if (lrc != 0) {
+                for (auto &e : ev) (void)hipEventDestroy(e);
+                if (lrc == -5) return TA3N_ERR_INVALID;      // (launch_gemm has set the message: an experiments-only launch list on the default library)
+                return fail(TA3N_ERR_HIP, "launch failed while timing");
+            }
         }
         HIP_TRY(hipEventRecord(ev[2 * i + 1], s));
     }

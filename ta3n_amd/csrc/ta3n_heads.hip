@@ -45,13 +45,13 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP float4 are demoted to scratch by hipcc)
 
-// Switches of the round-5 ISA fixes of the relation loops (bisect builds: -DTA3N_HEADS_FIX=n): 1 = tuple ranges by v_readlane, 2 = label
-// by scalar load, 8 = branch-free Zr loads.  DEFAULT 7.  Do NOT enable 1 and 8 together: that combination gave wrong class logits at 12
-// segments on hipcc 7.2 (each alone is correct; GPU call 9 of round 5, tools/r5_session9.sh: lib_h7 and lib_h14 pass, 15 fails); 7 is the
-// binary the round's test tiers ran on.
-#ifndef TA3N_HEADS_FIX
-#define TA3N_HEADS_FIX 7
-#endif
+// (Round 6: the bisect switches of round 5's ISA pass - TA3N_HEADS_FIX - are gone.  The two changes every validated build carried are
+// unconditional now: the tuple ranges of all relations by ONE vector load + v_readlane, the label by a scalar load.  The third -
+// branch-free Zr loads through an address select into the block of zeros - gave wrong class logits at 12 segments together with the
+// v_readlane ranges on hipcc 7.2 and was never root-caused (no documented VALU-writes-SGPR hazard in either binary:
+// tools/isa_hazard_scan.py over the -save-temps ISA of all instantiations); it bought nothing measurable on its own, so the code
+// is deleted rather than kept behind a switch.  Likewise the four-videos-per-workgroup instantiation, which faulted and which no
+// plan ever selected.)
 
 constexpr int NBH = 256;           // num_bottleneck of trn-m (models.py:223); thread t <-> channel t
 constexpr int RPW = HEADS_RPW;
@@ -59,14 +59,14 @@ constexpr int WROW = 68;           // padded row of the forward tile [256 n][64 
 constexpr int TROW = 260;          // padded row of the backward tile [64 n][256 k] and of the classifier weights [C][256]
 
 // LDS carve-up (floats) of a workgroup that handles VPW videos at once (Geom::heads_vpw: 1 where every video can have a compute unit of
-// its own - the headline shape - and 2 or 4 for larger batches: a video workgroup owns its CU (256 registers of weights per lane), so
+// its own - the headline shape - and 2 for larger batches: a video workgroup owns its CU (256 registers of weights per lane), so
 // with more videos than CUs the launch ran in ROUNDS of one video per CU, each a ~26-30 k-cycle chain of dependent single-wave stages
 // (tools/heads_timing.py, round 4: 7-11 k of it in the relation stages A and G, ~13 k in B-F whatever the shape).  With VPW videos per
 // workgroup the per-video stages run one video per wave (or per wave pair) side by side and the 256x256 layer multiplies VPW vectors
 // from the one register copy of its weights.)
 template <int VPW>
 struct Lds {
-    static_assert(VPW == 1 || VPW == 2 || VPW == 4, "1, 2 or 4 videos per workgroup");
+    static_assert(VPW == 1 || VPW == 2, "1 or 2 videos per workgroup");
     static constexpr int W = 0;                                 // weight tile (17408 floats)
     static constexpr int VD = W + NBH * WROW;                   // [VPW][256] dropped-out video feature
     static constexpr int HV = VD + VPW * NBH;                   // [VPW][256] video-discriminator hidden
@@ -171,31 +171,22 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     // read with v_readlane afterwards: a load of tuple_first[j] inside load_rel made the compiler wait for EVERYTHING outstanding
     // (s_waitcnt vmcnt(0): the counter is in order) before it could form the next relation's addresses - a full round trip per relation
     // at the top of each loop iteration (found in the ISA in round 5).
-    const int tfv = ((TA3N_HEADS_FIX & 1) && lane <= NR) ? tf[lane] : 0;
+    const int tfv = lane <= NR ? tf[lane] : 0;
     struct RelIn { float hr[4], w0[4], w1[4], zr[3][4], b0, b1; int nt; };
     auto load_rel = [&](int j, RelIn &o) {
         const float *__restrict__ W2f = P + g.p_W2_0 + (size_t)j * g.p_W2_stride;
         const float *__restrict__ hrf = wsr + g.o_Hr + ((size_t)b * NR + j) * NBH;
         const int ju = __builtin_amdgcn_readfirstlane(j);
-        const int t_lo = (TA3N_HEADS_FIX & 1) ? __builtin_amdgcn_readlane(tfv, ju) : __builtin_amdgcn_readfirstlane(tf[j]);
-        const int t_hi = (TA3N_HEADS_FIX & 1) ? __builtin_amdgcn_readlane(tfv, ju + 1) : __builtin_amdgcn_readfirstlane(tf[j + 1]);
+        const int t_lo = __builtin_amdgcn_readlane(tfv, ju);
+        const int t_hi = __builtin_amdgcn_readlane(tfv, ju + 1);
         o.nt = t_hi - t_lo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o.hr[q] = hrf[q * 64 + lane]; o.w0[q] = W2f[q * 64 + lane]; o.w1[q] = W2f[NBH + q * 64 + lane]; }
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {         // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num); a tuple past the
-            // range is read from the block of zeros (the test selects the ADDRESS: no branch between the loads, nothing for the
-            // compiler to hang the consumer on - it used to fuse `if (tt < nt) load` with `if (tt < nt) add` and wait right there)
+        for (int tt = 0; tt < 3; ++tt) {         // a relation sums at most 3 tuples (TRNmodule.py:32 subsample_num); a tuple past the range reads as +0
             const bool on = tt < o.nt;
-            if (TA3N_HEADS_FIX & 8) {
-                const float *__restrict__ row = on ? wsr + g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + lane : wsr + g.o_zeros + lane;
-                const int qs = on ? 64 : 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o.zr[tt][q] = row[q * qs];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o.zr[tt][q] = on ? wsr[g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + q * 64 + lane] : 0.f;
-            }
+            for (int q = 0; q < 4; ++q) o.zr[tt][q] = on ? wsr[g.o_Zr + ((size_t)b * NT + t_lo + tt) * NBH + q * 64 + lane] : 0.f;
         }
         o.b0 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride];
         o.b1 = P[g.p_b2_0 + (size_t)j * g.p_b2_stride + 1];
@@ -229,7 +220,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
     const float bcdv0 = P[g.p_bcdv], bcdv1 = P[g.p_bcdv + 1];
     // (a SCALAR load: as a vector load at the end of the burst above, its consumer `lane == label` - which the compiler hoists up here to
     // keep the result as a lane mask - waited for the whole 256 KB weight burst with s_waitcnt vmcnt(0) before stage A could start)
-    const int label = (have && b < g.Bs) ? labels[(TA3N_HEADS_FIX & 2) ? __builtin_amdgcn_readfirstlane(b) : b] : -1;
+    const int label = (have && b < g.Bs) ? labels[__builtin_amdgcn_readfirstlane(b)] : -1;
     // small operands of the later stages, requested now as well (each used to cost its stage an exposed round trip):
     // the class bias of this thread's class, the video-discriminator bias of its channel, and for the first relation this
     // wave handles the tuple range and the output-layer bias
@@ -692,7 +683,6 @@ int launch_fq_vpw(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 
 template <int FQ>
 int launch_fq(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    if (g.heads_vpw == 4) return launch_fq_vpw<FQ, 4>(g, ptrs, stream);
     if (g.heads_vpw == 2) return launch_fq_vpw<FQ, 2>(g, ptrs, stream);
     return launch_fq_vpw<FQ, 1>(g, ptrs, stream);
 }

@@ -4,7 +4,8 @@
 // `pytest -m gpu_ab` with the same TA3N_LIBDIR) keeps the step-level variants that were built, measured and rejected - chained launches
 // (ta3n_config.chain), split-K tiles (split_k), time-based tile order (cost_model), the optimiser inside the gradient tiles
 // (ta3n_train_steps_fused_update), the four-wave 192x128 / 256x128 and four-half-stage kernels.  The default library carries only what a
-// plan can select by default; ta3n_plan_create refuses those options without the flag.  History: docs/history/.
+// plan can select by default.  ta3n_plan_create still BUILDS such launch lists (host code, checked on the CPU by tests/plan_interp.py); launching one
+// on the default library fails with TA3N_ERR_INVALID and a message naming the flag (launch_gemm returns -5, every caller maps it).  History: docs/history/.
 #ifndef TA3N_EXPERIMENTS
 #define TA3N_EXPERIMENTS 0
 #endif

@@ -1175,7 +1175,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_hyper = (int32_t)b.add_region("hyper", 32);
     g.o_labels = (int32_t)b.add_region("labels", B);
     g.o_tuple_first = (int32_t)b.add_region("tuple_first", NR + 1);
-    // Videos per video workgroup (ta3n_heads.hip; TA3N_HEADS_VPW in the environment forces 1 / 2 / 4 for A/B runs).  A video workgroup owns
+    // Videos per video workgroup (ta3n_heads.hip; TA3N_HEADS_VPW in the environment forces 1 / 2 for A/B runs).  A video workgroup owns
     // its compute unit, so what matters is how many ROUNDS the launch needs and how long a workgroup lives - and a workgroup's life is
     // dominated by the relation stages, whose per-wave chain grows with the relations a wave handles.  Measured (profiles/r04_heads_vpw_ab.txt):
     // 128+128 videos x 12 segments (configs[4]): 2 per workgroup turns 1.2 rounds into one, launch 40.6 -> 29.1 us, two-stream step 477 -> 470;

@@ -170,7 +170,7 @@ struct Geom {
     // hi = bf16(x); the lo plane of ANY twin element lives pair_delta floats behind its hi plane (the four lo regions are laid out
     // like the four hi regions).  0: no lo planes.
     int32_t pair_delta;
-    int32_t heads_vpw;                   // videos per video workgroup of the fused heads kernel (1, 2 or 4; 0 = 1)
+    int32_t heads_vpw;                   // videos per video workgroup of the fused heads kernel (1 or 2; 0 = 1)
 };
 
 // Register-blocking digit of a tile code (ten-thousands): 32x32 blocks per wave, rows x columns.

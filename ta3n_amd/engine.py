@@ -85,7 +85,8 @@ class TrainEngine:
                  bf16: bool = False, bf16_store: bool = False, aggregation: str = "trn-m", wgrads_late: bool = False,
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
                  dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
-                 ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None, sharded_update: Optional[bool] = None):
+                 ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None, sharded_update: Optional[bool] = None,
+                 peer_exchange: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -248,7 +249,8 @@ class TrainEngine:
         # TA3N_DDP_PEER=1: the exchange as a two-shot all-reduce over peer-mapped buffers (csrc/ta3n_peer.hip) instead of ncclAllReduce;
         # opt-in (only its protocol could be exercised on the one-GPU boxes this was built on); any backend of the process group
         self.peer = None
-        if (self.world > 1 or self._ddp_selftest) and os.environ.get("TA3N_DDP_PEER", "0") == "1":
+        want_peer = (os.environ.get("TA3N_DDP_PEER", "0") == "1") if peer_exchange is None else bool(peer_exchange)
+        if (self.world > 1 or self._ddp_selftest) and want_peer:
             want16 = (grad_transport == "bf16") if grad_transport is not None else os.environ.get("TA3N_DDP_BF16", "0") == "1"
             try:
                 self.peer = parallel.PeerComm(self.pg if self.world > 1 else None, self.device, p.live_floats, bf16=want16)
@@ -811,6 +813,10 @@ class TrainEngine:
         n = len(schedule)
         if n == 0:
             return
+        if _split:      # a caller's call (not a piece of one): what the pieces enqueue must outlive the enqueued gathers - every piece
+            # APPENDS its id tables / scalar arrays (a piece used to replace the previous piece's), and the previous call's
+            # are dropped only when the call after it starts
+            self._feed_keep_prev, self._feed_keep = getattr(self, "_feed_keep", None), []
         ddp = self.world > 1 or self._ddp_selftest
         if fused_update is None:
             fused_update = os.environ.get("TA3N_FUSED_UPDATE", "0") == "1"
@@ -827,7 +833,7 @@ class TrainEngine:
                 hy, n, C.byref(fd[0]) if fd[0] is not None else None, C.byref(fd[1]) if fd[1] is not None else None, self._stream()),
                 "ta3n_train_steps_fused_update")
             if keep:
-                self._feed_keep = keep
+                self._feed_keep.append(keep)
             self._hyper = _lib.Hyper.from_buffer_copy(hy[n - 1])
             self.step_count += n
             return
@@ -913,7 +919,9 @@ class TrainEngine:
 
     def _steps_done(self, schedule, keep, n_run: int) -> None:
         if keep:                              # the id tables must outlive the enqueued gathers
-            self._feed_keep = keep
+            if not isinstance(getattr(self, "_feed_keep", None), list):
+                self._feed_keep = []
+            self._feed_keep.append(keep)
         last = schedule[-1]
         self._pending = (float(last[2]), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self._hyper = self._job_last_hyper if self._job_last_hyper is not None else self.hyper_for(*last, step=self.step_count + n_run - 1)

@@ -66,8 +66,7 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16", pytest.param("sharded", marks=pytest.mark.gpu_ab),
-                                  pytest.param("sharded_bf16", marks=pytest.mark.gpu_ab)])      # (sharded update: opt-in, `-m gpu_ab`)
+@pytest.mark.parametrize("mode", ["fused", "unfused", "bf16", "sharded", "sharded_bf16"])      # (sharded update: opt-in, shipped in the default library)
 def test_two_ranks_equal_single_process_global_batch(tmp_path, mode):
     c = CFG
     out = str(tmp_path / "P")

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu_ab      # measured-and-rejected variant / opt-in transport: `pytest -m gpu_ab` on the experiments build (tests/conftest.py)
+pytestmark = pytest.mark.gpu      # opt-in transport, but SHIPPED in the default library (bench.py probes it at N > 1): part of `-m gpu`
 
 
 def _free_port():

@@ -55,7 +55,7 @@ def test_one_rank_rccl_step_equals_the_plain_step(monkeypatch, buckets):
     assert not torch.equal(got, synth_flat(eng))
 
 
-@pytest.mark.gpu_ab      # opt-in exchange (TA3N_DDP_SHARDED=1), measured slower at one rank: `pytest -m gpu_ab`
+# (opt-in exchange TA3N_DDP_SHARDED=1: shipped in the default library and probed by bench.py at N > 1, so part of `-m gpu`)
 @pytest.mark.parametrize("how", ["per_step", "pipelined", "one_call_two_streams", "one_call_one_stream", "bf16_arithmetic"])
 def test_one_rank_sharded_update_equals_the_plain_step(monkeypatch, how):
     """TA3N_DDP_SHARDED=1: reduce-scatter -> per-shard sum of squares -> all-gather of one float per rank -> clip + SGD on the own

@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC for cross-process device memory (RCCL ranks, the opt-in peer transport): must be in the environment before the HIP runtime
+# initialises, i.e. before `import torch` (only tests/conftest.py used to set it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
