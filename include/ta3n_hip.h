@@ -107,7 +107,7 @@ typedef struct {
                               * 128x128 tiles); 46221 / 56221: 192x128 / 256x128 (four waves, three half stages; launches whose A
                               * operands are K-contiguous, the builder's own choice elsewhere).  Codes a launch cannot use fall back. */
     int32_t phase_tiles[16]; /* per GEMM phase (in launch order) override of tile_config; 0 = use tile_config/auto */
-    int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD */
+    int32_t xcd_aware;       /* 0 = default (on), 1 = on, 2 = off: order tiles so panels sharing an operand sit on one XCD; 3 = on, with affinity groups (specs that share operand slabs stay on one XCD, back to back) */
     int32_t aggregation;     /* TA3N_AGG_*: frame aggregation (opts.py --frame_aggregation) */
     int32_t wgrads_late;     /* fused step, 0 (default): the TRN / frame-discriminator weight gradients share the launch of the
                               * gradient at the frame features; 1: that launch holds only the (critical-path) gradient at the frame

@@ -59,6 +59,7 @@ struct GemmSpec {
     std::vector<Seg> segs;
     Task proto;   // epilogue fields; m0/n0/seg range filled on expansion
     int split = 0;   // 2: two tasks per tile, each over part of the Segs (EPI_SPLITK; the Segs' order is kept: a Seg with a scale stays first)
+    int affinity = -1;   // >= 0: specs with the same value read (mostly) the same operand slabs - xcd_aware 3 keeps their tiles on one XCD, back to back
 };
 
 Task proto(int32_t c_base, int64_t c_off, int32_t c_ld) {
@@ -234,9 +235,11 @@ struct Builder {
         // (one per XCD: workgroup b runs on XCD b % 8 - a speed assumption only) so
         // the larger operand is partitioned across the private L2s and only the
         // smaller one is replicated.
-        struct Panel { std::vector<Task> tiles; int64_t cost; };
+        struct Panel { std::vector<Task> tiles; int64_t cost; int group; };
         std::vector<Panel> panels;
+        int spec_index = -1;
         for (auto &g : specs) {
+            ++spec_index;
             const int seg_begin = (int)p.segs.size();
             int cost = 0;
             for (auto &s : g.segs)   // the kernel selects its K loop by the operand kinds of the task's first Seg
@@ -264,6 +267,7 @@ struct Builder {
             for (int o0 = 0; o0 < outer; o0 += bo) {
                 Panel pn;
                 pn.cost = 0;
+                pn.group = g.affinity >= 0 ? g.affinity : -1 - spec_index;      // (no affinity given: the spec's own panels form a group)
                 for (int i0 = 0; i0 < inner; i0 += bi) {
                     Task t = g.proto;
                     t.m0 = split_m ? o0 : i0; t.n0 = split_m ? i0 : o0;
@@ -308,26 +312,83 @@ struct Builder {
             std::stable_sort(local.begin(), local.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
         } else {
             constexpr int NX = 8;
-            std::stable_sort(panels.begin(), panels.end(), [](const Panel &a, const Panel &b) { return a.cost > b.cost; });
             std::vector<std::vector<Task>> q(NX);
             std::vector<int64_t> load(NX, 0);
-            for (auto &pn : panels) {   // heaviest panel first onto the least loaded XCD queue
-                int best = 0;
-                for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
-                for (auto &t : pn.tiles) q[best].push_back(t);
-                load[best] += pn.cost;
+            if (p.cfg.xcd_aware == 3) {
+                // Affinity groups (round 6): the panels of specs that share operand slabs - the row panels of one frame's
+                // gradient-at-F1 GEMM (same TRN weight slabs), the (scale, position) weight-gradient GEMMs of one scale (same gZ_t), the
+                // tuple GEMMs of one scale (same W_j) - stay on ONE XCD and run back to back, so that XCD's L2 fetches the shared slab once
+                // for all of them instead of once per panel wherever it landed.  A group heavier than ~0.45 of an XCD's fair share is cut into
+                // chunks of consecutive panels; chunks go heaviest first onto the least loaded queue, preferring a queue that already holds
+                // a chunk of the same group when that costs less than half a chunk of balance.
+                int64_t total = 0;
+                for (auto &pn : panels) total += pn.cost;
+                const int64_t limit = std::max<int64_t>(1, total * 45 / (100 * NX));
+                struct Chunk { std::vector<int> panels; int64_t cost; int group; int64_t tile_cost; };
+                std::vector<Chunk> chunks;
+                std::vector<int> order;                       // group ids in order of first appearance
+                for (auto &pn : panels) if (std::find(order.begin(), order.end(), pn.group) == order.end()) order.push_back(pn.group);
+                for (int gid : order) {
+                    Chunk ck{{}, 0, gid, 0};
+                    for (int i = 0; i < (int)panels.size(); ++i) {
+                        if (panels[i].group != gid) continue;
+                        if (!ck.panels.empty() && ck.cost + panels[i].cost > limit) { chunks.push_back(ck); ck = Chunk{{}, 0, gid, 0}; }
+                        ck.panels.push_back(i);
+                        ck.cost += panels[i].cost;
+                        for (auto &t : panels[i].tiles) ck.tile_cost = std::max<int64_t>(ck.tile_cost, t.cost);
+                    }
+                    if (!ck.panels.empty()) chunks.push_back(ck);
+                }
+                std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.cost > b.cost; });
+                std::vector<std::vector<int>> held(NX);       // chunk indices per queue
+                for (int ci = 0; ci < (int)chunks.size(); ++ci) {
+                    int best = 0;
+                    for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
+                    for (int x = 0; x < NX; ++x) {
+                        bool same = false;
+                        for (int h : held[x]) same = same || chunks[h].group == chunks[ci].group;
+                        if (same && load[x] <= load[best] + chunks[ci].cost / 2) { best = x; break; }
+                    }
+                    held[best].push_back(ci);
+                    load[best] += chunks[ci].cost;
+                }
+                for (int x = 0; x < NX; ++x) {                // per queue: chunks with the longest tiles first, a group's chunks adjacent
+                    std::stable_sort(held[x].begin(), held[x].end(), [&](int a, int b) {
+                        if (chunks[a].tile_cost != chunks[b].tile_cost) return chunks[a].tile_cost > chunks[b].tile_cost;
+                        return chunks[a].group < chunks[b].group;
+                    });
+                    for (int h : held[x]) for (int i : chunks[h].panels) for (auto &t : panels[i].tiles) q[x].push_back(t);
+                }
+            } else {
+                std::stable_sort(panels.begin(), panels.end(), [](const Panel &a, const Panel &b) { return a.cost > b.cost; });
+                for (auto &pn : panels) {   // heaviest panel first onto the least loaded XCD queue
+                    int best = 0;
+                    for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
+                    for (auto &t : pn.tiles) q[best].push_back(t);
+                    load[best] += pn.cost;
+                }
+                for (auto &v : q) std::stable_sort(v.begin(), v.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
             }
             size_t depth = 0;
-            for (auto &v : q) {
-                std::stable_sort(v.begin(), v.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
-                depth = std::max(depth, v.size());
-            }
+            for (auto &v : q) depth = std::max(depth, v.size());
             Task nop;
             std::memset(&nop, 0, sizeof(nop));   // seg_count == 0: the workgroup exits immediately
             nop.c_base = BASE_NONE; nop.bias_base = BASE_NONE; nop.aux_base = BASE_NONE; nop.add_base = BASE_NONE;
-            for (size_t d = 0; d < depth; ++d)
+            // (affinity groups leave queues of very different LENGTH - one of many short tiles beside seven of few long ones.  Padding the
+            // short queues with empty workgroups keeps "workgroup b runs on XCD b % 8" exact, but only pays while most queues still have
+            // tiles: once fewer than half do, the rest is appended unpadded and spreads over all XCDs - short tiles, balance over locality.)
+            size_t padded_depth = depth;
+            if (p.cfg.xcd_aware == 3) {
+                std::vector<size_t> sizes;
+                for (auto &v : q) sizes.push_back(v.size());
+                std::sort(sizes.begin(), sizes.end());
+                padded_depth = sizes[NX / 2];      // depth at which half of the queues have run out
+            }
+            for (size_t d = 0; d < padded_depth; ++d)
                 for (int x = 0; x < NX; ++x) local.push_back(d < q[x].size() ? q[x][d] : nop);
             while (!local.empty() && local.back().seg_count == 0) local.pop_back();
+            for (size_t d = padded_depth; d < depth; ++d)
+                for (int x = 0; x < NX; ++x) if (d < q[x].size()) local.push_back(q[x][d]);
         }
         if (sum8[0] >= 0 && !local.empty()) {
             // on the LAST task of the list - a real tile (trailing padding was popped) and the launch's lightest, so the side job's
@@ -1038,7 +1099,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     if (!tile_ok(c.tile_config)) { err = "tile_config must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages; + 10000 / 20000 / 30000: 2 row / 2 column / 2 x 2 blocks per wave with 222 or 221, bf16 twins)"; return TA3N_ERR_INVALID; }
     for (int i = 0; i < 16; ++i)
         if (!tile_ok(c.phase_tiles[i])) { err = "phase_tiles entries must be 0 or one of 114, 118, 212, 122, 214, 124, 221, 222 (+ 2000 / 3000: bf16 stages; + 10000 / 20000 / 30000: 2 row / 2 column / 2 x 2 blocks per wave with 222 or 221, bf16 twins)"; return TA3N_ERR_INVALID; }
-    if (c.xcd_aware < 0 || c.xcd_aware > 2) { err = "xcd_aware must be 0, 1 or 2"; return TA3N_ERR_INVALID; }
+    if (c.xcd_aware < 0 || c.xcd_aware > 3) { err = "xcd_aware must be 0, 1, 2 or 3"; return TA3N_ERR_INVALID; }
     const int B = Bs + Bt, BT = B * T, NR = T - 1;
     if ((int64_t)BT * D >= (1ll << 31) || (int64_t)BT * F >= (1ll << 31)) { err = "problem too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     if (c.aggregation == TA3N_AGG_AVGPOOL)      // source-only: the fused fast path (BASELINE configs[0]); with adversarial branches or a module-path option: the general one
@@ -1238,6 +1299,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         const int j = p.scale_id[t], sl = p.scale_len[t];
         GemmSpec z;
         z.M = B; z.N = NB;
+        z.affinity = 300 + j;               // the tuples of scale j read the same W_j
         for (int pos = 0; pos < sl; ++pos)
             z.segs.push_back(mkseg(KC(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF),
                                    KC(BASE_P, trnW(j) + (int64_t)pos * F, sl * F), F));
@@ -1372,6 +1434,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             for (int pos = 0; pos < sl; ++pos) {   // dW_j[:, pos*F:(pos+1)*F] = sum_t gZ_t^T F1[:, tau_t[pos]]
                 GemmSpec gw;
                 gw.M = NB; gw.N = F;
+                gw.affinity = 100 + j;      // every position of scale j reads the same gZ_t
                 for (int t = p.tuple_first[j]; t < p.tuple_first[j + 1]; ++t)
                     gw.segs.push_back(mkseg(KM(BASE_WS, g.o_gZ + (int64_t)t * NB, ldZ),
                                             KM(BASE_WS, g.o_F1 + (int64_t)tau(t, pos) * F, ldF), B));
@@ -1386,6 +1449,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         for (int f = 0; f < T; ++f) {   // gZ1[:, f] = ( -beta2 gHf[:, f] Wfd + sum_{(t,pos): tau_t[pos]==f} gZ_t W_j[:, pos] ) * [F1>0] / keep
             GemmSpec gz;
             gz.M = B; gz.N = F;
+            gz.affinity = 200 + f;          // the row panels of frame f read the same weight slabs (Wfd, W_j[:, pos] of every tuple that holds f)
             gz.segs.push_back(mkseg(KC(BASE_WS, g.o_gHf + (int64_t)f * F, ldF), KM(BASE_P, Wfd, F), F, SK_NEG_BETA_FRM));
             for (int t = 0; t < NT; ++t) {
                 const int j = p.scale_id[t], sl = p.scale_len[t];
@@ -1455,7 +1519,10 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     // Same arithmetic in 7 launches instead of 15: everything between (Hr, Hf) and (gHr, gHf) - both
     // discriminator heads, the attention pooling, the classifier, the losses and their backward - is one
     // kernel (ta3n_heads.hip); its small weight gradients ride along with the relation level.
-    if (heads_supported(NB, C, F) && !mcd && !feat_grads && !bn_shared) {   // (the fused heads kernel knows neither the second classifier nor an outside gradient)
+    // (The fused heads kernel knows neither the second classifier nor an outside gradient.  use_bn - round 6 - IS part of the fused
+    // step: the two BatchNorm launches sit where the unfused lists have them, behind the shared-FC product and in front of its weight
+    // gradient: 10 launches instead of 17, models.py:490-543, 569-570; chained launches stay without it.)
+    if (heads_supported(NB, C, F) && !mcd && !feat_grads && !(bn_shared && c.chain != 0)) {
         const bool chain = c.chain != 0;
         std::string cerr;
         // chain: the three forward GEMM levels are ONE launch (tile-level hand-offs inside it, Builder::end_chain), likewise the
@@ -1469,6 +1536,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
                 else { for (auto &t : *side) p.tasks.push_back(t); p.phases.back().task_count += (int32_t)side->size(); }
             }
             if (!chain && group == 5) return;      // unchained: the pipelined variant only mirrors the first launch
+            if (bn_shared) b.add_simple_phase(PH_BN_FWD, group);      // F1 = dropout_i(relu(BatchNorm_domain(Z0))), batch statistics
             {
                 std::vector<GemmSpec> s{spec_Hf()};
                 for (int t = 0; t < NT; ++t) s.push_back(spec_Z(t));
@@ -1522,6 +1590,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             }
             b.add_gemm_phase(4, s);
         }
+        if (bn_shared) b.add_simple_phase(PH_BN_BWD, 4);      // gZ0 + the BatchNorm weight / bias gradients from gZ1
         {
             std::vector<GemmSpec> s;
             push_shared_fc_wgrad(s);
@@ -1561,15 +1630,26 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             if (ph.group == 4 && ph.kind == PH_GEMM)
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
                     if ((p.tasks[i].seg_count > 0 || (p.tasks[i].epi & EPI_COLSUM)) && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
-        g.n_sumsq = (int32_t)grad_tasks.size();
+        // use_bn: the BatchNorm weight / bias gradients come from the PH_BN_BWD launch, not from a tile - its workgroups ((F + 15) / 16
+        // column blocks x 2 domains) leave their sums of squares in the LAST slots of the same region (bn_shared_bwd_kernel)
+        const int n_bn_slots = bn_shared ? 2 * ((F + 15) / 16) : 0;
+        g.n_sumsq = (int32_t)grad_tasks.size() + n_bn_slots;
         g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
         for (size_t k = 0; k < grad_tasks.size(); ++k) {
             p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
             p.tasks[grad_tasks[k]].pad[3] = g.o_sumsq + (int32_t)k;
         }
-        // (the heads kernel keeps the twin of gHf; gZ and gZ1 are read by GEMM launches only: twin-only when those read twins)
-        add_bf16_twins(p, b, g, BT, D, {Span{g.o_gHf, g.o_gHf + (int64_t)BT * F}},
-                       {Span{g.o_gZ, g.o_gZ + (int64_t)B * NT * NB}, Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F}});
+        // (the heads kernel keeps the twin of gHf; gZ and gZ1 are read by GEMM launches only: twin-only when those read twins.
+        // use_bn: the BatchNorm launches keep the twins of what they produce - F1 and gZ0 - and READ gZ1 in fp32)
+        std::vector<Span> kept{Span{g.o_gHf, g.o_gHf + (int64_t)BT * F}};
+        std::vector<Span> gemm_only{Span{g.o_gZ, g.o_gZ + (int64_t)B * NT * NB}};
+        if (bn_shared) {
+            kept.push_back(Span{g.o_F1, g.o_F1 + (int64_t)BT * F});
+            kept.push_back(Span{g.o_gZ0, g.o_gZ0 + (int64_t)BT * F});
+        } else {
+            gemm_only.push_back(Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F});
+        }
+        add_bf16_twins(p, b, g, BT, D, kept, gemm_only);
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }

@@ -726,11 +726,19 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     const bool drop = hy->train && hy->p_drop_i > 0.f;
     const float inv_keep = hyper_scale(hy, SK_INV_KEEP_I);
     float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
+    // bf16 twin of F1 (TA3N_FLAG_BF16_STORE): in the fused step the next launch reads it as a GEMM operand (ta3n_plan.cpp: add_bf16_twins)
+    unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_F1 + (size_t)row0 * F : nullptr;
     for (int i = r; i < n; i += 16) {
         float y = fmaf((z[(size_t)i * F + c] - mean) * invstd, w, b);
         y = fmaxf(y, 0.f);
         if (drop) y *= keep_mask(hy->seed_i, (uint32_t)((row0 + i) * F + c), hy->p_drop_i);
-        out[(size_t)i * F + c] = y * inv_keep;
+        y *= inv_keep;
+        out[(size_t)i * F + c] = y;
+        if (tw) {
+            const unsigned hb = pack_bf16(y, 0.f);
+            tw[(size_t)i * F + c] = (unsigned short)hb;
+            if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(y, 0.f, hb);
+        }
     }
 }
 
@@ -741,7 +749,13 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     float *__restrict__ ws = ptrs.ws;
     const int dom = blockIdx.y, r = threadIdx.x >> 4, c = blockIdx.x * 16 + (threadIdx.x & 15);
     const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
-    if (n == 0) return;
+    // fused step: this workgroup's share of the gradient norm (sum of squares of the 2 x 16 BatchNorm gradients it writes) goes to ITS
+    // slot at the end of ws["sumsq"] (ta3n_plan.cpp: the last 2 * gridDim.x slots) - the fused optimiser adds the slots in a fixed order
+    float *slot = g.n_sumsq > 0 ? ws + g.o_sumsq + g.n_sumsq - 2 * (int)gridDim.x + dom * (int)gridDim.x + (int)blockIdx.x : nullptr;
+    if (n == 0) {
+        if (slot && threadIdx.x == 0) *slot = 0.f;
+        return;
+    }
     const bool col_ok = c < F;
     const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
     const float *__restrict__ gy = ws + g.o_gZ1 + (size_t)row0 * F;
@@ -756,6 +770,16 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
         }
     sg = bn_colsum16(sg, red);
     sgx = bn_colsum16(sgx, red);
+    if (slot) {      // (every thread of a column holds that column's sums: threads 0..15 cover the 16 columns; added in column order)
+        __syncthreads();
+        if (threadIdx.x < 16) red[threadIdx.x] = col_ok ? fmaf(sgx, sgx, sg * sg) : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float q = 0.f;
+            for (int k = 0; k < 16; ++k) q += red[k];
+            *slot = q;
+        }
+    }
     if (!col_ok) return;
     if (r == 0) {
         ptrs.g[g.p_bn_w[dom] + c] = sgx;
@@ -764,9 +788,16 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     const float w = ptrs.p[g.p_bn_w[dom] + c];
     const float k = w * invstd, mg = sg / (float)n, mgx = sgx / (float)n;
     float *__restrict__ out = ws + g.o_gZ0 + (size_t)row0 * F;
+    unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_gZ0 + (size_t)row0 * F : nullptr;
     for (int i = r; i < n; i += 16) {
         const float xh = (z[(size_t)i * F + c] - mean) * invstd;
-        out[(size_t)i * F + c] = k * (gy[(size_t)i * F + c] - mg - xh * mgx);
+        const float v = k * (gy[(size_t)i * F + c] - mg - xh * mgx);
+        out[(size_t)i * F + c] = v;
+        if (tw) {      // bf16 twin of gZ0: the shared-FC weight-gradient launch reads it
+            const unsigned hb = pack_bf16(v, 0.f);
+            tw[(size_t)i * F + c] = (unsigned short)hb;
+            if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(v, 0.f, hb);
+        }
     }
 }
 

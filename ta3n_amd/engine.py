@@ -106,16 +106,16 @@ class TrainEngine:
             flags |= _lib.FLAG_FEATURE_GRADS
             fused = False
         # use_bn AdaBN / AutoDIAL (models.py:194-198, 490-543, 569-570): BatchNorm1d per domain between the shared frame FC and its
-        # ReLU - batch statistics over the rows of each domain, so the step runs as the unfused launch lists with the two BN
-        # launches (TA3N_FLAG_BN_SHARED); the running statistics are buffers of this engine (state_dict names as in the reference).
+        # ReLU - batch statistics over the rows of each domain: two pointwise launches (TA3N_FLAG_BN_SHARED) behind the shared-FC product
+        # and in front of its weight gradient, in the fused step as in the unfused lists; the running statistics are buffers of this
+        # engine (state_dict names as in the reference), moved by a stream-ordered update after every train-mode forward.
         # Single rank: the statistics are taken over the rank's own rows (what each nn.DataParallel replica of the reference
         # does too, but not the same numbers as one GPU on the whole batch).  AutoDIAL's mixing parameter stays at its initial 1.
         if use_bn not in ("none", "AdaBN", "AutoDIAL"):
             raise NotImplementedError(f"use_bn {use_bn!r} (built: AdaBN, AutoDIAL)")
         self.use_bn = use_bn
-        if use_bn != "none":
+        if use_bn != "none":       # (round 6: the fused step carries the two BatchNorm launches - 10 launches instead of 17; fused=False keeps the unfused lists)
             flags |= _lib.FLAG_BN_SHARED
-            fused = False
         # ens_DA MCD (Maximum Classifier Discrepancy; models.py:276-279, 682-684, 716-720; main.py:447-448, 548-556): a second video
         # classifier, its cross-entropy on the source rows, and a SECOND forward with GradReverse(mu) behind dropout_v whose loss is
         # -mean |softmax(out_target) - softmax(out_target_2)|.  Here: the unfused launch lists with the second classifier
@@ -398,15 +398,22 @@ class TrainEngine:
             self.region("bn_run").copy_(self.bn_running.reshape(-1))
         _lib.check(self._L.ta3n_forward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws.data_ptr(),
                                         self._stream()), "ta3n_forward")
-        if bn and self._hyper.train:          # nn.BatchNorm1d's buffer update from the kernel's batch statistics (bn_batch [S, T][mean, biased var, 1/std][F])
-            st = self.region("bn_batch").view(2, 3, -1)[:, :2]
-            if min(self._bn_rows) > 0:
-                self.bn_running.mul_(0.9).add_(st * self._bn_unbias, alpha=0.1)
-            else:
-                for d, r in enumerate(self._bn_rows):
-                    if r > 0:
-                        self.bn_running[d].mul_(0.9).add_(st[d] * self._bn_unbias[d], alpha=0.1)
-            self.bn_batches += 1
+        if bn and self._hyper.train:
+            self._bn_track()
+
+    def _bn_track(self) -> None:
+        """nn.BatchNorm1d's buffer update (momentum 0.1, unbiased variance) from the batch statistics the BatchNorm launch of a
+        train-mode forward left in ws["bn_batch"] ([S, T][mean, biased var, 1/std][F]); stream-ordered, no host sync."""
+        if self.bn_running is None:
+            return
+        st = self.region("bn_batch").view(2, 3, -1)[:, :2]
+        if min(self._bn_rows) > 0:
+            self.bn_running.mul_(0.9).add_(st * self._bn_unbias, alpha=0.1)
+        else:
+            for d, r in enumerate(self._bn_rows):
+                if r > 0:
+                    self.bn_running[d].mul_(0.9).add_(st[d] * self._bn_unbias[d], alpha=0.1)
+        self.bn_batches += 1
 
     def loss(self) -> None:
         _lib.check(self._L.ta3n_loss(self.plan.handle, self.ws.data_ptr(), self._stream()), "ta3n_loss")
@@ -558,6 +565,7 @@ class TrainEngine:
         """forward + loss + backward through the fused launch sequence (include/ta3n_hip.h: ta3n_train_step)."""
         _lib.check(self._L.ta3n_train_step(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                            self.ws.data_ptr(), self._stream()), "ta3n_train_step")
+        self._bn_track()
 
     def _fused_step_overlapped_allreduce(self) -> None:
         """N > 1: the all-reduce of every gradient but the shared frame FC's (the last launch's output, 4.2 of the
@@ -570,6 +578,7 @@ class TrainEngine:
                                                    self.G.data_ptr(), self.ws.data_ptr(),
                                                    self._g16.data_ptr() if self._g16 is not None else None, self._stream(),
                                                    C.c_void_p(self._comm_stream.cuda_stream)), "ta3n_train_step_ddp")
+            self._bn_track()
             return
         n = self._L.ta3n_num_phases(self.plan.handle, 4)
         args = (self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(), self.ws.data_ptr())
@@ -580,6 +589,7 @@ class TrainEngine:
         for w in (w1, w2):
             if w is not None:
                 w.wait()
+        self._bn_track()
 
     def _enqueue_step(self) -> None:
         if self._sharded:
@@ -691,6 +701,7 @@ class TrainEngine:
         ev = C.c_void_p(join.cuda_event) if join is not None else None
         _lib.check(self._L.ta3n_train_step_join(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.G.data_ptr(),
                                                 self.ws.data_ptr(), self._stream(), ev), "ta3n_train_step_join")
+        self._bn_track()
         self.all_reduce_grads()
         self._pending = (float(lr), float(self.momentum), float(self.weight_decay), float(self.clip) if self.clip is not None else 0.0)
         self.step_count += 1
@@ -725,6 +736,7 @@ class TrainEngine:
                                                                 self.G.data_ptr(), self.M.data_ptr(), self.ws.data_ptr(), fused_norm,
                                                                 lr_p, mu, wd, clip, C.byref(self._hyper), self._stream()),
                            "ta3n_train_step_after_update")
+                self._bn_track()
                 stepped = True
             else:
                 _lib.check(self._L.ta3n_sgd_step_next(self.plan.handle, self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(),
@@ -820,7 +832,7 @@ class TrainEngine:
         ddp = self.world > 1 or self._ddp_selftest
         if fused_update is None:
             fused_update = os.environ.get("TA3N_FUSED_UPDATE", "0") == "1"
-        if fused_update and not ddp and self.fused and self._L.ta3n_has_fused_update(self.plan.handle) == 1:
+        if fused_update and not ddp and self.fused and self.bn_running is None and self._L.ta3n_has_fused_update(self.plan.handle) == 1:
             # the optimiser inside the gradient launches (ta3n_train_steps_fused_update): no separate update launches at all
             self.flush()
             if self._P2 is None:
@@ -883,6 +895,8 @@ class TrainEngine:
         ddp = self.world > 1 or self._ddp_selftest
         if self._sharded:
             return bool(self.comm is not None and not self.skip_collective)
+        if self.bn_running is not None:      # the running statistics move between the steps (a stream-ordered torch update per step)
+            return False
         return bool(self.fused and self._side_update and
                     not (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)))
 

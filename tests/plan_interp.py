@@ -456,12 +456,21 @@ class Interp:
         for dom, (pw, pb) in enumerate(((g.p_bn_w0, g.p_bn_b0), (g.p_bn_w1, g.p_bn_b1))):
             r0, n = self._bn_rows(dom)
             if n == 0:
+                if g.n_sumsq > 0:
+                    nb = (F + 15) // 16
+                    first = g.o_sumsq + g.n_sumsq - 2 * nb + dom * nb
+                    self.ws[first:first + nb] = 0
                 continue
             st = self.r(g.o_bn_batch + dom * 3 * F, (3, F))
             xh = (Z0[r0:r0 + n] - st[0]) * st[2]
             gg = gy[r0:r0 + n]
             sg, sgx = gg.sum(0), (gg * xh).sum(0)
             self.G[pw:pw + F] = sgx; self.G[pb:pb + F] = sg
+            if g.n_sumsq > 0:      # fused step: the launch's workgroups (16 columns x one domain each) leave their share of the gradient norm in the last slots of ws["sumsq"]
+                nb = (F + 15) // 16
+                q = np.zeros(nb * 16); q[:F] = sgx.astype(np.float64) ** 2 + sg.astype(np.float64) ** 2
+                first = g.o_sumsq + g.n_sumsq - 2 * nb + dom * nb
+                self.ws[first:first + nb] = q.reshape(nb, 16).sum(1)
             gZ0[r0:r0 + n] = self.P[pw:pw + F] * st[2] * (gg - sg / n - xh * sgx / n)
 
     def run_pool_bwd(self):

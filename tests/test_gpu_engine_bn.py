@@ -12,17 +12,21 @@ from ta3n_amd.synthetic import synth_batch, synth_state
 pytestmark = pytest.mark.gpu
 
 
-def _engine(c):
-    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"], use_bn=c["use_bn"])
+def _engine(c, fused=True, **kw):
+    return TrainEngine(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], dropout_i=0.0, dropout_v=0.0, clip=c["clip"], use_bn=c["use_bn"],
+                       fused=fused, **kw)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 @pytest.mark.parametrize("name", BN_CASES)
-def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name):
+def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name, fused):
+    """fused (round 6, the default): ta3n_train_step with the two BatchNorm launches inside it (10 launches) and the fused gradient
+    norm; unfused: the forward / loss / backward lists (17 launches) + a norm pass."""
     g = Golden(name)
     c = case_config(g)
     T, C = c["T"], c["C"]
-    eng = _engine(c)
-    assert not eng.fused and eng.use_bn == c["use_bn"]
+    eng = _engine(c, fused)
+    assert eng.fused == fused and eng.use_bn == c["use_bn"]
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     assert "bn_shared_S.weight" in shapes and "bn_shared_T.bias" in shapes
     eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
@@ -64,7 +68,7 @@ def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name):
         assert torch.allclose(got.cpu().reshape(want.shape), want, rtol=3e-4, atol=3e-4), key
     assert eng.bn_batches == len(step_schedule(c)) + 1          # the eval pass does not move the buffers
     # a second engine restored from the state dict continues bit-identically
-    eng2 = _engine(c)
+    eng2 = _engine(c, fused)
     eng2.load_state({k: v for k, v in sd.items()})
     eng2.M.copy_(eng.M)
     eng2.step_count = eng.step_count
@@ -74,3 +78,40 @@ def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name):
         e.train_step([0.75, 0.75, 0.5], 0.003, 1e-3, seed=5)
     torch.cuda.synchronize()
     assert torch.equal(eng.P, eng2.P) and torch.equal(eng.bn_running, eng2.bn_running) and eng.bn_batches == eng2.bn_batches
+
+
+@pytest.mark.parametrize("name", ["tiny_adabn", "mid_adabn"])
+def test_fused_batchnorm_step_pipelined_and_on_bf16_twins(name):
+    """The fused BatchNorm step through the other ways a caller runs it: train_step_pipelined / train_steps (the update opens the next
+    step; per-step calls - the running statistics move between steps) must equal train_step bit for bit, and the bf16 arithmetic
+    on twins (the BatchNorm launches keep the twins of F1 and gZ0) stays close to the fp32 step."""
+    g = Golden(name)
+    c = case_config(g)
+    shapes = None
+    runs = {}
+    for how in ("plain", "pipelined", "steps", "bf16"):
+        eng = _engine(c, True, **(dict(bf16=True, bf16_store=True) if how == "bf16" else {}))
+        assert eng.fused and not eng.can_batch_steps()
+        shapes = {n: s for n, _, s, _ in eng.plan.params}
+        eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+        sched = []
+        for s, st in enumerate(step_schedule(c)):
+            sched.append(([0.75, 0.75, 0.5], 0.003, st["lr"]))
+        xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=step_schedule(c)[0]["xseed"])
+        eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+        if how in ("plain", "bf16"):
+            for b_, g_, lr_ in sched:
+                eng.train_step(b_, g_, lr_)
+        elif how == "pipelined":
+            for b_, g_, lr_ in sched:
+                eng.train_step_pipelined(b_, g_, lr_)
+            eng.flush()
+        else:
+            eng.train_steps(sched)
+            eng.flush()
+        torch.cuda.synchronize()
+        runs[how] = (eng.P.clone(), eng.bn_running.clone(), eng.bn_batches)
+    assert torch.equal(runs["plain"][0], runs["pipelined"][0]) and torch.equal(runs["plain"][1], runs["pipelined"][1])
+    assert torch.equal(runs["plain"][0], runs["steps"][0]) and runs["plain"][2] == runs["steps"][2] == runs["pipelined"][2]
+    d = (runs["bf16"][0] - runs["plain"][0]).norm() / (runs["plain"][0].norm() + 1e-30)
+    assert torch.isfinite(runs["bf16"][0]).all() and d < 2e-2, d

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, Golden, case_config, step_schedule
+from golden_util import BN_CASES, CASES, Golden, case_config, step_schedule
 from plan_interp import Interp
 from ta3n_amd import _lib
 from ta3n_amd.synthetic import synth_batch, synth_state
@@ -405,3 +405,85 @@ def test_third_stage_rule_keeps_the_second_workgroup_on_unfused_launches_only(mo
     first_fused = next(p_ for p_ in ph if p_["group"] == 4)
     assert first_unfused["task_count"] == 384 and first_unfused["tile"] % 1000 == 222 and stages(first_unfused) == 2
     assert first_fused["task_count"] == 384 and first_fused["tile"] % 1000 == 222 and stages(first_fused) == 3
+
+
+@pytest.mark.parametrize("name", BN_CASES)
+def test_fused_plan_with_domain_batchnorm_reproduces_reference(name):
+    """use_bn AdaBN / AutoDIAL inside the FUSED step (round 6; models.py:490-543, 569-570): the ta3n_train_step list
+    with its two BatchNorm launches - behind the shared-FC product and in front of its weight gradient - and the fused gradient norm
+    (the BatchNorm gradients' share comes from the slots the backward launch leaves) against the reference's own trajectory."""
+    g = Golden(name)
+    c = case_config(g)
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS | _lib.FLAG_BN_SHARED)
+    assert plan.has_fused_step
+    kinds = [ph["kind"] for ph in plan.description["phases"] if ph["group"] == 4]
+    assert kinds == [0, 10, 0, 0, 6, 0, 0, 11, 0], kinds        # GEMM, BN fwd, GEMM, GEMM, heads, GEMM, GEMM, BN bwd, GEMM
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    assert live == set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        it.run_group(4)
+        total = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for k, v in it.get_params(it.G).items() if k in live))
+        slots = np.sqrt(it.ws[it.g.o_sumsq:it.g.o_sumsq + it.g.n_sumsq].sum())
+        assert abs(slots - total) <= 1e-6 * total, (slots, total)      # the slots hold the WHOLE norm, BatchNorm gradients included
+        it.run_group(3, fused_norm=True)
+        new = it.get_params()
+        for k in shapes:
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+    # with bf16 twins the launch behind the BatchNorm reads F1's twin (the BatchNorm launch keeps it), the last one gZ0's
+    p16 = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], ALL_FLAGS | _lib.FLAG_BN_SHARED | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE)
+    ph4 = [ph for ph in p16.description["phases"] if ph["group"] == 4 and ph["kind"] == 0]
+    assert p16.has_fused_step and len(ph4) == 6
+
+
+def _tile_keys(plan):
+    it = Interp(plan)
+    out = []
+    for ph in it.phases:
+        if ph.kind != 0:
+            continue
+        ts = it.tasks[ph.task_begin:ph.task_begin + ph.task_count]
+        # (EPI_SUMROWS8 = 64: the loss-scalar side job rides on whichever tile comes last - order-dependent by design)
+        out.append(sorted((t.c_base, t.c_off, t.m0, t.n0, t.seg_begin, t.seg_count, t.epi & ~64) for t in ts if t.seg_count > 0 or t.epi))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(128, 74, 5, 12), (48, 40, 9, 30)])
+def test_affinity_group_tile_order_is_a_permutation_of_the_default_order(shape):
+    """xcd_aware 3 (round 6): specs that share operand slabs keep their tiles on one XCD, back to back.  Only the
+    ORDER of a launch's tiles changes: the same tiles, each exactly once, in every launch - and the numbers the launch lists compute
+    are the reference's (tiny_T5 through the interpreter)."""
+    Bs, Bt, T, Cn = shape
+    a = _lib.Plan(Bs, Bt, T, 2048, 512, Cn, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE, xcd_aware=0)
+    b = _lib.Plan(Bs, Bt, T, 2048, 512, Cn, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE, xcd_aware=3)
+    ka, kb = _tile_keys(a), _tile_keys(b)
+    assert len(ka) == len(kb)
+    for x, y in zip(ka, kb):
+        assert x == y
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    plan = _lib.Plan(c["Bs"], c["Bt"], c["T"], c["D"], c["fc_dim"], c["C"], ALL_FLAGS, xcd_aware=3)
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    st = step_schedule(c)[0]
+    xs, xt, ys, yt = synth_batch(c["C"], c["T"], c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+    xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+    it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+    it.labels[:c["Bs"]] = ys.numpy()
+    it.hy = make_hyper(c, st, c["T"], st["lr"])
+    it.G[:] = 0
+    it.run_group(4)
+    it.run_group(3, fused_norm=True)
+    new = it.get_params()
+    for k in shapes:
+        g.check(f"step0/param/{k}", new[k], 1e-4, 2e-5)
