@@ -25,11 +25,7 @@ TA3N_KIND_CONFIGS(TA3N_EXTERN_KIND)
     extern template __global__ void gemm_tiles<wm, wn, wk, 5, ns, rm, rn>(const Task *, const Seg *, Ptrs, int, int, int, SgdSide, const Wait *, int, int, int, int);
 TA3N_HS_CONFIGS(TA3N_EXTERN_HS)
 
-#ifdef TA3N_GEMM_STAMPS
-extern "C" int ta3n_debug_stamps(unsigned long long *dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ta3n_dbg_stamps), sizeof(unsigned long long) * (size_t)n);
-}
-#endif
+// (-DTA3N_GEMM_STAMPS: the stamps live in the workspace region "stamps" - ta3n_gemm_kernel.h; tools/gemm_stamps.py reads them there)
 
 bool tile_config_ok(int cfg) {
     // optional ten-thousands digit: register blocking of the bf16-twin kernel (1: 2 row blocks per wave, 2: 2 column blocks, 3: 2 x 2)

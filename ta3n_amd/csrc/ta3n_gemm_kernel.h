@@ -702,11 +702,29 @@ __device__ __forceinline__ const float *base_ptr(const Ptrs &p, int base) {
 
 }  // namespace
 
+// -DTA3N_GEMM_STAMPS (a build directory of its own: TA3N_LIBDIR=ta3n_amd/lib_stamps; tools/gemm_stamps.py): every workgroup of a GEMM launch leaves
+// 16 x 8-byte stamps in the workspace region "stamps", which the plan builder of such a build lays out directly in front of "zeros" (the
+// kernel knows zeros_off): [0] entry, [1] descriptors / bias loaded, [2] K loop done, [3] all waves done, [4] accumulators in LDS, [5] stores
+// issued, [6] the task's cost (its K), [7] its Seg count, [8] cycles thread 0 spent in the K loop waiting for "stage landed + barrier",
+// [9] cycles it spent issuing the next stage's DMA + LDS reads + MFMAs, [10] stages.  (Round 6: the stamps used to live in a __device__
+// array, of which every instantiation unit has its own copy - the reader only saw the launcher's.)
 #ifdef TA3N_GEMM_STAMPS
-__device__ unsigned long long ta3n_dbg_stamps[8192 * 8];
-#define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ta3n_dbg_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TA3N_STAMP_SLOTS 16
+#define TA3N_STAMP_FLOATS (8192 * TA3N_STAMP_SLOTS * 2)
+#define GSTAMP_PTR (reinterpret_cast<unsigned long long *>(const_cast<float *>(ptrs.ws) + zeros_off - TA3N_STAMP_FLOATS))
+#define GSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) GSTAMP_PTR[blockIdx.x * TA3N_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GSTAMP_VAL(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) GSTAMP_PTR[blockIdx.x * TA3N_STAMP_SLOTS + (i)] = (unsigned long long)(v); } while (0)
+#define KSTAMP_DECL unsigned long long ks_wait = 0, ks_comp = 0, ks_t = 0; int ks_n = 0
+#define KSTAMP_BEGIN_WAIT do { ks_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define KSTAMP_END_WAIT do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ks_wait += n_ - ks_t; ks_t = n_; ++ks_n; } while (0)
+#define KSTAMP_END_COMP do { if (ks_t != 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ks_comp += n_ - ks_t; } } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
+#define GSTAMP_VAL(i, v) do { } while (0)
+#define KSTAMP_DECL do { } while (0)
+#define KSTAMP_BEGIN_WAIT do { } while (0)
+#define KSTAMP_END_WAIT do { } while (0)
+#define KSTAMP_END_COMP do { } while (0)
 #endif
 
 namespace ta3n {
@@ -928,6 +946,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     // buffer just read into registers - were built and measured slower in round 4 (profiles/r04_dma_interleave_ab.txt,
     // r04_early_refill_ab.txt) and removed from the tree in round 5: docs/history/round4.md, git 545b5f2.)
     (void)knobs;
+    KSTAMP_DECL;
     constexpr int KVE = BM > 128 ? (KV & (1 | 2 | 32)) : KV;      // tiles taller than 128 rows: K-contiguous A only (the plan keeps them off other launches)
     auto k_loop = [&](auto akm, auto bkm, auto rsum) {
         constexpr bool AKM = decltype(akm)::value, BKM = decltype(bkm)::value, RS = decltype(rsum)::value;
@@ -955,9 +974,12 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 ob.issue(k0, klen - k0, st + BM * ROWF * 4, wave, lane, zeros);
             };
             auto stage_ready = [&]() {
+                KSTAMP_END_COMP;
+                KSTAMP_BEGIN_WAIT;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current stage have landed
                 __builtin_amdgcn_s_barrier();                        // ... everyone's; and everyone is done reading the other stage
                 asm volatile("" ::: "memory");
+                KSTAMP_END_WAIT;
             };
             int buf = 0;
             open_seg(cseg);
@@ -1024,6 +1046,8 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
             };
             auto wait_landed = [&](int younger) {     // the oldest chunk in flight has landed once only the younger ones' DMAs are out
                 static_assert((NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+                KSTAMP_END_COMP;
+                KSTAMP_BEGIN_WAIT;
                 if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (NS == 3 || younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
                 else if (NS == 4 || younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
@@ -1031,6 +1055,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPW) : "memory");
                 __builtin_amdgcn_s_barrier();          // ... everyone's pieces have; and everyone is done reading the stage refilled next
                 asm volatile("" ::: "memory");
+                KSTAMP_END_WAIT;
             };
             open_issue_seg();
     #pragma unroll 1
@@ -1101,7 +1126,11 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     }
 
     // ---- epilogue: accumulators -> LDS (reduces the K split, makes rows contiguous) ----
+    KSTAMP_END_COMP;
     GSTAMP(2);
+#ifdef TA3N_GEMM_STAMPS
+    GSTAMP_VAL(8, ks_wait); GSTAMP_VAL(9, ks_comp); GSTAMP_VAL(10, ks_n);
+#endif
     __syncthreads();
     GSTAMP(3);
 #pragma unroll
@@ -1359,7 +1388,7 @@ __device__ __forceinline__ void gemm_tile(const Task &t, const Seg *__restrict__
     }
     GSTAMP(5);
 #if defined(TA3N_GEMM_STAMPS) && TA3N_GEMM_STAMPS == 1
-    if (threadIdx.x == 0 && blockIdx.x < 8192) { ta3n_dbg_stamps[blockIdx.x * 8 + 6] = (unsigned long long)t.cost; ta3n_dbg_stamps[blockIdx.x * 8 + 7] = (unsigned long long)t.seg_count; }
+    GSTAMP_VAL(6, t.cost); GSTAMP_VAL(7, t.seg_count);
 #endif
     if (epi & EPI_SUMSQ) {   // wave-uniform: fixed-order block sum -> this tile's slot (fused grad-norm partial)
         __syncthreads();

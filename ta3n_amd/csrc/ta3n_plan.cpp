@@ -1226,6 +1226,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         g.o_Y2 = (int32_t)b.add_region("Y2", (int64_t)B * C);
         g.o_gY2 = (int32_t)b.add_region("gY2", (int64_t)B * C);
     }
+#ifdef TA3N_GEMM_STAMPS
+    b.add_region("stamps", 8192 * 16 * 2);            // (debug build: per-workgroup cycle stamps of the GEMM launches, directly in front of "zeros")
+#endif
     g.o_zeros = (int32_t)b.add_region("zeros", 64);   // never written: source of out-of-range operand elements
     g.o_ones = (int32_t)b.add_region("ones", (int64_t)BT * 4);   // [BT][4] block of ones (k-major A operand of the column sums)
     if (g.o_ones != g.o_zeros + 64) { err = "internal: ones must follow zeros"; return TA3N_ERR_INVALID; }
