@@ -276,7 +276,10 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
 
 
 def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, steps=12, warm=4):
-    """Times the pipelined train step under each gradient exchange ("allreduce", "sharded", "peer") and without any (every rank skips
+    """Times the pipelined train step under each gradient exchange ("allreduce": one RCCL ncclAllReduce after the last launch;
+    "allreduce_overlapped": everything but the shared frame FC's gradient reduced on a second stream WHILE the last launch computes that
+    gradient, the rest after it; "sharded": RCCL reduce-scatter, own-shard clip + SGD, all-gather; "peer": the in-tree two-shot all-reduce
+    over peer-mapped buffers) and without any (every rank skips
     it: the numbers trained on are then wrong, the time is what is wanted): `steps` steps after `warm`, fenced, MAX over ranks.
     Returns ({candidate: {...}}, fastest candidate).  Every rank takes the same decisions: availability is what the engine
     constructors agreed on collectively, times are all-reduced, ties go to the earlier (simpler) candidate."""
@@ -295,11 +298,11 @@ def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, ste
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return 1e3 * t.item() / n
 
-    for cand in ("allreduce", "sharded", "peer"):
+    for cand in ("allreduce", "allreduce_overlapped", "sharded", "peer"):
         row = {}
         try:
             eng = build_engines(cand)[0]
-            got = "sharded" if eng._sharded else "peer" if eng.peer is not None else "allreduce"
+            got = "sharded" if eng._sharded else "peer" if eng.peer is not None else "allreduce_overlapped" if eng._ddp_buckets == 2 else "allreduce"
             if got != cand:
                 row["unavailable"] = "the engine kept the default exchange" + (f" ({eng.comm_fallback})" if eng.comm_fallback else "")
             else:
@@ -430,9 +433,9 @@ def main():
     ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32", help="N > 1: what the gradient all-reduce moves - fp32 (default: "
                     "the exact sum up to the reduction order), or bf16 (every rank's gradients rounded to bf16 and summed in bf16: half the xGMI bytes; "
                     "stated in the line)")
-    ap.add_argument("--exchange", choices=("auto", "allreduce", "sharded", "peer"), default="auto", help="N > 1: the gradient exchange of the timed "
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "allreduce_overlapped", "sharded", "peer"), default="auto", help="N > 1: the gradient exchange of the timed "
                     "region - auto (default): the fastest of the three as measured during warm-up (config.exchange_probe names all times); "
-                    "allreduce: one RCCL ncclAllReduce per step; sharded: RCCL reduce-scatter + own-shard update + all-gather; peer: the in-tree "
+                    "allreduce: one RCCL ncclAllReduce per step; allreduce_overlapped: two, the first beside the last launch; sharded: RCCL reduce-scatter + own-shard update + all-gather; peer: the in-tree "
                     "two-shot all-reduce over peer-mapped buffers")
     ap.add_argument("--no-other-configs", action="store_true", help="do not add the 20-step timings of configs[0] / [3] / [4] to the line")
     ap.add_argument("--no-fresh-batch", action="store_true", help="skip the second timed loop with a new device-gathered batch per step")
@@ -496,7 +499,8 @@ def main():
             """The engine(s) of this arithmetic with one gradient exchange (N > 1): None = whatever the environment selects (default: ONE
             RCCL ncclAllReduce per step), "allreduce" / "sharded" (RCCL reduce-scatter, own-shard clip + SGD, all-gather) / "peer" (the
             in-tree two-shot all-reduce over peer-mapped buffers)."""
-            kw = {} if exchange is None else dict(sharded_update=exchange == "sharded", peer_exchange=exchange == "peer")
+            kw = {} if exchange is None else dict(sharded_update=exchange == "sharded", peer_exchange=exchange == "peer",
+                                                  ddp_buckets=2 if exchange == "allreduce_overlapped" else 1)
             es = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                               clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
                               fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],

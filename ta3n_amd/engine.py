@@ -86,7 +86,7 @@ class TrainEngine:
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
                  dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
                  ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None, sharded_update: Optional[bool] = None,
-                 peer_exchange: Optional[bool] = None):
+                 peer_exchange: Optional[bool] = None, ddp_buckets: Optional[int] = None):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -220,7 +220,7 @@ class TrainEngine:
                              self._L.ta3n_has_pipelined_step(self.plan.handle) == 1)
         # 1 (default): one all-reduce after the last launch; 2: everything but the shared frame FC's gradient is reduced while
         # the last launch runs (worth it only when that launch is longer than an extra collective's fixed cost)
-        self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1"))
+        self._ddp_buckets = int(os.environ.get("TA3N_DDP_BUCKETS", "1")) if ddp_buckets is None else int(ddp_buckets)
         self._n_first = next(off for name, off, _, _ in p.params if not name.startswith("fc_feature_shared_source"))
         # N > 1 (or the 1-rank self-test): RCCL straight from the C ABI on the step's streams (TA3N_DDP_NATIVE=0: through
         # torch.distributed instead).

@@ -112,7 +112,43 @@ static void sweep_depth(const Bufs &B, int pattern, int grid) {
     run<NW, MODE, 8>(B, pattern, grid);
 }
 
-int main() {
+// `proto_fill middle` (round 6): the weight-streaming floor of a FUSED relation-level middle (Hr GEMM -> heads -> gR
+// dgrad as one kernel per block of videos).  Such a workgroup owns whole rows, so it must pull EVERY weight matrix of the middle through
+// its own LDS: 4 x W1_j (fwd) + W_dv + 4 x W1_j (bwd) = 9 x 128 KiB of bf16 = 1.125 MiB, all workgroups the same bytes (L2 / MALL
+// resident).  With 202 videos there are 13 / 26 / 52 / 104 such workgroups (16 / 8 / 4 / 2 videos each) on 256 CUs.  No compute.
+template <int NW, int MODE>
+static void run_middle(const Bufs &B, int grid) {
+    const size_t region_bytes = (size_t)1152 << 10, bytes = region_bytes;      // every workgroup streams the same 1.125 MiB once
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((fill<NW, MODE, 4>), dim3(grid), dim3(64 * NW), 0, 0, B.src, region_bytes, 0, 1, bytes, B.sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0) best = ms < best ? ms : best;
+    }
+    printf("middle %-4s waves %2d grid %3d (%2d videos per workgroup): %6.1f us to stream 1.125 MiB of weights per workgroup = %5.1f GB/s = %4.1f B/clk per workgroup\n",
+           MODE == 0 ? "dma" : "reg", NW, grid, (202 + grid - 1) / grid, best * 1e3, bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 2.4e9);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'm') {
+        Bufs B;
+        B.total = (size_t)8 << 20;
+        CK(hipMalloc(&B.src, B.total));
+        CK(hipMalloc(&B.sink, 4096 * sizeof(float)));
+        CK(hipMemset(B.src, 1, B.total));
+        CK(hipDeviceSynchronize());
+        for (int grid : {13, 26, 52, 104, 202}) {
+            run_middle<8, 0>(B, grid); run_middle<16, 0>(B, grid); run_middle<8, 1>(B, grid); run_middle<16, 1>(B, grid);
+        }
+        return 0;
+    }
     Bufs B;
     B.total = (size_t)3 << 30;      // 3 GiB: 768 regions of 4 MiB - every cold workgroup of a 512-workgroup grid has its own
     CK(hipMalloc(&B.src, B.total));

@@ -44,3 +44,8 @@ for a in "f32 2" "bf16 2" "bf16 4"; do
 done
 cat $O/pmc_per_launch.txt | cut -c1-260 | tee -a $O/summary.txt
 cat $O/gemm_stamps.txt | grep -v "^$" | cut -c1-300 | tee -a $O/summary.txt
+timeout 120 tools/proto_fill middle > $O/proto_fused_middle_floor.txt 2>&1; cat $O/proto_fused_middle_floor.txt | tee -a $O/summary.txt
+for i in 1 2 3 4 5 6 7 8 9 10; do
+  timeout 600 python -m pytest tests/test_gpu_peer.py -m gpu -x -q > $O/peer.$i.txt 2>&1
+  echo "peer tests (IPC export retried in the library) rep $i rc=$? $(grep -E 'passed|failed|skipped' $O/peer.$i.txt | tail -1)" | tee -a $O/summary.txt
+done
