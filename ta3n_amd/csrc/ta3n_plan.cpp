@@ -765,9 +765,18 @@ int build_plan_avgpool(ta3n_plan &p, std::string &err) {
     g.live_floats = (int32_t)p.live_floats;
     g.p_Wcv = (int32_t)Wcv; g.p_bcv = (int32_t)bcv;
 
+    int split_shared_fc = 0;    // (set for the fused step's first launch: ta3n_config.split_k bit 2)
     auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
         GemmSpec s;
         s.M = BT; s.N = F;
+        if (split_shared_fc && D >= 512 && (D / 2) % 128 == 0) {
+            // split_k bit 2 (round 6 experiment): the launch has ONE tile per compute unit at the headline shape - one resident workgroup
+            // pulls its stages at ~15 B/clk where two pull ~21 - so every tile becomes two workgroups over the two halves of K
+            // (EPI_SPLITK: partial tile through L2 + ticket, the second to arrive adds and runs the epilogue)
+            s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D / 2));
+            s.segs.push_back(mkseg(KC(BASE_X, D / 2, D), KC(BASE_P, Wsh + D / 2, D), D / 2));
+            s.split = 2;
+        } else
         s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
         s.proto = proto(BASE_WS, g.o_F1, F);
         with_bias(s.proto, bsh);
@@ -948,9 +957,18 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
         if (relu) s.proto.epi |= EPI_RELU;
         return s;
     };
+    int split_shared_fc = 0;    // (set for the fused step's first launch: ta3n_config.split_k bit 2)
     auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
         GemmSpec s;
         s.M = BT; s.N = F;
+        if (split_shared_fc && D >= 512 && (D / 2) % 128 == 0) {
+            // split_k bit 2 (round 6 experiment): the launch has ONE tile per compute unit at the headline shape - one resident workgroup
+            // pulls its stages at ~15 B/clk where two pull ~21 - so every tile becomes two workgroups over the two halves of K
+            // (EPI_SPLITK: partial tile through L2 + ticket, the second to arrive adds and runs the epilogue)
+            s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D / 2));
+            s.segs.push_back(mkseg(KC(BASE_X, D / 2, D), KC(BASE_P, Wsh + D / 2, D), D / 2));
+            s.split = 2;
+        } else
         s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
         if (bn_shared) {   // the linear output only: BatchNorm, ReLU and dropout follow in the PH_BN_FWD launch
             s.proto = proto(BASE_WS, g.o_Z0, F);
@@ -1274,9 +1292,18 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     auto tau = [&](int t, int pos) { return p.tuples[(size_t)t * T + pos]; };
 
     // ---- GEMM specs (one per affine contraction of the step) ----
+    int split_shared_fc = 0;    // (set for the fused step's first launch: ta3n_config.split_k bit 2)
     auto spec_F1 = [&]() {   // shared frame FC + ReLU + dropout_i (models.py:565-575)
         GemmSpec s;
         s.M = BT; s.N = F;
+        if (split_shared_fc && D >= 512 && (D / 2) % 128 == 0) {
+            // split_k bit 2 (round 6 experiment): the launch has ONE tile per compute unit at the headline shape - one resident workgroup
+            // pulls its stages at ~15 B/clk where two pull ~21 - so every tile becomes two workgroups over the two halves of K
+            // (EPI_SPLITK: partial tile through L2 + ticket, the second to arrive adds and runs the epilogue)
+            s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D / 2));
+            s.segs.push_back(mkseg(KC(BASE_X, D / 2, D), KC(BASE_P, Wsh + D / 2, D), D / 2));
+            s.split = 2;
+        } else
         s.segs.push_back(mkseg(KC(BASE_X, 0, D), KC(BASE_P, Wsh, D), D));
         if (bn_shared) {   // the linear output only: BatchNorm, ReLU and dropout follow in the PH_BN_FWD launch (models.py:565-575)
             s.proto = proto(BASE_WS, g.o_Z0, F);
@@ -1552,6 +1579,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             }
             if (chain) { const std::string e = b.end_chain(); if (!e.empty()) cerr = e; }
         };
+        split_shared_fc = ((c.split_k & 4) && !chain && !bn_shared) ? 1 : 0;
         forward_levels(4, nullptr);
         b.add_simple_phase(PH_HEADS, 4);
         b.sum8[0] = g.o_losses; b.sum8[1] = g.o_loss_part; b.sum8[2] = g.n_vid_wg + g.n_frm_wg;   // logging scalars
@@ -1579,7 +1607,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         const bool late_fd = (late_mask >> 1) & 1;
         const unsigned late_trn = late_mask >> 2;
         if (chain) b.begin_chain();
-        split_f1_grad = (c.split_k == 2 && !chain) ? 2 : 0;
+        split_f1_grad = ((c.split_k & 2) && !chain) ? 2 : 0;
         {
             std::vector<GemmSpec> s;
             if (chain) {      // one launch: the tiles everything else waits for (the gradient at F1) are dispatched first

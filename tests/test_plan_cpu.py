@@ -270,9 +270,10 @@ def test_every_task_carries_a_copy_of_its_first_segment():
         assert n > 100
 
 
+@pytest.mark.parametrize("split_k", [2, 4, 6])      # 2: the gradient at the frame features; 4 (round 6): the shared-FC product, its single K segment halved; 6: both
 @pytest.mark.parametrize("flags", [ALL_FLAGS, ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE])
 @pytest.mark.parametrize("name", ["tiny_T5", "tiny_T9"])
-def test_split_k_plan_on_cpu(name, flags):
+def test_split_k_plan_on_cpu(name, flags, split_k):
     """ta3n_config.split_k = 2: every tile of the gradient at the frame features is two tasks, each over part of the K segments, that
     meet through a partial-tile buffer and a ticket.  Structure of the pairs, and - executed in list order AND with every pair's
     halves swapped - the reference's golden vectors."""
@@ -280,7 +281,7 @@ def test_split_k_plan_on_cpu(name, flags):
     g = Golden(name)
     c = case_config(g)
     T = c["T"]
-    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, split_k=2)
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags, split_k=split_k)
     plain = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags)
     it = Interp(plan)
     part_off, part_n = plan.regions["splitk_part"]
