@@ -67,7 +67,7 @@ HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "gemm_traffic.json")   # written by tools/measure_traffic.py from rocprofv3 PMC passes
 
 
-def measured_traffic(dtype):
+def measured_traffic(dtype, key=None):
     """HBM-side bytes per GEMM launch (FETCH_SIZE x 2 [gfx950 half-count correction] + WRITE_SIZE, average over the GEMM
     launches of a fused step) of the headline configuration, as measured by tools/measure_traffic.py on a GPU box and
     committed under profiles/ together with the raw counter tables.  PMC collection needs its own rocprofv3 passes (it
@@ -77,7 +77,7 @@ def measured_traffic(dtype):
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
         from ta3n_amd.build import source_hash
-        e = t[dtype]
+        e = t[key or dtype]
         return e["bytes_per_gemm_launch"], {"file": "profiles/gemm_traffic.json", "measured_on_sources": t.get("source_hash"),
                                             "current_sources": source_hash(), "fresh": t.get("source_hash") == source_hash(),
                                             "passes": e.get("passes")}
@@ -298,7 +298,16 @@ def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, ste
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return 1e3 * t.item() / n
 
-    for cand in ("allreduce", "allreduce_overlapped", "sharded", "peer"):
+    # Which candidates: all four when bench.py started the ranks itself (a job that dies in the probe is started again on the plain
+    # all-reduce: launch_ranks) or when asked (TA3N_BENCH_PROBE=all); under a CALLER's launcher only the two RCCL all-reduce schedules -
+    # what cannot be retried must not be risked on transports that have only ever run in 1-rank groups and on shared devices.
+    want = os.environ.get("TA3N_BENCH_PROBE", "all" if os.environ.get("TA3N_BENCH_OWN_LAUNCHER") == "1" or world == 1 else "safe")
+    cands = ("allreduce", "allreduce_overlapped", "sharded", "peer") if want == "all" else ("allreduce", "allreduce_overlapped")
+    for cand in ("sharded", "peer"):
+        if cand not in cands:
+            table[cand] = {"not_probed": "under a caller's launcher only the RCCL all-reduce schedules are probed (TA3N_BENCH_PROBE=all, or the bare "
+                                         "`python bench.py --gpus N`, probes every exchange)"}
+    for cand in cands:
         row = {}
         try:
             eng = build_engines(cand)[0]
@@ -361,7 +370,18 @@ def launch_ranks(n_gpus: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     print("[bench] launching " + " ".join(cmd[1:8]) + " bench.py " + " ".join(sys.argv[1:]), file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
+    env["TA3N_BENCH_OWN_LAUNCHER"] = "1"      # the ranks know a failed job can be started again: they probe EVERY exchange (probe_exchanges)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0 and "--exchange" not in sys.argv and not LAUNCH_TEST:
+        # The automatic probe includes exchanges that only ever ran on one-GPU boxes (the peer-mapped transport: 1-rank groups and two
+        # processes sharing a device).  If the job died, the measurement is still owed: once more on the plain RCCL all-reduce.
+        print(f"[bench] the {n_gpus}-rank job exited with {rc}; once more with --exchange allreduce (one RCCL ncclAllReduce per step, no probe)",
+              file=sys.stderr, flush=True)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            cmd[cmd.index("--master-port") + 1] = str(s.getsockname()[1])
+        rc = subprocess.call(cmd + ["--exchange", "allreduce"], env=env)
+    return rc
 
 
 def rank_environment(n_gpus: int):
@@ -792,6 +812,13 @@ def main():
                                                         "bound": ws["bound"], "bound_us": ws["bound_us"], "frac_of_bound": ws["frac"]}
                 if "gemm_launches" in r:
                     configs_line[f"configs[{cnum - 1}]"]["gemm_launches"] = r["gemm_launches"]
+                # measured HBM-side traffic of this configuration's GEMM launches, where a PMC measurement is committed (VERDICT r05 item 3:
+                # the ratio per configuration, not only for the headline) against the algorithmic bytes of its contractions
+                tr, tr_src = measured_traffic(cf["dtype"], key=f"configs[{cnum - 1}]")
+                if tr is not None:
+                    alg = algorithmic_gemm_bytes_bf16(**cf["shape"], agg=cf["agg"]) / max(len(r.get("gemm_launches", [])), 1)
+                    configs_line[f"configs[{cnum - 1}]"].update({"traffic": tr, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": tr / alg,
+                                                                 "traffic_source": tr_src})
             except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
                 configs_line[f"configs[{cnum - 1}]"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if rank == 0:
