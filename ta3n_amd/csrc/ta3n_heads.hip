@@ -402,11 +402,9 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                 g1 += ce * Hc * (-s.p1 * (s.lp1 + s.H));
             }
             if (lane < C) ws[g.o_gY + (size_t)b * C + lane] = gy;
-            if (lane < g.Cp) ws[g.o_gYp + (size_t)b * g.Cp + lane] = gy;      // zero-padded copy ([B][Cp], gy = 0 in lanes >= C): 16-byte operand rows for the weight-gradient tiles
             if (lane == 0) {
                 ws[g.o_Pv + (size_t)b * 2] = d0; ws[g.o_Pv + (size_t)b * 2 + 1] = d1;
                 ws[g.o_gPv + (size_t)b * 2] = g0; ws[g.o_gPv + (size_t)b * 2 + 1] = g1;
-                *reinterpret_cast<f32x4 *>(&ws[g.o_gPvp + (size_t)b * 4]) = f32x4{g0, g1, 0.f, 0.f};
             }
         }
         if (lead) {
@@ -521,10 +519,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
                 g1 += dot * s.p1 * (s.lp1 + s.H);
                 w1 = 1.f + (1.f - s.H);
             }
-            if (lane == 0) {
-                ws[g.o_gPrT + bj * 2] = g0; ws[g.o_gPrT + bj * 2 + 1] = g1;
-                *reinterpret_cast<f32x4 *>(&ws[g.o_gPrTp + bj * 4]) = f32x4{g0, g1, 0.f, 0.f};
-            }
+            if (lane == 0) { ws[g.o_gPrT + bj * 2] = g0; ws[g.o_gPrT + bj * 2 + 1] = g1; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = q * 64 + lane;

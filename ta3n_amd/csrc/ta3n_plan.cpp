@@ -1226,10 +1226,6 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     g.o_gHf = (int32_t)b.add_region("gHf", (int64_t)BT * F);
     g.o_gVt = (int32_t)b.add_region("gVt", (int64_t)B * NB);
     g.o_gPrT = (int32_t)b.add_region("gPrT", (int64_t)B * NR * 2);
-    g.Cp = (C + 3) / 4 * 4;      // (fused heads kernel only: padded copies for the relation-level backward launch, ta3n_types.h)
-    g.o_gYp = (int32_t)b.add_region("gYp", (int64_t)B * g.Cp);
-    g.o_gPvp = (int32_t)b.add_region("gPvp", (int64_t)B * 4);
-    g.o_gPrTp = (int32_t)b.add_region("gPrTp", (int64_t)B * NR * 4);
     g.o_gRa = (int32_t)b.add_region("gRa", (int64_t)B * NR * NB);
     g.o_gHr = (int32_t)b.add_region("gHr", (int64_t)B * NR * NB);
     g.o_gR = (int32_t)b.add_region("gR", (int64_t)B * NR * NB);
@@ -1408,12 +1404,10 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     };
     // dW = G^T X; bias_dst >= 0: the tiles of the first column block also write db = column sums of G, i.e. the row sums of
     // their own A operand (EPI_ROWSUM_A) - no separate ones^T G tasks, which were as long as a weight-gradient tile each
-    // a_rows > 0: the A table has that many readable rows (> M: zero-padded, ta3n_types.h Geom::o_gYp) - what makes a 2- or C-row operand
-    // movable 16 bytes at a time
-    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int64_t x_off, int x_ld, int64_t dst, int64_t bias_dst = -1, int a_rows = 0) {
+    auto wgrad = [&](int M, int N, int K, int64_t g_off, int g_ld, int64_t x_off, int x_ld, int64_t dst, int64_t bias_dst = -1) {
         GemmSpec gw;
         gw.M = M; gw.N = N;
-        gw.segs.push_back(mkseg(KM(BASE_WS, g_off, g_ld), KM(BASE_WS, x_off, x_ld), K, SK_ONE, a_rows));
+        gw.segs.push_back(mkseg(KM(BASE_WS, g_off, g_ld), KM(BASE_WS, x_off, x_ld), K));
         gw.proto = proto(BASE_G, dst, N);
         if (bias_dst >= 0) { gw.proto.epi |= EPI_ROWSUM_A; gw.proto.bias_base = BASE_G; gw.proto.bias_off = (int32_t)bias_dst; }
         return gw;
@@ -1445,13 +1439,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         }
         return gr;
     };
-    bool padded_heads = false;   // (set for the fused step's relation-level launch: the heads kernel's padded logit-gradient tables)
     auto push_video_head_wgrads = [&](std::vector<GemmSpec> &s) {   // dWcdv, dbcdv, dWcv, dbcv
-        if (padded_heads) {
-            s.push_back(wgrad(2, NB, B, g.o_gPvp, 4, g.o_Hv, NB, Wcdv, bcdv, 4));
-            s.push_back(wgrad(C, NB, B, g.o_gYp, g.Cp, g.o_Vd, NB, Wcv, bcv, g.Cp));
-            return;      // (no second classifier in the fused step)
-        }
         s.push_back(wgrad(2, NB, B, g.o_gPv, 2, g.o_Hv, NB, Wcdv, bcdv));
         s.push_back(wgrad(C, NB, B, g.o_gY, C, g.o_Vd, NB, Wcv, bcv));
         if (mcd) s.push_back(wgrad(C, NB, B, g.o_gY2, C, g.o_Vd, NB, Wcv2, bcv2));
@@ -1466,8 +1454,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         for (int j = 0; j < NR; ++j) {
             s.push_back(spec_gR(j));
             s.push_back(wgrad(NB, NB, B, g.o_gHr + (int64_t)j * NB, ldR, g.o_R + (int64_t)j * NB, ldR, W1(j), B1(j)));
-            if (padded_heads) s.push_back(wgrad(2, NB, B, g.o_gPrTp + (int64_t)j * 4, NR * 4, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j), 4));
-            else s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j)));
+            s.push_back(wgrad(2, NB, B, g.o_gPrT + (int64_t)j * 2, NR * 2, g.o_Hr + (int64_t)j * NB, ldR, W2(j), B2(j)));
         }
     };
     auto push_trn_wgrads = [&](std::vector<GemmSpec> &s, unsigned scale_mask = ~0u) {   // TRN weight (and bias) gradients of the scales in the mask
@@ -1598,10 +1585,8 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
         b.sum8[0] = g.o_losses; b.sum8[1] = g.o_loss_part; b.sum8[2] = g.n_vid_wg + g.n_frm_wg;   // logging scalars
         {
             std::vector<GemmSpec> s;
-            padded_heads = true;
             push_relation_level(s);
             push_video_head_wgrads(s);
-            padded_heads = false;
             push_video_disc_wgrads(s);
             // dWcd, dbcd = sums over the frame workgroups of their partial sums: exact fp32 column sums in a fixed order
             b.colsum_pending(g.o_fh_part, g.n_frm_wg, 2 * F, 2 * F, Wcd);

@@ -171,10 +171,6 @@ struct Geom {
     // like the four hi regions).  0: no lo planes.
     int32_t pair_delta;
     int32_t heads_vpw;                   // videos per video workgroup of the fused heads kernel (1 or 2; 0 = 1)
-    // Round 6: zero-PADDED copies of the three narrow logit-gradient tables the fused heads kernel leaves for the relation-level backward
-    // launch - gY [B][Cp] (Cp = C rounded up to 4), gPv [B][4], gPrT [B][n_rel][4] - so that the weight-gradient tiles that read them as
-    // k-major A operands (rows = classes / the 2 domain logits) can move 16 bytes per lane instead of 4 (ta3n_gemm_kernel.h: OperandStream).
-    int32_t o_gYp, o_gPvp, o_gPrTp, Cp;
 };
 
 // Register-blocking digit of a tile code (ten-thousands): 32x32 blocks per wave, rows x columns.

@@ -58,7 +58,7 @@ _GEOM_FIELDS = ["Bs", "Bt", "B", "T", "D", "F", "NB", "C", "n_tuples", "n_rel", 
                 "p_Wcd", "p_bcd", "p_Wdv", "p_bdv", "p_Wcv", "p_bcv", "p_Wcdv", "p_bcdv", "o_fh_part", "o_fh_bpart",
                 "o_loss_part", "n_vid_wg", "n_frm_wg", "heads_rpw", "o_sumsq", "n_sumsq", "o_metrics", "o_confusion",
                 "o_ws16", "o_p16", "o_x16", "ws16_span", "o_gV_ext", "o_Y2", "o_gY2", "o_Z0", "o_gZ0", "o_bn_batch", "o_bn_run",
-                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b", "pair_delta", "heads_vpw", "o_gYp", "o_gPvp", "o_gPrTp", "Cp"]
+                "p_bn_w0", "p_bn_w1", "p_bn_b0", "p_bn_b1", "o_p16b", "pair_delta", "heads_vpw"]
 
 
 class Geom(C.Structure):
@@ -524,10 +524,6 @@ class Interp:
         self.r(g.o_gVt, (B, NB))[:] = gVt * self.scale(5)
         self.r(g.o_gattn, (B, g.n_rel))[:] = 0          # the fused step does not consume an upstream attention gradient
         self.run_pool_bwd()
-        # zero-padded copies of the narrow logit-gradient tables for the relation-level backward launch (Geom::o_gYp / o_gPvp / o_gPrTp)
-        gYp = self.r(g.o_gYp, (B, g.Cp)); gYp[:] = 0; gYp[:, :Cn] = gY
-        gPvp = self.r(g.o_gPvp, (B, 4)); gPvp[:] = 0; gPvp[:, :2] = gPv
-        gPrTp = self.r(g.o_gPrTp, (B * g.n_rel, 4)); gPrTp[:] = 0; gPrTp[:, :2] = self.r(g.o_gPrT, (B * g.n_rel, 2))
         self.r(g.o_gHf, (B * T, F))[:] = np.where(Hf > 0, gPf @ Wcd, 0)
         lp = self.r(g.o_loss_part, (g.n_vid_wg + g.n_frm_wg, 8))
         lp[:] = 0
