@@ -318,13 +318,20 @@ def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, ste
                 row["ms_per_step"] = timed(eng, steps)
                 row["bytes"] = eng.plan.live_floats * (2 if eng._g16 is not None else 4)
                 row["through"] = ("C-ABI RCCL communicator" if eng.comm is not None else "torch.distributed") if cand != "peer" else "csrc/ta3n_peer.hip"
+                # sound on EVERY rank, or rejected on every rank: a rank whose peer wait gave up (sticky error word, NaN from then on) must
+                # not leave the others inside a collective it skipped - the verdict is local, the decision an all-reduce
+                sound = bool(torch.isfinite(eng.P).all().item())
+                why = "non-finite parameters after the probe"
                 if cand == "peer":
-                    eng.check_exchange()
-                fin = torch.tensor([float(torch.isfinite(eng.P).all().item())], device=dev)
+                    try:
+                        eng.check_exchange()
+                    except Exception as ex:      # noqa: BLE001
+                        sound, why = False, f"{ex}"[:160]
+                fin = torch.tensor([float(sound)], device=dev)
                 if world > 1:
                     torch.distributed.all_reduce(fin, op=torch.distributed.ReduceOp.MIN)
                 if fin.item() != 1.0:
-                    row["rejected"] = "non-finite parameters after the probe"
+                    row["rejected"] = why if not sound else "another rank's exchange failed or delivered non-finite parameters"
                 elif best_ms is None or row["ms_per_step"] < best_ms:
                     best, best_ms = cand, row["ms_per_step"]
                 if cand == "allreduce":      # the same engine once more without its collective: what each exchange leaves exposed
@@ -345,6 +352,10 @@ def probe_exchanges(build_engines, beta, gamma, lr, fence, world, dev, rank, ste
             "what": "the pipelined train step under each gradient exchange, MAX over ranks; the timed region runs on `chosen`"}, best
 
 
+# tests/test_gpu_bench_two_ranks.py: the WHOLE N > 1 path of this file - launcher, rank checks, exchange probe, MAX-over-ranks timing, the
+# line - with two ranks that SHARE cuda:0 over gloo (RCCL does not put two ranks on one device; the one-GPU boxes this is built on have no
+# other way to run world_size 2 on hardware).  The line says so (`shared_gpu_test`), its numbers are not a measurement of two GPUs.
+SHARED_GPU_TEST = os.environ.get("TA3N_BENCH_SHARED_GPU") == "1"
 LAUNCH_TEST = os.environ.get("TA3N_BENCH_LAUNCH_TEST") == "1"      # tests/test_bench_launcher.py: the launcher and the rank handshake on CPU (gloo), no engine, no measurement
 
 
@@ -357,7 +368,7 @@ def launch_ranks(n_gpus: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n_gpus and not LAUNCH_TEST:
+    if have < n_gpus and not LAUNCH_TEST and not (SHARED_GPU_TEST and have >= 1):
         print(f"[bench] --gpus {n_gpus}: this box has {have} visible GPU(s); refusing to run a {n_gpus}-rank job on fewer devices "
               f"(one process per GPU, RCCL does not share a device between ranks)", file=sys.stderr, flush=True)
         return 2
@@ -393,7 +404,7 @@ def rank_environment(n_gpus: int):
     if world != n_gpus:
         raise SystemExit(f"[bench] --gpus {n_gpus} but this job has WORLD_SIZE={world}: launch `python bench.py --gpus {n_gpus}` bare (it "
                          f"starts its own ranks) or give torch.distributed.run --nproc-per-node {n_gpus}")
-    if not LAUNCH_TEST and torch.cuda.device_count() < (world if world > 1 else 1):
+    if not LAUNCH_TEST and torch.cuda.device_count() < (1 if SHARED_GPU_TEST else world if world > 1 else 1):
         raise SystemExit(f"[bench] rank {rank}: {torch.cuda.device_count()} visible GPU(s) for a {world}-rank job (one process per GPU)")
     return world, rank, local_rank
 
@@ -476,12 +487,17 @@ def main():
     if LAUNCH_TEST:
         launch_test_line(world, rank)
         return
+    if SHARED_GPU_TEST:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1" and "RANK" in os.environ   # N > 1 code path on 1 rank
     if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if SHARED_GPU_TEST:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -707,7 +723,8 @@ def main():
             res["gradient_exchange"] = ("RCCL ncclAllReduce from the C ABI on the step's stream, " +
                                         ("bf16" if eng._g16 is not None else "fp32") + " transport")
         else:
-            res["gradient_exchange"] = ("torch.distributed all_reduce (backend nccl = RCCL), fp32" +
+            res["gradient_exchange"] = ((f"torch.distributed all_reduce (backend {torch.distributed.get_backend()}), fp32" if SHARED_GPU_TEST else
+                                         "torch.distributed all_reduce (backend nccl = RCCL), fp32") +
                                         (f" [C-ABI communicator unavailable: {eng.comm_fallback}]" if eng.comm_fallback else ""))
         # the number of ranks the exchange really spans: the library's communicator, else the torch.distributed (RCCL) group
         res["rccl_ranks"] = (int(eng._L.ta3n_comm_world(eng.comm.handle)) if eng.comm is not None else
@@ -841,7 +858,8 @@ def main():
                       "src+tgt videos/sec per train step (BASELINE configs[%d])" % (args.config - 1),
             "value": main_res["value"], "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic", **({"shared_gpu_test": "the ranks of this run SHARE one GPU over gloo: a test of the N > 1 path, "
+                                                           "not a measurement of N GPUs"} if SHARED_GPU_TEST else {}),
             "config": {"workload": conf["name"] + ", dropout 0.5/0.5, clip 20, Nesterov SGD; " + arith[args.dtype],
                        "baseline_config": args.config - 1,
                        "global_batch": (SH["Bs"] + SH["Bt"]) * world, "parallelism": f"dp{world}",

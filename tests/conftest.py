@@ -26,7 +26,7 @@ def pytest_configure(config):
 # longer hide the rows in front of it.
 ORDER = [
     "test_gpu_parity.py", "test_gpu_gradients.py", "test_gpu_masked_gradients.py", "test_gpu_bf16.py", "test_gpu_train_steps.py",
-    "test_gpu_two_stream.py", "test_gpu_rccl.py", "test_gpu_ddp_engine.py", "test_gpu_peer.py", "test_main_dropin.py", "test_train_ddp.py",
+    "test_gpu_two_stream.py", "test_gpu_rccl.py", "test_gpu_ddp_engine.py", "test_gpu_peer.py", "test_gpu_bench_two_ranks.py", "test_main_dropin.py", "test_train_ddp.py",
     "test_gpu_module.py", "test_gpu_training_equivalence.py", "test_gpu_pair_twins.py", "test_gpu_kind_kernels.py",
     "test_feature_store.py", "test_index.py", "test_gpu_avgpool.py", "test_avgpool_da.py", "test_gpu_da_extras.py",
     "test_gpu_engine_bn.py", "test_gpu_engine_mcd.py", "test_gpu_engine_avgpool_da.py", "test_gpu_da_over_ranks.py", "test_gpu_accel.py",

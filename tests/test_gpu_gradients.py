@@ -24,6 +24,10 @@ SHAPES = {
     "config4_T9_C30_b512": dict(Bs=512, Bt=512, T=9, D=2048, F=512, C=30),
     "config5_T12_D1024": dict(Bs=128, Bt=128, T=12, D=1024, F=512, C=12),
     "headline": dict(Bs=128, Bt=74, T=5, D=2048, F=512, C=12),
+    # (round 6) the heads kernel's pipelined relation loops with TWO videos per workgroup run for every batch above 224 videos
+    # since round 5: more than 448 videos at 12 segments (11 relations: 5-6 per wave) and an odd count at 9, narrow features so the oracle stays fast
+    "pipe_T12_b480": dict(Bs=256, Bt=224, T=12, D=256, F=128, C=12),
+    "pipe_T9_b463": dict(Bs=232, Bt=231, T=9, D=256, F=128, C=30),
 }
 
 
@@ -122,8 +126,8 @@ def test_every_gradient_element_matches_the_oracle(name, arith, fused, capsys): 
     _check(grad_m, logit_err, arith)
 
 
-@pytest.mark.parametrize("arith", ["f32", "f32x3", "f32x3p"])
-@pytest.mark.parametrize("shape", ["config4_T9_C30_b512", "config5_T12_D1024"])
+@pytest.mark.parametrize("shape,arith", [(sh, a) for sh in ("config4_T9_C30_b512", "config5_T12_D1024") for a in ("f32", "f32x3", "f32x3p")] +
+                         [("pipe_T12_b480", "f32"), ("pipe_T9_b463", "f32")])
 def test_full_shape_gradients_match_the_oracle(shape, arith, capsys):
     """BASELINE configs[3] / configs[4] at full size, two steps, all gradients in full, fp32 MFMA and the split arithmetic."""
     grad_m, logit_err = _steps_against_resynced_oracle(SHAPES[shape], arith, steps=2)
@@ -133,7 +137,7 @@ def test_full_shape_gradients_match_the_oracle(shape, arith, capsys):
     _check(grad_m, logit_err, arith)
 
 
-@pytest.mark.parametrize("shape", ["headline", "config4_T9_C30_b512", "config5_T12_D1024"])
+@pytest.mark.parametrize("shape", ["headline", "config4_T9_C30_b512", "config5_T12_D1024", "pipe_T12_b480"])
 def test_bf16_distance_from_the_fp32_reference_logits_and_gradients(shape, capsys):
     """What rounding the contraction operands to bf16 costs against the REFERENCE's fp32 arithmetic, for the logits and for every
     gradient tensor, at the benchmarked shapes (the gate against the bf16-operand oracle is tests/test_gpu_bf16.py)."""
