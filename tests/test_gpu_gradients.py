@@ -137,7 +137,7 @@ def test_full_shape_gradients_match_the_oracle(shape, arith, capsys):
     _check(grad_m, logit_err, arith)
 
 
-@pytest.mark.parametrize("shape", ["headline", "config4_T9_C30_b512", "config5_T12_D1024", "pipe_T12_b480"])
+@pytest.mark.parametrize("shape", ["headline", "config4_T9_C30_b512", "config5_T12_D1024"])      # (the benchmarked shapes: the bounds are their measured floors)
 def test_bf16_distance_from_the_fp32_reference_logits_and_gradients(shape, capsys):
     """What rounding the contraction operands to bf16 costs against the REFERENCE's fp32 arithmetic, for the logits and for every
     gradient tensor, at the benchmarked shapes (the gate against the bf16-operand oracle is tests/test_gpu_bf16.py)."""
