@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 6, GPU call 7: the peer transport after "park and take back" (no free + re-export of an exchange buffer any more): its tests 12 x, the
+# two-rank bench test 3 x, the DDP-engine / RCCL tests once.
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r6s7; rm -rf $O; mkdir -p $O
+cd $R
+for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+  timeout 900 python -m pytest tests/test_gpu_peer.py -m gpu -x -q -rs > $O/peer.$i.txt 2>&1
+  echo "peer tests rep $i rc=$? $(grep -E 'passed|failed|skipped' $O/peer.$i.txt | tail -1) $(grep -c SKIPPED $O/peer.$i.txt) skip lines" | tee -a $O/summary.txt
+done
+for i in 1 2 3; do
+  timeout 1000 python -m pytest tests/test_gpu_bench_two_ranks.py -m gpu -x -q > $O/two_ranks.$i.txt 2>&1
+  echo "two-rank bench test rep $i rc=$? $(grep -E 'passed|failed|skipped' $O/two_ranks.$i.txt | tail -1)" | tee -a $O/summary.txt
+done
+timeout 900 python -m pytest tests/test_gpu_ddp_engine.py tests/test_gpu_rccl.py -m gpu -x -q > $O/ddp.txt 2>&1; echo "ddp engine + rccl tests rc=$? $(tail -1 $O/ddp.txt)" | tee -a $O/summary.txt
