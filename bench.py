@@ -537,6 +537,8 @@ def main():
             in-tree two-shot all-reduce over peer-mapped buffers)."""
             kw = {} if exchange is None else dict(sharded_update=exchange == "sharded", peer_exchange=exchange == "peer",
                                                   ddp_buckets=2 if exchange == "allreduce_overlapped" else 1)
+            if n_streams == 1 and (world > 1 or selftest):
+                kw["share_comm"] = True      # the probe's engines and the timed one share ONE RCCL communicator (one ncclCommInitRank per process)
             es = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                               clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
                               fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],

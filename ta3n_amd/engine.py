@@ -86,7 +86,7 @@ class TrainEngine:
                  f32_split: bool = False, chain: Optional[bool] = None, grad_transport: Optional[str] = None,
                  dis_DA: str = "none", place_dis: Sequence[str] = ("N", "Y", "N"), alpha: float = 0.0, use_bn: str = "none",
                  ens_DA: str = "none", mu: float = 0.0, split_k: Optional[int] = None, sharded_update: Optional[bool] = None,
-                 peer_exchange: Optional[bool] = None, ddp_buckets: Optional[int] = None):
+                 peer_exchange: Optional[bool] = None, ddp_buckets: Optional[int] = None, share_comm: bool = False):
         if not torch.cuda.is_available():
             raise _lib.Ta3nError("TrainEngine needs a HIP device (no CPU fallback)")
         if flags is None:        # default: the full TA3N configuration for trn-m, the source-only one (BASELINE configs[0]) for avgpool
@@ -233,7 +233,7 @@ class TrainEngine:
             # Either EVERY rank uses the library's communicator or none does (parallel.NativeComm agrees on that over the torch group
             # before and after ncclCommInitRank): ranks that disagreed would enqueue different collectives and hang.
             try:
-                self.comm = parallel.NativeComm(self.pg if self.world > 1 else None, self.device)
+                self.comm = (parallel.shared_native_comm if share_comm else parallel.NativeComm)(self.pg if self.world > 1 else None, self.device)
             except Exception as ex:      # noqa: BLE001 - raised on every rank together: still RCCL, through torch.distributed
                 self.comm = None
                 self.comm_fallback = f"{type(ex).__name__}: {ex}"
@@ -260,6 +260,8 @@ class TrainEngine:
                 self.peer = None
                 if self.rank == 0:
                     print(f"[ta3n] peer all-reduce unavailable ({type(ex).__name__}: {ex}); using the default exchange", flush=True)
+        if self.comm is not None and self.peer is None and getattr(self.comm, "shared", False):
+            self._L.ta3n_comm_attach_peer(self.comm.handle, None)      # (a shared communicator may still carry the previous engine's transport)
         # use_bn: running [source, target][mean, var][F] (nn.BatchNorm1d: zeros / ones, momentum 0.1, unbiased variance) + batch counter
         self.bn_running: Optional[torch.Tensor] = None
         self.bn_batches = 0

@@ -14,3 +14,12 @@ for i in 1 2 3; do
   echo "two-rank bench test rep $i rc=$? $(grep -E 'passed|failed|skipped' $O/two_ranks.$i.txt | tail -1)" | tee -a $O/summary.txt
 done
 timeout 900 python -m pytest tests/test_gpu_ddp_engine.py tests/test_gpu_rccl.py -m gpu -x -q > $O/ddp.txt 2>&1; echo "ddp engine + rccl tests rc=$? $(tail -1 $O/ddp.txt)" | tee -a $O/summary.txt
+TA3N_DDP_SELFTEST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29613 python bench.py --steps 100 --warmup 10 --skip-cpu-baseline --single-dtype --no-other-configs > $O/bench_selftest.json 2> $O/bench_selftest.err; echo "selftest bench (shared communicator) rc=$?" | tee -a $O/summary.txt
+python - <<'PY' | tee -a gpurun_out/r6s7/summary.txt
+import json
+try:
+    d = json.loads([l for l in open("gpurun_out/r6s7/bench_selftest.json") if l.startswith("{")][-1])
+    print(d["ms_per_step"], d["config"]["exchange"], d["config"]["rccl_ranks"], json.dumps(d["config"]["exchange_probe"]["candidates"])[:900])
+except Exception as ex:
+    print("unreadable", ex)
+PY
