@@ -429,6 +429,32 @@ def launch_test_line(world: int, rank: int) -> None:
                           "config": {"parallelism": f"dp{world}", "rccl_ranks": None}}), flush=True)
 
 
+_SAVED_STDOUT = None
+
+
+def _stdout_to_stderr():
+    """From here on everything written to file descriptor 1 - by Python or by any library's printf - goes to stderr."""
+    global _SAVED_STDOUT
+    if _SAVED_STDOUT is None:
+        sys.stdout.flush()
+        _SAVED_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _restore_stdout():
+    global _SAVED_STDOUT
+    if _SAVED_STDOUT is not None:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # the C library's buffered streams (RCCL's banner) - out through stderr before stdout comes back
+        except Exception:      # noqa: BLE001
+            pass
+        os.dup2(_SAVED_STDOUT, 1)
+        os.close(_SAVED_STDOUT)
+        _SAVED_STDOUT = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -489,6 +515,7 @@ def main():
         return
     if SHARED_GPU_TEST:
         local_rank = 0
+    _stdout_to_stderr()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     selftest = os.environ.get("TA3N_DDP_SELFTEST") == "1" and "RANK" in os.environ   # N > 1 code path on 1 rank
@@ -927,7 +954,12 @@ def main():
             out["config"]["scaling_projection"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         if not args.skip_cpu_baseline and world == 1:       # the CPU path is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(conf)
+        # ONE JSON line on stdout and nothing else: libraries print there too (RCCL's version banner sits in the C stdio buffer until the
+        # process exits and would land BEHIND the line), so file descriptor 1 was pointed at stderr for the whole run (_stdout_to_stderr);
+        # flush whatever C and Python still hold, give stdout back, print the line
+        _restore_stdout()
         print(json.dumps(out), flush=True)
+        _stdout_to_stderr()      # (whatever is printed while the process group shuts down is not part of the answer either)
     if world > 1 or selftest:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

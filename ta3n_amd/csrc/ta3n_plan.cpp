@@ -1074,7 +1074,9 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
         if (ph.group == 4 && ph.kind == PH_GEMM)
             for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
                 if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
-    g.n_sumsq = (int32_t)grad_tasks.size();
+    // use_bn: the BatchNorm weight / bias gradients come from the PH_BN_BWD launch - its workgroups leave their sums of squares in the LAST
+    // 2 * ((F + 15) / 16) slots of the region (bn_shared_bwd_kernel), as in the trn-m plan
+    g.n_sumsq = (int32_t)grad_tasks.size() + (bn_shared ? 2 * ((F + 15) / 16) : 0);
     g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
     for (size_t k = 0; k < grad_tasks.size(); ++k) {
         p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;

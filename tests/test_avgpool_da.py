@@ -105,6 +105,36 @@ def test_plan_reproduces_reference_on_cpu(name, fused):
             g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
 
 
+def test_fused_tempooling_plan_with_domain_batchnorm_on_cpu():
+    """use_bn on TemPooling through the FUSED list (round 6: TrainEngine runs use_bn fused): the reference's tiny_avgpool_adabn trajectory,
+    and the sumsq slots hold the whole gradient norm - the BatchNorm gradients' share in the LAST slots, no tile's slot overwritten."""
+    g, c, _, _, flags = _setup("tiny_avgpool_adabn")
+    T = c["T"]
+    plan = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags | _lib.FLAG_BN_SHARED, aggregation=_lib.AGG_AVGPOOL)
+    assert plan.has_fused_step
+    it = Interp(plan)
+    shapes = {n: s for n, _, s, _ in plan.params}
+    it.set_params(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
+    live = {n for n, _, _, lv in plan.params if lv}
+    assert live == set(str(k) for k in g.meta("live"))
+    for s, st in enumerate(step_schedule(c)):
+        xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+        xs[st["n_src"]:] = 0; xt[st["n_tgt"]:] = 0
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.hy["gamma"] = 0.0
+        it.G[:] = 0
+        it.run_group(4)
+        total = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for k, v in it.get_params(it.G).items() if k in live))
+        slots = np.sqrt(it.ws[it.g.o_sumsq:it.g.o_sumsq + it.g.n_sumsq].sum())
+        assert abs(slots - total) <= 1e-6 * total, (slots, total)
+        it.run_group(3, fused_norm=True)
+        new = it.get_params()
+        for k in shapes:
+            g.check(f"step{s}/param/{k}", new[k], 1e-4, 2e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", AVG_DA_CASES)

@@ -23,6 +23,7 @@ def test_bare_gpus_2_runs_two_ranks_probes_the_exchanges_and_prints_one_line():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[-2000:]      # nothing but the line on stdout (RCCL's banner etc. go to stderr)
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["rccl_ranks"] == 2 and "shared_gpu_test" in d
     assert d["config"]["global_batch"] == 2 * (128 + 74) and d["value"] > 0 and d["config"]["finite"] is True

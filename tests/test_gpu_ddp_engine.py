@@ -128,7 +128,7 @@ def _worker_da(rank, world, port, out, opt):
     lo, hi = parallel.shard_range(c["Bs"], world, rank)
     lo_t, hi_t = parallel.shard_range(c["Bt"], world, rank)
     eng = _engine_da(hi - lo, hi_t - lo_t, opt)
-    assert eng.world == world and not eng.fused
+    assert eng.world == world and eng.fused == (opt == "adabn")      # (use_bn is part of the fused step since round 6; DAN / JAN / MCD are unfused lists)
     shapes = {n: s for n, _, s, _ in eng.plan.params}
     eng.load_state(synth_state(shapes, seed=3))
     res = _run_da(eng, xs[lo:hi], xt[lo_t:hi_t], ys[lo:hi], 2, global_source=c["Bs"], global_target=c["Bt"])
