@@ -5,6 +5,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r6s7; rm -rf $O; mkdir -p $O
 cd $R
+python -m pytest tests -m gpu -q > $O/gpu_tier.txt 2>&1; echo "full gpu tier (no -x) rc=$? $(grep -E 'passed|failed' $O/gpu_tier.txt | tail -1)" | tee -a $O/summary.txt
+grep -E "^FAILED|^ERROR" $O/gpu_tier.txt | cut -c1-200 | tee -a $O/summary.txt
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
   timeout 900 python -m pytest tests/test_gpu_peer.py -m gpu -x -q -rs > $O/peer.$i.txt 2>&1
   echo "peer tests rep $i rc=$? $(grep -E 'passed|failed|skipped' $O/peer.$i.txt | tail -1) $(grep -c SKIPPED $O/peer.$i.txt) skip lines" | tee -a $O/summary.txt
