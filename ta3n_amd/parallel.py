@@ -209,8 +209,10 @@ class NativeComm:
             raise
         self.handle, self.world, self.rank, self._L = h, world, rank, L
 
+    shared = False      # shared_native_comm: not destroyed with the engine that asked for it
+
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not self.shared:
             self._L.ta3n_comm_destroy(self.handle)
             self.handle = None
 
@@ -219,6 +221,23 @@ class NativeComm:
             self.close()
         except Exception:
             pass
+
+
+_SHARED_COMMS: Dict[tuple, "NativeComm"] = {}
+
+
+def shared_native_comm(group=None, device=None) -> "NativeComm":
+    """ONE RCCL communicator of the library per (process group, device) for engines that are built one after another on the same ranks
+    (bench.py probes every gradient exchange with an engine of its own and then builds the chosen one: five engines, one ncclCommInitRank).
+    Every rank must ask in the same order - creation is collective.  The communicator lives until the process exits; whoever uses it
+    attaches / detaches its own peer transport (ta3n_comm_attach_peer)."""
+    key = (id(group) if group is not None else None, str(device))
+    c = _SHARED_COMMS.get(key)
+    if c is None or getattr(c, "handle", None) is None:
+        c = NativeComm(group, device)
+        c.shared = True
+        _SHARED_COMMS[key] = c
+    return c
 
 
 class PeerComm:
