@@ -25,11 +25,12 @@ cd $R
 for i in 1 2; do python bench.py --steps 20 --warmup 5 > $O/bench_driver_protocol_$i.json 2>> $O/bench.err; done
 python bench.py > $O/bench.json 2>> $O/bench.err
 TA3N_DDP_SELFTEST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29612 python bench.py --steps 100 --warmup 10 --skip-cpu-baseline --single-dtype --no-other-configs > $O/bench_selftest.json 2>> $O/bench.err
+TA3N_BENCH_SHARED_GPU=1 TA3N_PEER_TIMEOUT_S=10 python bench.py --gpus 2 --steps 20 --warmup 5 --skip-cpu-baseline --single-dtype --no-other-configs > $O/bench_two_ranks_shared_gpu.json 2> $O/bench_two_ranks_shared_gpu.err; echo "bench --gpus 2, two ranks sharing the GPU over gloo (test mode) rc=$?; stdout lines: $(grep -c . $O/bench_two_ranks_shared_gpu.json)" | tee -a $O/summary.txt
 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_gpus2.out 2> $O/bench_gpus2.err; echo "bench --gpus 2 on this 1-GPU box rc=$? (must be non-zero): $(tail -1 $O/bench_gpus2.err)" | tee -a $O/summary.txt
 head -14 $O/bench_kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt
 head -14 $O/gaps_driver_protocol.txt | tee -a $O/summary.txt
 cat $O/gemm_traffic.json | tee -a $O/summary.txt
 for f in bench_driver_protocol_1 bench_driver_protocol_2 bench bench_selftest; do python -c "
-import json,sys; d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); r=d['roofline']
+import json,sys; d=json.loads([l for l in open('$O/$f.json') if l.startswith('{')][-1]); r=d['roofline']
 print('$f', d['ms_per_step'], d['value'], 'fresh', d.get('ms_per_step_fresh_batch'), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), 'traffic_fresh', r['traffic_source'].get('fresh'), 'f32', (r.get('other_arithmetic') or {}).get('ms_per_step'), {k:(round(v['ms_per_step'],4), round(v.get('traffic_over_algorithmic', 0), 2)) for k,v in (d.get('configs') or {}).items()}, 'cpu', (d.get('cpu_baseline') or {}).get('kind'), (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline') or {}).get('probe_ms_per_step_by_threads'), 'exchange', d['config'].get('exchange'))" 2>&1 | tee -a $O/summary.txt; done
 tail -30 $O/pmc_per_launch.txt | cut -c1-250 >> $O/summary.txt
