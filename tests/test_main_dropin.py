@@ -197,14 +197,15 @@ def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path,
 
 
 @pytest.mark.gpu
-def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path):
+@pytest.mark.parametrize("bn", ["none", "AdaBN"])      # (round 6: use_bn is part of the fused step, so main.py's fast path takes those runs too)
+def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):
     """main.py's train() takes the fused step (TrainEngine) where the options allow it; TA3N_MAIN_FAST=0 keeps the module path
     (VideoModel.forward + torch loss assembly + autograd + clip + SGD).  Same arithmetic up to fp32 summation order, the same dropout
     masks (both draw the two stream seeds from the global torch RNG, one draw per train forward - which also keeps the samplers of the
     next epoch in step): the logged losses agree line by line and the checkpoints hold the same parameters and momentum buffers."""
     import re
     data = make_dataset(str(tmp_path / "data"))
-    common = list(COMMON)                                     # dropout 0.5 / 0.5: the two paths draw the same masks
+    common = list(COMMON) + (["--use_bn", bn] if bn != "none" else [])      # dropout 0.5 / 0.5: the two paths draw the same masks
     outs, cks = [], []
     for fast in ("1", "0"):
         exp = str(tmp_path / f"exp{fast}")
@@ -214,7 +215,7 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path):
         outs.append([ln for ln in open(exp + "/RGB/train.log") if ln.startswith("Train:")])
         cks.append(torch.load(exp + "/RGB/checkpoint.pth.tar", map_location="cpu", weights_only=False))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "main_fast_vs_module_path.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "main_fast_vs_module_path%s.txt" % ("" if bn == "none" else "_" + bn)), "w") as f:
         f.write("# train.log of main.py with the fused step (TA3N_MAIN_FAST=1), then with the module path (=0); dropout 0.5 / 0.5\n" + "".join(outs[0]) + "# ----\n" + "".join(outs[1]))
     assert len(outs[0]) == len(outs[1]) == 6
     # (Prec@1 is not compared: from the 0.001-std initialisation the five class logits of a video differ in the sixth digit, so the
