@@ -294,22 +294,20 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
 
     STAMP(2);
     // ---- B: class logits: 4 threads per class, each a quarter of K; combined on the DPP quad network; one video after the other ----
-    // (Round 6: branch-free - threads past the last class redo class C - 1 and store nothing - and NO barrier between B and C: the two
-    // stages only read S_VD and write different blocks (S_Y / S_HV), so they form one basic block and the 64-FMA chain of the class logits
-    // runs under the 256 FMAs + DPP sums of the video-discriminator layer instead of in front of them.)
     {
         const int c = tid >> 2, part = tid & 3;
-        const int cc = c < C ? c : C - 1;
 #pragma unroll
         for (int v = 0; v < VPW; ++v) {
             float acc = 0.f;
-            const float *wr = &smem[S_W + cc * TROW + part * 64];
-            const float *vd = &smem[S_VD + v * NBH + part * 64];
+            if (c < C) {
+                const float *wr = &smem[S_W + c * TROW + part * 64];
+                const float *vd = &smem[S_VD + v * NBH + part * 64];
 #pragma unroll
-            for (int k4 = 0; k4 < 64; k4 += 4) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
-                const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
-                acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
+                for (int k4 = 0; k4 < 64; k4 += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wr + k4);
+                    const float4 x4 = *reinterpret_cast<const float4 *>(vd + k4);
+                    acc = fmaf(w4.x, x4.x, acc); acc = fmaf(w4.y, x4.y, acc); acc = fmaf(w4.z, x4.z, acc); acc = fmaf(w4.w, x4.w, acc);
+                }
             }
             acc += dpp_move<0xB1, 0xF>(0.f, acc);      // quad_perm [1,0,3,2]
             acc += dpp_move<0x4E, 0xF>(0.f, acc);      // quad_perm [2,3,0,1]: every lane of the quad holds the class logit
@@ -320,6 +318,8 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
             }
         }
     }
+    __syncthreads();   // logits visible; done with the classifier tile
+    const float y = (lane < C) ? smem[S_Y + vloc * 64 + lane] : -INFINITY;
 
     STAMP(3);
     // ---- C: Hv = relu(Wdv Vd + bdv) straight from the register copy of Wdv, for the workgroup's VPW videos ----
@@ -353,8 +353,7 @@ __device__ __forceinline__ void video_wg(const Geom g, const Ptrs ptrs, float *s
             if (v < nv) ws[g.o_Hv + (size_t)(b0 + v) * NBH + n] = h;
         }
     }
-    __syncthreads();   // class logits (B) and Hv (C) visible
-    const float y = (lane < C) ? smem[S_Y + vloc * 64 + lane] : -INFINITY;
+    __syncthreads();
 
     STAMP(4);
     // ---- D: video domain logits, losses, gY, gPv (the video's lead wave, lane = class) ----
