@@ -569,7 +569,7 @@ def main():
             es = [TrainEngine(SH["Bs"], SH["Bt"], SH["T"], SH["D"], SH["F"], SH["C"], dropout_i=0.5, dropout_v=0.5,
                               clip=20.0, device=dev, tile_config=args.tile, phase_tiles=phase_tiles, xcd_aware=args.xcd,
                               fused=not args.unfused, bf16=bf16, bf16_store=twins, wgrads_late=args.wgrads_late, aggregation=conf["agg"],
-                              f32_split=split, grad_transport=args.grad_transport, **kw)
+                              f32_split=split, grad_transport=args.grad_transport, use_bn=conf.get("use_bn", "none"), **kw)
                   for _ in range(n_streams)]
             for k, e in enumerate(es):
                 shapes = {n: s for n, _, s, _ in e.plan.params}
@@ -867,6 +867,18 @@ def main():
                                                                  "traffic_source": tr_src})
             except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
                 configs_line[f"configs[{cnum - 1}]"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    # SURVEY 8(f)4 on the fused path (round 6): the headline step with use_bn AdaBN - two BatchNorm launches inside ta3n_train_step, 10 launches
+    # instead of 8; its engine steps call by call (the running statistics move between steps), which is what is timed
+    variants = None
+    if headline and world == 1 and not args.single_dtype and not selftest and not args.no_other_configs:
+        variants = {}
+        try:
+            cf = dict(CONFIGS[2], use_bn="AdaBN", name=CONFIGS[2]["name"] + ", use_bn AdaBN (domain BatchNorm behind the shared frame FC) inside the fused step")
+            r = run(cf["dtype"], 20, 5, conf=cf, brief=True)
+            variants["headline+AdaBN"] = {"workload": cf["name"], "dtype": cf["dtype"], "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "videos/s",
+                                          "steps": 20, "warmup": 5, "launches_per_step": 10}
+        except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
+            variants["headline+AdaBN"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if rank == 0:
         from ta3n_amd import tolerances as tol
         arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "
@@ -934,6 +946,8 @@ def main():
                 out["other_arithmetic"]["ms_per_step_fresh_batch"] = other["fresh_batch"]["ms_per_step"]
         if configs_line:
             out["configs"] = configs_line
+        if variants:
+            out["variants"] = variants
         try:      # projection for every configuration timed in this run (at N > 1: the benched one, from the step without the collective)
             t1 = {}
             if world == 1 and not selftest:
