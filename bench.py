@@ -868,7 +868,7 @@ def main():
             except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
                 configs_line[f"configs[{cnum - 1}]"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     # SURVEY 8(f)4 on the fused path (round 6): the headline step with use_bn AdaBN - two BatchNorm launches inside ta3n_train_step, 10 launches
-    # instead of 8; its engine steps call by call (the running statistics move between steps), which is what is timed
+    # instead of 8, the running statistics tracked by the BatchNorm launch itself (K steps from one library call, like the headline)
     variants = None
     if headline and world == 1 and not args.single_dtype and not selftest and not args.no_other_configs:
         variants = {}

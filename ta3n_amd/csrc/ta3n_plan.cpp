@@ -1075,8 +1075,8 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
             for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
                 if (p.tasks[i].seg_count > 0 && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
     // use_bn: the BatchNorm weight / bias gradients come from the PH_BN_BWD launch - its workgroups leave their sums of squares in the LAST
-    // 2 * ((F + 15) / 16) slots of the region (bn_shared_bwd_kernel), as in the trn-m plan
-    g.n_sumsq = (int32_t)grad_tasks.size() + (bn_shared ? 2 * ((F + 15) / 16) : 0);
+    // 2 * ((F + BN_COLS - 1) / BN_COLS) slots of the region (bn_shared_bwd_kernel), as in the trn-m plan
+    g.n_sumsq = (int32_t)grad_tasks.size() + (bn_shared ? 2 * ((F + BN_COLS - 1) / BN_COLS) : 0);
     g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
     for (size_t k = 0; k < grad_tasks.size(); ++k) {
         p.tasks[grad_tasks[k]].epi |= EPI_SUMSQ;
@@ -1663,9 +1663,9 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             if (ph.group == 4 && ph.kind == PH_GEMM)
                 for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i)
                     if ((p.tasks[i].seg_count > 0 || (p.tasks[i].epi & EPI_COLSUM)) && p.tasks[i].c_base == BASE_G) grad_tasks.push_back((size_t)i);
-        // use_bn: the BatchNorm weight / bias gradients come from the PH_BN_BWD launch, not from a tile - its workgroups ((F + 15) / 16
+        // use_bn: the BatchNorm weight / bias gradients come from the PH_BN_BWD launch, not from a tile - its workgroups ((F + BN_COLS - 1) / BN_COLS
         // column blocks x 2 domains) leave their sums of squares in the LAST slots of the same region (bn_shared_bwd_kernel)
-        const int n_bn_slots = bn_shared ? 2 * ((F + 15) / 16) : 0;
+        const int n_bn_slots = bn_shared ? 2 * ((F + BN_COLS - 1) / BN_COLS) : 0;
         g.n_sumsq = (int32_t)grad_tasks.size() + n_bn_slots;
         g.o_sumsq = (int32_t)b.add_region("sumsq", g.n_sumsq);
         for (size_t k = 0; k < grad_tasks.size(); ++k) {

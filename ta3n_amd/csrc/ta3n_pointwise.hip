@@ -682,14 +682,15 @@ int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 // mean first, then the sum of squared deviations (two passes); eps = 1e-5 (nn.BatchNorm1d default).
 constexpr float BN_EPS = 1e-5f;
 
-__device__ __forceinline__ float bn_colsum16(float v, float *red) {      // sum over the 16 row lanes of this thread's column
-    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+constexpr int BN_ROWS = 256 / BN_COLS;      // row lanes per column
+__device__ __forceinline__ float bn_colsum(float v, float *red) {      // sum over the BN_ROWS row lanes of this thread's column (fixed order)
+    const int r = threadIdx.x / BN_COLS, c = threadIdx.x % BN_COLS;
     __syncthreads();
-    red[r * 16 + c] = v;
+    red[r * BN_COLS + c] = v;
     __syncthreads();
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i * 16 + c];
+    for (int i = 0; i < BN_ROWS; ++i) t += red[i * BN_COLS + c];
     return t;
 }
 
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     __shared__ float red[256];
     const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
     float *__restrict__ ws = ptrs.ws;
-    const int dom = blockIdx.y, r = threadIdx.x >> 4, c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int dom = blockIdx.y, r = threadIdx.x / BN_COLS, c = blockIdx.x * BN_COLS + threadIdx.x % BN_COLS;
     const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
     if (n == 0) return;
     const bool col_ok = c < F;
@@ -705,15 +706,21 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     float mean, var, invstd;
     if (hy->train) {
         float sacc = 0.f;
-        if (col_ok) for (int i = r; i < n; i += 16) sacc += z[(size_t)i * F + c];
-        mean = bn_colsum16(sacc, red) / (float)n;
+        if (col_ok) for (int i = r; i < n; i += BN_ROWS) sacc += z[(size_t)i * F + c];
+        mean = bn_colsum(sacc, red) / (float)n;
         float q = 0.f;
-        if (col_ok) for (int i = r; i < n; i += 16) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
-        var = bn_colsum16(q, red) / (float)n;
+        if (col_ok) for (int i = r; i < n; i += BN_ROWS) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
+        var = bn_colsum(q, red) / (float)n;
         invstd = 1.f / sqrtf(var + BN_EPS);
         if (col_ok && r == 0) {
             float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
             st[c] = mean; st[F + c] = var; st[2 * F + c] = invstd;
+            // nn.BatchNorm1d's buffer update, on the device (round 6: a K-step call has no host between its steps): momentum 0.1, unbiased
+            // batch variance (models.py:195-198 modules in train mode); the eval-mode branch below reads the same region
+            float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
+            const float unb = (float)n / (float)(n > 1 ? n - 1 : 1);
+            run[c] = run[c] * 0.9f + 0.1f * mean;
+            run[F + c] = run[F + c] * 0.9f + 0.1f * (var * unb);
         }
     } else {
         const float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
     // bf16 twin of F1 (TA3N_FLAG_BF16_STORE): in the fused step the next launch reads it as a GEMM operand (ta3n_plan.cpp: add_bf16_twins)
     unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_F1 + (size_t)row0 * F : nullptr;
-    for (int i = r; i < n; i += 16) {
+    for (int i = r; i < n; i += BN_ROWS) {
         float y = fmaf((z[(size_t)i * F + c] - mean) * invstd, w, b);
         y = fmaxf(y, 0.f);
         if (drop) y *= keep_mask(hy->seed_i, (uint32_t)((row0 + i) * F + c), hy->p_drop_i);
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
 __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     __shared__ float red[256];
     float *__restrict__ ws = ptrs.ws;
-    const int dom = blockIdx.y, r = threadIdx.x >> 4, c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int dom = blockIdx.y, r = threadIdx.x / BN_COLS, c = blockIdx.x * BN_COLS + threadIdx.x % BN_COLS;
     const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
     // fused step: this workgroup's share of the gradient norm (sum of squares of the 2 x 16 BatchNorm gradients it writes) goes to ITS
     // slot at the end of ws["sumsq"] (ta3n_plan.cpp: the last 2 * gridDim.x slots) - the fused optimiser adds the slots in a fixed order
@@ -763,20 +770,20 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     const float mean = col_ok ? st[c] : 0.f, invstd = col_ok ? st[2 * F + c] : 0.f;
     float sg = 0.f, sgx = 0.f;
     if (col_ok)
-        for (int i = r; i < n; i += 16) {
+        for (int i = r; i < n; i += BN_ROWS) {
             const float gv = gy[(size_t)i * F + c];
             sg += gv;
             sgx = fmaf(gv, (z[(size_t)i * F + c] - mean) * invstd, sgx);
         }
-    sg = bn_colsum16(sg, red);
-    sgx = bn_colsum16(sgx, red);
-    if (slot) {      // (every thread of a column holds that column's sums: threads 0..15 cover the 16 columns; added in column order)
+    sg = bn_colsum(sg, red);
+    sgx = bn_colsum(sgx, red);
+    if (slot) {      // (every thread of a column holds that column's sums: threads 0 .. BN_COLS - 1 cover the columns; added in column order)
         __syncthreads();
-        if (threadIdx.x < 16) red[threadIdx.x] = col_ok ? fmaf(sgx, sgx, sg * sg) : 0.f;
+        if (threadIdx.x < BN_COLS) red[threadIdx.x] = col_ok ? fmaf(sgx, sgx, sg * sg) : 0.f;
         __syncthreads();
         if (threadIdx.x == 0) {
             float q = 0.f;
-            for (int k = 0; k < 16; ++k) q += red[k];
+            for (int k = 0; k < BN_COLS; ++k) q += red[k];
             *slot = q;
         }
     }
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     const float k = w * invstd, mg = sg / (float)n, mgx = sgx / (float)n;
     float *__restrict__ out = ws + g.o_gZ0 + (size_t)row0 * F;
     unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_gZ0 + (size_t)row0 * F : nullptr;
-    for (int i = r; i < n; i += 16) {
+    for (int i = r; i < n; i += BN_ROWS) {
         const float xh = (z[(size_t)i * F + c] - mean) * invstd;
         const float v = k * (gy[(size_t)i * F + c] - mg - xh * mgx);
         out[(size_t)i * F + c] = v;
@@ -802,11 +809,11 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
 }
 
 int launch_bn_shared_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_shared_fwd_kernel, dim3((g.F + 15) / 16, 2), dim3(256), 0, stream, g, ptrs);
+    hipLaunchKernelGGL(bn_shared_fwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(256), 0, stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_shared_bwd_kernel, dim3((g.F + 15) / 16, 2), dim3(256), 0, stream, g, ptrs);
+    hipLaunchKernelGGL(bn_shared_bwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(256), 0, stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -266,11 +266,11 @@ class TrainEngine:
         self.bn_running: Optional[torch.Tensor] = None
         self.bn_batches = 0
         if self.use_bn != "none":
-            self.bn_running = torch.zeros(2, 2, self.F, dtype=torch.float32, device=self.device)
+            # (round 6) the buffers ARE the workspace region the BatchNorm launch reads in eval mode and - since it tracks them itself, on the
+            # device, momentum 0.1 / unbiased variance like nn.BatchNorm1d - updates in train mode: a K-step call needs no host in between
+            self.bn_running = self.region("bn_run").view(2, 2, self.F)
+            self.bn_running[:, 0] = 0.0
             self.bn_running[:, 1] = 1.0
-            rows = [self.Bs * self.T, self.Bt * self.T]
-            self._bn_unbias = torch.tensor([[[1.0], [r / max(r - 1, 1)]] for r in rows], dtype=torch.float32, device=self.device)
-            self._bn_rows = rows
         # Sharded update (TA3N_DDP_SHARDED=1 / sharded_update=True; N > 1 or the 1-rank self-test, fused step): the gradient exchange as
         # reduce-scatter + all-gather around an optimiser pass that touches only this rank's 1 / world of the parameters
         # (include/ta3n_hip.h: ta3n_sharded_update).  Every rank must make the same choice.
@@ -395,27 +395,16 @@ class TrainEngine:
 
     # ---- launches ----
     def forward(self) -> None:
-        bn = self.bn_running is not None
-        if bn and not self._hyper.train:      # eval mode: the kernel normalises with the running statistics (region bn_run [S, T][mean, var][F])
-            self.region("bn_run").copy_(self.bn_running.reshape(-1))
         _lib.check(self._L.ta3n_forward(self.plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws.data_ptr(),
                                         self._stream()), "ta3n_forward")
-        if bn and self._hyper.train:
+        if self.bn_running is not None and self._hyper.train:
             self._bn_track()
 
-    def _bn_track(self) -> None:
-        """nn.BatchNorm1d's buffer update (momentum 0.1, unbiased variance) from the batch statistics the BatchNorm launch of a
-        train-mode forward left in ws["bn_batch"] ([S, T][mean, biased var, 1/std][F]); stream-ordered, no host sync."""
-        if self.bn_running is None:
-            return
-        st = self.region("bn_batch").view(2, 3, -1)[:, :2]
-        if min(self._bn_rows) > 0:
-            self.bn_running.mul_(0.9).add_(st * self._bn_unbias, alpha=0.1)
-        else:
-            for d, r in enumerate(self._bn_rows):
-                if r > 0:
-                    self.bn_running[d].mul_(0.9).add_(st[d] * self._bn_unbias[d], alpha=0.1)
-        self.bn_batches += 1
+    def _bn_track(self, steps: int = 1) -> None:
+        """use_bn: `steps` train-mode forwards were enqueued - the BatchNorm launch moved the running statistics itself (ws["bn_run"], which
+        self.bn_running views); what is left to the host is nn.BatchNorm1d's num_batches_tracked."""
+        if self.bn_running is not None:
+            self.bn_batches += int(steps)
 
     def loss(self) -> None:
         _lib.check(self._L.ta3n_loss(self.plan.handle, self.ws.data_ptr(), self._stream()), "ta3n_loss")
@@ -897,8 +886,6 @@ class TrainEngine:
         ddp = self.world > 1 or self._ddp_selftest
         if self._sharded:
             return bool(self.comm is not None and not self.skip_collective)
-        if self.bn_running is not None:      # the running statistics move between the steps (a stream-ordered torch update per step)
-            return False
         return bool(self.fused and self._side_update and
                     not (ddp and (self.comm is None or self._ddp_buckets == 2 or self.skip_collective)))
 
@@ -943,6 +930,7 @@ class TrainEngine:
         self._hyper = self._job_last_hyper if self._job_last_hyper is not None else self.hyper_for(*last, step=self.step_count + n_run - 1)
         self._job_last_hyper = None
         self.step_count += n_run
+        self._bn_track(n_run)
 
     def chain_status(self) -> None:
         """Raises if a chained launch enqueued so far left a hand-off unserved (synchronises; tests / end of a run)."""

@@ -42,6 +42,9 @@ class Phase(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16", "rm", "rn", "chain_off", "chain_n")]
 
 
+BN_COLS = 8      # ta3n_types.h: columns per workgroup of the BatchNorm launches
+
+
 def round_bf16(a):
     """Round-to-nearest-even to bfloat16 precision (what v_cvt_pk_bf16_f32 does), returned in the input dtype."""
     f = np.ascontiguousarray(a, dtype=np.float32)
@@ -440,6 +443,8 @@ class Interp:
             if h["train"]:
                 mean = z.mean(0); var = ((z - mean) ** 2).mean(0); inv = 1.0 / np.sqrt(var + 1e-5)
                 st = self.r(g.o_bn_batch + dom * 3 * F, (3, F)); st[0] = mean; st[1] = var; st[2] = inv
+                run = self.r(g.o_bn_run + dom * 2 * F, (2, F))      # nn.BatchNorm1d's buffer update on the device (momentum 0.1, unbiased variance)
+                run[0] = 0.9 * run[0] + 0.1 * mean; run[1] = 0.9 * run[1] + 0.1 * var * (n / max(n - 1, 1))
             else:
                 run = self.r(g.o_bn_run + dom * 2 * F, (2, F)); mean = run[0]; inv = 1.0 / np.sqrt(run[1] + 1e-5)
             y = np.maximum((z - mean) * inv * self.P[pw:pw + F] + self.P[pb:pb + F], 0)
@@ -457,7 +462,7 @@ class Interp:
             r0, n = self._bn_rows(dom)
             if n == 0:
                 if g.n_sumsq > 0:
-                    nb = (F + 15) // 16
+                    nb = (F + BN_COLS - 1) // BN_COLS
                     first = g.o_sumsq + g.n_sumsq - 2 * nb + dom * nb
                     self.ws[first:first + nb] = 0
                 continue
@@ -467,10 +472,10 @@ class Interp:
             sg, sgx = gg.sum(0), (gg * xh).sum(0)
             self.G[pw:pw + F] = sgx; self.G[pb:pb + F] = sg
             if g.n_sumsq > 0:      # fused step: the launch's workgroups (16 columns x one domain each) leave their share of the gradient norm in the last slots of ws["sumsq"]
-                nb = (F + 15) // 16
-                q = np.zeros(nb * 16); q[:F] = sgx.astype(np.float64) ** 2 + sg.astype(np.float64) ** 2
+                nb = (F + BN_COLS - 1) // BN_COLS
+                q = np.zeros(nb * BN_COLS); q[:F] = sgx.astype(np.float64) ** 2 + sg.astype(np.float64) ** 2
                 first = g.o_sumsq + g.n_sumsq - 2 * nb + dom * nb
-                self.ws[first:first + nb] = q.reshape(nb, 16).sum(1)
+                self.ws[first:first + nb] = q.reshape(nb, BN_COLS).sum(1)
             gZ0[r0:r0 + n] = self.P[pw:pw + F] * st[2] * (gg - sg / n - xh * sgx / n)
 
     def run_pool_bwd(self):

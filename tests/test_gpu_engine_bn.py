@@ -83,15 +83,16 @@ def test_engine_with_domain_batchnorm_follows_the_reference_trajectory(name, fus
 @pytest.mark.parametrize("name", ["tiny_adabn", "mid_adabn"])
 def test_fused_batchnorm_step_pipelined_and_on_bf16_twins(name):
     """The fused BatchNorm step through the other ways a caller runs it: train_step_pipelined / train_steps (the update opens the next
-    step; per-step calls - the running statistics move between steps) must equal train_step bit for bit, and the bf16 arithmetic
-    on twins (the BatchNorm launches keep the twins of F1 and gZ0) stays close to the fp32 step."""
+    step; K steps in ONE library call - the BatchNorm launch moves the running statistics itself) must equal train_step bit for bit,
+    running statistics included, and the bf16 arithmetic on twins (the BatchNorm launches keep the twins of F1 and gZ0) stays close to
+    the fp32 step."""
     g = Golden(name)
     c = case_config(g)
     shapes = None
     runs = {}
     for how in ("plain", "pipelined", "steps", "bf16"):
         eng = _engine(c, True, **(dict(bf16=True, bf16_store=True) if how == "bf16" else {}))
-        assert eng.fused and not eng.can_batch_steps()
+        assert eng.fused and eng.can_batch_steps()      # (the BatchNorm launch tracks the running statistics on the device: K steps in one library call)
         shapes = {n: s for n, _, s, _ in eng.plan.params}
         eng.load_state(synth_state(shapes, seed=c["wseed"], scale=c["wscale"]))
         sched = []
