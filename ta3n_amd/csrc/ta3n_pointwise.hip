@@ -683,6 +683,7 @@ int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 constexpr float BN_EPS = 1e-5f;
 
 constexpr int BN_ROWS = 256 / BN_COLS;      // row lanes per column
+constexpr int BN_KEEP = 24;                 // rows per thread the BatchNorm launches keep in registers (batches of up to BN_ROWS * BN_KEEP rows per domain)
 __device__ __forceinline__ float bn_colsum(float v, float *red) {      // sum over the BN_ROWS row lanes of this thread's column (fixed order)
     const int r = threadIdx.x / BN_COLS, c = threadIdx.x % BN_COLS;
     __syncthreads();
@@ -704,12 +705,27 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     const bool col_ok = c < F;
     const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
     float mean, var, invstd;
+    // Up to BN_KEEP rows per thread (n <= BN_ROWS * BN_KEEP = 768: the headline's 640 / 370 frame rows per domain) stay in registers between the
+    // three passes - mean, variance, apply - so the column slab crosses the memory system once instead of three times; same additions in the
+    // same order as the streaming loops (bit-identical results).  Taller batches stream.
+    float zreg[BN_KEEP];
+    const bool keep = n <= BN_ROWS * BN_KEEP;      // (uniform)
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; zreg[j] = (col_ok && i < n) ? z[(size_t)i * F + c] : 0.f; }
+    }
     if (hy->train) {
         float sacc = 0.f;
-        if (col_ok) for (int i = r; i < n; i += BN_ROWS) sacc += z[(size_t)i * F + c];
+        if (keep) {
+#pragma unroll
+            for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) sacc += zreg[j];
+        } else if (col_ok) for (int i = r; i < n; i += BN_ROWS) sacc += z[(size_t)i * F + c];
         mean = bn_colsum(sacc, red) / (float)n;
         float q = 0.f;
-        if (col_ok) for (int i = r; i < n; i += BN_ROWS) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
+        if (keep) {
+#pragma unroll
+            for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) { const float d = zreg[j] - mean; q = fmaf(d, d, q); }
+        } else if (col_ok) for (int i = r; i < n; i += BN_ROWS) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
         var = bn_colsum(q, red) / (float)n;
         invstd = 1.f / sqrtf(var + BN_EPS);
         if (col_ok && r == 0) {
@@ -735,8 +751,8 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
     float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
     // bf16 twin of F1 (TA3N_FLAG_BF16_STORE): in the fused step the next launch reads it as a GEMM operand (ta3n_plan.cpp: add_bf16_twins)
     unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_F1 + (size_t)row0 * F : nullptr;
-    for (int i = r; i < n; i += BN_ROWS) {
-        float y = fmaf((z[(size_t)i * F + c] - mean) * invstd, w, b);
+    auto apply = [&](int i, float zv) {
+        float y = fmaf((zv - mean) * invstd, w, b);
         y = fmaxf(y, 0.f);
         if (drop) y *= keep_mask(hy->seed_i, (uint32_t)((row0 + i) * F + c), hy->p_drop_i);
         y *= inv_keep;
@@ -746,6 +762,12 @@ __global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
             tw[(size_t)i * F + c] = (unsigned short)hb;
             if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(y, 0.f, hb);
         }
+    };
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; if (i < n) apply(i, zreg[j]); }
+    } else {
+        for (int i = r; i < n; i += BN_ROWS) apply(i, z[(size_t)i * F + c]);
     }
 }
 
@@ -769,7 +791,19 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     const float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
     const float mean = col_ok ? st[c] : 0.f, invstd = col_ok ? st[2 * F + c] : 0.f;
     float sg = 0.f, sgx = 0.f;
-    if (col_ok)
+    float greg[BN_KEEP], xreg[BN_KEEP];      // (as in the forward launch: gradient and normalised input of up to BN_KEEP rows per thread stay in registers)
+    const bool keep = n <= BN_ROWS * BN_KEEP;
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) {
+            const int i = r + j * BN_ROWS;
+            const bool on = col_ok && i < n;
+            greg[j] = on ? gy[(size_t)i * F + c] : 0.f;
+            xreg[j] = on ? (z[(size_t)i * F + c] - mean) * invstd : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) { sg += greg[j]; sgx = fmaf(greg[j], xreg[j], sgx); }
+    } else if (col_ok)
         for (int i = r; i < n; i += BN_ROWS) {
             const float gv = gy[(size_t)i * F + c];
             sg += gv;
@@ -796,15 +830,20 @@ __global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
     const float k = w * invstd, mg = sg / (float)n, mgx = sgx / (float)n;
     float *__restrict__ out = ws + g.o_gZ0 + (size_t)row0 * F;
     unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_gZ0 + (size_t)row0 * F : nullptr;
-    for (int i = r; i < n; i += BN_ROWS) {
-        const float xh = (z[(size_t)i * F + c] - mean) * invstd;
-        const float v = k * (gy[(size_t)i * F + c] - mg - xh * mgx);
+    auto emit = [&](int i, float gv, float xh) {
+        const float v = k * (gv - mg - xh * mgx);
         out[(size_t)i * F + c] = v;
         if (tw) {      // bf16 twin of gZ0: the shared-FC weight-gradient launch reads it
             const unsigned hb = pack_bf16(v, 0.f);
             tw[(size_t)i * F + c] = (unsigned short)hb;
             if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(v, 0.f, hb);
         }
+    };
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; if (i < n) emit(i, greg[j], xreg[j]); }
+    } else {
+        for (int i = r; i < n; i += BN_ROWS) emit(i, gy[(size_t)i * F + c], (z[(size_t)i * F + c] - mean) * invstd);
     }
 }
 
