@@ -218,21 +218,23 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
     # apart), so probe {16, 32, 64} (what the host has of them; 8 on a small one) - two steps each - time the best, report all.
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     counts = [c for c in (16, 32, 64) if c <= avail] or [min(avail, 8)]
-    probe = {}
+    # every candidate count is TIMED (an equal share of the budget each, at least three steps), the best one is the value and all of them
+    # travel in the line: a two-step probe picked the wrong count on a busy host more than once (2.9 k against 5.2 k videos/s on the same box)
+    probe, runs = {}, {}
     one()
     for t in counts:
         torch.set_num_threads(t)
         one()
-        t1 = time.perf_counter(); one(); one(); probe[t] = 1e3 * (time.perf_counter() - t1) / 2
+        t1 = time.perf_counter()
+        k = 0
+        while k < 3 or (k < max_steps and time.perf_counter() - t1 < seconds / len(counts)):
+            one()
+            k += 1
+        runs[t] = (k, time.perf_counter() - t1)
+        probe[t] = 1e3 * runs[t][1] / k
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    one()
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and (time.perf_counter() - t0) < seconds:
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
+    n, dt = runs[cores]
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -247,8 +249,8 @@ def cpu_baseline(conf=None, seconds=12.0, max_steps=400):
     out = dict(value=(CFG["Bs"] + CFG["Bt"]) * n / dt, unit="videos/s", cores=cores, kind="port", ms_per_step=1e3 * dt / n,
                probe_ms_per_step_by_threads={str(k): round(v, 2) for k, v in probe.items()},
                sample=f"{n} full train steps ({shape}) of oracle/ta3n_oracle.py (the CPU restatement of the reference's main.train + VideoModel: the "
-                      f"same ATen CPU ops, incl. the frame classifier the reference computes and never uses) on {cores} torch threads (best of "
-                      f"{sorted(probe)}; {host}) = {1e3 * dt / n:.1f} ms/step")
+                      f"same ATen CPU ops, incl. the frame classifier the reference computes and never uses) on {cores} torch threads (the best of "
+                      f"{sorted(probe)}, each timed for {seconds / len(counts):.0f} s; {host}) = {1e3 * dt / n:.1f} ms/step")
     # OPT-IN second figure: the reference's own main.train, when somebody staged it explicitly (oracle/reference_runner.py --stage: files
     # verified against pinned sha256 values; never done by build()).  `value` above keeps ONE definition on every box.
     cnum = next(k for k, v in CONFIGS.items() if v is conf)
