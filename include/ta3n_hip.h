@@ -54,10 +54,12 @@ typedef enum {
 #define TA3N_FLAG_FEATURE_GRADS  (1u << 6)
 /* use_bn 'AdaBN' / 'AutoDIAL' (models.py:195-198, 490-543, 569-570): a BatchNorm1d per domain ("bn_shared_S", "bn_shared_T":
  * weight and bias are parameters of the plan) between the shared frame FC and its ReLU.  Train mode: batch statistics over
- * the domain's rows (region "bn_batch" [2 domains][3][F] = mean, biased variance, 1/sqrt(var + eps) for the caller's running
- * averages); eval mode (hyper.train == 0): the statistics the caller wrote to region "bn_run" [2][2][F] = mean, variance.
- * alpha = 1 (no source/target batch mixing: what the reference's own program always runs).  Unfused entry points;
- * TA3N_AGG_TRN_M and TA3N_AGG_AVGPOOL (there also ta3n_train_step's launch sequence, whose loss kernel ignores the options). */
+ * the domain's rows (region "bn_batch" [2 domains][3][F] = mean, biased variance, 1/sqrt(var + eps)), and - round 6 - the launch
+ * itself moves the running averages in region "bn_run" [2][2][F] = mean, variance the way nn.BatchNorm1d does (momentum 0.1,
+ * unbiased variance); eval mode (hyper.train == 0) normalises with that region (a caller may also write it: loading a checkpoint).
+ * alpha = 1 (no source/target batch mixing: what the reference's own program always runs).  Unfused entry points AND - round 6 -
+ * the fused ta3n_train_step / ta3n_train_steps sequences of both aggregations: two BatchNorm launches behind the shared-FC product and
+ * in front of its weight gradient; their gradients' share of the clip norm sits in the last slots of region "sumsq". */
 #define TA3N_FLAG_BN_SHARED      (1u << 7)
 /* Arithmetic of BASELINE.json configs[1]: every contraction rounds its two operands to bf16 (round to nearest
  * even) and multiplies them on the bf16 MFMA with fp32 accumulation.  Parameters, optimiser state, gradients and
@@ -132,6 +134,9 @@ typedef struct {
                               * the tile's K segments.  Each publishes its partial tile (write-through stores) and takes a ticket; the
                               * second to arrive adds the other's partial to its own and runs the epilogue.  a + b = b + a: the result
                               * does not depend on who arrives last; it differs from the unsplit tile by fp32 summation order.
+                              * Bit mask since round 6: 2 = those tiles; 4 = every tile of the step's first launch (shared-FC product, one
+                              * tile per compute unit), its single K segment halved (measured slower in both arithmetics,
+                              * profiles/r06_split_k_shared_fc_ab.txt); 6 = both.
                               * 0: one workgroup per tile.  Experiments build only (measured 114.8 us against 113.6). */
     int32_t reserved[1];
 } ta3n_config;
