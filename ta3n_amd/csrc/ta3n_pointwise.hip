@@ -677,182 +677,299 @@ int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
 }
 
 // ---- use_bn AdaBN / AutoDIAL: BatchNorm1d per domain between the shared frame FC and its ReLU (models.py:490-543, 569-570) ----
-// One workgroup = 16 feature columns of one domain (blockIdx.y: 0 source rows [0, Bs T), 1 target rows [Bs T, B T)); thread
-// (r, c) = (threadIdx.x / 16, threadIdx.x % 16) walks rows r, r + 16, ...  Statistics as torch's CPU kernel takes them: the
-// mean first, then the sum of squared deviations (two passes); eps = 1e-5 (nn.BatchNorm1d default).
+// One workgroup = BN_COLS (= 4) feature columns of one domain (blockIdx.y: 0 source rows [0, Bs T), 1 target rows [Bs T, B T)), 1 024
+// threads; thread t owns ROWS t, t + 1024, ... and moves the four columns of a row as ONE 16-byte access (row-contiguous float4 loads and
+// stores, one 8-byte twin store) - the 8 x 32 layout of the first fused version read 32-byte row pieces four bytes per lane and ran on half
+// the CUs with one wave per SIMD (11.5 + 9.8 us for a 2 MB matrix).  Column sums: DPP butterfly inside a wave, then the sixteen waves'
+// partials in wave order from LDS (fixed order: bitwise reproducible).  Statistics as torch's CPU kernel takes them: the mean first, then the
+// sum of squared deviations (two passes); eps = 1e-5 (nn.BatchNorm1d default).
 constexpr float BN_EPS = 1e-5f;
+constexpr int BN_THREADS = 1024;
+constexpr int BN_WAVES = BN_THREADS / 64;
+constexpr int BN_KEEP = 5;      // rows per thread that stay in registers between the passes: batches of up to 5 120 frame rows per domain (configs[3]: 4 608)
+static_assert(BN_COLS == 4, "the BatchNorm launches move one float4 per row");
 
-constexpr int BN_ROWS = 256 / BN_COLS;      // row lanes per column
-constexpr int BN_KEEP = 24;                 // rows per thread the BatchNorm launches keep in registers (batches of up to BN_ROWS * BN_KEEP rows per domain)
-__device__ __forceinline__ float bn_colsum(float v, float *red) {      // sum over the BN_ROWS row lanes of this thread's column (fixed order)
-    const int r = threadIdx.x / BN_COLS, c = threadIdx.x % BN_COLS;
-    __syncthreads();
-    red[r * BN_COLS + c] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < BN_ROWS; ++i) t += red[i * BN_COLS + c];
-    return t;
-}
+struct BnRow { float v[BN_COLS]; };
 
-__global__ __launch_bounds__(256) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
-    __shared__ float red[256];
-    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
-    float *__restrict__ ws = ptrs.ws;
-    const int dom = blockIdx.y, r = threadIdx.x / BN_COLS, c = blockIdx.x * BN_COLS + threadIdx.x % BN_COLS;
-    const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
-    if (n == 0) return;
-    const bool col_ok = c < F;
-    const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
-    float mean, var, invstd;
-    // Up to BN_KEEP rows per thread (n <= BN_ROWS * BN_KEEP = 768: the headline's 640 / 370 frame rows per domain) stay in registers between the
-    // three passes - mean, variance, apply - so the column slab crosses the memory system once instead of three times; same additions in the
-    // same order as the streaming loops (bit-identical results).  Taller batches stream.
-    float zreg[BN_KEEP];
-    const bool keep = n <= BN_ROWS * BN_KEEP;      // (uniform)
-    if (keep) {
+// the four columns [c0, c0 + 4) of one row; vec (F % 4 == 0, uniform): one 16-byte load, else guarded scalars (columns >= F read as 0)
+__device__ __forceinline__ BnRow bn_load(const float *__restrict__ row, int c0, int F, bool vec) {
+    BnRow o;
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4 *>(row + c0);
+        o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+    } else {
 #pragma unroll
-        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; zreg[j] = (col_ok && i < n) ? z[(size_t)i * F + c] : 0.f; }
+        for (int e = 0; e < BN_COLS; ++e) o.v[e] = c0 + e < F ? row[c0 + e] : 0.f;
     }
-    if (hy->train) {
-        float sacc = 0.f;
-        if (keep) {
-#pragma unroll
-            for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) sacc += zreg[j];
-        } else if (col_ok) for (int i = r; i < n; i += BN_ROWS) sacc += z[(size_t)i * F + c];
-        mean = bn_colsum(sacc, red) / (float)n;
-        float q = 0.f;
-        if (keep) {
-#pragma unroll
-            for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) { const float d = zreg[j] - mean; q = fmaf(d, d, q); }
-        } else if (col_ok) for (int i = r; i < n; i += BN_ROWS) { const float d = z[(size_t)i * F + c] - mean; q = fmaf(d, d, q); }
-        var = bn_colsum(q, red) / (float)n;
-        invstd = 1.f / sqrtf(var + BN_EPS);
-        if (col_ok && r == 0) {
-            float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
-            st[c] = mean; st[F + c] = var; st[2 * F + c] = invstd;
-            // nn.BatchNorm1d's buffer update, on the device (round 6: a K-step call has no host between its steps): momentum 0.1, unbiased
-            // batch variance (models.py:195-198 modules in train mode); the eval-mode branch below reads the same region
-            float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
-            const float unb = (float)n / (float)(n > 1 ? n - 1 : 1);
-            run[c] = run[c] * 0.9f + 0.1f * mean;
-            run[F + c] = run[F + c] * 0.9f + 0.1f * (var * unb);
+    return o;
+}
+__device__ __forceinline__ void bn_store(float *__restrict__ row, unsigned short *__restrict__ tw, int pair_delta, int c0, int F, bool vec, const BnRow &y) {
+    if (vec) {
+        *reinterpret_cast<float4 *>(row + c0) = make_float4(y.v[0], y.v[1], y.v[2], y.v[3]);
+        if (tw) {      // bf16 twin (TA3N_FLAG_BF16_STORE): the next GEMM launch reads it as an operand (ta3n_plan.cpp: add_bf16_twins)
+            const unsigned h0 = pack_bf16(y.v[0], y.v[1]), h1 = pack_bf16(y.v[2], y.v[3]);
+            *reinterpret_cast<uint2 *>(tw + c0) = make_uint2(h0, h1);
+            if (pair_delta) *reinterpret_cast<uint2 *>(tw + c0 + 2 * (size_t)pair_delta) = make_uint2(pack_bf16_lo(y.v[0], y.v[1], h0), pack_bf16_lo(y.v[2], y.v[3], h1));
         }
     } else {
-        const float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
-        mean = col_ok ? run[c] : 0.f;
-        var = col_ok ? run[F + c] : 1.f;
-        invstd = 1.f / sqrtf(var + BN_EPS);
-    }
-    if (!col_ok) return;
-    const float w = ptrs.p[g.p_bn_w[dom] + c], b = ptrs.p[g.p_bn_b[dom] + c];
-    const bool drop = hy->train && hy->p_drop_i > 0.f;
-    const float inv_keep = hyper_scale(hy, SK_INV_KEEP_I);
-    float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
-    // bf16 twin of F1 (TA3N_FLAG_BF16_STORE): in the fused step the next launch reads it as a GEMM operand (ta3n_plan.cpp: add_bf16_twins)
-    unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_F1 + (size_t)row0 * F : nullptr;
-    auto apply = [&](int i, float zv) {
-        float y = fmaf((zv - mean) * invstd, w, b);
-        y = fmaxf(y, 0.f);
-        if (drop) y *= keep_mask(hy->seed_i, (uint32_t)((row0 + i) * F + c), hy->p_drop_i);
-        y *= inv_keep;
-        out[(size_t)i * F + c] = y;
-        if (tw) {
-            const unsigned hb = pack_bf16(y, 0.f);
-            tw[(size_t)i * F + c] = (unsigned short)hb;
-            if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(y, 0.f, hb);
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) if (c0 + e < F) {
+            row[c0 + e] = y.v[e];
+            if (tw) {
+                const unsigned hb = pack_bf16(y.v[e], 0.f);
+                tw[c0 + e] = (unsigned short)hb;
+                if (pair_delta) tw[c0 + e + 2 * (size_t)pair_delta] = (unsigned short)pack_bf16_lo(y.v[e], 0.f, hb);
+            }
         }
+    }
+}
+// NV per-thread values summed over the workgroup; every thread receives every total (wave butterfly, then waves 0 .. 15 in order)
+template <int NV>
+__device__ __forceinline__ void bn_block_sum(float (&v)[NV], float *red) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_allreduce_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BN_WAVES; ++w) t += red[w * NV + k];
+        v[k] = t;
+    }
+}
+
+// Which column group a workgroup owns.  Workgroup b of a launch runs on XCD b mod 8 and every XCD has an L2 of its own: with the groups dealt
+// in launch order the eight 16-byte pieces of one 128-byte line of a row belonged to eight XCDs - every line fetched eight times over the
+// fabric and written back as eight masked pieces.  Dealt this way the eight groups of a line share an XCD (its L2 fetches the line once and
+// merges the stores).  Needs the group count to be a multiple of 64; otherwise launch order.
+__device__ __forceinline__ int bn_column_group(int b, int n_groups) {
+    if (n_groups & 63) return b;
+    const int x = b & 7, k = b >> 3;
+    return ((x + 8 * (k >> 3)) << 3) + (k & 7);
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs ptrs) {
+    __shared__ float red[BN_WAVES * BN_COLS];
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ptrs.ws + g.o_hyper);
+    float *__restrict__ ws = ptrs.ws;
+    const int dom = blockIdx.y, tid = threadIdx.x, cg = bn_column_group((int)blockIdx.x, (int)gridDim.x), c0 = cg * BN_COLS;
+    const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
+    if (n == 0) return;
+    const bool vec = (F & 3) == 0;      // (uniform; regions start 256-byte aligned)
+    const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
+    // Everything else the launch reads - the step's scalars, the affine pair, the running statistics - is requested HERE, beside the column
+    // slab: `hy` and the statistics live in the workspace this kernel stores to, so a read placed behind a store is a new round trip behind
+    // that store's acknowledgement (vmcnt counts both on this target); the first version paid three of those one after the other.
+    const int train = hy->train;
+    const float p_drop = hy->p_drop_i;
+    const uint32_t seed = hy->seed_i;
+    float w[BN_COLS], b[BN_COLS], run_m[BN_COLS], run_v[BN_COLS];
+    {
+        const float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) {
+            const bool ok = c0 + e < F;
+            w[e] = ok ? ptrs.p[g.p_bn_w[dom] + c0 + e] : 0.f;
+            b[e] = ok ? ptrs.p[g.p_bn_b[dom] + c0 + e] : 0.f;
+            run_m[e] = ok ? run[c0 + e] : 0.f;
+            run_v[e] = ok ? run[F + c0 + e] : 1.f;
+        }
+    }
+    // Up to BN_KEEP rows per thread stay in registers between the three passes - mean, variance, apply - so the column slab crosses the
+    // memory system once; taller batches stream (same additions in the same order either way).
+    BnRow zreg[BN_KEEP];
+    const bool keep = n <= BN_THREADS * BN_KEEP;      // (uniform)
+    if (keep) {
+#pragma unroll
+        for (int j = 0; j < BN_KEEP; ++j) {
+            const int i = tid + j * BN_THREADS;
+            if (i < n) zreg[j] = bn_load(z + (size_t)i * F, c0, F, vec);
+            else {
+#pragma unroll
+                for (int e = 0; e < BN_COLS; ++e) zreg[j].v[e] = 0.f;
+            }
+        }
+    }
+    float mean[BN_COLS], invstd[BN_COLS];
+    if (train) {
+        float s[BN_COLS] = {0.f, 0.f, 0.f, 0.f};
+        if (keep) {
+#pragma unroll
+            for (int j = 0; j < BN_KEEP; ++j) if (tid + j * BN_THREADS < n) {
+#pragma unroll
+                for (int e = 0; e < BN_COLS; ++e) s[e] += zreg[j].v[e];
+            }
+        } else for (int i = tid; i < n; i += BN_THREADS) {
+            const BnRow t = bn_load(z + (size_t)i * F, c0, F, vec);
+#pragma unroll
+            for (int e = 0; e < BN_COLS; ++e) s[e] += t.v[e];
+        }
+        bn_block_sum<BN_COLS>(s, red);
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) mean[e] = s[e] / (float)n;
+        float q[BN_COLS] = {0.f, 0.f, 0.f, 0.f};
+        if (keep) {
+#pragma unroll
+            for (int j = 0; j < BN_KEEP; ++j) if (tid + j * BN_THREADS < n) {
+#pragma unroll
+                for (int e = 0; e < BN_COLS; ++e) { const float d = zreg[j].v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
+            }
+        } else for (int i = tid; i < n; i += BN_THREADS) {
+            const BnRow t = bn_load(z + (size_t)i * F, c0, F, vec);
+#pragma unroll
+            for (int e = 0; e < BN_COLS; ++e) { const float d = t.v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
+        }
+        bn_block_sum<BN_COLS>(q, red);
+        float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
+        // nn.BatchNorm1d's buffer update, on the device (round 6: a K-step call has no host between its steps): momentum 0.1, unbiased
+        // batch variance (models.py:195-198 modules in train mode); the eval-mode branch below reads the same region
+        float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
+        const float unb = (float)n / (float)(n > 1 ? n - 1 : 1);
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) {
+            const float var = q[e] / (float)n;
+            invstd[e] = 1.f / sqrtf(var + BN_EPS);
+            if (tid == 0 && c0 + e < F) {
+                const int c = c0 + e;
+                st[c] = mean[e]; st[F + c] = var; st[2 * F + c] = invstd[e];
+                run[c] = run_m[e] * 0.9f + 0.1f * mean[e];
+                run[F + c] = run_v[e] * 0.9f + 0.1f * (var * unb);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) { mean[e] = run_m[e]; invstd[e] = 1.f / sqrtf(run_v[e] + BN_EPS); }
+    }
+    const bool drop = train && p_drop > 0.f;
+    const float inv_keep = drop ? (p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f) : 1.f;      // (hyper_scale(hy, SK_INV_KEEP_I) on the scalars read above)
+    float *__restrict__ out = ws + g.o_F1 + (size_t)row0 * F;
+    unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_F1 + (size_t)row0 * F : nullptr;
+    auto apply = [&](int i, const BnRow &zv) {
+        BnRow y;
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) {
+            float t = fmaf((zv.v[e] - mean[e]) * invstd[e], w[e], b[e]);
+            t = fmaxf(t, 0.f);
+            if (drop) t *= keep_mask(seed, (uint32_t)((row0 + i) * F + c0 + e), p_drop);
+            y.v[e] = t * inv_keep;
+        }
+        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, F, vec, y);
     };
     if (keep) {
 #pragma unroll
-        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; if (i < n) apply(i, zreg[j]); }
+        for (int j = 0; j < BN_KEEP; ++j) { const int i = tid + j * BN_THREADS; if (i < n) apply(i, zreg[j]); }
     } else {
-        for (int i = r; i < n; i += BN_ROWS) apply(i, z[(size_t)i * F + c]);
+        for (int i = tid; i < n; i += BN_THREADS) apply(i, bn_load(z + (size_t)i * F, c0, F, vec));
     }
 }
 
 // gZ1 = dL/d(BatchNorm output) (ReLU mask and dropout already applied by the launch that made it)  ->
 // d weight = sum g xhat, d bias = sum g, gZ0 = weight invstd (g - mean(g) - xhat mean(g xhat))   (train mode)
-__global__ __launch_bounds__(256) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs ptrs) {
+    __shared__ float red[BN_WAVES * 2 * BN_COLS];
     float *__restrict__ ws = ptrs.ws;
-    const int dom = blockIdx.y, r = threadIdx.x / BN_COLS, c = blockIdx.x * BN_COLS + threadIdx.x % BN_COLS;
+    const int dom = blockIdx.y, tid = threadIdx.x, cg = bn_column_group((int)blockIdx.x, (int)gridDim.x), c0 = cg * BN_COLS;
     const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
-    // fused step: this workgroup's share of the gradient norm (sum of squares of the 2 x 16 BatchNorm gradients it writes) goes to ITS
+    // fused step: this workgroup's share of the gradient norm (sum of squares of the 2 x BN_COLS BatchNorm gradients it writes) goes to ITS
     // slot at the end of ws["sumsq"] (ta3n_plan.cpp: the last 2 * gridDim.x slots) - the fused optimiser adds the slots in a fixed order
-    float *slot = g.n_sumsq > 0 ? ws + g.o_sumsq + g.n_sumsq - 2 * (int)gridDim.x + dom * (int)gridDim.x + (int)blockIdx.x : nullptr;
+    float *slot = g.n_sumsq > 0 ? ws + g.o_sumsq + g.n_sumsq - 2 * (int)gridDim.x + dom * (int)gridDim.x + cg : nullptr;
     if (n == 0) {
-        if (slot && threadIdx.x == 0) *slot = 0.f;
+        if (slot && tid == 0) *slot = 0.f;
         return;
     }
-    const bool col_ok = c < F;
+    const bool vec = (F & 3) == 0;
     const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
     const float *__restrict__ gy = ws + g.o_gZ1 + (size_t)row0 * F;
     const float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
-    const float mean = col_ok ? st[c] : 0.f, invstd = col_ok ? st[2 * F + c] : 0.f;
-    float sg = 0.f, sgx = 0.f;
-    float greg[BN_KEEP], xreg[BN_KEEP];      // (as in the forward launch: gradient and normalised input of up to BN_KEEP rows per thread stay in registers)
-    const bool keep = n <= BN_ROWS * BN_KEEP;
+    float mean[BN_COLS], invstd[BN_COLS], wgt[BN_COLS];      // (all requested beside the slabs: a read behind this kernel's stores would wait for them)
+#pragma unroll
+    for (int e = 0; e < BN_COLS; ++e) {
+        const bool ok = c0 + e < F;
+        mean[e] = ok ? st[c0 + e] : 0.f;
+        invstd[e] = ok ? st[2 * F + c0 + e] : 0.f;
+        wgt[e] = ok ? ptrs.p[g.p_bn_w[dom] + c0 + e] : 0.f;
+    }
+    BnRow greg[BN_KEEP], xreg[BN_KEEP];      // (as in the forward launch: gradient and normalised input of up to BN_KEEP rows per thread stay in registers)
+    const bool keep = n <= BN_THREADS * BN_KEEP;
+    float sums[2 * BN_COLS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // [e]: sum g, [BN_COLS + e]: sum g xhat
     if (keep) {
 #pragma unroll
         for (int j = 0; j < BN_KEEP; ++j) {
-            const int i = r + j * BN_ROWS;
-            const bool on = col_ok && i < n;
-            greg[j] = on ? gy[(size_t)i * F + c] : 0.f;
-            xreg[j] = on ? (z[(size_t)i * F + c] - mean) * invstd : 0.f;
+            const int i = tid + j * BN_THREADS;
+            if (i < n) {
+                greg[j] = bn_load(gy + (size_t)i * F, c0, F, vec);
+                xreg[j] = bn_load(z + (size_t)i * F, c0, F, vec);
+            } else {
+#pragma unroll
+                for (int e = 0; e < BN_COLS; ++e) { greg[j].v[e] = 0.f; xreg[j].v[e] = 0.f; }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BN_KEEP; ++j) if (r + j * BN_ROWS < n) { sg += greg[j]; sgx = fmaf(greg[j], xreg[j], sgx); }
-    } else if (col_ok)
-        for (int i = r; i < n; i += BN_ROWS) {
-            const float gv = gy[(size_t)i * F + c];
-            sg += gv;
-            sgx = fmaf(gv, (z[(size_t)i * F + c] - mean) * invstd, sgx);
+        for (int j = 0; j < BN_KEEP; ++j) if (tid + j * BN_THREADS < n) {
+#pragma unroll
+            for (int e = 0; e < BN_COLS; ++e) {
+                xreg[j].v[e] = (xreg[j].v[e] - mean[e]) * invstd[e];
+                sums[e] += greg[j].v[e];
+                sums[BN_COLS + e] = fmaf(greg[j].v[e], xreg[j].v[e], sums[BN_COLS + e]);
+            }
         }
-    sg = bn_colsum(sg, red);
-    sgx = bn_colsum(sgx, red);
-    if (slot) {      // (every thread of a column holds that column's sums: threads 0 .. BN_COLS - 1 cover the columns; added in column order)
-        __syncthreads();
-        if (threadIdx.x < BN_COLS) red[threadIdx.x] = col_ok ? fmaf(sgx, sgx, sg * sg) : 0.f;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float q = 0.f;
-            for (int k = 0; k < BN_COLS; ++k) q += red[k];
-            *slot = q;
+    } else for (int i = tid; i < n; i += BN_THREADS) {
+        const BnRow gv = bn_load(gy + (size_t)i * F, c0, F, vec), zv = bn_load(z + (size_t)i * F, c0, F, vec);
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) {
+            sums[e] += gv.v[e];
+            sums[BN_COLS + e] = fmaf(gv.v[e], (zv.v[e] - mean[e]) * invstd[e], sums[BN_COLS + e]);
         }
     }
-    if (!col_ok) return;
-    if (r == 0) {
-        ptrs.g[g.p_bn_w[dom] + c] = sgx;
-        ptrs.g[g.p_bn_b[dom] + c] = sg;
+    bn_block_sum<2 * BN_COLS>(sums, red);
+    if (tid == 0) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) if (c0 + e < F) {      // (added in column order)
+            q += fmaf(sums[BN_COLS + e], sums[BN_COLS + e], sums[e] * sums[e]);
+            ptrs.g[g.p_bn_w[dom] + c0 + e] = sums[BN_COLS + e];
+            ptrs.g[g.p_bn_b[dom] + c0 + e] = sums[e];
+        }
+        if (slot) *slot = q;
     }
-    const float w = ptrs.p[g.p_bn_w[dom] + c];
-    const float k = w * invstd, mg = sg / (float)n, mgx = sgx / (float)n;
+    float k[BN_COLS], mg[BN_COLS], mgx[BN_COLS];
+#pragma unroll
+    for (int e = 0; e < BN_COLS; ++e) {
+        k[e] = wgt[e] * invstd[e]; mg[e] = sums[e] / (float)n; mgx[e] = sums[BN_COLS + e] / (float)n;
+    }
     float *__restrict__ out = ws + g.o_gZ0 + (size_t)row0 * F;
     unsigned short *__restrict__ tw = g.o_ws16 >= 0 ? reinterpret_cast<unsigned short *>(ws + g.o_ws16) + g.o_gZ0 + (size_t)row0 * F : nullptr;
-    auto emit = [&](int i, float gv, float xh) {
-        const float v = k * (gv - mg - xh * mgx);
-        out[(size_t)i * F + c] = v;
-        if (tw) {      // bf16 twin of gZ0: the shared-FC weight-gradient launch reads it
-            const unsigned hb = pack_bf16(v, 0.f);
-            tw[(size_t)i * F + c] = (unsigned short)hb;
-            if (g.pair_delta) tw[(size_t)i * F + c + 2 * (size_t)g.pair_delta] = (unsigned short)pack_bf16_lo(v, 0.f, hb);
-        }
+    auto emit = [&](int i, const BnRow &gv, const BnRow &xh) {      // (the twin of gZ0: the shared-FC weight-gradient launch reads it)
+        BnRow v;
+#pragma unroll
+        for (int e = 0; e < BN_COLS; ++e) v.v[e] = k[e] * (gv.v[e] - mg[e] - xh.v[e] * mgx[e]);
+        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, F, vec, v);
     };
     if (keep) {
 #pragma unroll
-        for (int j = 0; j < BN_KEEP; ++j) { const int i = r + j * BN_ROWS; if (i < n) emit(i, greg[j], xreg[j]); }
+        for (int j = 0; j < BN_KEEP; ++j) { const int i = tid + j * BN_THREADS; if (i < n) emit(i, greg[j], xreg[j]); }
     } else {
-        for (int i = r; i < n; i += BN_ROWS) emit(i, gy[(size_t)i * F + c], (z[(size_t)i * F + c] - mean) * invstd);
+        for (int i = tid; i < n; i += BN_THREADS) {
+            BnRow xh = bn_load(z + (size_t)i * F, c0, F, vec);
+#pragma unroll
+            for (int e = 0; e < BN_COLS; ++e) xh.v[e] = (xh.v[e] - mean[e]) * invstd[e];
+            emit(i, bn_load(gy + (size_t)i * F, c0, F, vec), xh);
+        }
     }
 }
 
 int launch_bn_shared_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_shared_fwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(256), 0, stream, g, ptrs);
+    hipLaunchKernelGGL(bn_shared_fwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(BN_THREADS), 0, stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_shared_bwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(256), 0, stream, g, ptrs);
+    hipLaunchKernelGGL(bn_shared_bwd_kernel, dim3((g.F + BN_COLS - 1) / BN_COLS, 2), dim3(BN_THREADS), 0, stream, g, ptrs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -135,9 +135,9 @@ struct Hyper {
     int32_t reserved[2];
 };
 
-// Columns per workgroup of the two BatchNorm launches (TA3N_FLAG_BN_SHARED): 256 threads = BN_COLS columns x 256 / BN_COLS row lanes; the
-// backward launch leaves one gradient-norm slot per workgroup, so the plan builder needs the number too.
-constexpr int BN_COLS = 8;
+// Columns per workgroup of the two BatchNorm launches (TA3N_FLAG_BN_SHARED): a thread moves the BN_COLS columns of one row as one 16-byte
+// access; the backward launch leaves one gradient-norm slot per workgroup, so the plan builder needs the number too.
+constexpr int BN_COLS = 4;
 
 // Device-side constant geometry handed to the pointwise kernels by value.
 struct Geom {

@@ -42,7 +42,7 @@ class Phase(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "group", "task_begin", "task_count", "wm", "wn", "wk", "bf16", "rm", "rn", "chain_off", "chain_n")]
 
 
-BN_COLS = 8      # ta3n_types.h: columns per workgroup of the BatchNorm launches
+BN_COLS = 4      # ta3n_types.h: columns per workgroup of the BatchNorm launches
 
 
 def round_bf16(a):
