@@ -328,7 +328,9 @@ int ta3n_train_step_after_update(ta3n_plan *plan, const float *x, float *params,
  * (apply it with ta3n_sgd_range or the next call).  Bit-identical to n_steps single calls.  The hypers' inv_n_* must be the
  * GLOBAL counts when a communicator is given.
  * source / target (either may be NULL = the rows already in x): TSNDataSet.__getitem__ + DataLoader collation of step k on the
- * device (dataset.py:118-144), i.e. ta3n_gather_segments[_bf16]_into with video_ids[k * ids_per_step ..] before step k. */
+ * device (dataset.py:118-144), i.e. ta3n_gather_segments[_bf16]_into with video_ids[k * ids_per_step ..] before step k - carried out by extra
+ * workgroups of the launch that opens step k (the update of the step before: the two jobs touch disjoint memory and both must be done before
+ * the step's first GEMM launch), not by launches of their own: a fresh batch per step costs 1-3 us at the headline shape instead of 8. */
 typedef struct {
     const void *store;          /* packed rows [total_frames, feature_dim]: fp32, or bf16 when bf16 != 0 */
     int32_t bf16;

@@ -579,6 +579,23 @@ static int feed_step(ta3n_plan *p, const ta3n_feed *f, int step, int first_video
     return rc == 0 ? TA3N_OK : fail(TA3N_ERR_HIP, std::string("gather launch failed: ") + hipGetErrorString(hipGetLastError()));
 }
 
+// The same batch half as a job of the launch that opens a pipelined step (launch_sgd_open_feed): same checks, same destinations as feed_step.
+static int feed_job(ta3n_plan *p, const ta3n_feed *f, int step, int first_video, int cap, float *x, float *ws, int32_t *labels_out, FeedJob *job) {
+    const Geom &g = p->geom;
+    if (!f->store || !f->first_row || !f->num_frames || !f->video_ids) return fail(TA3N_ERR_INVALID, "ta3n_feed: null table");
+    if (f->ids_per_step < 0 || f->ids_per_step > cap) return fail(TA3N_ERR_INVALID, "ta3n_feed: ids_per_step exceeds the batch half");
+    if (labels_out && !f->labels) return fail(TA3N_ERR_INVALID, "ta3n_feed: the source feed needs labels");
+    const size_t row0 = (size_t)first_video * g.T;
+    float *twin = g.o_x16 >= 0 ? ws + g.o_x16 + row0 * g.D / 2 : nullptr;
+    if (f->bf16 && !twin && !x) return fail(TA3N_ERR_INVALID, "ta3n_feed: a plan without bf16 twins needs the fp32 input rows");
+    job->store = f->store; job->first_row = f->first_row; job->num_frames = f->num_frames; job->labels = f->labels;
+    job->video_ids = f->video_ids + (size_t)step * f->ids_per_step;
+    job->n_videos = f->ids_per_step; job->bf16 = f->bf16 ? 1 : 0;
+    job->out = (f->bf16 && twin) ? nullptr : x + row0 * g.D;      // (a bf16 store feeding twins writes no fp32 rows: feed_step)
+    job->twin = twin; job->labels_out = labels_out;
+    return TA3N_OK;
+}
+
 // One pipelined step of a multi-step call: optional batch assembly, the update that opens the step (learning rate `lr` of the step
 // before, scalars `next` of this one), the step's launches, optional gradient exchange.
 static int enqueue_pipelined_step(ta3n_plan *p, const Ptrs &ptrs, float *params, float *grads, float *momentum, float *ws, int fused_norm,
@@ -586,14 +603,23 @@ static int enqueue_pipelined_step(ta3n_plan *p, const Ptrs &ptrs, float *params,
                                   const ta3n_feed *source, const ta3n_feed *target, ta3n_comm *comm, void *scratch_bf16, hipStream_t s) {
     const Geom &g = p->geom;
     int rc;
-    // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued)
-    if (source && (rc = feed_step(p, source, k, 0, g.Bs, const_cast<float *>(ptrs.x), ws,
-                                  reinterpret_cast<int32_t *>(ws + g.o_labels), s)) != TA3N_OK) return rc;
-    if (target && (rc = feed_step(p, target, k, g.Bs, g.Bt, const_cast<float *>(ptrs.x), ws, nullptr, s)) != TA3N_OK) return rc;
-    if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
-    if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
-                         reinterpret_cast<const Hyper *>(next), s) != 0)
-        return fail(TA3N_ERR_HIP, "sgd launch failed");
+    // the batch of step k (its input rows are last read by the final launch of step k - 1, already enqueued): assembled by extra workgroups
+    // of the launch that opens the step (sgd_open_feed_kernel) - the two gathers as launches of their own cost the step two boundaries
+    if (source || target) {
+        FeedJob jobs[2];
+        std::memset(jobs, 0, sizeof(jobs));
+        if (source && (rc = feed_job(p, source, k, 0, g.Bs, const_cast<float *>(ptrs.x), ws, reinterpret_cast<int32_t *>(ws + g.o_labels), &jobs[0])) != TA3N_OK) return rc;
+        if (target && (rc = feed_job(p, target, k, g.Bs, g.Bt, const_cast<float *>(ptrs.x), ws, nullptr, &jobs[1])) != TA3N_OK) return rc;
+        if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+        if (launch_sgd_open_feed(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                                 reinterpret_cast<const Hyper *>(next), jobs, s) != 0)
+            return fail(TA3N_ERR_HIP, "sgd + batch-assembly launch failed");
+    } else {
+        if (!fused_norm && launch_grad_norm(g, grads, ws, s) != 0) return fail(TA3N_ERR_HIP, "grad-norm launch failed");
+        if (launch_sgd_range(g, params, grads, momentum, ws, 0, p->first_floats, fused_norm != 0, lr, momentum_coef, weight_decay, clip,
+                             reinterpret_cast<const Hyper *>(next), s) != 0)
+            return fail(TA3N_ERR_HIP, "sgd launch failed");
+    }
     SgdSide side{params, momentum, lr, momentum_coef, weight_decay, clip, fused_norm ? g.o_sumsq : g.o_norm_part,
                  fused_norm ? g.n_sumsq : g.n_norm_blocks, g.o_p16};
     if ((rc = run_group(p, 5, ptrs, nullptr, nullptr, s, nullptr, 0, 1 << 30, &side)) != TA3N_OK) return rc;

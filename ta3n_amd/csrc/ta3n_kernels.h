@@ -173,6 +173,18 @@ int launch_sgd_fixup(const Geom &g, float *params, const float *grads, float *mo
                      float clip, const Hyper *next, hipStream_t stream);
 int launch_sgd_range(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
                      bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, hipStream_t stream, bool write_norm = false);
+// One batch half of the launch that opens a pipelined step together with its batch assembly (sgd_open_feed_kernel): device pointers of a packed
+// feature store, this step's video ids, where the rows go (fp32 rows / bf16 twin rows; either may be null) - n_videos = 0: nothing to assemble
+struct FeedJob {
+    const void *store;
+    const int64_t *first_row;
+    const int32_t *num_frames, *labels, *video_ids;
+    float *out, *twin;
+    int32_t *labels_out;
+    int32_t n_videos, bf16;
+};
+int launch_sgd_open_feed(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
+                         bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, const FeedJob feeds[2], hipStream_t stream);
 int launch_shard_sumsq(const Geom &g, const float *grads, float *ws, int64_t a0, int64_t a1, int64_t b0, int64_t b1, int rank, hipStream_t stream);
 int launch_eval_metrics(const Geom &g, float *ws, int n, int reset, hipStream_t stream);
 int launch_gather_segments(const float *store, const int64_t *first_row, const int32_t *num_frames, const int32_t *labels,

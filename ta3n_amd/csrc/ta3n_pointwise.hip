@@ -410,12 +410,12 @@ __global__ __launch_bounds__(256) void pool_avg_bwd_kernel(Geom g, Ptrs ptrs, in
 // TSNDataSet.__getitem__ for a whole batch on the device (reference dataset.py:103-116, 128-144, new_length 1):
 // one workgroup per output row (video v, segment x).  The segment index is computed in float64 exactly as the
 // reference's Python does (tick = n / T; int(tick / 2.0 + tick * x)); clips shorter than T repeat their last frame.
-__global__ __launch_bounds__(256) void gather_segments_kernel(const float *__restrict__ store, const int64_t *__restrict__ first_row,
-                                                              const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
-                                                              const int32_t *__restrict__ video_ids, int T, int D,
-                                                              float *__restrict__ out, int32_t *__restrict__ labels_out,
-                                                              int32_t *__restrict__ seg_out, uint2 *__restrict__ out16, int64_t pair_delta) {
-    const int row = blockIdx.x, v = row / T, x = row - v * T;
+__device__ __forceinline__ void gather_row_f32(int row, const float *__restrict__ store, const int64_t *__restrict__ first_row,
+                                               const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                               const int32_t *__restrict__ video_ids, int T, int D,
+                                               float *__restrict__ out, int32_t *__restrict__ labels_out,
+                                               int32_t *__restrict__ seg_out, uint2 *__restrict__ out16, int64_t pair_delta) {
+    const int v = row / T, x = row - v * T;
     const int vid = video_ids[v];
     const int nf = num_frames[vid];
     int off;
@@ -448,16 +448,23 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const float *__res
         for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
     }
 }
+__global__ __launch_bounds__(256) void gather_segments_kernel(const float *__restrict__ store, const int64_t *__restrict__ first_row,
+                                                              const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                                              const int32_t *__restrict__ video_ids, int T, int D,
+                                                              float *__restrict__ out, int32_t *__restrict__ labels_out,
+                                                              int32_t *__restrict__ seg_out, uint2 *__restrict__ out16, int64_t pair_delta) {
+    gather_row_f32((int)blockIdx.x, store, first_row, num_frames, labels, video_ids, T, D, out, labels_out, seg_out, out16, pair_delta);
+}
 
 // The same batch assembly from a bf16 packed store ("fp16/bf16 memory-mapped blob"): a quarter of the
 // bytes of the fp32 store + twin path when the step reads bf16 twins (2 B in, 2 B out per element; the fp32 rows are
 // written only if the caller wants them).  One workgroup per output row; D % 8 == 0.
-__global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *__restrict__ store, const int64_t *__restrict__ first_row,
-                                                                   const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
-                                                                   const int32_t *__restrict__ video_ids, int T, int D,
-                                                                   float4 *__restrict__ out, int32_t *__restrict__ labels_out,
-                                                                   uint4 *__restrict__ out16, int64_t pair_delta) {
-    const int row = blockIdx.x, v = row / T, x = row - v * T;
+__device__ __forceinline__ void gather_row_bf16(int row, const uint4 *__restrict__ store, const int64_t *__restrict__ first_row,
+                                                const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                                const int32_t *__restrict__ video_ids, int T, int D,
+                                                float4 *__restrict__ out, int32_t *__restrict__ labels_out,
+                                                uint4 *__restrict__ out16, int64_t pair_delta) {
+    const int v = row / T, x = row - v * T;
     const int vid = video_ids[v];
     const int nf = num_frames[vid];
     int off;
@@ -482,6 +489,13 @@ __global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *
                                                                  __builtin_bit_cast(float, q.w << 16), __builtin_bit_cast(float, q.w & 0xFFFF0000u));
         }
     }
+}
+__global__ __launch_bounds__(256) void gather_segments_bf16_kernel(const uint4 *__restrict__ store, const int64_t *__restrict__ first_row,
+                                                                   const int32_t *__restrict__ num_frames, const int32_t *__restrict__ labels,
+                                                                   const int32_t *__restrict__ video_ids, int T, int D,
+                                                                   float4 *__restrict__ out, int32_t *__restrict__ labels_out,
+                                                                   uint4 *__restrict__ out16, int64_t pair_delta) {
+    gather_row_bf16((int)blockIdx.x, store, first_row, num_frames, labels, video_ids, T, D, out, labels_out, out16, pair_delta);
 }
 
 // Validation metrics of main.validate / test_models.py (reference main.py:707-735, 809-822; test_models.py:155-198)
@@ -528,14 +542,14 @@ __global__ __launch_bounds__(1024) void eval_metrics_kernel(Geom g, float *__res
 // The same update over floats [4 i0, 4 i1) of the flat prefix with the step's scalars passed by value: lets the host
 // split the update so that the first launch of the NEXT step (which only reads the shared frame FC) runs beside the rest
 // of this one on a second stream, and keeps it independent of a newer ta3n_set_hyper upload.
-__global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
-                                                        float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
-                                                        int norm_n, float lr, float mu, float wd, float clip, Hyper next, int has_next) {
-    __shared__ float red[8];
+__device__ __forceinline__ void sgd_range_body(const Geom &g, float *__restrict__ params, const float *__restrict__ grads,
+                                               float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
+                                               int norm_n, float lr, float mu, float wd, float clip, const Hyper &next, int has_next,
+                                               int n_blocks, float *red) {
     float4 *__restrict__ p4 = reinterpret_cast<float4 *>(params);
     float4 *__restrict__ m4 = reinterpret_cast<float4 *>(mom);
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(grads);
-    const int stride = gridDim.x * blockDim.x;
+    const int stride = n_blocks * blockDim.x;
     int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, gr = p;
     if (i < i1) { p = p4[i]; m = m4[i]; gr = g4[i]; }      // in flight while the norm partials are added up
@@ -576,6 +590,52 @@ __global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restric
         }
         i = nxt; p = pn; m = mn; gr = gn;
     }
+}
+__global__ __launch_bounds__(256) void sgd_range_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
+                                                        float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
+                                                        int norm_n, float lr, float mu, float wd, float clip, Hyper next, int has_next) {
+    __shared__ float red[8];
+    sgd_range_body(g, params, grads, mom, ws, i0, i1, norm_off, norm_n, lr, mu, wd, clip, next, has_next, (int)gridDim.x, red);
+}
+
+// The launch that opens a pipelined step WITH its batch assembly (ta3n_train_steps with feeds): workgroups [0, sgd_blocks) are
+// sgd_range_kernel's - the previous step's update of the shared frame FC, this step's scalars - and the rest assemble the step's batch, one
+// input row each (gather_row_*: the source half's rows, then the target half's).  The two jobs touch disjoint memory (parameters / momentum /
+// scalars against input rows / labels) and both must be done before the step's first GEMM launch: as launches of their own the two gathers
+// cost the step two boundaries (fresh-batch step +8 us over the resident-batch step at the headline shape).
+struct FeedHalf {
+    const void *store;
+    const int64_t *first_row;
+    const int32_t *num_frames, *labels, *video_ids;
+    float *out;                  // fp32 input rows of this half (nullptr: a bf16 store feeding a plan that reads twins only)
+    int32_t *labels_out;         // nullptr: target half
+    float *twin;                 // bf16 twin rows of this half (nullptr: the plan keeps none)
+    int32_t rows, bf16;          // ids_per_step * T; the store holds bf16
+};
+struct FeedPair {
+    FeedHalf half[2];
+    int64_t pair_delta;
+    int32_t T, D;
+};
+__global__ __launch_bounds__(256) void sgd_open_feed_kernel(Geom g, float *__restrict__ params, const float *__restrict__ grads,
+                                                            float *__restrict__ mom, float *__restrict__ ws, int i0, int i1, int norm_off,
+                                                            int norm_n, float lr, float mu, float wd, float clip, Hyper next, int has_next,
+                                                            int sgd_blocks, FeedPair fp) {
+    __shared__ float red[8];
+    if ((int)blockIdx.x < sgd_blocks) {
+        sgd_range_body(g, params, grads, mom, ws, i0, i1, norm_off, norm_n, lr, mu, wd, clip, next, has_next, sgd_blocks, red);
+        return;
+    }
+    int row = (int)blockIdx.x - sgd_blocks;
+    const int h = row < fp.half[0].rows ? 0 : 1;
+    if (h) row -= fp.half[0].rows;
+    const FeedHalf &f = fp.half[h];
+    if (f.bf16)
+        gather_row_bf16(row, static_cast<const uint4 *>(f.store), f.first_row, f.num_frames, f.labels, f.video_ids, fp.T, fp.D,
+                        reinterpret_cast<float4 *>(f.out), f.labels_out, reinterpret_cast<uint4 *>(f.twin), f.twin ? fp.pair_delta : 0);
+    else
+        gather_row_f32(row, static_cast<const float *>(f.store), f.first_row, f.num_frames, f.labels, f.video_ids, fp.T, fp.D,
+                       f.out, f.labels_out, nullptr, reinterpret_cast<uint2 *>(f.twin), f.twin ? fp.pair_delta : 0);
 }
 
 // Closes a fused-update step (gemm_tiles with SgdSide::p_new: every gradient tile already applied the Nesterov step to its own
@@ -1071,6 +1131,31 @@ int launch_sgd_range(const Geom &g, float *params, const float *grads, float *mo
     hipLaunchKernelGGL(sgd_range_kernel, dim3(blocks), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
                        fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip, nh,
                        (next ? 1 : 0) | (write_norm ? 2 : 0));
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_sgd_open_feed(const Geom &g, float *params, const float *grads, float *momentum, float *ws, int64_t begin, int64_t end,
+                         bool fused_norm, float lr, float mu, float wd, float clip, const Hyper *next, const FeedJob feeds[2], hipStream_t stream) {
+    const int i0 = (int)(begin / 4), i1 = (int)(end / 4);
+    int blocks = (i1 - i0 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;      // (block 0 carries the step's scalars even when the range is empty)
+    Hyper nh;
+    std::memset(&nh, 0, sizeof(nh));
+    if (next) nh = *next;
+    FeedPair fp;
+    std::memset(&fp, 0, sizeof(fp));
+    fp.T = g.T; fp.D = g.D; fp.pair_delta = g.pair_delta;
+    for (int h = 0; h < 2; ++h) {
+        const FeedJob &j = feeds[h];
+        FeedHalf &f = fp.half[h];
+        f.store = j.store; f.first_row = j.first_row; f.num_frames = j.num_frames; f.labels = j.labels; f.video_ids = j.video_ids;
+        f.out = j.out; f.labels_out = j.labels_out; f.twin = j.twin; f.rows = j.n_videos > 0 ? j.n_videos * g.T : 0; f.bf16 = j.bf16;
+    }
+    const int rows = fp.half[0].rows + fp.half[1].rows;
+    hipLaunchKernelGGL(sgd_open_feed_kernel, dim3(blocks + rows), dim3(256), 0, stream, g, params, grads, momentum, ws, i0, i1,
+                       fused_norm ? g.o_sumsq : g.o_norm_part, fused_norm ? g.n_sumsq : g.n_norm_blocks, lr, mu, wd, clip, nh, next ? 1 : 0,
+                       blocks, fp);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
