@@ -873,6 +873,7 @@ int build_plan_avgpool_general(ta3n_plan &p, std::string &err) {
     const bool mcd = (c.flags & TA3N_FLAG_MCD) != 0;                   // the DA options of the TemPooling rows (module path)
     const bool feat_grads = (c.flags & TA3N_FLAG_FEATURE_GRADS) != 0;
     const bool bn_shared = (c.flags & TA3N_FLAG_BN_SHARED) != 0;
+    if (bn_shared && F % BN_COLS != 0) { err = "use_bn: fc_dim must be a multiple of 4 (the BatchNorm launches move a row's four columns as one 16-byte access)"; return TA3N_ERR_INVALID; }
     if (mcd) b.add_linear("fc_classifier_video_source_2", C, F, true); // :276-279
     if (bn_shared) {                                                   // :195-196
         b.add_param("bn_shared_S.weight", F, 0, true); b.add_param("bn_shared_S.bias", F, 0, true);
@@ -1169,6 +1170,7 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
     const bool mcd = (c.flags & TA3N_FLAG_MCD) != 0;
     const bool feat_grads = (c.flags & TA3N_FLAG_FEATURE_GRADS) != 0;
     const bool bn_shared = (c.flags & TA3N_FLAG_BN_SHARED) != 0;
+    if (bn_shared && F % BN_COLS != 0) { err = "use_bn: fc_dim must be a multiple of 4 (the BatchNorm launches move a row's four columns as one 16-byte access)"; return TA3N_ERR_INVALID; }
     if (bn_shared) {   // models.py:195-196 (nn.BatchNorm1d(feat_shared_dim) x 2): weight and bias are trained
         b.add_param("bn_shared_S.weight", F, 0, true); b.add_param("bn_shared_S.bias", F, 0, true);
         b.add_param("bn_shared_T.weight", F, 0, true); b.add_param("bn_shared_T.bias", F, 0, true);

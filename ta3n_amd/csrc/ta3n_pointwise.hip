@@ -751,36 +751,19 @@ static_assert(BN_COLS == 4, "the BatchNorm launches move one float4 per row");
 
 struct BnRow { float v[BN_COLS]; };
 
-// the four columns [c0, c0 + 4) of one row; vec (F % 4 == 0, uniform): one 16-byte load, else guarded scalars (columns >= F read as 0)
-__device__ __forceinline__ BnRow bn_load(const float *__restrict__ row, int c0, int F, bool vec) {
+// the four columns [c0, c0 + 4) of one row: one 16-byte access (ta3n_plan_create refuses use_bn with fc_dim % 4 != 0; regions start 256-byte aligned)
+__device__ __forceinline__ BnRow bn_load(const float *__restrict__ row, int c0) {
     BnRow o;
-    if (vec) {
-        const float4 t = *reinterpret_cast<const float4 *>(row + c0);
-        o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < BN_COLS; ++e) o.v[e] = c0 + e < F ? row[c0 + e] : 0.f;
-    }
+    const float4 t = *reinterpret_cast<const float4 *>(row + c0);
+    o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
     return o;
 }
-__device__ __forceinline__ void bn_store(float *__restrict__ row, unsigned short *__restrict__ tw, int pair_delta, int c0, int F, bool vec, const BnRow &y) {
-    if (vec) {
-        *reinterpret_cast<float4 *>(row + c0) = make_float4(y.v[0], y.v[1], y.v[2], y.v[3]);
-        if (tw) {      // bf16 twin (TA3N_FLAG_BF16_STORE): the next GEMM launch reads it as an operand (ta3n_plan.cpp: add_bf16_twins)
-            const unsigned h0 = pack_bf16(y.v[0], y.v[1]), h1 = pack_bf16(y.v[2], y.v[3]);
-            *reinterpret_cast<uint2 *>(tw + c0) = make_uint2(h0, h1);
-            if (pair_delta) *reinterpret_cast<uint2 *>(tw + c0 + 2 * (size_t)pair_delta) = make_uint2(pack_bf16_lo(y.v[0], y.v[1], h0), pack_bf16_lo(y.v[2], y.v[3], h1));
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < BN_COLS; ++e) if (c0 + e < F) {
-            row[c0 + e] = y.v[e];
-            if (tw) {
-                const unsigned hb = pack_bf16(y.v[e], 0.f);
-                tw[c0 + e] = (unsigned short)hb;
-                if (pair_delta) tw[c0 + e + 2 * (size_t)pair_delta] = (unsigned short)pack_bf16_lo(y.v[e], 0.f, hb);
-            }
-        }
+__device__ __forceinline__ void bn_store(float *__restrict__ row, unsigned short *__restrict__ tw, int pair_delta, int c0, const BnRow &y) {
+    *reinterpret_cast<float4 *>(row + c0) = make_float4(y.v[0], y.v[1], y.v[2], y.v[3]);
+    if (tw) {      // bf16 twin (TA3N_FLAG_BF16_STORE): the next GEMM launch reads it as an operand (ta3n_plan.cpp: add_bf16_twins)
+        const unsigned h0 = pack_bf16(y.v[0], y.v[1]), h1 = pack_bf16(y.v[2], y.v[3]);
+        *reinterpret_cast<uint2 *>(tw + c0) = make_uint2(h0, h1);
+        if (pair_delta) *reinterpret_cast<uint2 *>(tw + c0 + 2 * (size_t)pair_delta) = make_uint2(pack_bf16_lo(y.v[0], y.v[1], h0), pack_bf16_lo(y.v[2], y.v[3], h1));
     }
 }
 // NV per-thread values summed over the workgroup; every thread receives every total (wave butterfly, then waves 0 .. 15 in order)
@@ -821,7 +804,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
     const int dom = blockIdx.y, tid = threadIdx.x, cg = bn_column_group((int)blockIdx.x, (int)gridDim.x), c0 = cg * BN_COLS;
     const int row0 = dom == 0 ? 0 : g.Bs * g.T, n = dom == 0 ? g.Bs * g.T : g.Bt * g.T, F = g.F;
     if (n == 0) return;
-    const bool vec = (F & 3) == 0;      // (uniform; regions start 256-byte aligned)
     const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
     // Everything else the launch reads - the step's scalars, the affine pair, the running statistics - is requested HERE, beside the column
     // slab: `hy` and the statistics live in the workspace this kernel stores to, so a read placed behind a store is a new round trip behind
@@ -834,11 +816,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
         const float *run = ws + g.o_bn_run + (size_t)dom * 2 * F;
 #pragma unroll
         for (int e = 0; e < BN_COLS; ++e) {
-            const bool ok = c0 + e < F;
-            w[e] = ok ? ptrs.p[g.p_bn_w[dom] + c0 + e] : 0.f;
-            b[e] = ok ? ptrs.p[g.p_bn_b[dom] + c0 + e] : 0.f;
-            run_m[e] = ok ? run[c0 + e] : 0.f;
-            run_v[e] = ok ? run[F + c0 + e] : 1.f;
+            w[e] = ptrs.p[g.p_bn_w[dom] + c0 + e];
+            b[e] = ptrs.p[g.p_bn_b[dom] + c0 + e];
+            run_m[e] = run[c0 + e];
+            run_v[e] = run[F + c0 + e];
         }
     }
     // Up to BN_KEEP rows per thread stay in registers between the three passes - mean, variance, apply - so the column slab crosses the
@@ -849,7 +830,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
 #pragma unroll
         for (int j = 0; j < BN_KEEP; ++j) {
             const int i = tid + j * BN_THREADS;
-            if (i < n) zreg[j] = bn_load(z + (size_t)i * F, c0, F, vec);
+            if (i < n) zreg[j] = bn_load(z + (size_t)i * F, c0);
             else {
 #pragma unroll
                 for (int e = 0; e < BN_COLS; ++e) zreg[j].v[e] = 0.f;
@@ -866,7 +847,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
                 for (int e = 0; e < BN_COLS; ++e) s[e] += zreg[j].v[e];
             }
         } else for (int i = tid; i < n; i += BN_THREADS) {
-            const BnRow t = bn_load(z + (size_t)i * F, c0, F, vec);
+            const BnRow t = bn_load(z + (size_t)i * F, c0);
 #pragma unroll
             for (int e = 0; e < BN_COLS; ++e) s[e] += t.v[e];
         }
@@ -881,7 +862,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
                 for (int e = 0; e < BN_COLS; ++e) { const float d = zreg[j].v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
             }
         } else for (int i = tid; i < n; i += BN_THREADS) {
-            const BnRow t = bn_load(z + (size_t)i * F, c0, F, vec);
+            const BnRow t = bn_load(z + (size_t)i * F, c0);
 #pragma unroll
             for (int e = 0; e < BN_COLS; ++e) { const float d = t.v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
         }
@@ -895,7 +876,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
         for (int e = 0; e < BN_COLS; ++e) {
             const float var = q[e] / (float)n;
             invstd[e] = 1.f / sqrtf(var + BN_EPS);
-            if (tid == 0 && c0 + e < F) {
+            if (tid == 0) {
                 const int c = c0 + e;
                 st[c] = mean[e]; st[F + c] = var; st[2 * F + c] = invstd[e];
                 run[c] = run_m[e] * 0.9f + 0.1f * mean[e];
@@ -919,13 +900,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_fwd_kernel(Geom g, Ptrs 
             if (drop) t *= keep_mask(seed, (uint32_t)((row0 + i) * F + c0 + e), p_drop);
             y.v[e] = t * inv_keep;
         }
-        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, F, vec, y);
+        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, y);
     };
     if (keep) {
 #pragma unroll
         for (int j = 0; j < BN_KEEP; ++j) { const int i = tid + j * BN_THREADS; if (i < n) apply(i, zreg[j]); }
     } else {
-        for (int i = tid; i < n; i += BN_THREADS) apply(i, bn_load(z + (size_t)i * F, c0, F, vec));
+        for (int i = tid; i < n; i += BN_THREADS) apply(i, bn_load(z + (size_t)i * F, c0));
     }
 }
 
@@ -943,17 +924,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs 
         if (slot && tid == 0) *slot = 0.f;
         return;
     }
-    const bool vec = (F & 3) == 0;
     const float *__restrict__ z = ws + g.o_Z0 + (size_t)row0 * F;
     const float *__restrict__ gy = ws + g.o_gZ1 + (size_t)row0 * F;
     const float *st = ws + g.o_bn_batch + (size_t)dom * 3 * F;
     float mean[BN_COLS], invstd[BN_COLS], wgt[BN_COLS];      // (all requested beside the slabs: a read behind this kernel's stores would wait for them)
 #pragma unroll
     for (int e = 0; e < BN_COLS; ++e) {
-        const bool ok = c0 + e < F;
-        mean[e] = ok ? st[c0 + e] : 0.f;
-        invstd[e] = ok ? st[2 * F + c0 + e] : 0.f;
-        wgt[e] = ok ? ptrs.p[g.p_bn_w[dom] + c0 + e] : 0.f;
+        mean[e] = st[c0 + e];
+        invstd[e] = st[2 * F + c0 + e];
+        wgt[e] = ptrs.p[g.p_bn_w[dom] + c0 + e];
     }
     BnRow greg[BN_KEEP], xreg[BN_KEEP];      // (as in the forward launch: gradient and normalised input of up to BN_KEEP rows per thread stay in registers)
     const bool keep = n <= BN_THREADS * BN_KEEP;
@@ -963,8 +942,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs 
         for (int j = 0; j < BN_KEEP; ++j) {
             const int i = tid + j * BN_THREADS;
             if (i < n) {
-                greg[j] = bn_load(gy + (size_t)i * F, c0, F, vec);
-                xreg[j] = bn_load(z + (size_t)i * F, c0, F, vec);
+                greg[j] = bn_load(gy + (size_t)i * F, c0);
+                xreg[j] = bn_load(z + (size_t)i * F, c0);
             } else {
 #pragma unroll
                 for (int e = 0; e < BN_COLS; ++e) { greg[j].v[e] = 0.f; xreg[j].v[e] = 0.f; }
@@ -980,7 +959,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs 
             }
         }
     } else for (int i = tid; i < n; i += BN_THREADS) {
-        const BnRow gv = bn_load(gy + (size_t)i * F, c0, F, vec), zv = bn_load(z + (size_t)i * F, c0, F, vec);
+        const BnRow gv = bn_load(gy + (size_t)i * F, c0), zv = bn_load(z + (size_t)i * F, c0);
 #pragma unroll
         for (int e = 0; e < BN_COLS; ++e) {
             sums[e] += gv.v[e];
@@ -991,7 +970,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs 
     if (tid == 0) {
         float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < BN_COLS; ++e) if (c0 + e < F) {      // (added in column order)
+        for (int e = 0; e < BN_COLS; ++e) {      // (added in column order)
             q += fmaf(sums[BN_COLS + e], sums[BN_COLS + e], sums[e] * sums[e]);
             ptrs.g[g.p_bn_w[dom] + c0 + e] = sums[BN_COLS + e];
             ptrs.g[g.p_bn_b[dom] + c0 + e] = sums[e];
@@ -1009,17 +988,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_shared_bwd_kernel(Geom g, Ptrs 
         BnRow v;
 #pragma unroll
         for (int e = 0; e < BN_COLS; ++e) v.v[e] = k[e] * (gv.v[e] - mg[e] - xh.v[e] * mgx[e]);
-        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, F, vec, v);
+        bn_store(out + (size_t)i * F, tw ? tw + (size_t)i * F : nullptr, g.pair_delta, c0, v);
     };
     if (keep) {
 #pragma unroll
         for (int j = 0; j < BN_KEEP; ++j) { const int i = tid + j * BN_THREADS; if (i < n) emit(i, greg[j], xreg[j]); }
     } else {
         for (int i = tid; i < n; i += BN_THREADS) {
-            BnRow xh = bn_load(z + (size_t)i * F, c0, F, vec);
+            BnRow xh = bn_load(z + (size_t)i * F, c0);
 #pragma unroll
             for (int e = 0; e < BN_COLS; ++e) xh.v[e] = (xh.v[e] - mean[e]) * invstd[e];
-            emit(i, bn_load(gy + (size_t)i * F, c0, F, vec), xh);
+            emit(i, bn_load(gy + (size_t)i * F, c0), xh);
         }
     }
 }

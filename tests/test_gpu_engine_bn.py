@@ -5,6 +5,7 @@ parameters after every step, the BatchNorm buffers at the end, the eval-mode for
 import pytest
 import torch
 
+import oracle.ta3n_oracle as orc
 from golden_util import BN_CASES, Golden, case_config, step_schedule
 from ta3n_amd.engine import TrainEngine
 from ta3n_amd.synthetic import synth_batch, synth_state
@@ -116,3 +117,36 @@ def test_fused_batchnorm_step_pipelined_and_on_bf16_twins(name):
     assert torch.equal(runs["plain"][0], runs["steps"][0]) and runs["plain"][2] == runs["steps"][2] == runs["pipelined"][2]
     d = (runs["bf16"][0] - runs["plain"][0]).norm() / (runs["plain"][0].norm() + 1e-30)
     assert torch.isfinite(runs["bf16"][0]).all() and d < 2e-2, d
+
+
+@pytest.mark.parametrize("use_bn", ["AdaBN", "AutoDIAL"])
+def test_tall_batches_stream_through_the_batchnorm_launches(use_bn):
+    """More frame rows per domain than the BatchNorm launches keep in registers (1 024 row lanes x 5 rows = 5 120): their streaming
+    loops re-read the column slab for the mean, the variance and the apply pass.  One train step at 5 500 / 5 200 rows against the
+    oracle started from the same parameters: class logits, the BatchNorm affine gradients and every other gradient tensor."""
+    Bs, Bt, T, D, Fc, Cn = 1100, 1040, 5, 64, 64, 7
+    cfg = orc.Config(num_class=Cn, num_segments=T, feature_dim=D, fc_dim=Fc, dropout_i=0.0, dropout_v=0.0, use_bn=use_bn)
+    params = synth_state(orc.param_shapes(cfg), seed=3, scale="trained")
+    eng = TrainEngine(Bs, Bt, T, D, Fc, Cn, dropout_i=0.0, dropout_v=0.0, clip=20.0, use_bn=use_bn)
+    assert eng.fused and Bs * T > 5120 and Bt * T > 5120
+    eng.load_state(params)
+    xs, xt, ys, yt = synth_batch(Cn, T, D, Bs, Bt, seed=17)
+    state = orc.TrainState(params={k: v.detach().cpu().clone() for k, v in eng.param_views().items()}, lr=2e-3)
+    state.momentum = {k: v.detach().cpu().clone() for k, v in eng.momentum_views().items()}
+    eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
+    eng.train_step([0.75, 0.75, 0.5], 0.003, 2e-3)
+    torch.cuda.synchronize()
+    res = orc.train_step(state, xs, xt, ys, [0.75, 0.75, 0.5], 0.003, cfg, clip=20.0)
+    want = torch.cat((res["src"]["out"], res["tgt"]["out"]), 0).detach()
+    got = eng.outputs()["out"].cpu().reshape(want.shape)
+    assert (got - want).abs().max().item() < 1e-3
+    grads = eng.param_views(eng.G)
+    top = max(w.double().norm().item() for w in res["grads"].values())
+    for k, w in res["grads"].items():
+        err, ref = (grads[k].cpu().double() - w.double()).norm().item(), w.double().norm().item()
+        if ref < 1e-5 * top:      # the shared FC's bias in front of a BatchNorm: its gradient is zero in exact arithmetic, rounding noise in both
+            assert err < 1e-5 * top, (k, err, ref)
+        else:
+            assert err < 5e-3 * ref, (k, err / ref)
+    for k in ("bn_shared_S.weight", "bn_shared_S.bias", "bn_shared_T.weight", "bn_shared_T.bias"):
+        assert k in res["grads"]

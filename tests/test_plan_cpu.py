@@ -87,6 +87,9 @@ def test_plan_rejects_bad_configs():
         _lib.Plan(0, 0, 5, 512, 64, 12, ALL_FLAGS)
     with pytest.raises(ValueError):
         _lib.Plan(4, 4, 5, 512, 64, 12, ALL_FLAGS, tile_config=333)
+    with pytest.raises(ValueError):
+        _lib.Plan(4, 4, 5, 512, 30, 12, ALL_FLAGS | _lib.FLAG_BN_SHARED)      # use_bn: the BatchNorm launches move four columns of a row at a time
+    _lib.Plan(4, 4, 5, 512, 30, 12, ALL_FLAGS)                                # (without BatchNorm any fc_dim goes)
 
 
 def test_param_table_matches_reference_state_dict():
