@@ -421,6 +421,21 @@ int ta3n_gaussian_kernel(const float *total, int n, int d, float kernel_mul, int
                          float *scratch, void *stream);
 int ta3n_mmd_rowdiff(const float *c, const float *total, int n, int d, float scale, float *out, void *stream);
 
+/* The whole discrepancy term of ONE rank's step, enqueued without a framework in between (main.py:452-505 between the loss and the backward):
+ * kind 1 = DAN - mmd_rbf (loss.py:61-85, ver 2) of every selected feature (place_logits / place_feature: main.py's place_dis[0] / [1]) on the
+ * first min(valid_source, valid_target) videos of each domain, in chunks of <= 256 videos whose losses are averaged (main.py:459-476);
+ * kind 2 = JAN (loss.py:87-120, ver 2) - ONE joint kernel of logits and video feature over those videos (main.py:478-505); kernel_muls
+ * [2, 2], kernel_nums [2, 5], data-dependent bandwidths.  Reads the logits [B, num_class] at ws + o_logits and the video features
+ * [B, feat_dim] at ws + o_feature (source rows first); ADDS alpha * d loss / d logits to ws + o_grad_logits, WRITES alpha * d loss / d feature to
+ * ws + o_grad_feature (zero rows for videos that take no part) and the loss itself (not scaled by alpha: main.py's loss_d) to *loss_out
+ * (device).  Same kernels and the same gradient algebra as ta3n_gaussian_kernel / ta3n_mmd_rowdiff under autograd: gK = +-1 / half^2 per
+ * quadrant (x the other layer's kernel for JAN), c = 2 Kp o (gK + gK^T).  More than one rank gathers the valid rows first
+ * (ta3n_amd/parallel.py: discrepancy_over_ranks) - this entry is the single-rank path. */
+int64_t ta3n_discrepancy_scratch_floats(int batch_source, int batch_target, int num_class, int feat_dim);
+int ta3n_discrepancy(float *ws, int64_t o_logits, int num_class, int64_t o_feature, int feat_dim, int64_t o_grad_logits, int64_t o_grad_feature,
+                     int batch_source, int batch_target, int valid_source, int valid_target, int kind, int place_logits, int place_feature,
+                     float alpha, float *scratch, int64_t scratch_floats, float *loss_out, void *stream);
+
 /* ---- data parallelism: RCCL from the C ABI (replaces nn.DataParallel's per-step broadcast / gather / reduce, main.py:79) ----
  * One process per GPU.  Rank 0 makes a 128-byte id (ta3n_comm_unique_id), the launcher hands it to every rank (any
  * channel: torch.distributed store, MPI, a file), every rank calls ta3n_comm_create on its device - a collective over

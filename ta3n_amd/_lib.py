@@ -42,7 +42,7 @@ SYMBOLS = [
     "ta3n_gather_segments_bf16_into", "ta3n_train_steps", "ta3n_train_steps_multi", "ta3n_chain_status", "ta3n_debug_waits",
     "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
     "ta3n_comm_attach_peer", "ta3n_has_fused_update", "ta3n_train_steps_fused_update",
-    "ta3n_gaussian_kernel_scratch_floats", "ta3n_gaussian_kernel", "ta3n_mmd_rowdiff",
+    "ta3n_gaussian_kernel_scratch_floats", "ta3n_gaussian_kernel", "ta3n_mmd_rowdiff", "ta3n_discrepancy_scratch_floats", "ta3n_discrepancy",
     "ta3n_shard_ranges", "ta3n_shard_sumsq", "ta3n_sgd_shard", "ta3n_shard_reduce_scatter", "ta3n_sharded_update", "ta3n_train_steps_sharded",
 ]
 
@@ -189,6 +189,10 @@ def lib() -> C.CDLL:
     L.ta3n_gaussian_kernel_scratch_floats.restype = i64
     L.ta3n_gaussian_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp, vp, vp, vp]
     L.ta3n_mmd_rowdiff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
+    L.ta3n_discrepancy_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ta3n_discrepancy_scratch_floats.restype = i64
+    L.ta3n_discrepancy.argtypes = [vp, i64, C.c_int, i64, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, vp, i64, vp, vp]
     L.ta3n_last_error.restype = C.c_char_p
     L.ta3n_version.restype = C.c_char_p
     _LIB = L

@@ -100,6 +100,7 @@ class TrainEngine:
             raise NotImplementedError(f"dis_DA {dis_DA!r} (built: DAN, JAN)")
         self.dis_DA, self.place_dis, self.alpha = dis_DA, tuple(place_dis), float(alpha)
         self.loss_d = None                       # device scalar: the discrepancy loss of the last step (main.py's loss_d)
+        self._disc_scratch = None                # (native path: kernel matrices, stacked rows, the loss scalar in its last float)
         if dis_DA != "none":
             if dis_DA == "DAN" and len(self.place_dis) > 2 and self.place_dis[2] == "Y":
                 raise ValueError("place_dis[2]: the reference itself fails on the 3-D frame features (loss.py:49)")
@@ -417,6 +418,21 @@ class TrainEngine:
         if self.dis_DA == "none":
             return
         ns, nt = int(self._hyper.valid_source), int(self._hyper.valid_target)
+        if self.world == 1 and os.environ.get("TA3N_NATIVE_DISCREPANCY", "1") != "0":
+            # one rank: the whole term from the library (ta3n_discrepancy) - the torch glue around the same kernels (cat / slices / autograd /
+            # a dozen small allocations) cost 0.4 - 1.1 ms of host time per step against 0.2 ms for everything else the step launches
+            (oy, _), (ov, nv), (ogy, _), (ogv, _) = (self.plan.region(k) for k in ("Y", "V", "gY", "gV_ext"))
+            fv = nv // self.B
+            if self._disc_scratch is None:
+                n = int(self._L.ta3n_discrepancy_scratch_floats(self.Bs, self.Bt, self.C, fv))
+                self._disc_scratch = torch.empty(n + 1, dtype=torch.float32, device=self.device)
+            loss = self._disc_scratch[-1:]
+            _lib.check(self._L.ta3n_discrepancy(self.ws.data_ptr(), oy, self.C, ov, fv, ogy, ogv, self.Bs, self.Bt, ns, nt,
+                                                1 if self.dis_DA == "DAN" else 2, int(self.place_dis[0] == "Y"), int(self.place_dis[1] == "Y"),
+                                                float(self.alpha), self._disc_scratch.data_ptr(), self._disc_scratch.numel() - 1, loss.data_ptr(),
+                                                self._stream()), "ta3n_discrepancy")
+            self.loss_d = loss[0]
+            return
         y, v = self.region("Y", (self.B, self.C)), self.region("V", (self.B, -1))
         # more than one rank: the reference takes this loss after DataParallel's gather, on the global batch - the ranks' valid rows are
         # gathered in rank order (one sum all-reduce over per-rank slots) and every rank keeps its own gradient rows (parallel.discrepancy_over_ranks)
