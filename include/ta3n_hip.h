@@ -431,6 +431,22 @@ int ta3n_mmd_rowdiff(const float *c, const float *total, int n, int d, float sca
  * (device).  Same kernels and the same gradient algebra as ta3n_gaussian_kernel / ta3n_mmd_rowdiff under autograd: gK = +-1 / half^2 per
  * quadrant (x the other layer's kernel for JAN), c = 2 Kp o (gK + gK^T).  More than one rank gathers the valid rows first
  * (ta3n_amd/parallel.py: discrepancy_over_ranks) - this entry is the single-rank path. */
+/* ens_DA MCD (models.py:276-279, 716-720; main.py:447-448, 548-562; loss.py:29-30): what the reference's train loop does between the launches
+ * of a step with a second classifier, without a framework in between.  A step: ta3n_forward + ta3n_loss on `ws`; ta3n_mcd_source_loss;
+ * ta3n_set_hyper(reverse = 1, mu, fresh dropout seeds) + ta3n_forward on a SECOND workspace `ws2`; ta3n_mcd_second_loss; ta3n_backward on `ws`;
+ * ta3n_backward on `ws2` into a second gradient buffer; the two gradients are summed.
+ * ta3n_mcd_source_loss: + CrossEntropy(out_source_2, label) over the valid source rows - its logit gradient to ws["gY2"]; with
+ *   TA3N_FLAG_ATTN_ENTROPY the target rows of ws["gY"] are cleared (the reference rebinds out_target to the second pass's logits before it
+ *   assembles that loss, main.py:549 vs :559-562, so their entropy term belongs to the second pass).  out[0] = the loss (main.py's second loss_c term).
+ * ta3n_mcd_second_loss: clears the gradient entries of ws2 (it has no ta3n_loss of its own), then over the valid target rows:
+ *   loss_s = -mean |softmax(Y) - softmax(Y2)| of the second pass over (global_target x num_class) elements -> out[1], its gradients to
+ *   ws2["gY"] / ws2["gY2"]; with TA3N_FLAG_ATTN_ENTROPY the target half of the attentive entropy on the second pass's logits, weighted by the
+ *   FIRST pass's video-domain logits: + its gradient in ws2["gY"], ws["gPv"] moved by d(new - old) / d Pv, out[2] = what the move adds to the total
+ *   loss, out[3] = to main.py's loss_e.  scratch: 3 * (batch_source + batch_target) floats; out: 4 floats (device).  Both read the step's scalars
+ *   from ws["hyper"] (valid rows, inv_n_cls, gamma, inv_n_ent) and enqueue only; sums in a fixed order. */
+int ta3n_mcd_source_loss(ta3n_plan *plan, float *ws, float *scratch, float *out, void *stream);
+int ta3n_mcd_second_loss(ta3n_plan *plan, float *ws, float *ws2, int global_target, float *scratch, float *out, void *stream);
+
 int64_t ta3n_discrepancy_scratch_floats(int batch_source, int batch_target, int num_class, int feat_dim);
 int ta3n_discrepancy(float *ws, int64_t o_logits, int num_class, int64_t o_feature, int feat_dim, int64_t o_grad_logits, int64_t o_grad_feature,
                      int batch_source, int batch_target, int valid_source, int valid_target, int kind, int place_logits, int place_feature,

@@ -43,6 +43,7 @@ SYMBOLS = [
     "ta3n_peer_create", "ta3n_peer_handle", "ta3n_peer_connect", "ta3n_peer_all_reduce_sum", "ta3n_peer_status", "ta3n_peer_destroy",
     "ta3n_comm_attach_peer", "ta3n_has_fused_update", "ta3n_train_steps_fused_update",
     "ta3n_gaussian_kernel_scratch_floats", "ta3n_gaussian_kernel", "ta3n_mmd_rowdiff", "ta3n_discrepancy_scratch_floats", "ta3n_discrepancy",
+    "ta3n_mcd_source_loss", "ta3n_mcd_second_loss",
     "ta3n_shard_ranges", "ta3n_shard_sumsq", "ta3n_sgd_shard", "ta3n_shard_reduce_scatter", "ta3n_sharded_update", "ta3n_train_steps_sharded",
 ]
 
@@ -189,6 +190,8 @@ def lib() -> C.CDLL:
     L.ta3n_gaussian_kernel_scratch_floats.restype = i64
     L.ta3n_gaussian_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp, vp, vp, vp]
     L.ta3n_mmd_rowdiff.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
+    L.ta3n_mcd_source_loss.argtypes = [vp, vp, vp, vp, vp]
+    L.ta3n_mcd_second_loss.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.ta3n_discrepancy_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.ta3n_discrepancy_scratch_floats.restype = i64
     L.ta3n_discrepancy.argtypes = [vp, i64, C.c_int, i64, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -335,6 +335,28 @@ int ta3n_loss(ta3n_plan *p, float *ws, void *stream) {
     return run_group(p, 1, ptrs, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
+// ---- ens_DA MCD: the loss assembly around the second classifier and the second, reversed pass (include/ta3n_hip.h) ----
+int ta3n_mcd_source_loss(ta3n_plan *p, float *ws, float *scratch, float *out, void *stream) {
+    if (!p || !ws || !scratch || !out) return fail(TA3N_ERR_INVALID, "null argument");
+    if (!(p->cfg.flags & TA3N_FLAG_MCD) || p->geom.o_Y2 <= 0) return fail(TA3N_ERR_INVALID, "the plan was not created with TA3N_FLAG_MCD");
+    if (launch_mcd_source_loss(p->geom, ws, scratch, out, static_cast<hipStream_t>(stream)) != 0) return fail(TA3N_ERR_HIP, "MCD source-loss launch failed");
+    return TA3N_OK;
+}
+
+int ta3n_mcd_second_loss(ta3n_plan *p, float *ws, float *ws2, int global_target, float *scratch, float *out, void *stream) {
+    if (!p || !ws || !ws2 || !scratch || !out || ws == ws2) return fail(TA3N_ERR_INVALID, "null argument (or one workspace for both passes)");
+    if (!(p->cfg.flags & TA3N_FLAG_MCD) || p->geom.o_Y2 <= 0) return fail(TA3N_ERR_INVALID, "the plan was not created with TA3N_FLAG_MCD");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the second pass has no ta3n_loss of its own: every gradient entry its backward reads starts from zero
+    for (const char *name : {"gY", "gY2", "gPr", "gPv", "gPf", "g_attn", "gV_ext"})
+        for (const auto &r : p->regions)
+            if (r.name == name && r.size > 0 && hipMemsetAsync(ws2 + r.off, 0, (size_t)r.size * sizeof(float), s) != hipSuccess)
+                return fail(TA3N_ERR_HIP, "memset failed");
+    const float inv_count = 1.f / ((float)(global_target > 1 ? global_target : 1) * (float)p->geom.C);      // loss.py:30 torch.mean over (global target videos x classes)
+    if (launch_mcd_second_loss(p->geom, ws, ws2, inv_count, scratch, out, s) != 0) return fail(TA3N_ERR_HIP, "MCD second-loss launch failed");
+    return TA3N_OK;
+}
+
 int ta3n_backward(ta3n_plan *p, const float *x, const float *params, float *grads, float *ws, void *stream) {
     if (!p || !x || !params || !grads || !ws) return fail(TA3N_ERR_INVALID, "null argument");
     if (!aligned16(x) || !aligned16(params) || !aligned16(grads) || !aligned16(ws))

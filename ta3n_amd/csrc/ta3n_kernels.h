@@ -160,6 +160,8 @@ int launch_pool_cls(const Geom &g, const Ptrs &ptrs, hipStream_t stream);   // T
 int launch_pool_avg_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_bn_shared_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
+int launch_mcd_source_loss(const Geom &g, float *ws, float *part, float *out, hipStream_t stream);                            // ens_DA MCD glue (ta3n_mcd_*)
+int launch_mcd_second_loss(const Geom &g, float *ws, float *ws2, float inv_count, float *part, float *out, hipStream_t stream);
 int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_pool_fwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream);
 int launch_loss(const Geom &g, const Ptrs &ptrs, hipStream_t stream);

@@ -1012,6 +1012,118 @@ int launch_bn_shared_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- ens_DA MCD: what main.py does between its launches, without a framework in between (main.py:447-448, 548-562; loss.py:29-30) ----
+// A row of <= 64 class logits on one wave (lane c = class c): softmax, log_softmax and entropy the way torch takes them.
+struct RowSoft { float p, lp, H; };
+__device__ __forceinline__ RowSoft row_soft(float z, bool on) {
+    const float m = wave_allreduce_max(on ? z : -INFINITY);
+    const float e = on ? expf(z - m) : 0.f;
+    const float sum = wave_allreduce_sum(e);
+    RowSoft r;
+    r.p = e / sum;
+    r.lp = on ? z - m - logf(sum) : 0.f;
+    r.H = -wave_allreduce_sum(on ? r.p * r.lp : 0.f);
+    return r;
+}
+// + CrossEntropy(out_source_2, label) over the valid source rows (main.py:447-448): its logit gradient to gY2 (rows without a label: 0), the
+// per-row loss terms to part[b]; with the attentive entropy on, the target rows of gY are cleared - that term moves to the second pass
+// (mcd_second_loss_kernel).  One wave per video.
+__global__ __launch_bounds__(256) void mcd_source_loss_kernel(Geom g, float *__restrict__ ws, float *__restrict__ part) {
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= g.B) return;
+    const int C = g.C, ns = hy->valid_source;
+    const float inv = hy->inv_n_cls;
+    const bool on = lane < C;
+    float g2 = 0.f, term = 0.f;
+    if (b < ns) {
+        const int label = reinterpret_cast<const int *>(ws + g.o_labels)[b];
+        const RowSoft r = row_soft(on ? ws[g.o_Y2 + (size_t)b * C + lane] : 0.f, on);
+        g2 = (expf(r.lp) - (lane == label ? 1.f : 0.f)) * inv;
+        term = -wave_allreduce_sum(lane == label ? r.lp : 0.f);
+    }
+    if (on) {
+        ws[g.o_gY2 + (size_t)b * C + lane] = g2;
+        if ((g.flags & TA3N_FLAG_ATTN_ENTROPY) && b >= g.Bs) ws[g.o_gY + (size_t)b * C + lane] = 0.f;
+    }
+    if (lane == 0) part[b] = term;
+}
+// The second, reversed pass's loss (main.py:548-562): loss_s = -mean |softmax(out_target) - softmax(out_target_2)| over the valid target
+// rows of the GLOBAL batch (loss.py:29-30) and - the reference REBINDS out_target before it assembles the attentive entropy - the target
+// half of that loss on THIS pass's logits, weighted by the FIRST pass's video-domain logits: gY / gY2 of the second workspace, the first
+// pass's gPv moved by d(e_new - e_old) / d Pv, per-row terms {sum |dp|, w H(y second), w H(y first)} to part[r][0..2].  One wave per row.
+__global__ __launch_bounds__(256) void mcd_second_loss_kernel(Geom g, float *__restrict__ ws, float *__restrict__ ws2, float inv_count,
+                                                              float *__restrict__ part) {
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nt = hy->valid_target, C = g.C;
+    if (r >= nt) return;
+    const int b = g.Bs + r;
+    const bool on = lane < C;
+    const RowSoft a = row_soft(on ? ws2[g.o_Y + (size_t)b * C + lane] : 0.f, on);
+    const RowSoft c = row_soft(on ? ws2[g.o_Y2 + (size_t)b * C + lane] : 0.f, on);
+    const float dp = a.p - c.p;
+    const float sgn = dp > 0.f ? 1.f : dp < 0.f ? -1.f : 0.f;
+    // loss = -inv_count * sum |dp|:  d / d p = -inv_count sgn,  d / d p2 = +inv_count sgn;  softmax backward  g_k = p_k (d_k - sum_c p_c d_c)
+    const float d1 = on ? -inv_count * sgn : 0.f;
+    float g1 = a.p * (d1 - wave_allreduce_sum(a.p * d1));
+    const float g2 = c.p * (-d1 - wave_allreduce_sum(c.p * -d1));
+    const float sabs = wave_allreduce_sum(on ? fabsf(dp) : 0.f);
+    float e_new = 0.f, e_old = 0.f;
+    if (g.flags & TA3N_FLAG_ATTN_ENTROPY) {
+        const float scale = hy->gamma * hy->inv_n_ent;
+        const RowSoft f = row_soft(on ? ws[g.o_Y + (size_t)b * C + lane] : 0.f, on);
+        const Soft2 pv = soft2(ws[g.o_Pv + (size_t)b * 2], ws[g.o_Pv + (size_t)b * 2 + 1]);
+        const float w = 1.f + pv.H;
+        e_new = w * a.H; e_old = w * f.H;
+        g1 += on ? scale * w * (-a.p * (a.lp + a.H)) : 0.f;                  // d H(z) / d z_k = -p_k (log p_k + H)
+        if (lane < 2) {
+            const float pj = lane == 0 ? pv.p0 : pv.p1, lpj = lane == 0 ? pv.lp0 : pv.lp1;
+            ws[g.o_gPv + (size_t)b * 2 + lane] += scale * (a.H - f.H) * (-pj * (lpj + pv.H));
+        }
+    }
+    if (on) {
+        ws2[g.o_gY + (size_t)b * C + lane] = g1;
+        ws2[g.o_gY2 + (size_t)b * C + lane] = g2;
+    }
+    if (lane == 0) { part[(size_t)r * 3] = sabs; part[(size_t)r * 3 + 1] = e_new; part[(size_t)r * 3 + 2] = e_old; }
+}
+// out[slot + k] = scale[k] * sum_r part[r * stride + k]  (k < n_out; rows in order: one wave, fixed order)
+__global__ __launch_bounds__(64) void mcd_finish_kernel(const float *__restrict__ part, const Geom g, const float *__restrict__ ws, int which,
+                                                        float inv_count, float *__restrict__ out) {
+    const Hyper *__restrict__ hy = reinterpret_cast<const Hyper *>(ws + g.o_hyper);
+    if (which == 0) {      // loss_c2
+        const int n = hy->valid_source;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < n; i += 64) acc += part[i];
+        acc = wave_allreduce_sum(acc);
+        if (threadIdx.x == 0) out[0] = acc * hy->inv_n_cls;
+        return;
+    }
+    const int n = hy->valid_target;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) { s0 += part[(size_t)i * 3]; s1 += part[(size_t)i * 3 + 1]; s2 += part[(size_t)i * 3 + 2]; }
+    s0 = wave_allreduce_sum(s0); s1 = wave_allreduce_sum(s1); s2 = wave_allreduce_sum(s2);
+    if (threadIdx.x == 0) {
+        const float scale = hy->gamma * hy->inv_n_ent;
+        const float de = (g.flags & TA3N_FLAG_ATTN_ENTROPY) ? scale * s1 - scale * s2 : 0.f;
+        out[1] = -inv_count * s0;                                    // loss_s
+        out[2] = de;                                                 // what moving the target rows' entropy term to this pass adds to the total loss
+        out[3] = hy->gamma != 0.f ? de / hy->gamma : 0.f;            // ... and to main.py's loss_e
+    }
+}
+
+int launch_mcd_source_loss(const Geom &g, float *ws, float *part, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(mcd_source_loss_kernel, dim3((g.B + 3) / 4), dim3(256), 0, stream, g, ws, part);
+    hipLaunchKernelGGL(mcd_finish_kernel, dim3(1), dim3(64), 0, stream, part, g, ws, 0, 0.f, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int launch_mcd_second_loss(const Geom &g, float *ws, float *ws2, float inv_count, float *part, float *out, hipStream_t stream) {
+    if (g.Bt > 0) hipLaunchKernelGGL(mcd_second_loss_kernel, dim3((g.Bt + 3) / 4), dim3(256), 0, stream, g, ws, ws2, inv_count, part);
+    hipLaunchKernelGGL(mcd_finish_kernel, dim3(1), dim3(64), 0, stream, part, g, ws, 1, inv_count, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_pool_avg_bwd(const Geom &g, const Ptrs &ptrs, hipStream_t stream) {
     hipLaunchKernelGGL(pool_avg_bwd_kernel, dim3(g.B * g.T), dim3(256), 0, stream, g, ptrs, g.o_gHf < 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -201,6 +201,7 @@ class TrainEngine:
             _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws.data_ptr(), self._stream()), "ta3n_init_workspace")
         off, n = p.region("labels")
         self._labels = self.ws[off:off + n].view(torch.int32)
+        self._mcd_buf: Optional[torch.Tensor] = None
         self.ws2: Optional[torch.Tensor] = None      # ens_DA MCD: workspace and gradient buffer of the reversed second pass
         self.G2: Optional[torch.Tensor] = None
         if self.ens_DA == "MCD":
@@ -208,6 +209,10 @@ class TrainEngine:
                 self.ws2 = torch.zeros(p.ws_floats, dtype=torch.float32, device=self.device)
                 self.G2 = torch.zeros(p.param_floats, dtype=torch.float32, device=self.device)
                 _lib.check(self._L.ta3n_init_workspace(p.handle, self.ws2.data_ptr(), self._stream()), "ta3n_init_workspace")
+                # the loss assembly of the two passes from the library (ta3n_mcd_source_loss / ta3n_mcd_second_loss; TA3N_NATIVE_MCD=0: the torch
+                # form of rounds 4-5, kept for A/B): per-row terms [3 B] + the four scalars {loss_c2, loss_s, d total, d loss_e} at the end
+                self._mcd_buf = torch.zeros(3 * self.B + 4, dtype=torch.float32, device=self.device)
+        self._mcd_native = self.ens_DA == "MCD" and os.environ.get("TA3N_NATIVE_MCD", "1") != "0"
         # fused: forward + loss + backward as ONE C-ABI call (ta3n_train_step, 7 launches) when the plan has it
         self.fused = bool(fused) and p.has_fused_step
         # deferred update: the optimiser step of call s is enqueued at the start of call s + 1, split so that everything but
@@ -466,6 +471,11 @@ class TrainEngine:
         logit gradient goes to region gY2 (the loss kernel knows nothing of the second classifier)."""
         if self.ens_DA != "MCD":
             return
+        if self._mcd_native:      # the library's kernels (ta3n_mcd_source_loss): the torch assembly below cost ~0.2 ms of host time per step
+            _lib.check(self._L.ta3n_mcd_source_loss(self.plan.handle, self.ws.data_ptr(), self._mcd_buf.data_ptr(), self._mcd_buf[-4:].data_ptr(),
+                                                    self._stream()), "ta3n_mcd_source_loss")
+            self.loss_c2 = self._mcd_buf[-4]
+            return
         ns = int(self._hyper.valid_source)
         if self._flags & _lib.FLAG_ATTN_ENTROPY:      # the attentive entropy of the TARGET rows is taken on the second pass's logits
             # (mcd_second_forward); right after ta3n_loss those rows of gY carry nothing but that term
@@ -499,6 +509,13 @@ class TrainEngine:
         _lib.check(L.ta3n_set_hyper(plan.handle, self.ws2.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
         _lib.check(L.ta3n_forward(plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws2.data_ptr(), self._stream()), "ta3n_forward")
         nt = int(self._hyper.valid_target)
+        if self._mcd_native:      # ta3n_mcd_second_loss: clears the second workspace's gradient entries, loss_s, the moved entropy term, all gradients
+            _lib.check(L.ta3n_mcd_second_loss(plan.handle, self.ws.data_ptr(), self.ws2.data_ptr(), int(self._global_target), self._mcd_buf.data_ptr(),
+                                              self._mcd_buf[-4:].data_ptr(), self._stream()), "ta3n_mcd_second_loss")
+            self.loss_s = self._mcd_buf[-3]
+            if nt > 0 and (self._flags & _lib.FLAG_ATTN_ENTROPY):
+                self.loss_e_shift = (self._mcd_buf[-2], self._mcd_buf[-1])
+            return
         for name in ("gY", "gY2", "gPr", "gPv", "gPf", "g_attn", "gV_ext"):
             if name in plan.regions:
                 self._region2(name).zero_()
