@@ -17,10 +17,13 @@ for bf16 in (True, False):
             print(f"{name}: {type(ex).__name__}: {ex}"[:200]); continue
         eng.load_state(synth_state({n: s for n, _, s, _ in eng.plan.params}, seed=7, scale="init"))
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
-        for _ in range(10):
+        for _ in range(30):
             eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
-        torch.cuda.synchronize()
-        print(f"{'bf16' if bf16 else 'f32 '} {name:14s} fused={eng.fused}: {1e6 * (time.perf_counter() - t0) / steps:.0f} us/step (one library call per launch group, host included)")
+        best = 1e9
+        for rep in range(3):      # best of three runs: the first run of a configuration also pays one-time costs (code objects, allocator)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.train_step([0.75, 0.75, 0.5], 0.003, 0.03)
+            torch.cuda.synchronize()
+            best = min(best, 1e6 * (time.perf_counter() - t0) / steps)
+        print(f"{'bf16' if bf16 else 'f32 '} {name:14s} fused={eng.fused}: {best:.0f} us/step (one library call per launch group, host included; best of 3 x {steps})")
