@@ -881,6 +881,33 @@ def main():
                                           "steps": 20, "warmup": 5, "launches_per_step": 10}
         except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
             variants["headline+AdaBN"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        # The paper's other baseline rows - ens_DA MCD, dis_DA DAN / JAN - stay unfused launch lists (they couple the two halves of what the
+        # heads kernel fuses); since round 6 their loss assembly comes from the library too (ta3n_mcd_*, ta3n_discrepancy), no framework between the
+        # launches.  One train_step call per step (several library calls each), host included.
+        SHv, bf = CONFIGS[2]["shape"], CONFIGS[2]["dtype"] == "bf16"
+        for key, kw in (("headline+MCD", dict(ens_DA="MCD", mu=0.5)), ("headline+DAN", dict(dis_DA="DAN", alpha=0.5)),
+                        ("headline+JAN", dict(dis_DA="JAN", alpha=0.5, place_dis=("Y", "Y", "N")))):
+            try:
+                e = TrainEngine(SHv["Bs"], SHv["Bt"], SHv["T"], SHv["D"], SHv["F"], SHv["C"], dropout_i=0.5, dropout_v=0.5, clip=20.0, device=dev,
+                                bf16=bf, bf16_store=bf, **kw)
+                e.load_state(synth_state({n: s_ for n, _, s_, _ in e.plan.params}, seed=7, scale="init"))
+                xs, xt, ys, yt = synth_batch(SHv["C"], SHv["T"], SHv["D"], SHv["Bs"], SHv["Bt"], seed=1234 + rank)
+                e.set_batch(xs.to(dev), xt.to(dev), ys.to(dev))
+                for _ in range(15):      # (the first steps of a configuration pay one-time costs: code objects, allocator)
+                    e.train_step([0.75, 0.75, 0.5], 0.003, 3e-2)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    e.train_step([0.75, 0.75, 0.5], 0.003, 3e-2)
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t0) / 20
+                variants[key] = {"workload": CONFIGS[2]["name"] + ", " + ", ".join(f"{k}={v}" for k, v in kw.items()), "dtype": CONFIGS[2]["dtype"],
+                                 "ms_per_step": 1e3 * dt, "value": (SHv["Bs"] + SHv["Bt"]) / dt, "unit": "videos/s", "steps": 20, "warmup": 15,
+                                 "what": "unfused launch lists, the option's loss assembly from the library; one train_step call per step, host included",
+                                 "finite": bool(torch.isfinite(e.P).all().item())}
+                del e
+            except Exception as ex:      # noqa: BLE001 - an extra entry must not cost the headline line
+                variants[key] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if rank == 0:
         from ta3n_amd import tolerances as tol
         arith = {"bf16": "bf16 MFMA on operands rounded to nearest-even, fp32 accumulation, fp32 parameters / gradients / optimiser state "

@@ -31,6 +31,10 @@ rows = {
     "C4": ([d["configs"]["configs[4]"]["ms_per_step"] for d in lines], [d["configs"]["configs[4]"]["value"] for d in lines]),
     "CPU": ([d["cpu_baseline"]["ms_per_step"] for d in lines], [d["cpu_baseline"]["value"] for d in lines]),
 }
+for key, name in (("BN", "headline+AdaBN"), ("MCD", "headline+MCD"), ("DAN", "headline+DAN"), ("JAN", "headline+JAN")):
+    got = [d["variants"][name] for d in lines if "ms_per_step" in (d.get("variants") or {}).get(name, {})]
+    if got:
+        rows[key] = ([g["ms_per_step"] for g in got], [g["value"] for g in got])
 s = open("README.md").read()
 for k, (m, v) in rows.items():
     s = s.replace(f"@{k}_MS@", ms(m)).replace(f"@{k}_V@", vps(v))

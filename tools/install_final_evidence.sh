@@ -31,7 +31,7 @@ python - <<'PY'
 p = "README.md"
 s = open(p).read()
 rows = [("FRESH", "**headline as a training loop runs it"), ("HEAD", "| the same with one resident batch"), ("F32", "| same, fp32 MFMA"), ("X3", "| same, fp32-grade split"),
-        ("C0", "| TemPooling source-only"), ("C3", "| 512+512 videos"), ("C4", "| two-stream 1024-d"), ("CPU", "| CPU path on the box")]
+        ("BN", "| headline + `use_bn AdaBN`"), ("C0", "| TemPooling source-only"), ("C3", "| 512+512 videos"), ("C4", "| two-stream 1024-d"), ("CPU", "| CPU path on the box")]
 out = []
 for ln in s.split("\n"):
     for k, pre in rows:
@@ -39,6 +39,10 @@ for ln in s.split("\n"):
             cells = ln.split("|")
             cells[-3], cells[-2] = f" @{k}_MS@ ", f" @{k}_V@ "
             ln = "|".join(cells)
+    if "| headline + `ens_DA MCD`" in ln and ln.count("|") >= 4:
+        cells = ln.split("|")
+        cells[-3], cells[-2] = " @MCD_MS@ / @DAN_MS@ / @JAN_MS@ ", " @MCD_V@ / @DAN_V@ / @JAN_V@ "
+        ln = "|".join(cells)
     out.append(ln)
 open(p, "w").write("\n".join(out))
 PY
