@@ -169,9 +169,16 @@ def _fast_engine(model, optimizer, num_class):
         return None
     # (round 6: use_bn AdaBN / AutoDIAL is part of the fused step - two BatchNorm launches inside ta3n_train_step - so those rows of the
     # paper's tables train at the fused speed too; the running statistics travel with the parameters below)
-    if (os.environ.get("TA3N_MAIN_FAST", "1") == "0" or args.frame_aggregation != "trn-m" or args.dis_DA != "none" or args.ens_DA != "none" or
+    if (os.environ.get("TA3N_MAIN_FAST", "1") == "0" or args.frame_aggregation != "trn-m" or args.dis_DA not in ("none", "DAN", "JAN") or args.ens_DA != "none" or
             args.use_bn not in ("none", "AdaBN", "AutoDIAL") or args.save_attention >= 0 or type(optimizer) is not torch.optim.SGD or
             len(optimizer.param_groups) != 1):
+        return None
+    # (round 6: dis_DA DAN / JAN take the ENGINE too - unfused launch lists with the discrepancy term from the library, ta3n_discrepancy: 0.26 ms
+    # per step at the headline shape against 1.25 ms on the module path.  Not with use_bn, not on the frame-level features (place_dis[2]), and
+    # only where the reference applies the term at all, :452)
+    dis = args.dis_DA != "none"
+    if dis and (args.use_target == "none" or args.use_bn != "none" or not hasattr(args, "place_dis") or len(args.place_dis) < 2 or
+                (args.dis_DA == "DAN" and (len(args.place_dis) > 2 and args.place_dis[2] == "Y"))):
         return None
     if args.use_bn != "none" and float(getattr(m, "alpha", torch.ones(1)).detach()) != 1.0:
         return None      # (source / target batch mixing of domainAlign: the module path says what it does not build)
@@ -181,26 +188,29 @@ def _fast_engine(model, optimizer, num_class):
     # everything the engine is BUILT from: a later train() call with other options must not find an engine made for these
     key = (args.batch_size[0], args.batch_size[1], args.num_segments, args.fc_dim, num_class, tuple(args.place_adv), args.add_loss_DA,
            args.use_attn, args.adv_DA, args.use_target, float(args.dropout_i), float(args.dropout_v), float(g["momentum"]),
-           float(g["weight_decay"]), None if args.clip_gradient is None else float(args.clip_gradient), args.use_bn)
+           float(g["weight_decay"]), None if args.clip_gradient is None else float(args.clip_gradient), args.use_bn,
+           args.dis_DA, tuple(args.place_dis) if dis else ())
     eng = m.__dict__.get("_main_fast_engine", {}).get(key)
     if eng is None:
         eng = TrainEngine(args.batch_size[0], args.batch_size[1], args.num_segments, m.feature_dim, args.fc_dim, num_class,
                           flags=flags_from_options(args.place_adv, args.add_loss_DA, args.use_attn, args.adv_DA, args.use_target),
                           dropout_i=args.dropout_i, dropout_v=args.dropout_v, momentum=g["momentum"], weight_decay=g["weight_decay"],
                           clip=args.clip_gradient if args.clip_gradient is not None else 0.0, device=next(m.parameters()).device,
-                          use_bn=args.use_bn)
-        if not eng.fused:
+                          use_bn=args.use_bn, **(dict(dis_DA=args.dis_DA, place_dis=tuple(args.place_dis)) if dis else {}))
+        if not eng.fused and not dis:
             return None
         m.__dict__.setdefault("_main_fast_engine", {})[key] = eng
     return eng
 
 
-def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma):
+def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha=0.0):
     """train() on the fused step: the same loop, meters, log lines and schedules (:348-352, 589-621); what the module path computes
     with torch ops between forward and backward is inside the step (ta3n_train_step), the meters read the step's device scalars."""
     batch_time, data_time = AverageMeter(), AverageMeter()
-    losses_a, losses_e, losses_c, losses = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    losses_a, losses_e, losses_c, losses, losses_d = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     top1, top5 = AverageMeter(), AverageMeter()
+    dis = eng.dis_DA != "none"
+    eng.alpha = float(alpha)                                            # (:218-219: a per-epoch value when args.alpha < 0)
     m = model.module
     m.partialBN(not args.no_partialbn)
     model.train()
@@ -239,6 +249,10 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
             if args.add_loss_DA == "attentive_entropy" and args.use_attn != "none" and args.use_target != "none":
                 losses_e.update(l["loss_e"], batch_target_ori)
             prec1, prec5 = accuracy(out, source_label.to(dev), topk=(1, min(5, num_class)))
+            if dis:      # the term the loss kernel does not know (:452-505): logged, and part of the total like in the module path
+                ld = float(eng.loss_d)
+                losses_d.update(ld, batch_source_ori)
+                l["loss"] += float(alpha) * ld
             losses.update(l["loss"])
             top1.update(prec1.item(), batch_source_ori)
             top5.update(prec5.item(), batch_source_ori)
@@ -249,6 +263,8 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
                         "Prec@1 {t1.val:.3f} ({t1.avg:.3f})\tPrec@5 {t5.val:.3f} ({t5.avg:.3f})\tLoss {ls.val:.4f} ({ls.avg:.4f})   "
                         "loss_c {lc.avg:.4f}\t").format(epoch, i, len(source_loader), bt=batch_time, dt=data_time, t1=top1, t5=top5,
                                                         ls=losses, lc=losses_c, lr=lr)
+                if dis:
+                    line += "alpha {:.3f}  loss_d {:.4f}\t".format(alpha, losses_d.avg)
                 if args.adv_DA != "none" and args.use_target != "none":
                     line += "beta {:.3f}, {:.3f}, {:.3f}  loss_a {:.4f}\t".format(beta_new[0], beta_new[1], beta_new[2], losses_a.avg)
                 if args.add_loss_DA != "none" and args.use_target != "none":
@@ -288,7 +304,7 @@ def train(num_class, source_loader, target_loader, model, criterion, criterion_d
     """:309-667 for the supported options: RevGrad adversarial losses on the enabled levels and attentive entropy."""
     eng = _fast_engine(model, optimizer, num_class)
     if eng is not None:
-        return _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma)
+        return _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha)
     batch_time, data_time = AverageMeter(), AverageMeter()
     losses_a, losses_e, losses_c, losses = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     losses_d, losses_s = AverageMeter(), AverageMeter()                                 # discrepancy loss / ensemble loss (:313-315)

@@ -197,15 +197,15 @@ def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bn", ["none", "AdaBN"])      # (round 6: use_bn is part of the fused step, so main.py's fast path takes those runs too)
-def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):
+@pytest.mark.parametrize("bn", ["none", "AdaBN", "DAN", "JAN"])      # (round 6: use_bn is part of the fused step, so main.py's fast path takes those runs too -
+def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):      # and dis_DA DAN / JAN run on the ENGINE: unfused lists + ta3n_discrepancy)
     """main.py's train() takes the fused step (TrainEngine) where the options allow it; TA3N_MAIN_FAST=0 keeps the module path
     (VideoModel.forward + torch loss assembly + autograd + clip + SGD).  Same arithmetic up to fp32 summation order, the same dropout
     masks (both draw the two stream seeds from the global torch RNG, one draw per train forward - which also keeps the samplers of the
     next epoch in step): the logged losses agree line by line and the checkpoints hold the same parameters and momentum buffers."""
     import re
     data = make_dataset(str(tmp_path / "data"))
-    common = list(COMMON) + (["--use_bn", bn] if bn != "none" else [])      # dropout 0.5 / 0.5: the two paths draw the same masks
+    common = list(COMMON) + (["--use_bn", bn] if bn == "AdaBN" else ["--dis_DA", bn, "--place_dis", "Y", "Y", "N", "--alpha", "0.5"] if bn in ("DAN", "JAN") else [])      # dropout 0.5 / 0.5: the two paths draw the same masks
     outs, cks = [], []
     for fast in ("1", "0"):
         exp = str(tmp_path / f"exp{fast}")
@@ -220,7 +220,9 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):
     assert len(outs[0]) == len(outs[1]) == 6
     # (Prec@1 is not compared: from the 0.001-std initialisation the five class logits of a video differ in the sixth digit, so the
     # argmax is decided by fp32 summation order)
-    num = re.compile(r"(Loss|loss_c|loss_a|loss_e|lr:) ([0-9.]+)")
+    num = re.compile(r"(Loss|loss_c|loss_d|loss_a|loss_e|lr:) ([0-9.]+)")
+    if bn in ("DAN", "JAN"):
+        assert all("loss_d" in ln for ln in outs[0] + outs[1])
     for a, b in zip(*outs):
         fa, fb = num.findall(a), num.findall(b)
         assert [k for k, _ in fa] == [k for k, _ in fb]
@@ -233,4 +235,9 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):
     ma, mb = cks[0]["optimizer"]["state"], cks[1]["optimizer"]["state"]      # keyed by the parameter's index in the optimiser's group
     assert set(ma) == set(mb), (sorted(ma), sorted(mb))
     for k in ma:
-        assert torch.allclose(ma[k]["momentum_buffer"], mb[k]["momentum_buffer"], rtol=5e-3, atol=1e-5), k
+        a_, b_ = ma[k]["momentum_buffer"].float(), mb[k]["momentum_buffer"].float()
+        if bn in ("DAN", "JAN"):      # the discrepancy gradients are two orders of magnitude above the plain step's and a hidden unit that lands on
+            # the other side of its ReLU in one of the two paths moves single entries (measured: ONE entry of a 64-element bias buffer, 7.5e-3 of the tensor): per tensor in rel. L2 (ta3n_amd/tolerances.py's measure)
+            assert (a_ - b_).norm().item() <= 1e-2 * b_.norm().item() + 1e-7, (k, (a_ - b_).norm().item(), b_.norm().item(), (a_ - b_).abs().max().item())
+        else:
+            assert torch.allclose(a_, b_, rtol=5e-3, atol=1e-5), k
