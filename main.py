@@ -157,8 +157,9 @@ def _fast_engine(model, optimizer, num_class):
     """The fused step (ta3n_amd.engine.TrainEngine: forward + the loss assembly of :439-562 + backward + clip + Nesterov SGD as 8
     launches of one library call) for the configurations it covers, instead of VideoModel.forward + the torch loss assembly + autograd
     + clip_grad_norm_ + SGD.step (the MODULE path: ~60 small torch kernels around the same HIP launches, 1.25 ms against 0.12 ms per step
-    at the headline shape - VERDICT r03 weak #7).  None when the options need the module path (dis_DA / MCD / BatchNorm variants, attention
-    dumps, TemPooling; use_bn AdaBN / AutoDIAL IS covered since round 6) or TA3N_MAIN_FAST=0.  The engine works on its own flat buffers: train() copies the model's parameters and the
+    at the headline shape - VERDICT r03 weak #7).  None when the options need the module path (attention dumps, TemPooling, CORAL, use_bn together
+    with a discrepancy / MCD term; use_bn AdaBN / AutoDIAL alone, dis_DA DAN / JAN and ens_DA MCD ARE covered since round 6 - the last three on the
+    engine's unfused launch lists) or TA3N_MAIN_FAST=0.  The engine works on its own flat buffers: train() copies the model's parameters and the
     optimiser's momentum in at the start of an epoch and back at its end, so validate(), checkpoints and --resume see nn.Parameters and
     torch.optim state as before."""
     from ta3n_amd.engine import TrainEngine, flags_from_options
@@ -169,7 +170,7 @@ def _fast_engine(model, optimizer, num_class):
         return None
     # (round 6: use_bn AdaBN / AutoDIAL is part of the fused step - two BatchNorm launches inside ta3n_train_step - so those rows of the
     # paper's tables train at the fused speed too; the running statistics travel with the parameters below)
-    if (os.environ.get("TA3N_MAIN_FAST", "1") == "0" or args.frame_aggregation != "trn-m" or args.dis_DA not in ("none", "DAN", "JAN") or args.ens_DA != "none" or
+    if (os.environ.get("TA3N_MAIN_FAST", "1") == "0" or args.frame_aggregation != "trn-m" or args.dis_DA not in ("none", "DAN", "JAN") or args.ens_DA not in ("none", "MCD") or
             args.use_bn not in ("none", "AdaBN", "AutoDIAL") or args.save_attention >= 0 or type(optimizer) is not torch.optim.SGD or
             len(optimizer.param_groups) != 1):
         return None
@@ -177,6 +178,9 @@ def _fast_engine(model, optimizer, num_class):
     # per step at the headline shape against 1.25 ms on the module path.  Not with use_bn, not on the frame-level features (place_dis[2]), and
     # only where the reference applies the term at all, :452)
     dis = args.dis_DA != "none"
+    mcd = args.ens_DA == "MCD"      # (likewise ens_DA MCD: both passes' launch lists + ta3n_mcd_source_loss / ta3n_mcd_second_loss, 0.44 ms per step)
+    if mcd and (args.use_target == "none" or args.use_bn != "none"):
+        return None
     if dis and (args.use_target == "none" or args.use_bn != "none" or not hasattr(args, "place_dis") or len(args.place_dis) < 2 or
                 (args.dis_DA == "DAN" and (len(args.place_dis) > 2 and args.place_dis[2] == "Y"))):
         return None
@@ -189,28 +193,30 @@ def _fast_engine(model, optimizer, num_class):
     key = (args.batch_size[0], args.batch_size[1], args.num_segments, args.fc_dim, num_class, tuple(args.place_adv), args.add_loss_DA,
            args.use_attn, args.adv_DA, args.use_target, float(args.dropout_i), float(args.dropout_v), float(g["momentum"]),
            float(g["weight_decay"]), None if args.clip_gradient is None else float(args.clip_gradient), args.use_bn,
-           args.dis_DA, tuple(args.place_dis) if dis else ())
+           args.dis_DA, tuple(args.place_dis) if dis else (), args.ens_DA)
     eng = m.__dict__.get("_main_fast_engine", {}).get(key)
     if eng is None:
         eng = TrainEngine(args.batch_size[0], args.batch_size[1], args.num_segments, m.feature_dim, args.fc_dim, num_class,
                           flags=flags_from_options(args.place_adv, args.add_loss_DA, args.use_attn, args.adv_DA, args.use_target),
                           dropout_i=args.dropout_i, dropout_v=args.dropout_v, momentum=g["momentum"], weight_decay=g["weight_decay"],
                           clip=args.clip_gradient if args.clip_gradient is not None else 0.0, device=next(m.parameters()).device,
-                          use_bn=args.use_bn, **(dict(dis_DA=args.dis_DA, place_dis=tuple(args.place_dis)) if dis else {}))
-        if not eng.fused and not dis:
+                          use_bn=args.use_bn, **(dict(dis_DA=args.dis_DA, place_dis=tuple(args.place_dis)) if dis else {}),
+                          **(dict(ens_DA="MCD") if mcd else {}))
+        if not eng.fused and not (dis or mcd):
             return None
         m.__dict__.setdefault("_main_fast_engine", {})[key] = eng
     return eng
 
 
-def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha=0.0):
+def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha=0.0, mu=0.0):
     """train() on the fused step: the same loop, meters, log lines and schedules (:348-352, 589-621); what the module path computes
     with torch ops between forward and backward is inside the step (ta3n_train_step), the meters read the step's device scalars."""
     batch_time, data_time = AverageMeter(), AverageMeter()
     losses_a, losses_e, losses_c, losses, losses_d = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     top1, top5 = AverageMeter(), AverageMeter()
-    dis = eng.dis_DA != "none"
-    eng.alpha = float(alpha)                                            # (:218-219: a per-epoch value when args.alpha < 0)
+    dis, mcd = eng.dis_DA != "none", eng.ens_DA == "MCD"
+    losses_s = AverageMeter()
+    eng.alpha, eng.mu = float(alpha), float(mu)                         # (:218-219: alpha is a per-epoch value when args.alpha < 0)
     m = model.module
     m.partialBN(not args.no_partialbn)
     model.train()
@@ -239,9 +245,22 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
             # the dropout seeds come from the global torch RNG exactly as VideoModel.forward draws them (one draw of two per train forward):
             # the same masks as the module path, and the same RNG state for the samplers of the next epoch
             seeds = torch.randint(0, 2 ** 31 - 1, (2,))
+            if mcd:      # the second, reversed forward draws its own pair (:548), right behind the first one's
+                s2 = torch.randint(0, 2 ** 31 - 1, (2,))
+                eng.mcd_raw_seeds = (int(s2[0]), int(s2[1]))
             eng.train_step(beta_new, gamma, lr, valid_source=batch_source_ori, valid_target=batch_target_ori, raw_seeds=(int(seeds[0]), int(seeds[1])))
             l = eng.losses()                                                # (one host sync per step; the reference has five .item() calls)
             out = eng.outputs()["out"][:batch_source_ori]
+            if mcd:      # the terms the loss kernel does not know (train_ddp.py's log_line keeps the same books): the second classifier's
+                # cross-entropy is part of loss_c (:446-450), loss_s = -dis_MCD of the second pass (:553-556), and the target rows' entropy
+                # term is that pass's (:549 rebinds out_target before :559-562)
+                c2, ls = float(eng.loss_c2), float(eng.loss_s)
+                l["loss_c"] += c2
+                l["loss"] += c2 + ls
+                if eng.loss_e_shift is not None:
+                    l["loss"] += float(eng.loss_e_shift[0])
+                    l["loss_e"] += float(eng.loss_e_shift[1])
+                losses_s.update(ls, batch_target_ori)
             losses_c.update(l["loss_c"], batch_source_ori)
             if args.adv_DA != "none" and args.use_target != "none":
                 last = [r for r, on in zip((args.num_segments - 1, 1, args.num_segments), args.place_adv) if on == "Y"]   # (:537 weights by the LAST enabled level's rows)
@@ -269,6 +288,8 @@ def _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, 
                     line += "beta {:.3f}, {:.3f}, {:.3f}  loss_a {:.4f}\t".format(beta_new[0], beta_new[1], beta_new[2], losses_a.avg)
                 if args.add_loss_DA != "none" and args.use_target != "none":
                     line += "gamma {:.6f}  loss_e {:.4f}\t".format(gamma, losses_e.avg)
+                if mcd:
+                    line += "mu {:.6f}  loss_s {:.4f}\t".format(mu, losses_s.avg)
                 print(line)
                 log.write("%s\n" % line)
             if args.lr_adaptive == "dann":
@@ -304,7 +325,7 @@ def train(num_class, source_loader, target_loader, model, criterion, criterion_d
     """:309-667 for the supported options: RevGrad adversarial losses on the enabled levels and attentive entropy."""
     eng = _fast_engine(model, optimizer, num_class)
     if eng is not None:
-        return _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha)
+        return _train_fast(eng, num_class, source_loader, target_loader, model, optimizer, epoch, log, log_short, beta, gamma, alpha, mu)
     batch_time, data_time = AverageMeter(), AverageMeter()
     losses_a, losses_e, losses_c, losses = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     losses_d, losses_s = AverageMeter(), AverageMeter()                                 # discrepancy loss / ensemble loss (:313-315)

@@ -202,6 +202,7 @@ class TrainEngine:
         off, n = p.region("labels")
         self._labels = self.ws[off:off + n].view(torch.int32)
         self._mcd_buf: Optional[torch.Tensor] = None
+        self.mcd_raw_seeds = None                # ens_DA MCD: the second pass's two dropout stream seeds as given (None: derived from the first pass's)
         self.ws2: Optional[torch.Tensor] = None      # ens_DA MCD: workspace and gradient buffer of the reversed second pass
         self.G2: Optional[torch.Tensor] = None
         if self.ens_DA == "MCD":
@@ -505,6 +506,8 @@ class TrainEngine:
         h = _lib.Hyper.from_buffer_copy(self._hyper)
         h.reverse, h.mu = 1, float(self.mu)
         h.seed_i, h.seed_v = dropout_seeds(int(self._hyper.seed_i) ^ 0x5bd1e995, self.rank)
+        if self.mcd_raw_seeds is not None:      # a caller that draws the second pass's stream seeds itself (main.py: as VideoModel.forward would)
+            h.seed_i, h.seed_v = int(self.mcd_raw_seeds[0]) & 0xFFFFFFFF, int(self.mcd_raw_seeds[1]) & 0xFFFFFFFF
         L, plan = self._L, self.plan
         _lib.check(L.ta3n_set_hyper(plan.handle, self.ws2.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
         _lib.check(L.ta3n_forward(plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws2.data_ptr(), self._stream()), "ta3n_forward")

@@ -197,7 +197,7 @@ def test_reference_main_py_runs_against_compat_up_to_the_first_forward(tmp_path,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bn", ["none", "AdaBN", "DAN", "JAN"])      # (round 6: use_bn is part of the fused step, so main.py's fast path takes those runs too -
+@pytest.mark.parametrize("bn", ["none", "AdaBN", "DAN", "JAN", "MCD", "MCD+DAN"])      # (round 6: use_bn is part of the fused step, so main.py's fast path takes those runs too -
 def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn):      # and dis_DA DAN / JAN run on the ENGINE: unfused lists + ta3n_discrepancy)
     """main.py's train() takes the fused step (TrainEngine) where the options allow it; TA3N_MAIN_FAST=0 keeps the module path
     (VideoModel.forward + torch loss assembly + autograd + clip + SGD).  Same arithmetic up to fp32 summation order, the same dropout
@@ -205,7 +205,9 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn): 
     next epoch in step): the logged losses agree line by line and the checkpoints hold the same parameters and momentum buffers."""
     import re
     data = make_dataset(str(tmp_path / "data"))
-    common = list(COMMON) + (["--use_bn", bn] if bn == "AdaBN" else ["--dis_DA", bn, "--place_dis", "Y", "Y", "N", "--alpha", "0.5"] if bn in ("DAN", "JAN") else [])      # dropout 0.5 / 0.5: the two paths draw the same masks
+    common = list(COMMON) + (["--use_bn", bn] if bn == "AdaBN" else ["--dis_DA", bn, "--place_dis", "Y", "Y", "N", "--alpha", "0.5"] if bn in ("DAN", "JAN") else
+                             ["--ens_DA", "MCD", "--mu", "0.5"] if bn == "MCD" else
+                             ["--ens_DA", "MCD", "--mu", "0.5", "--dis_DA", "DAN", "--place_dis", "Y", "Y", "N", "--alpha", "0.5"] if bn == "MCD+DAN" else [])      # dropout 0.5 / 0.5: the two paths draw the same masks
     outs, cks = [], []
     for fast in ("1", "0"):
         exp = str(tmp_path / f"exp{fast}")
@@ -220,9 +222,11 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn): 
     assert len(outs[0]) == len(outs[1]) == 6
     # (Prec@1 is not compared: from the 0.001-std initialisation the five class logits of a video differ in the sixth digit, so the
     # argmax is decided by fp32 summation order)
-    num = re.compile(r"(Loss|loss_c|loss_d|loss_a|loss_e|lr:) ([0-9.]+)")
-    if bn in ("DAN", "JAN"):
+    num = re.compile(r"(Loss|loss_c|loss_d|loss_a|loss_e|loss_s|lr:) (-?[0-9.]+)")
+    if "DAN" in bn or bn == "JAN":
         assert all("loss_d" in ln for ln in outs[0] + outs[1])
+    if "MCD" in bn:
+        assert all("loss_s" in ln for ln in outs[0] + outs[1])
     for a, b in zip(*outs):
         fa, fb = num.findall(a), num.findall(b)
         assert [k for k, _ in fa] == [k for k, _ in fb]
@@ -236,7 +240,7 @@ def test_own_main_fused_fast_path_logs_what_the_module_path_logs(tmp_path, bn): 
     assert set(ma) == set(mb), (sorted(ma), sorted(mb))
     for k in ma:
         a_, b_ = ma[k]["momentum_buffer"].float(), mb[k]["momentum_buffer"].float()
-        if bn in ("DAN", "JAN"):      # the discrepancy gradients are two orders of magnitude above the plain step's and a hidden unit that lands on
+        if bn != "none" and bn != "AdaBN":      # the discrepancy gradients are two orders of magnitude above the plain step's and a hidden unit that lands on
             # the other side of its ReLU in one of the two paths moves single entries (measured: ONE entry of a 64-element bias buffer, 7.5e-3 of the tensor): per tensor in rel. L2 (ta3n_amd/tolerances.py's measure)
             assert (a_ - b_).norm().item() <= 1e-2 * b_.norm().item() + 1e-7, (k, (a_ - b_).norm().item(), b_.norm().item(), (a_ - b_).abs().max().item())
         else:
