@@ -181,3 +181,29 @@ def test_workspace_pool_release_is_tied_to_the_checkout():
     gc.collect()
     f = m._ws_checkout(plan, Ctx(), True)
     assert f.data_ptr() == e.data_ptr()
+
+
+def test_da_entry_points_validate_their_arguments_before_touching_a_device():
+    """ta3n_discrepancy / ta3n_mcd_source_loss / ta3n_mcd_second_loss (round 6: the DA options' loss assembly from the library): argument
+    errors come back as TA3N_ERR_INVALID with a message - no HIP call is made for them, so this runs without a GPU."""
+    import ctypes as C
+    from ta3n_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_float * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    n = L.ta3n_discrepancy_scratch_floats(128, 74, 12, 256)
+    assert n >= 2 * 148 * (12 + 256) + 4 * 148 * 148                       # two stacks + gradients, two kernel matrices + derivatives
+    assert L.ta3n_discrepancy_scratch_floats(0, 74, 12, 256) > 0          # (an empty domain still gets a non-empty buffer)
+    args = dict(ws=p, o_y=0, c=12, o_v=64, f=256, o_gy=128, o_gv=192, bs=8, bt=6, ns=8, nt=6, kind=1, pl=1, pf=1, alpha=C.c_float(0.5), scr=p, n=4096, loss=p, st=None)
+
+    def call(**kw):
+        a = dict(args, **kw)
+        return L.ta3n_discrepancy(a["ws"], a["o_y"], a["c"], a["o_v"], a["f"], a["o_gy"], a["o_gv"], a["bs"], a["bt"], a["ns"], a["nt"], a["kind"],
+                                  a["pl"], a["pf"], a["alpha"], a["scr"], a["n"], a["loss"], a["st"])
+    for bad in (dict(ws=None), dict(scr=None), dict(loss=None), dict(kind=0), dict(kind=3), dict(ns=9), dict(nt=-1), dict(c=0)):
+        assert call(**bad) == -1, bad
+        assert L.ta3n_last_error()
+    plan = _lib.Plan(4, 4, 5, 512, 64, 12, 0x1F)                            # no TA3N_FLAG_MCD
+    assert L.ta3n_mcd_source_loss(plan.handle, p, p, p, None) == -1 and b"TA3N_FLAG_MCD" in L.ta3n_last_error()
+    assert L.ta3n_mcd_second_loss(plan.handle, p, p, 4, p, p, None) == -1      # one workspace for both passes
+    assert L.ta3n_mcd_source_loss(None, p, p, p, None) == -1
