@@ -227,27 +227,29 @@ def test_engine_path_with_discrepancy_losses_matches_the_reference(name):
 
 
 @pytest.mark.parametrize("dis_DA,place,ns,nt", [("DAN", ("Y", "Y", "N"), 40, 33), ("DAN", ("N", "Y", "N"), 37, 37), ("DAN", ("Y", "N", "N"), 5, 40),
-                                               ("JAN", ("Y", "Y", "N"), 40, 29), ("DAN", ("Y", "Y", "N"), 512, 512), ("DAN", ("Y", "Y", "N"), 0, 12)])
+                                               ("JAN", ("Y", "Y", "N"), 40, 29), ("DAN", ("Y", "Y", "N"), 512, 512), ("DAN", ("Y", "Y", "N"), 0, 12),
+                                               ("DAN", ("Y", "Y", "N"), 128, 74), ("JAN", ("Y", "Y", "N"), 128, 74)])      # (the last two: BASELINE configs[1]'s full shape)
 def test_native_discrepancy_matches_the_autograd_path(dis_DA, place, ns, nt, monkeypatch):
     """ta3n_discrepancy (one rank: the whole DAN / JAN term from the library) against the torch-autograd assembly around the same kernels
     (parallel.discrepancy_over_ranks, what more than one rank still runs): loss, the gradient added to the logit gradient and the one written
     to the feature-gradient entry - ragged valid counts, one feature only, two chunks of 256 videos, an empty domain."""
     from ta3n_amd.engine import TrainEngine
     Bs, Bt = max(ns, 8), max(nt, 8)
+    T, D, F, C = (5, 2048, 512, 12) if (ns, nt) == (128, 74) else (3, 64, 64, 7)
     out = {}
     for native in ("1", "0"):
         monkeypatch.setenv("TA3N_NATIVE_DISCREPANCY", native)
-        eng = TrainEngine(Bs, Bt, 3, 64, 64, 7, dropout_i=0.0, dropout_v=0.0, clip=20.0, dis_DA=dis_DA, place_dis=place, alpha=0.7)
+        eng = TrainEngine(Bs, Bt, T, D, F, C, dropout_i=0.0, dropout_v=0.0, clip=20.0, dis_DA=dis_DA, place_dis=place, alpha=0.7)
         eng.load_state(synth_state({n: s for n, _, s, _ in eng.plan.params}, seed=5, scale="trained"))
-        xs, xt, ys, yt = synth_batch(7, 3, 64, Bs, Bt, seed=9)
+        xs, xt, ys, yt = synth_batch(C, T, D, Bs, Bt, seed=9)
         eng.set_batch(xs.cuda(), xt.cuda(), ys.cuda())
         eng.set_hyper([0.75, 0.75, 0.5], 0.003, 1e-3, train=True, valid_source=ns, valid_target=nt)
         eng.forward(); eng.loss()
-        gy0 = eng.region("gY", (Bs + Bt, 7)).clone()
+        gy0 = eng.region("gY", (Bs + Bt, C)).clone()
         eng.discrepancy()
         torch.cuda.synchronize()
         assert (eng._disc_scratch is not None) == (native == "1")
-        out[native] = (float(eng.loss_d), (eng.region("gY", (Bs + Bt, 7)) - gy0).cpu(), eng.region("gV_ext", (Bs + Bt, -1)).clone().cpu())
+        out[native] = (float(eng.loss_d), (eng.region("gY", (Bs + Bt, C)) - gy0).cpu(), eng.region("gV_ext", (Bs + Bt, -1)).clone().cpu())
     (l1, gy1, gv1), (l0, gy0_, gv0) = out["1"], out["0"]
     assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0)), (l1, l0)
     for a, b in ((gy1, gy0_), (gv1, gv0)):

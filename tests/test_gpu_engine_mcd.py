@@ -48,12 +48,12 @@ def test_engine_with_mcd_follows_the_reference_trajectory(name):
 
 
 @pytest.mark.parametrize("entropy", [True, False], ids=["attentive_entropy", "no_entropy"])
-@pytest.mark.parametrize("ns,nt", [(24, 17), (9, 0), (0, 12)])
+@pytest.mark.parametrize("ns,nt", [(24, 17), (9, 0), (0, 12), (128, 74)])      # (the last: BASELINE configs[1]'s full shape)
 def test_native_mcd_assembly_matches_the_torch_form(entropy, ns, nt, monkeypatch):
     """ta3n_mcd_source_loss / ta3n_mcd_second_loss (the library's kernels) against the torch assembly they replace (TA3N_NATIVE_MCD=0): the
     second classifier's cross-entropy, loss_s, the moved entropy term and - through three whole steps with dropout, i.e. different masks in
     the two passes - every parameter; ragged valid rows, an empty domain."""
-    Bs, Bt, T, D, F, C = 24, 20, 3, 64, 64, 7
+    Bs, Bt, T, D, F, C = (128, 74, 5, 2048, 512, 12) if (ns, nt) == (128, 74) else (24, 20, 3, 64, 64, 7)
     flags = ALL_FLAGS if entropy else ALL_FLAGS & ~_lib.FLAG_ATTN_ENTROPY
     runs = {}
     for native in ("1", "0"):
