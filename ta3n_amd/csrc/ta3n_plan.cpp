@@ -570,12 +570,20 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
         base = BASE_WS;
     };
     auto overlaps = [](const Span &a, const Span &b) { return a.first < b.second && b.first < a.second; };
-    // who keeps a twin up to date: GEMM tiles of the fused step (their C and their fan-out copies) and the heads
+    // Two launch sequences share the workspace and its twin regions: the FUSED step (groups 4 / 5) and - round 6 - the UNFUSED lists
+    // (groups 0 / 2: ta3n_forward / ta3n_backward, what the DA options with a loss term between forward and backward run; their GEMM launches
+    // were twice as long on fp32 stages rounded in registers as the fused step's on twins).  Each family is analysed on its own: who keeps a
+    // twin up to date, which launch may read twins, which producers store them.  Not with TA3N_FLAG_MCD: its second pass runs on a second
+    // workspace whose parameter / input twins nobody writes.
+    auto fused_family = [](int group) { return group == 4 || group == 5; };
+    auto unfused_family = [](int group) { return group == 0 || group == 2; };
+    auto analyse = [&](bool (*in_family)(int), const std::vector<Span> &extra) {
+    // who keeps a twin up to date: GEMM tiles of the family (their C and their fan-out copies) and - fused step - the heads
     // kernel for gHf.  A launch may read twins only of such data (plus parameters and the input).
     std::vector<Span> produced;   // (Span = [first, last) in ws floats)
-    for (auto &sp : extra_produced) produced.push_back(sp);
+    for (auto &sp : extra) produced.push_back(sp);
     for (const Phase &ph : p.phases) {
-        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
+        if (!in_family(ph.group) || ph.kind != PH_GEMM) continue;
         for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
             const Task &t = p.tasks[i];
             if (t.seg_count == 0) continue;
@@ -586,7 +594,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     }
     std::vector<Span> read16;   // ws spans some twin-reading Seg covers
     for (Phase &ph : p.phases) {
-        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
+        if (!in_family(ph.group) || ph.kind != PH_GEMM) continue;
         bool ok = true;
         std::vector<Span> reads;
         std::vector<char> seen(p.segs.size(), 0);
@@ -631,7 +639,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     }
     // producers whose output some twin-reading Seg covers store the twin as well
     for (const Phase &ph : p.phases) {
-        if ((ph.group != 4 && ph.group != 5) || ph.kind != PH_GEMM) continue;
+        if (!in_family(ph.group) || ph.kind != PH_GEMM) continue;
         for (int i = ph.task_begin; i < ph.task_begin + ph.task_count; ++i) {
             Task &t = p.tasks[i];
             if (t.seg_count == 0) continue;
@@ -647,6 +655,10 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
             }
         }
     }
+    };
+    analyse(fused_family, extra_produced);
+    const char *ue = std::getenv("TA3N_UNFUSED_TWINS");      // (=0: the unfused lists on fp32 stages rounded in registers, as before round 6 - A/B aid)
+    if (!(c.flags & TA3N_FLAG_MCD) && !(ue && std::atoi(ue) == 0)) analyse(unfused_family, {});
     // gemm_only: workspace regions that only GEMM launches read (no pointwise kernel, no API output).  If every launch
     // that reads such a region reads its twin, the producers skip the fp32 store (EPI_TWIN_ONLY): the fp32 region then
     // holds nothing meaningful in this configuration.
@@ -1685,6 +1697,11 @@ static int build_plan_once(ta3n_plan &p, std::string &err) {
             gemm_only.push_back(Span{g.o_gZ1, g.o_gZ1 + (int64_t)BT * F});
         }
         add_bf16_twins(p, b, g, BT, D, kept, gemm_only);
+        if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
+    } else {
+        // no fused step (TA3N_FLAG_FEATURE_GRADS: dis_DA DAN / JAN put a gradient between forward and backward; TA3N_FLAG_MCD; a shape the heads
+        // kernel does not cover): the unfused lists are all there is - round 6: they read twins too (add_bf16_twins: the unfused family)
+        add_bf16_twins(p, b, g, BT, D, {}, {});
         if (p.ws_floats >= (1ll << 31)) { err = "workspace too large for 32-bit offsets"; return TA3N_ERR_INVALID; }
     }
     if (b.mixed_kinds) { err = "internal: a GEMM spec mixes operand kinds across its K segments"; return TA3N_ERR_INVALID; }

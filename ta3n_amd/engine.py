@@ -1041,6 +1041,7 @@ class TrainEngine:
         if n > self.Bs:
             raise ValueError(f"at most batch_source = {self.Bs} validation videos per call")
         self.X[: n * self.T].copy_(val_data.reshape(-1, self.D), non_blocking=True)
+        self.refresh_bf16(x=True)      # (the forward launches of a twin plan read the input's bf16 twin - since round 6 the unfused lists do too)
         self._labels[:n].copy_(val_label.to(torch.int32), non_blocking=True)
         self.set_hyper([0.0, 0.0, 0.0], 0.0, 0.0, train=False, valid_source=n, valid_target=0)
         self.forward()

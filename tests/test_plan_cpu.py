@@ -491,3 +491,51 @@ def test_affinity_group_tile_order_is_a_permutation_of_the_default_order(shape):
     new = it.get_params()
     for k in shapes:
         g.check(f"step0/param/{k}", new[k], 1e-4, 2e-5)
+
+
+def test_unfused_lists_read_twins_on_cpu(monkeypatch):
+    """Round 6: with TA3N_FLAG_BF16_STORE the UNFUSED lists (ta3n_forward / ta3n_backward - what the DA options with a loss term between
+    forward and backward run) read bf16 twins too, analysed as a launch family of their own.  The numpy execution of groups 0, 1, 2 with and
+    without them (TA3N_UNFUSED_TWINS=0: fp32 stages rounded in registers, the lists of the rounds before): every weight gradient is the SAME
+    number (same operands: RNE of the same fp32 values), the bias gradients that ride on a tile's own A operand (EPI_ROWSUM_A) are sums of the
+    rounded values instead of the fp32 ones - as in the fused step - and stay within bf16 rounding.  TA3N_FLAG_MCD keeps the lists off the
+    twins (its second pass runs on a workspace without parameter / input twins)."""
+    g = Golden("tiny_T5")
+    c = case_config(g)
+    T = c["T"]
+    flags = ALL_FLAGS | _lib.FLAG_BF16_MFMA | _lib.FLAG_BF16_STORE
+    st = step_schedule(c)[0]
+    xs, xt, ys, yt = synth_batch(c["C"], T, c["D"], c["Bs"], c["Bt"], seed=st["xseed"])
+    grads, plans = {}, {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("TA3N_UNFUSED_TWINS", env)
+        plan = plans[env] = _lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags)
+        it = Interp(plan)
+        unfused_twin = [ph for ph in it.phases if ph.group in (0, 2) and ph.kind == 0 and (ph.bf16 & 16)]
+        assert (len(unfused_twin) >= 5) if env == "1" else not unfused_twin, len(unfused_twin)      # shared FC, TRN tuples, relation hidden, gradient at F1 + TRN weight gradients, dWsh
+        assert len([ph for ph in it.phases if ph.group == 4 and ph.kind == 0 and (ph.bf16 & 16)]) == 5      # (the fused step's family is analysed on its own)
+        it.set_params(synth_state({n: s for n, _, s, _ in plan.params}, seed=c["wseed"], scale=c["wscale"]))
+        it.X = torch.cat((xs, xt), 0).double().numpy().reshape(-1)
+        it.labels[:c["Bs"]] = ys.numpy()
+        it.hy = make_hyper(c, st, T, st["lr"])
+        it.G[:] = 0
+        for gr in (0, 1, 2):
+            it.run_group(gr)
+        grads[env] = np.array(it.G[:plan.live_floats], dtype=np.float64)
+        if env == "1":
+            B, Bs = c["Bs"] + c["Bt"], c["Bs"]
+            out = it.r(it.g.o_Y, (B, c["C"]))
+            for dom, sl in (("s", slice(0, Bs)), ("t", slice(Bs, B))):
+                g.check(f"fwd/out_{dom}", out[sl], 0.0, 0.1 * g.rms(f"fwd/out_{dom}"), "bf16 operands vs fp32 reference")
+    for name, off, shape, live in plans["1"].params:
+        k = int(np.prod(shape))
+        if off + k > len(grads["1"]):
+            continue
+        a_, b_ = grads["1"][off:off + k], grads["0"][off:off + k]
+        if name.endswith(".weight"):
+            assert np.array_equal(a_, b_), name
+        else:
+            assert np.linalg.norm(a_ - b_) <= 5e-3 * np.linalg.norm(b_) + 1e-12, (name, np.linalg.norm(a_ - b_) / np.linalg.norm(b_))
+    monkeypatch.setenv("TA3N_UNFUSED_TWINS", "1")
+    mcd = Interp(_lib.Plan(c["Bs"], c["Bt"], T, c["D"], c["fc_dim"], c["C"], flags | _lib.FLAG_MCD))
+    assert not [ph for ph in mcd.phases if ph.group in (0, 2) and ph.kind == 0 and (ph.bf16 & 16)]
