@@ -573,8 +573,8 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     // Two launch sequences share the workspace and its twin regions: the FUSED step (groups 4 / 5) and - round 6 - the UNFUSED lists
     // (groups 0 / 2: ta3n_forward / ta3n_backward, what the DA options with a loss term between forward and backward run; their GEMM launches
     // were twice as long on fp32 stages rounded in registers as the fused step's on twins).  Each family is analysed on its own: who keeps a
-    // twin up to date, which launch may read twins, which producers store them.  Not with TA3N_FLAG_MCD: its second pass runs on a second
-    // workspace whose parameter / input twins nobody writes.
+    // twin up to date, which launch may read twins, which producers store them.  (TA3N_FLAG_MCD: the second pass runs on a second workspace -
+    // its caller copies the parameter / input twins over from the first before it, TrainEngine.mcd_second_forward.)
     auto fused_family = [](int group) { return group == 4 || group == 5; };
     auto unfused_family = [](int group) { return group == 0 || group == 2; };
     auto analyse = [&](bool (*in_family)(int), const std::vector<Span> &extra) {
@@ -658,7 +658,7 @@ void add_bf16_twins(ta3n_plan &p, Builder &b, Geom &g, int BT, int D, const std:
     };
     analyse(fused_family, extra_produced);
     const char *ue = std::getenv("TA3N_UNFUSED_TWINS");      // (=0: the unfused lists on fp32 stages rounded in registers, as before round 6 - A/B aid)
-    if (!(c.flags & TA3N_FLAG_MCD) && !(ue && std::atoi(ue) == 0)) analyse(unfused_family, {});
+    if (!(ue && std::atoi(ue) == 0)) analyse(unfused_family, {});
     // gemm_only: workspace regions that only GEMM launches read (no pointwise kernel, no API output).  If every launch
     // that reads such a region reads its twin, the producers skip the fp32 store (EPI_TWIN_ONLY): the fp32 region then
     // holds nothing meaningful in this configuration.

@@ -510,6 +510,12 @@ class TrainEngine:
             h.seed_i, h.seed_v = int(self.mcd_raw_seeds[0]) & 0xFFFFFFFF, int(self.mcd_raw_seeds[1]) & 0xFFFFFFFF
         L, plan = self._L, self.plan
         _lib.check(L.ta3n_set_hyper(plan.handle, self.ws2.data_ptr(), C.byref(h), self._stream()), "ta3n_set_hyper")
+        if self.bf16_store:      # the second workspace's launches read the parameter / input twins too (round 6: the unfused lists on twins) - the
+            # optimiser and set_batch keep them in the FIRST workspace: copied over, 11 MB at the headline shape
+            for name in ("p16", "x16", "p16_lo", "x16_lo"):
+                if name in plan.regions:
+                    off, n = plan.region(name)
+                    self.ws2[off:off + n].copy_(self.ws[off:off + n], non_blocking=True)
         _lib.check(L.ta3n_forward(plan.handle, self.X.data_ptr(), self.P.data_ptr(), self.ws2.data_ptr(), self._stream()), "ta3n_forward")
         nt = int(self._hyper.valid_target)
         if self._mcd_native:      # ta3n_mcd_second_loss: clears the second workspace's gradient entries, loss_s, the moved entropy term, all gradients
